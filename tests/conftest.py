@@ -1,0 +1,40 @@
+import json
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    return json.load(open(os.path.join(GOLDEN, "state_manifest_cmflow.json")))
+
+
+@pytest.fixture(scope="session")
+def manifest_t():
+    return json.load(open(os.path.join(GOLDEN, "state_manifest_cmflow_t.json")))
+
+
+class Args:
+    num_points = 256
+    stat_thres = 0.5
+    vr_thres = 0.3
+
+
+@pytest.fixture(scope="session")
+def args():
+    return Args()

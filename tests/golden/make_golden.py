@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the REFERENCE's own Python modules.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  The
+reference has no CPU path (hard-coded .cuda(), CUDA-only extension), so it is imported on
+torch-CPU behind the shims of SURVEY.md Appendix A; its native extension `pointnet2_cuda`
+is replaced by oracle/ops.py (the C restatement of lib/src/ball_query_gpu.cu:9-45 and
+lib/src/group_points_gpu.cu:8-25,47-66).  Everything above that seam -- QueryAndGroup, the
+set-conv / cost-volume modules, CMFlow(.forward), RadarFlowLoss, the label prep of
+main_util.py -- is the reference's own code, executed unmodified.
+
+Outputs (all small): tests/golden/*.npz + state_manifest_{cmflow,cmflow_t}.json.
+Weights are NOT stored: they are regenerated from the manifest by
+cmflow_amd.synth.synth_state_dict(seed=1234).
+
+    python tests/golden/make_golden.py
+"""
+import glob
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import ops as oracle_ops  # noqa: E402
+from cmflow_amd import synth  # noqa: E402
+
+
+def install_shims():
+    for name in ("open3d", "cv2", "h5py"):
+        sys.modules[name] = types.ModuleType(name)
+    uj = types.ModuleType("ujson")
+    uj.load, uj.dump = json.load, json.dump
+    sys.modules["ujson"] = uj
+    time.clock = time.perf_counter
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.FloatTensor = lambda *s: torch.empty(*s, dtype=torch.float32)
+    torch.cuda.IntTensor = lambda *s: torch.empty(*s, dtype=torch.int32)
+    p = types.ModuleType("pointnet2_cuda")
+    for n in ("ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper",
+              "gather_points_wrapper", "gather_points_grad_wrapper", "three_nn_wrapper",
+              "three_interpolate_wrapper", "furthest_point_sampling_wrapper"):
+        setattr(p, n, getattr(oracle_ops, n))
+    sys.modules["pointnet2_cuda"] = p
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+
+
+class Args:
+    num_points = 256
+    stat_thres = 0.5
+    vr_thres = 0.3
+    model = "cmflow"
+    camera_projection_matrix = np.array(synth.CAMERA_PROJECTION, dtype=np.float32)
+    t_camera_radar = np.array(synth.T_CAMERA_RADAR, dtype=np.float32)
+
+
+def manifest_of(net):
+    return [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in net.state_dict().items()]
+
+
+def real_clouds(n_files=4, N=256, seed=7):
+    """xyz of a few real VoD radar clouds saved by the reference
+    (checkpoints/raflow_cvpr/results/**.json), resampled to N as dataset/vod.py:93-122
+    does (pad by duplication / subsample without replacement); features are synthetic."""
+    files = sorted(glob.glob(os.path.join(REF, "checkpoints/raflow_cvpr/results/*/*.json")))
+    rng = np.random.RandomState(seed)
+    pick = [files[i] for i in rng.choice(len(files), n_files, replace=False)]
+    pcs1, pcs2, fts1, fts2 = [], [], [], []
+    for f in pick:
+        d = json.load(open(f))
+        for key, dst, fdst in (("pc1", pcs1, fts1), ("pc2", pcs2, fts2)):
+            p = np.asarray(d[key], dtype=np.float32).T            # (n,3)
+            n = p.shape[0]
+            vr = 2.0 * rng.randn(n, 1)
+            rcs = -20.0 + 40.0 * rng.rand(n, 1)
+            ft = np.concatenate([vr, rcs, rcs], axis=1).astype(np.float32)   # [v_r, RCS, RCS] per SOURCE point
+            if n < N:
+                ix = np.append(np.arange(n), rng.choice(n, N - n, replace=True))
+            else:
+                ix = rng.choice(n, N, replace=False)
+            dst.append(p[ix])
+            fdst.append(ft[ix])                                    # duplicates carry the same features
+    tt = lambda a: torch.from_numpy(np.stack(a)).transpose(2, 1).contiguous()
+    return {"pc1": tt(pcs1), "pc2": tt(pcs2), "ft1": tt(fts1), "ft2": tt(fts2),
+            "files": [os.path.relpath(f, REF) for f in pick]}
+
+
+class Recorder:
+    """Records what crosses the op boundary while the reference model runs."""
+
+    def __init__(self, putils, rutil):
+        self.bq, self.knn, self.feat = [], [], {}
+        self._putils, self._rutil = putils, rutil
+        self._bq0, self._knn0 = putils.ball_query, rutil.knn_point
+
+        def bq(radius, nsample, xyz, new_xyz):
+            idx = self._bq0(radius, nsample, xyz, new_xyz)
+            self.bq.append((radius, nsample, idx.clone()))
+            return idx
+
+        def knn(nsample, xyz, new_xyz):
+            idx = self._knn0(nsample, xyz, new_xyz)
+            self.knn.append(idx.clone())
+            return idx
+
+        putils.ball_query = bq
+        rutil.knn_point = knn
+
+    def hook(self, net):
+        hs = []
+        for name in ("mse_layer", "fc_layer", "mse_layer2"):
+            def fn(mod, inp, out, name=name):
+                self.feat.setdefault(name, []).append(out.detach().clone())
+            hs.append(getattr(net, name).register_forward_hook(fn))
+        return hs
+
+    def reset(self):
+        self.bq, self.knn, self.feat = [], [], {}
+
+    def restore(self):
+        self._putils.ball_query, self._rutil.knn_point = self._bq0, self._knn0
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def main():
+    install_shims()
+    from lib import pointnet2_utils as putils
+    from utils.model_utils import radarflow_util as rutil
+    from models.cmflow import CMFlow
+    from models.cmflow_t import CMFlow_T
+    import main_util
+    from losses import RadarFlowLoss
+
+    torch.manual_seed(1234)
+    torch.set_num_threads(8)
+    args = Args()
+    rec = Recorder(putils, rutil)
+
+    # ---- state-dict manifests (row a17) --------------------------------------------------
+    net = CMFlow(args)
+    man = manifest_of(net)
+    json.dump(man, open(os.path.join(HERE, "state_manifest_cmflow.json"), "w"), indent=0)
+    net_t = CMFlow_T(args)
+    man_t = manifest_of(net_t)
+    json.dump(man_t, open(os.path.join(HERE, "state_manifest_cmflow_t.json"), "w"), indent=0)
+    print("manifest:", len(man), "tensors,", sum(int(np.prod(s)) for k, s, d in man if "num_batches" not in k and "running" not in k), "params")
+
+    # ---- BN calibration: running statistics of a "trained-like" network ----------------------
+    # Random conv weights with arbitrary running stats blow activations up to 1e4 (1e-4 absolute
+    # tolerances would be meaningless).  One train-mode pass of the REFERENCE model with BN
+    # momentum 1.0 sets running_mean/var to the batch statistics of a calibration batch; they are
+    # committed (50 KB) and overlaid on the seeded weights by synth.synth_state_dict(calib=...).
+    def calibrate(model, manifest, path, fwd):
+        model.load_state_dict(synth.synth_state_dict(manifest, seed=1234))
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.momentum = 1.0
+        with torch.no_grad():
+            fwd(model, synth.make_batch(8, seed=555))
+        sd = model.state_dict()
+        calib = {k: np_(v) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+        np.savez_compressed(path, **calib)
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.momentum = 0.1
+        return calib
+
+    CAL = os.path.join(HERE, "bn_calib_cmflow.npz")
+    CAL_T = os.path.join(HERE, "bn_calib_cmflow_t.npz")
+    calibrate(net, man, CAL, lambda m, b: m(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test"))
+    calibrate(net_t, man_t, CAL_T, lambda m, b: m(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test", None))
+    net.load_state_dict(synth.synth_state_dict(man, seed=1234, calib=CAL))
+    hooks = rec.hook(net)
+
+    def run_eval(batch, tag):
+        net.eval()
+        rec.reset()
+        with torch.no_grad():
+            sf, cls, trans, mask = net(batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"], None, "test")
+        out = {k: np_(batch[k]) for k in ("pc1", "pc2", "ft1", "ft2")}
+        out.update(sf_agg=np_(sf), stat_cls=np_(cls), pre_trans=np_(trans), mask=np_(mask))
+        # 12 ball queries: mse_layer(pc1) x4, mse_layer(pc2) x4, mse_layer2(pc1) x4
+        for i, (r, ns, idx) in enumerate(rec.bq):
+            out["bq%02d_r%g_ns%d" % (i, r, ns)] = np_(idx)
+        out["knn_cross_sorted"] = np.sort(np_(rec.knn[0]), axis=-1).astype(np.int32)
+        out["knn_self_sorted"] = np.sort(np_(rec.knn[1]), axis=-1).astype(np.int32)
+        # intermediate features: sample 0, every 4th channel (keeps the fixture small)
+        out["pc1_features"] = np_(rec.feat["mse_layer"][0])[0, ::4]
+        out["pc2_features"] = np_(rec.feat["mse_layer"][1])[0, ::4]
+        out["cor_features"] = np_(rec.feat["fc_layer"][0])[0, ::4]
+        out["prop_features"] = np_(rec.feat["mse_layer2"][0])[0, ::4]
+        # one grouped tensor slice through QueryAndGroup (row a4): scale 0 of mse_layer on pc1
+        xyz_t = batch["pc1"].permute(0, 2, 1).contiguous()
+        qg = net.mse_layer.ms_ls[1].queryandgroup
+        out["qg_scale1_b0"] = np_(qg(xyz_t, xyz_t, batch["ft1"])[0])
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+        print(tag, "sf_agg abs mean %.4f" % np.abs(out["sf_agg"]).mean(), "mask frac %.3f" % out["mask"].mean())
+
+    run_eval(synth.make_batch(2, seed=1234), "cmflow_eval_synth_b2")
+    run_eval(synth.make_batch(1, seed=99), "cmflow_eval_synth_b1")
+    real = real_clouds()
+    json.dump(real.pop("files"), open(os.path.join(HERE, "real_cloud_sources.json"), "w"))
+    run_eval(real, "cmflow_eval_real_b4")
+
+    # ---- train step (rows a3, a15 'train', losses) -- main_util.py:63-76 sequence ------------
+    def run_train(batch, tag, B):
+        net.load_state_dict(synth.synth_state_dict(man, seed=1234, calib=CAL))
+        net.train()
+        rec.reset()
+        pc1, pc2, ft1, ft2 = batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"]
+        gt_trans, flow_label = batch["gt_trans"], batch["flow_label"]
+        fg_mask, interval = batch["fg_mask"].clone(), batch["interval"]
+        vel1 = ft1[:, 0]
+        dyn_mask = main_util.extract_dynamic_from_fg(fg_mask, pc1, gt_trans, flow_label.transpose(2, 1))
+        mseg_gt, _ = main_util.mseg_label_RRV(pc1, gt_trans, vel1, interval, args)
+        mseg_gt[torch.logical_not(dyn_mask == 1)] = dyn_mask[torch.logical_not(dyn_mask == 1)]
+        opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=1e-4)      # main.py:107
+        pred_f, mseg_pre, pre_trans, mask = net(pc1, pc2, ft1, ft2, mseg_gt, "train")
+        loss, items = RadarFlowLoss()(args, pc1, pc2, pred_f, vel1, flow_label.transpose(2, 1), pre_trans,
+                                      mseg_pre, gt_trans, mseg_gt, dyn_mask, batch["radar_u"],
+                                      batch["radar_v"], batch["opt_flow"])
+        opt.zero_grad()
+        loss.backward()
+        out = {k: np_(v) for k, v in batch.items()}
+        out.update(dyn_mask=np_(dyn_mask), mseg_gt=np_(mseg_gt), sf_agg=np_(pred_f), stat_cls=np_(mseg_pre),
+                   pre_trans=np_(pre_trans), mask=np_(mask), loss=np.float32(loss.item()))
+        for k, v in items.items():
+            out["item_" + k] = np.float32(v)
+        names, norms = [], []
+        for k, p in net.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        out["grad_names"] = np.array(names)
+        out["grad_norms"] = np.array(norms, dtype=np.float64)
+        for k in ("mse_layer.ms_ls.0.mlp_convs.0.weight", "fc_layer.mlp_convs.0.weight",
+                  "mse_layer2.ms_ls.3.mlp_convs.0.weight", "fp.conv2.weight", "mp.conv2.weight",
+                  "fc_layer.weightnet1.mlp_convs.2.bias"):
+            out["grad::" + k] = np_(dict(net.named_parameters())[k].grad).reshape(-1)[:64]
+        opt.step()
+        sd = net.state_dict()
+        for k in ("mse_layer2.ms_ls.1.mlp_bns.1.running_mean", "mse_layer2.ms_ls.1.mlp_bns.1.running_var",
+                  "fp.sf_mlp.0.1.running_mean", "fp.conv2.weight", "mse_layer.ms_ls.2.mlp_bns.0.num_batches_tracked"):
+            out["after::" + k] = np_(sd[k]).reshape(-1)[:64]
+        np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+        print(tag, "loss", loss.item(), items)
+
+    run_train(synth.make_batch(4, seed=4321, train_extras=True), "cmflow_train_synth_b4", 4)
+
+    # ---- CMFlow-T: two consecutive frames with the GRU state hand-off (row a16) ----------------
+    args_t = Args()
+    args_t.model = "cmflow_t"
+    net_t.load_state_dict(synth.synth_state_dict(man_t, seed=1234, calib=CAL_T))
+    net_t.eval()
+    fa, fb = synth.make_batch(2, seed=11), synth.make_batch(2, seed=12)
+    with torch.no_grad():
+        o1 = net_t(fa["pc1"], fa["pc2"], fa["ft1"], fa["ft2"], None, "test", None)
+        o2 = net_t(fb["pc1"], fb["pc2"], fb["ft1"], fb["ft2"], None, "test", o1[4])
+    out = {}
+    for tag, f, o in (("a", fa, o1), ("b", fb, o2)):
+        for k in ("pc1", "pc2", "ft1", "ft2"):
+            out["%s_%s" % (tag, k)] = np_(f[k])
+        for k, v in zip(("sf_agg", "stat_cls", "pre_trans", "mask", "gfeat"), o):
+            out["%s_%s" % (tag, k)] = np_(v)
+    np.savez_compressed(os.path.join(HERE, "cmflow_t_eval_synth_b2.npz"), **out)
+    print("cmflow_t gfeat abs mean", np.abs(out["b_gfeat"]).mean())
+
+    # ---- weighted-Kabsch KATs (row a13): models/cmflow.py:128-169 run directly ---------------
+    g = torch.Generator().manual_seed(5)
+    N = 256
+    A = synth.make_batch(5, seed=77)["pc1"]
+    T = synth.rigid_transform(yaw_deg=0.5, t=(-0.5, 0.1, 0.02), B=5)
+    Bm = T[:, :3, :3] @ A + T[:, :3, 3:4]
+    Bm[0] = A[0]                                                       # identity
+    Bm[2] = A[2] * torch.tensor([1.0, 1.0, -1.0]).view(3, 1)            # mirrored cloud: reflection branch
+    Bm[3] = Bm[3] + 0.05 * torch.randn(3, N, generator=g)
+    W = torch.rand(5, N, generator=g) + 1e-3
+    W[1] = 1.0                                                         # all-equal weights
+    W[4] = 1e-4
+    W[4, :5] = 1.0                                                     # one-hot-ish weights
+    W = W / W.sum(dim=1, keepdim=True)
+    Tk = net.WeightedKabsch(A, Bm, W)
+    np.savez_compressed(os.path.join(HERE, "kabsch_kat.npz"), A=np_(A), B=np_(Bm), W=np_(W), trans=np_(Tk))
+    print("kabsch det(R):", [round(float(torch.linalg.det(Tk[i, :3, :3])), 4) for i in range(5)])
+
+    # ---- reference CPU-path timing (informational) ----------------------
+    net.load_state_dict(synth.synth_state_dict(man, seed=1234, calib=CAL))
+    net.eval()
+    b1 = synth.make_batch(1, seed=1)
+    with torch.no_grad():
+        for _ in range(2):
+            net(b1["pc1"], b1["pc2"], b1["ft1"], b1["ft2"], None, "test")
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            net(b1["pc1"], b1["pc2"], b1["ft1"], b1["ft2"], None, "test")
+            ts.append(time.perf_counter() - t0)
+    print("reference CPU fwd B=1: median %.3f s on %d threads" % (float(np.median(ts)), torch.get_num_threads()))
+    json.dump({"ref_cpu_fwd_b1_s": float(np.median(ts)), "threads": torch.get_num_threads()},
+              open(os.path.join(HERE, "ref_cpu_timing.json"), "w"))
+    for h in hooks:
+        h.remove()
+    rec.restore()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""CPU: pins the oracle (oracle/) against golden vectors produced by the reference's own
+Python modules (tests/golden/make_golden.py).  No GPU, no product code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cmflow_amd import synth
+from oracle import cmflow_oracle as O
+from oracle import ops, train_oracle as TO
+
+EVAL_CASES = ["cmflow_eval_synth_b2", "cmflow_eval_synth_b1", "cmflow_eval_real_b4"]
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def same_neighbours(pc, idx_a, idx_b):
+    """kNN index sets agree, where indices of exactly duplicated points (the dataset pads
+    clouds by duplication, dataset/vod.py:102-106) are interchangeable: torch.topk leaves
+    tie-breaking unspecified.  pc (B,3,N); idx (B,S,K)."""
+    xyz = np.ascontiguousarray(np.transpose(pc, (0, 2, 1)))          # (B,N,3)
+    for b in range(xyz.shape[0]):
+        a = np.sort(idx_a[b], -1)
+        c = np.sort(idx_b[b], -1)
+        for q in np.nonzero((a != c).any(-1))[0]:
+            pa = np.sort(xyz[b][idx_a[b, q]].view([("x", "f4"), ("y", "f4"), ("z", "f4")]), axis=0)
+            pb = np.sort(xyz[b][idx_b[b, q]].view([("x", "f4"), ("y", "f4"), ("z", "f4")]), axis=0)
+            if not np.array_equal(pa, pb):
+                return False
+    return True
+
+
+def _net(manifest, golden_dir, args, cls=O.CMFlow, calib="bn_calib_cmflow.npz"):
+    net = cls(args)
+    net.load_state_dict(synth.synth_state_dict(manifest, seed=1234, calib=os.path.join(golden_dir, calib)))
+    return net
+
+
+def test_state_dict_layout(manifest, manifest_t, args):
+    """Row a17: 374 / 378 tensors, same keys, shapes, dtypes and order as the reference."""
+    for man, cls in ((manifest, O.CMFlow), (manifest_t, O.CMFlow_T)):
+        sd = cls(args).state_dict()
+        assert [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()] == man
+    assert len(manifest) == 374 and len(manifest_t) == 378
+    n_param = sum(p.numel() for p in O.CMFlow(args).parameters())
+    assert n_param == 4230672
+
+
+@pytest.mark.parametrize("case", EVAL_CASES)
+def test_forward_matches_reference(case, manifest, golden_dir, args):
+    g = _load(golden_dir, case)
+    net = _net(manifest, golden_dir, args).eval()
+    bq, knn = O.set_trace(net)
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        sf, cls, trans, mask = net(t("pc1"), t("pc2"), t("ft1"), t("ft2"), None, "test")
+    # a1: all 12 ball queries bit-exact, in call order
+    keys = sorted(k for k in g if k.startswith("bq"))
+    assert len(keys) == 12 == len(bq)
+    for k, idx in zip(keys, bq):
+        assert np.array_equal(g[k], idx.numpy()), k
+    # a7: kNN sets equal to torch.topk's on the reference side (up to duplicate points)
+    assert same_neighbours(g["pc2"], knn[0].numpy(), g["knn_cross_sorted"])
+    assert same_neighbours(g["pc1"], knn[1].numpy(), g["knn_self_sorted"])
+    # a5/a6/a9/a11 intermediate features (sample 0, every 4th channel)
+    for k in ("pc1_features", "pc2_features", "cor_features", "prop_features"):
+        np.testing.assert_allclose(net.last[k][0, ::4].numpy(), g[k], rtol=1e-5, atol=2e-5, err_msg=k)
+    # a12-a15 outputs: flow/seg within 1e-4 fp32 (north_star), mask equal
+    assert np.array_equal(mask.numpy(), g["mask"])
+    np.testing.assert_allclose(cls.numpy(), g["stat_cls"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(trans.numpy(), g["pre_trans"], rtol=0, atol=1e-4)
+    epe = np.linalg.norm(sf.numpy() - g["sf_agg"], axis=1).mean()
+    assert epe < 1e-4, epe
+    # a4: QueryAndGroup slice
+    xyz_t = t("pc1").permute(0, 2, 1).contiguous()
+    grouped, _ = O.query_and_group(4.0, 8, xyz_t, xyz_t, t("ft1"))
+    assert np.array_equal(grouped[0].numpy(), g["qg_scale1_b0"])
+
+
+def test_cmflow_t_matches_reference(manifest_t, golden_dir, args):
+    g = _load(golden_dir, "cmflow_t_eval_synth_b2")
+    net = _net(manifest_t, golden_dir, args, O.CMFlow_T, "bn_calib_cmflow_t.npz").eval()
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        o1 = net(t("a_pc1"), t("a_pc2"), t("a_ft1"), t("a_ft2"), None, "test", None)
+        o2 = net(t("b_pc1"), t("b_pc2"), t("b_ft1"), t("b_ft2"), None, "test", o1[4])
+    for tag, o in (("a", o1), ("b", o2)):
+        assert np.array_equal(o[3].numpy(), g[tag + "_mask"])
+        np.testing.assert_allclose(o[0].numpy(), g[tag + "_sf_agg"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o[1].numpy(), g[tag + "_stat_cls"], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(o[2].numpy(), g[tag + "_pre_trans"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o[4].numpy(), g[tag + "_gfeat"], rtol=0, atol=1e-5)
+
+
+def test_train_step_matches_reference(manifest, golden_dir, args):
+    """Rows a3 + a15('train') + the 7 loss terms + Adam: main_util.py:63-76 sequence."""
+    g = _load(golden_dir, "cmflow_train_synth_b4")
+    net = _net(manifest, golden_dir, args).train()
+    batch = {k: torch.from_numpy(g[k]) for k in ("pc1", "pc2", "ft1", "ft2", "gt_trans", "flow_label", "fg_mask",
+                                                   "interval", "radar_u", "radar_v", "opt_flow")}
+    P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
+    opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=1e-4)
+    loss, items, outs, (dyn, mseg) = TO.train_step(net, opt, batch, P, Tcr)
+    assert np.array_equal(dyn.numpy(), g["dyn_mask"]) and np.array_equal(mseg.numpy(), g["mseg_gt"])
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    for k, v in items.items():
+        assert abs(v - float(g["item_" + k])) < 1e-4, k
+    np.testing.assert_allclose(outs[0].detach().numpy(), g["sf_agg"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(outs[2].detach().numpy(), g["pre_trans"], rtol=0, atol=1e-4)
+    params = dict(net.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        p = params[str(name)]
+        if ref < 0:
+            assert p.grad is None, name          # 12 WeightNet-BN params never get a gradient
+        else:
+            # fp32 gradients of this net sit ~1e-3 (rel.) from an fp64 evaluation: two fp32
+                # implementations cannot agree tighter than that
+                assert abs(float(p.grad.norm()) - ref) <= 5e-3 * max(ref, 1e-3), (name, float(p.grad.norm()), ref)
+    for k in g:
+        if k.startswith("grad::"):
+            got = params[k[6:]].grad.reshape(-1)[:64].numpy()
+            np.testing.assert_allclose(got, g[k], rtol=5e-3, atol=5e-3 * np.abs(g[k]).max(), err_msg=k)
+    sd = net.state_dict()
+    for k in g:
+        if k.startswith("after::"):
+            np.testing.assert_allclose(sd[k[7:]].reshape(-1)[:64].numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_kabsch_kat(golden_dir):
+    """Row a13 KATs: identity, equal weights, mirrored cloud (reflection branch), noise, one-hot-ish."""
+    g = _load(golden_dir, "kabsch_kat")
+    T = O.weighted_kabsch(torch.from_numpy(g["A"]), torch.from_numpy(g["B"]), torch.from_numpy(g["W"]))
+    np.testing.assert_allclose(T.numpy(), g["trans"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(T[0, :3, :3].numpy(), np.eye(3), atol=1e-5)
+
+
+def test_canonical_distance_is_torch_matmul_form():
+    """The oracle's square_distance is bit-equal to the reference expression evaluated by
+    torch-CPU (radarflow_util.py:26-29), so kNN sets agree wherever there is no exact tie."""
+    g = torch.Generator().manual_seed(3)
+    for B, N in ((3, 256), (2, 100), (1, 1024)):
+        src = torch.rand(B, N, 3, generator=g) * torch.tensor([90.0, 50.0, 6.0]) - torch.tensor([0.0, 25.0, 3.0])
+        dst = torch.rand(B, N, 3, generator=g) * torch.tensor([90.0, 50.0, 6.0]) - torch.tensor([0.0, 25.0, 3.0])
+        d = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+        d += torch.sum(src ** 2, -1).view(B, N, 1)
+        d += torch.sum(dst ** 2, -1).view(B, 1, N)
+        d = torch.maximum(d, torch.zeros(d.size()))
+        assert torch.equal(d, ops.square_distance(src, dst))
+        ref = torch.topk(d, 8, dim=-1, largest=False, sorted=False)[1]
+        assert torch.equal(ref.sort(-1)[0], ops.knn(8, dst, src).long().sort(-1)[0])
+
+
+def test_ball_query_edge_cases():
+    """Strict '<', pad-fill with the first hit, empty ball leaves the pre-zeroed idx, N < nsample."""
+    xyz = torch.tensor([[[0.0, 0, 0], [1.0, 0, 0], [2.0, 0, 0], [0.5, 0, 0]]])
+    idx = ops.ball_query(1.0, 3, xyz, xyz)
+    assert idx[0].tolist() == [[0, 3, 0], [1, 3, 1], [2, 2, 2], [0, 1, 3]]      # d2 == r2 is NOT a hit
+    far = torch.tensor([[[100.0, 0, 0]]])
+    assert ops.ball_query(1.0, 4, xyz, far)[0].tolist() == [[0, 0, 0, 0]]         # empty ball: untouched zeros
+    assert ops.ball_query(10.0, 8, xyz, xyz)[0, 0].tolist() == [0, 1, 2, 3, 0, 0, 0, 0]
+    dup = torch.zeros(1, 6, 3)
+    assert ops.ball_query(0.5, 4, dup, dup)[0, 5].tolist() == [0, 1, 2, 3]
+
+
+def test_group_points_and_grad():
+    g = torch.Generator().manual_seed(0)
+    pts = torch.randn(2, 5, 16, generator=g)
+    idx = torch.randint(0, 16, (2, 16, 4), generator=g, dtype=torch.int32)
+    out = ops.group_points(pts, idx)
+    ref = torch.gather(pts.unsqueeze(2).expand(-1, -1, 16, -1), 3, idx.long().unsqueeze(1).expand(-1, 5, -1, -1))
+    assert torch.equal(out, ref)
+    go = torch.randn(2, 5, 16, 4, generator=g)
+    gp = ops.group_points_grad(go, idx, 16)
+    ref = torch.zeros(2, 5, 16).scatter_add_(2, idx.long().view(2, 1, -1).expand(-1, 5, -1), go.view(2, 5, -1))
+    np.testing.assert_allclose(gp.numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
