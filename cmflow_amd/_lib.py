@@ -1,0 +1,77 @@
+"""ctypes loader for libcmflow_hip.so (the C-ABI declared in include/cmflow_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a kernel launch
+fails, an exception is raised.  Nothing here imports ``oracle/``.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcmflow_hip.so")
+
+_vp, _ci, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (restype is int = hipError_t unless noted); mirrors include/cmflow_hip.h
+SIGNATURES = {
+    "cmf_ball_query": [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp],
+    "cmf_group_points": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_group_points_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_knn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_weighted_kabsch": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_weighted_kabsch_grad": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.run(args, check=True, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                "cmflow_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU/PyTorch fallback for the HIP path)" % SO_PATH)
+        _lib = ctypes.CDLL(SO_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _ci
+        _lib.cmf_version.restype = ctypes.c_char_p
+    return _lib
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (what at::cuda::getCurrentCUDAStream() is to the
+    reference wrappers, lib/src/ball_query.cpp:22)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev_ptr(t, dtype):
+    """Device pointer of a dense tensor; refuses CPU tensors loudly (no fallback)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("cmflow_amd HIP op got a %s tensor: the product path runs on the GPU only" % t.device)
+    if t.dtype != dtype:
+        raise TypeError("expected %s, got %s" % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")          # lib/pointnet2_utils.py:195-196,241-242
+    return t.data_ptr()
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError("%s failed: hipError_t %d" % (what, err))

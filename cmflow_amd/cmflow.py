@@ -1,0 +1,153 @@
+"""CMFlow / CMFlow_T with the reference's module API and checkpoint layout.
+
+``CMFlow(args)`` takes ``args.num_points`` / ``args.stat_thres`` (models/cmflow.py:17-18);
+``forward(pc1, pc2, feature1, feature2, label_m, mode)`` returns
+``(sf_agg (B,3,N), stat_cls (B,1,N), pre_trans (B,4,4), mask (B,N) bool)`` (:171-197); the
+state_dict has the reference's 374 (CMFlow) / 378 (CMFlow_T) tensors, so reference
+checkpoints load unchanged (models/model.py:38 uses strict=False).
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScaleEncoder, weighted_kabsch)
+
+
+class CMFlow(nn.Module):
+    score_eps = 1e-4            # models/cmflow.py:105; CMFlow_T has none (cmflow_t.py:119)
+
+    def __init__(self, args):
+        super().__init__()
+        self.npoints = args.num_points
+        self.stat_thres = args.stat_thres
+        # multi-scale set feature abstraction (cmflow.py:20-27)
+        sa_radius = [2.0, 4.0, 8.0, 16.0]
+        sa_nsamples = [4, 8, 16, 32]
+        sa_mlps = [32, 32, 64]
+        sa_mlp2s = [64, 64, 64]
+        num_sas = len(sa_radius)
+        self.mse_layer = MultiScaleEncoder(sa_radius, sa_nsamples, in_channel=3, mlp=sa_mlps, mlp2=sa_mlp2s)
+        # feature correlation layer / cost volume (cmflow.py:29-32)
+        fc_inch = num_sas * sa_mlp2s[-1] * 2
+        self.fc_layer = FeatureCorrelator(8, in_channel=fc_inch * 2 + 3, mlp=[fc_inch, fc_inch, fc_inch])
+        # second multi-scale encoder on the embeddings (cmflow.py:34-42)
+        ep_inch = fc_inch * 2 + 3
+        ep_mlps = [fc_inch, fc_inch // 2, fc_inch // 8]
+        ep_mlp2s = [fc_inch // 8, fc_inch // 8, fc_inch // 8]
+        self.mse_layer2 = MultiScaleEncoder(sa_radius, sa_nsamples, in_channel=ep_inch, mlp=ep_mlps, mlp2=ep_mlp2s)
+        self._declare_recurrent(len(sa_radius) * ep_mlp2s[-1])
+        # heads (cmflow.py:44-48)
+        sf_inch = len(sa_radius) * ep_mlp2s[-1] * 2
+        sf_mlps = [sf_inch // 2, sf_inch // 4, sf_inch // 8]
+        self.fp = FlowHead(in_channel=sf_inch, mlp=sf_mlps)
+        self.mp = MotionHead(in_channel=sf_inch, mlp=sf_mlps)
+
+    def _declare_recurrent(self, width):
+        pass
+
+    @staticmethod
+    def rigid_to_flow(pc, trans):
+        """cmflow.py:51-55"""
+        h_pc = torch.cat((pc, torch.ones((pc.size(0), 1, pc.size(2)), dtype=pc.dtype, device=pc.device)), dim=1)
+        return torch.matmul(trans, h_pc)[:, :3] - pc
+
+    def _propagate(self, pc1, pc2, feature1, feature2):
+        """cmflow.py:59-88: everything of Backbone up to prop_features."""
+        N = pc1.size(2)
+        pc1_features = self.mse_layer(pc1, feature1)
+        pc2_features = self.mse_layer(pc2, feature2)
+        gfeat_1 = torch.max(pc1_features, -1)[0].unsqueeze(2).expand(-1, -1, N)
+        gfeat_2 = torch.max(pc2_features, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
+        pc1_features = torch.cat((pc1_features, gfeat_1), dim=1)
+        pc2_features = torch.cat((pc2_features, gfeat_2), dim=1)
+        cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
+        embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
+        prop_features = self.mse_layer2(pc1, embeddings)
+        self.last = {"pc1_features": pc1_features[:, :256], "pc2_features": pc2_features[:, :256],
+                     "cor_features": cor_features, "prop_features": prop_features}
+        return prop_features
+
+    def Backbone(self, pc1, pc2, feature1, feature2):
+        prop_features = self._propagate(pc1, pc2, feature1, feature2)
+        gfeat = torch.max(prop_features, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
+        return torch.cat((prop_features, gfeat), dim=1)
+
+    def EgoMotionHead(self, flow, pc1, score):
+        """cmflow.py:96-110"""
+        pc1_warp = pc1 + flow
+        score = score.squeeze(1) + self.score_eps if self.score_eps else score.squeeze(1)
+        weight = score / score.sum(dim=1).unsqueeze(1)
+        return self.WeightedKabsch(pc1, pc1_warp, weight)
+
+    def refine_with_transform(self, flow, pc1, trans, mask):
+        """cmflow.py:112-125 (the per-sample boolean-index loop is one select; no host syncs)."""
+        return torch.where(mask.unsqueeze(1), self.rigid_to_flow(pc1, trans), flow)
+
+    @staticmethod
+    def WeightedKabsch(A, B, W):
+        """cmflow.py:128-169"""
+        return weighted_kabsch(A, B, W)
+
+    def _heads(self, final_features, pc1, label_m, mode):
+        output = self.fp(final_features)
+        stat_cls = self.mp(final_features)
+        if (mode == 'train') and (label_m is not None):
+            scores = label_m.unsqueeze(1)
+        else:
+            scores = stat_cls
+        mask = (scores > self.stat_thres).squeeze(1)
+        pre_trans = self.EgoMotionHead(output, pc1, scores)
+        sf_agg = self.refine_with_transform(output, pc1, pre_trans, mask)
+        return sf_agg, stat_cls, pre_trans, mask
+
+    def forward(self, pc1, pc2, feature1, feature2, label_m, mode):
+        final_features = self.Backbone(pc1, pc2, feature1, feature2)
+        return self._heads(final_features, pc1, label_m, mode)
+
+
+class CMFlow_T(CMFlow):
+    """models/cmflow_t.py: CMFlow + nn.GRU(256,256) on the global feature, carried across the
+    frames of a mini-clip (clip_util.py:34-62)."""
+    score_eps = 0.0
+
+    def __init__(self, args):
+        super().__init__(args)
+        self.stat_thres = 0.50                       # cmflow_t.py:18
+
+    def _declare_recurrent(self, width):             # cmflow_t.py:46 (declared before the heads)
+        self.gru = nn.GRU(input_size=width, hidden_size=width, num_layers=1)
+
+    def Backbone(self, pc1, pc2, feature1, feature2, gfeat_prev):
+        prop_features = self._propagate(pc1, pc2, feature1, feature2)
+        gfeat = torch.max(prop_features, -1)[0]
+        if gfeat_prev is None:
+            gfeat_prev = torch.zeros_like(gfeat)
+        gfeat_new = self.gru(gfeat.unsqueeze(0), gfeat_prev.unsqueeze(0))[0].squeeze(0)
+        expand = gfeat_new.unsqueeze(2).expand(-1, -1, pc1.size(2))
+        return torch.cat((prop_features, expand), dim=1), gfeat_new
+
+    def forward(self, pc1, pc2, feature1, feature2, label_m, mode, gfeat):
+        final_features, gfeat = self.Backbone(pc1, pc2, feature1, feature2, gfeat)
+        return (*self._heads(final_features, pc1, label_m, mode), gfeat)
+
+
+def init_model(args, device="cuda"):
+    """models/model.py:19-47 without nn.DataParallel: multi-GPU is one process per GPU with an
+    RCCL gradient all-reduce (cmflow_amd/dp.py)."""
+    if args.model == 'cmflow':
+        net = CMFlow(args)
+    elif args.model == 'cmflow_t':
+        net = CMFlow_T(args)
+    else:
+        raise Exception('Not implemented')
+    net = net.to(device)
+    path = getattr(args, 'model_path', '')
+    if getattr(args, 'eval', False) or getattr(args, 'load_checkpoint', False):
+        if path == '':
+            path = 'checkpoints/' + args.exp_name + '/models/model.best.t7'
+        if not os.path.exists(path):
+            print("can't find pretrained model")
+            return None
+        net.load_state_dict(torch.load(path, map_location=device), strict=False)
+    return net

@@ -1,0 +1,177 @@
+// Neighbour search kernels: ball query (lib/src/ball_query_gpu.cu:9-45) and the torch-level
+// kNN of utils/model_utils/radarflow_util.py:8-30,88-99.
+//
+// Both decide integer outputs from fp32 compares, so the arithmetic is CANONICAL:
+// every operation individually rounded, no FMA contraction, except the kNN dot product which
+// is the k-ordered FMA chain of a GEMM (bit-equal to torch-CPU matmul).  This file is built
+// with -ffp-contract=off and the pragma below; tests/test_build.py checks the ISA.
+#include "cmf_common.h"
+#include "../../include/cmflow_hip.h"
+
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------------------------
+// Ball query.  One lane per centre; the cloud is staged through LDS in tiles and every lane
+// scans it in index order (all lanes read the same LDS address -> broadcast, conflict free).
+// The scan order is the semantics (first nsample hits in index order), so there is no
+// reordering to exploit; the kernel is latency bound at N=256.
+// ---------------------------------------------------------------------------------------------
+constexpr int BQ_TILE = 1024;       // points per LDS tile (12 KiB)
+
+__global__ __launch_bounds__(CMF_WAVE) void ball_query_kernel(
+    int n, int m, float radius2, int nsample,
+    const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx)
+{
+    __shared__ float tile[BQ_TILE * 3];
+    const int bs = blockIdx.y;
+    const int pt = blockIdx.x * CMF_WAVE + threadIdx.x;
+    const bool live = pt < m;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (live) {
+        const float *c = new_xyz + ((size_t)bs * m + pt) * 3;
+        cx = c[0]; cy = c[1]; cz = c[2];
+    }
+    int *out = idx + ((size_t)bs * m + (live ? pt : 0)) * nsample;
+    int cnt = live ? 0 : nsample;       // dead lanes count as finished
+    int first = 0;
+
+    for (int base = 0; base < n; base += BQ_TILE) {
+        const int len = min(BQ_TILE, n - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len * 3; i += CMF_WAVE) tile[i] = pts[(size_t)base * 3 + i];
+        __syncthreads();
+        if (__all(cnt >= nsample)) break;           // wave-uniform early exit
+        for (int k = 0; k < len; ++k) {
+            const float dx = cx - tile[k * 3 + 0];
+            const float dy = cy - tile[k * 3 + 1];
+            const float dz = cz - tile[k * 3 + 2];
+            const float xx = dx * dx;
+            const float yy = dy * dy;
+            const float zz = dz * dz;
+            const float s = xx + yy;
+            const float d2 = s + zz;
+            if (d2 < radius2 && cnt < nsample) {
+                if (cnt == 0) first = base + k;
+                out[cnt] = base + k;
+                ++cnt;
+            }
+        }
+    }
+    // pad with the first hit (ball_query_gpu.cu:37-41); an empty ball leaves idx untouched
+    if (live && cnt > 0)
+        for (int l = cnt; l < nsample; ++l) out[l] = first;
+}
+
+extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
+                              const float *new_xyz, const float *xyz, int *idx, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample > 0);
+    if (b == 0 || m == 0 || n == 0) return 0;
+    CMF_CHECK_ARG(new_xyz && xyz && idx);
+    dim3 grid(cmf_divup(m, CMF_WAVE), b);
+    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
+                       n, m, radius * radius, nsample, new_xyz, xyz, idx);
+    return cmf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN.  One lane per query; database points + their squared norms staged in LDS (16 B/point);
+// the K best (distance, index) pairs live in registers as a sorted list.  Strict '<' in both
+// the admission test and the bubble-up keeps the earliest index ahead on ties (= the oracle).
+// ---------------------------------------------------------------------------------------------
+constexpr int KNN_TILE = 1024;      // 16 KiB
+
+__device__ __forceinline__ float sqnorm3(float x, float y, float z)
+{
+    const float xx = x * x;
+    const float yy = y * y;
+    const float zz = z * z;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+template <int K>
+__global__ __launch_bounds__(CMF_WAVE) void knn_kernel(
+    int n, int s, int nsample, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    int *__restrict__ idx, float *__restrict__ dist)
+{
+    __shared__ float4 tile[KNN_TILE];
+    const int bs = blockIdx.y;
+    const int q = blockIdx.x * CMF_WAVE + threadIdx.x;
+    const bool live = q < s;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (live) {
+        const float *c = new_xyz + ((size_t)bs * s + q) * 3;
+        qx = c[0]; qy = c[1]; qz = c[2];
+    }
+    const float ss = sqnorm3(qx, qy, qz);
+    float bd[K];
+    int bi[K];
+#pragma unroll
+    for (int t = 0; t < K; ++t) { bd[t] = __builtin_inff(); bi[t] = 0; }
+
+    for (int base = 0; base < n; base += KNN_TILE) {
+        const int len = min(KNN_TILE, n - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += CMF_WAVE) {
+            const float x = pts[(size_t)(base + i) * 3 + 0];
+            const float y = pts[(size_t)(base + i) * 3 + 1];
+            const float z = pts[(size_t)(base + i) * 3 + 2];
+            tile[i] = make_float4(x, y, z, sqnorm3(x, y, z));
+        }
+        __syncthreads();
+        for (int k = 0; k < len; ++k) {
+            const float4 p = tile[k];
+            const float p0 = qx * p.x;
+            const float p01 = __builtin_fmaf(qy, p.y, p0);
+            const float dot = __builtin_fmaf(qz, p.z, p01);
+            const float t = -2.0f * dot;
+            const float u = t + ss;
+            float v = u + p.w;
+            v = (v > 0.0f) ? v : 0.0f;
+            if (v < bd[K - 1]) {
+                bd[K - 1] = v;
+                bi[K - 1] = base + k;
+#pragma unroll
+                for (int j = K - 1; j > 0; --j) {
+                    if (bd[j] < bd[j - 1]) {
+                        const float td = bd[j]; bd[j] = bd[j - 1]; bd[j - 1] = td;
+                        const int ti = bi[j]; bi[j] = bi[j - 1]; bi[j - 1] = ti;
+                    }
+                }
+            }
+        }
+    }
+    if (live) {
+        int *o = idx + ((size_t)bs * s + q) * nsample;
+#pragma unroll
+        for (int t = 0; t < K; ++t)
+            if (t < nsample) o[t] = (bd[t] == __builtin_inff()) ? 0 : bi[t];
+        if (dist) {
+            float *d = dist + ((size_t)bs * s + q) * nsample;
+#pragma unroll
+            for (int t = 0; t < K; ++t)
+                if (t < nsample) d[t] = (bd[t] == __builtin_inff()) ? 0.0f : bd[t];
+        }
+    }
+}
+
+extern "C" int cmf_knn(int b, int n, int s, int nsample, const float *xyz, const float *new_xyz,
+                       int *idx, float *dist, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n >= 0 && s >= 0 && nsample > 0 && nsample <= 32);
+    if (b == 0 || s == 0) return 0;
+    CMF_CHECK_ARG(xyz && new_xyz && idx);
+    dim3 grid(cmf_divup(s, CMF_WAVE), b), block(CMF_WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    // the list length is a compile-time constant so it stays in registers; the list is sorted,
+    // so running a longer list and emitting its first nsample entries is exact.
+    if (nsample <= 1)       hipLaunchKernelGGL(knn_kernel<1>,  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else if (nsample <= 4)  hipLaunchKernelGGL(knn_kernel<4>,  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else if (nsample <= 8)  hipLaunchKernelGGL(knn_kernel<8>,  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else if (nsample <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else                    hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    return cmf_launch_status();
+}

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's building blocks (utils/model_utils/radarflow_util.py).
+
+Module names, constructor arguments, parameter names (=> state_dict keys) and tensor
+contracts follow the reference; the hot inner loops run in libcmflow_hip.so:
+
+  knn_point (:88-99)            -> cmf_knn            (canonical distance + ordered top-k)
+  index_points_group (:52-63)   -> cmf_group_points   (+ cmf_group_points_grad in backward)
+  PointLocalFeature (:121-162)  -> QueryAndGroup over cmf_ball_query / cmf_group_points
+  FeatureCorrelator (:164-237)  -> cmf_knn + cmf_group_points
+  WeightedKabsch (models/cmflow.py:128-169) -> cmf_weighted_kabsch(+_grad)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+from . import pointnet2_utils as pointutils
+
+_f32, _i32 = torch.float32, torch.int32
+
+
+def square_distance(src, dst):
+    """radarflow_util.py:8-30: (B,N,C),(B,M,C) -> (B,N,M) squared distances, clamped at 0."""
+    B, N, _ = src.shape
+    _, M, _ = dst.shape
+    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+    dist += torch.sum(src ** 2, -1).view(B, N, 1)
+    dist += torch.sum(dst ** 2, -1).view(B, 1, M)
+    return torch.clamp_min(dist, 0.0)
+
+
+def index_points_group(points, knn_idx):
+    """radarflow_util.py:52-63: points (B,N,C), knn_idx (B,N,K) -> (B,N,K,C)."""
+    points_flipped = points.permute(0, 2, 1).contiguous()
+    return pointutils.grouping_operation(points_flipped, knn_idx.int().contiguous()).permute(0, 2, 3, 1)
+
+
+def knn_point(nsample, xyz, new_xyz, return_dist=False):
+    """radarflow_util.py:88-99: xyz (B,N,3) database, new_xyz (B,S,3) queries -> (B,S,nsample)
+    int64 (torch.topk's dtype).  Order is canonical (ascending distance, lowest index first);
+    the reference's topk(sorted=False) order is unspecified."""
+    xyz = xyz.detach().contiguous()
+    new_xyz = new_xyz.detach().contiguous()
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty(B, S, nsample, dtype=_i32, device=xyz.device)
+    dist = torch.empty(B, S, nsample, dtype=_f32, device=xyz.device) if return_dist else None
+    err = _lib.lib().cmf_knn(B, N, S, nsample, _lib.dev_ptr(xyz, _f32), _lib.dev_ptr(new_xyz, _f32),
+                             _lib.dev_ptr(idx, _i32), _lib.dev_ptr(dist, _f32), _lib.stream_ptr())
+    _lib.check(err, "cmf_knn")
+    return (idx.long(), dist) if return_dist else idx.long()
+
+
+class _WeightedKabsch(Function):
+    @staticmethod
+    def forward(ctx, A, Bm, W):
+        A, Bm, W = A.contiguous(), Bm.contiguous(), W.contiguous()
+        b, _, n = A.shape
+        trans = torch.empty(b, 4, 4, dtype=_f32, device=A.device)
+        aux = torch.empty(b, 32, dtype=torch.float64, device=A.device)
+        err = _lib.lib().cmf_weighted_kabsch(b, n, _lib.dev_ptr(A, _f32), _lib.dev_ptr(Bm, _f32), _lib.dev_ptr(W, _f32),
+                                             _lib.dev_ptr(trans, _f32), _lib.dev_ptr(aux, torch.float64),
+                                             _lib.stream_ptr())
+        _lib.check(err, "cmf_weighted_kabsch")
+        ctx.save_for_backward(A, Bm, W, aux)
+        return trans
+
+    @staticmethod
+    def backward(ctx, grad_trans):
+        A, Bm, W, aux = ctx.saved_tensors
+        b, _, n = A.shape
+        need = ctx.needs_input_grad
+        gA = torch.empty_like(A) if need[0] else None
+        gB = torch.empty_like(Bm) if need[1] else None
+        gW = torch.empty_like(W) if need[2] else None
+        err = _lib.lib().cmf_weighted_kabsch_grad(
+            b, n, _lib.dev_ptr(A, _f32), _lib.dev_ptr(Bm, _f32), _lib.dev_ptr(W, _f32),
+            _lib.dev_ptr(aux, torch.float64), _lib.dev_ptr(grad_trans.contiguous(), _f32),
+            _lib.dev_ptr(gA, _f32), _lib.dev_ptr(gB, _f32), _lib.dev_ptr(gW, _f32), _lib.stream_ptr())
+        _lib.check(err, "cmf_weighted_kabsch_grad")
+        return gA, gB, gW
+
+
+def weighted_kabsch(A, B, W):
+    """models/cmflow.py:128-169: A, B (b,3,N), W (b,N) -> (b,4,4)."""
+    assert A.size() == B.size()
+    return _WeightedKabsch.apply(A, B, W)
+
+
+class MultiScaleEncoder(nn.Module):
+    """radarflow_util.py:101-118"""
+
+    def __init__(self, radius, nsample, in_channel, mlp, mlp2):
+        super().__init__()
+        self.ms_ls = nn.ModuleList()
+        for l in range(len(radius)):
+            self.ms_ls.append(PointLocalFeature(radius[l], nsample[l], in_channel=in_channel, mlp=mlp, mlp2=mlp2))
+
+    def forward(self, xyz, features):
+        return torch.cat([sa(xyz, features) for sa in self.ms_ls], dim=1)
+
+
+class PointLocalFeature(nn.Module):
+    """radarflow_util.py:121-162 -- set-conv: group -> (conv1x1+BN+ReLU)x3 -> max over the ball
+    -> (conv1x1+BN+ReLU)x3."""
+
+    def __init__(self, radius, nsample, in_channel, mlp, mlp2):
+        super().__init__()
+        self.radius = radius
+        self.nsample = nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.mlp2_convs = nn.ModuleList()
+        self.mlp2_bns = nn.ModuleList()
+        last_channel = in_channel + 3
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1, bias=False))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        last_channel = mlp[-1]
+        for out_channel in mlp2:
+            self.mlp2_convs.append(nn.Conv2d(last_channel, out_channel, 1, bias=False))
+            self.mlp2_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.queryandgroup = pointutils.QueryAndGroup(radius, nsample)
+
+    def forward(self, xyz, points):
+        xyz_t = xyz.permute(0, 2, 1).contiguous()
+        new_points = self.queryandgroup(xyz_t, xyz_t, points.contiguous())
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            new_points = F.relu(bn(conv(new_points)))
+        new_points = torch.max(new_points, -1)[0].unsqueeze(2)
+        for conv, bn in zip(self.mlp2_convs, self.mlp2_bns):
+            new_points = F.relu(bn(conv(new_points)))
+        return new_points.squeeze(2)
+
+
+class WeightNet(nn.Module):
+    """radarflow_util.py:287-318 (bn=False: the BN modules exist for the state_dict only)."""
+
+    def __init__(self, in_channel, out_channel, hidden_unit=(8, 8), bn=False):
+        super().__init__()
+        self.bn = bn
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        chans = [in_channel, *hidden_unit, out_channel]
+        for a, b in zip(chans[:-1], chans[1:]):
+            self.mlp_convs.append(nn.Conv2d(a, b, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(b))
+        if not bn:      # never touched by forward: no gradient, and the optimizer must skip them (as torch
+            for p in self.mlp_bns.parameters():      # skips grad=None params in the reference's Adam)
+                p._cmf_unused = True
+
+    def forward(self, localized_xyz):
+        weights = localized_xyz
+        for i, conv in enumerate(self.mlp_convs):
+            weights = F.relu(self.mlp_bns[i](conv(weights))) if self.bn else F.relu(conv(weights))
+        return weights
+
+
+class FeatureCorrelator(nn.Module):
+    """radarflow_util.py:164-237 -- cost volume (point-to-patch, then patch-to-patch)."""
+
+    def __init__(self, nsample, in_channel, mlp, bn=False, use_leaky=True):
+        super().__init__()
+        self.nsample = nsample
+        self.bn = bn
+        self.mlp_convs = nn.ModuleList()
+        if bn:
+            self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1))
+            if bn:
+                self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.weightnet1 = WeightNet(3, last_channel)
+        self.weightnet2 = WeightNet(3, last_channel)
+        self.relu = nn.ReLU(inplace=True) if not use_leaky else nn.LeakyReLU(0.1, inplace=True)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        B, C, N1 = xyz1.shape
+        _, D1, _ = points1.shape
+        xyz1 = xyz1.permute(0, 2, 1)
+        xyz2 = xyz2.permute(0, 2, 1)
+        points1 = points1.permute(0, 2, 1)
+        points2 = points2.permute(0, 2, 1)
+
+        knn_idx = knn_point(self.nsample, xyz2, xyz1)
+        neighbor_xyz = index_points_group(xyz2, knn_idx)
+        direction_xyz = neighbor_xyz - xyz1.view(B, N1, 1, C)
+        grouped_points2 = index_points_group(points2, knn_idx)
+        grouped_points1 = points1.view(B, N1, 1, D1).repeat(1, 1, self.nsample, 1)
+        new_points = torch.cat([grouped_points1, grouped_points2, direction_xyz], dim=-1).permute(0, 3, 2, 1)
+        for i, conv in enumerate(self.mlp_convs):
+            new_points = self.relu(self.mlp_bns[i](conv(new_points))) if self.bn else self.relu(conv(new_points))
+        weights = self.weightnet1(direction_xyz.permute(0, 3, 2, 1))
+        point_to_patch_cost = torch.sum(weights * new_points, dim=2)
+
+        knn_idx = knn_point(self.nsample, xyz1, xyz1)
+        neighbor_xyz = index_points_group(xyz1, knn_idx)
+        direction_xyz = neighbor_xyz - xyz1.view(B, N1, 1, C)
+        weights = self.weightnet2(direction_xyz.permute(0, 3, 2, 1))
+        grouped = index_points_group(point_to_patch_cost.permute(0, 2, 1), knn_idx)
+        return torch.sum(weights * grouped.permute(0, 3, 2, 1), dim=2)
+
+
+class FlowHead(nn.Module):
+    """radarflow_util.py:240-261"""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.sf_mlp = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.sf_mlp.append(nn.Sequential(nn.Conv2d(last_channel, out_channel, 1, bias=False),
+                                             nn.BatchNorm2d(out_channel), nn.ReLU(inplace=False)))
+            last_channel = out_channel
+        self.conv2 = nn.Conv2d(mlp[-1], 3, 1, bias=False)
+
+    def forward(self, feat):
+        feat = feat.unsqueeze(3)
+        for conv in self.sf_mlp:
+            feat = conv(feat)
+        return self.conv2(feat).squeeze(3)
+
+
+class MotionHead(nn.Module):
+    """radarflow_util.py:263-285"""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.sf_mlp = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.sf_mlp.append(nn.Sequential(nn.Conv2d(last_channel, out_channel, 1, bias=False),
+                                             nn.BatchNorm2d(out_channel), nn.ReLU(inplace=False)))
+            last_channel = out_channel
+        self.conv2 = nn.Conv2d(mlp[-1], 1, 1, bias=False)
+        self.m = nn.Sigmoid()
+
+    def forward(self, feat):
+        feat = feat.unsqueeze(3)
+        for conv in self.sf_mlp:
+            feat = conv(feat)
+        return self.m(self.conv2(feat)).squeeze(3)

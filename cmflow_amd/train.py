@@ -1,0 +1,51 @@
+"""The reference's training-step sequence (main_util.py:63-76 / clip_util.py:34-62) on device.
+
+    labels -> net(..., mseg_gt, 'train') -> RadarFlowLoss -> zero_grad / backward / [all-reduce] / step
+
+``TrainStep`` owns the optimizer (Adam lr 1e-3, weight decay 1e-4: main.py:107), the flat
+gradient bucket and the loss module; ``__call__(batch)`` runs one optimizer step and returns
+(loss, items) as device tensors.
+"""
+import torch
+
+from . import synth
+from .dp import FlatGradBucket
+from .losses import RadarFlowLoss, make_labels
+
+
+class TrainStep:
+    def __init__(self, net, vr_thres=0.3, lr=0.001, weight_decay=1e-4, camera_projection=None, t_camera_radar=None):
+        self.net = net
+        dev = next(net.parameters()).device
+        self.vr_thres = vr_thres
+        self.loss_obj = RadarFlowLoss(camera_projection or synth.CAMERA_PROJECTION,
+                                      t_camera_radar or synth.T_CAMERA_RADAR).to(dev)
+        self.bucket = FlatGradBucket(net)
+        self.opt = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay)
+        self.recurrent = hasattr(net, "gru")
+        self.gfeat = None
+
+    def reset_clip(self):
+        """clip_util.py:51-52: the first frame of a mini-clip starts from gfeat=None."""
+        self.gfeat = None
+
+    def forward_loss(self, batch):
+        dyn_mask, mseg_gt = make_labels(batch, self.vr_thres)
+        pc1, pc2, ft1, ft2 = batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"]
+        if self.recurrent:
+            g = self.gfeat.detach() if self.gfeat is not None else None          # clip_util.py:54
+            pred_f, mseg_pre, pre_trans, mask, self.gfeat = self.net(pc1, pc2, ft1, ft2, mseg_gt, 'train', g)
+        else:
+            pred_f, mseg_pre, pre_trans, mask = self.net(pc1, pc2, ft1, ft2, mseg_gt, 'train')
+        loss, items = self.loss_obj(pc1, pc2, pred_f, ft1[:, 0], batch["flow_label"].transpose(2, 1), pre_trans,
+                                    mseg_pre, batch["gt_trans"], mseg_gt, dyn_mask, batch["radar_u"],
+                                    batch["radar_v"], batch["opt_flow"])
+        return loss, items, (pred_f, mseg_pre, pre_trans, mask), (dyn_mask, mseg_gt)
+
+    def __call__(self, batch):
+        loss, items, outs, labels = self.forward_loss(batch)
+        self.bucket.zero()
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        return loss.detach(), items, outs, labels

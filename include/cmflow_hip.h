@@ -1,0 +1,72 @@
+/*
+ * cmflow_hip.h -- C ABI of libcmflow_hip.so, the MI355X (gfx950) drop-in for the native
+ * layer of the CMFlow hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers to DEVICE memory + sizes; no torch / ATen types cross this boundary.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  Work is
+ *     enqueued asynchronously, nothing is synchronised, nothing is retained after return --
+ *     same threading model as the reference wrappers, which enqueue on
+ *     at::cuda::getCurrentCUDAStream() (lib/src/ball_query.cpp:22).
+ *   - the caller allocates every buffer, outputs included (lib/pointnet2_utils.py:200-202,246-248).
+ *   - return value: hipError_t as int (0 = hipSuccess).  The reference launchers print and
+ *     exit(-1) on a launch failure (lib/src/ball_query_gpu.cu:62-66); this library reports the
+ *     error to the caller instead.  Invalid arguments return hipErrorInvalidValue (1).
+ *   - all floating point is fp32, all indices int32, tensors dense row-major ("contiguous").
+ */
+#ifndef CMFLOW_HIP_H
+#define CMFLOW_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the three kernels CMFlow uses from the reference's `pointnet2_cuda` extension -------- */
+
+/* Replaces ball_query_kernel_launcher_fast (lib/src/ball_query_gpu.cu:48-49; binding
+ * lib/src/ball_query.cpp:14-25).  new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample).
+ * First `nsample` points with d2 < radius*radius in index order, padded with the first hit;
+ * idx is left untouched for an empty ball (caller pre-zeroes it, lib/pointnet2_utils.py:246). */
+int cmf_ball_query(int b, int n, int m, float radius, int nsample,
+                   const float *new_xyz, const float *xyz, int *idx, void *stream);
+
+/* Replaces group_points_kernel_launcher_fast (lib/src/group_points_gpu.cu:69-70).
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
+int cmf_group_points(int b, int c, int n, int npoints, int nsample,
+                     const float *points, const int *idx, float *out, void *stream);
+
+/* Replaces group_points_grad_kernel_launcher_fast (lib/src/group_points_gpu.cu:27-28).
+ * grad_out (b,c,npoints,nsample), idx -> grad_points (b,c,n) += scatter (caller zero-fills,
+ * lib/pointnet2_utils.py:218). */
+int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                          const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* ---- torch-level hot loops of the reference, as kernels ------------------------------------ */
+
+/* knn_point (utils/model_utils/radarflow_util.py:88-99 = square_distance :8-30 + topk).
+ * xyz (b,n,3) database, new_xyz (b,s,3) queries -> idx (b,s,nsample) int32 in canonical order
+ * (ascending distance, ties by lowest index); dist (b,s,nsample) optional (may be NULL).
+ * nsample <= 32. */
+int cmf_knn(int b, int n, int s, int nsample, const float *xyz, const float *new_xyz,
+            int *idx, float *dist, void *stream);
+
+/* WeightedKabsch (models/cmflow.py:128-169).  A, Bm (b,3,n) point sets, W (b,n) weights
+ * (normalised by the caller, cmflow.py:105-106) -> trans (b,4,4).  aux (b,32) doubles receives
+ * {U,S,V of H, cA, cB, D} for the backward pass (may be NULL). */
+int cmf_weighted_kabsch(int b, int n, const float *A, const float *Bm, const float *W,
+                        float *trans, double *aux, void *stream);
+
+/* Backward of cmf_weighted_kabsch.  grad_trans (b,4,4) -> grad_A, grad_B (b,3,n), grad_W (b,n)
+ * (any of the three may be NULL).  Uses the polar-factor derivative (well conditioned: divides
+ * by s_i + s_j, not s_i^2 - s_j^2 as a generic SVD backward does). */
+int cmf_weighted_kabsch_grad(int b, int n, const float *A, const float *Bm, const float *W,
+                             const double *aux, const float *grad_trans,
+                             float *grad_A, float *grad_B, float *grad_W, void *stream);
+
+/* Library / device identification: returns a static NUL-terminated string. */
+const char *cmf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMFLOW_HIP_H */

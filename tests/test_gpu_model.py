@@ -1,0 +1,185 @@
+"""GPU: module-level parity -- the product CMFlow / CMFlow_T (HIP path) against (i) golden
+vectors produced by the reference's own Python modules and (ii) the CPU oracle on fresh inputs.
+
+Tolerances (north_star): neighbour indices bit-exact, flow / seg within 1e-4 fp32.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cmflow_amd import synth
+from oracle import cmflow_oracle as O
+from oracle import train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+EVAL_CASES = ["cmflow_eval_synth_b2", "cmflow_eval_synth_b1", "cmflow_eval_real_b4"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    return torch.device("cuda:0")
+
+
+def _load(golden_dir, name):
+    with np.load(os.path.join(golden_dir, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _weights(manifest, golden_dir, t=False):
+    return synth.synth_state_dict(manifest, seed=1234,
+                                  calib=os.path.join(golden_dir, "bn_calib_cmflow_t.npz" if t else "bn_calib_cmflow.npz"))
+
+
+def _epe(a, b):
+    return float(np.linalg.norm(a - b, axis=1).mean())
+
+
+@pytest.mark.parametrize("case", EVAL_CASES)
+def test_forward_matches_reference_golden(case, dev, manifest, golden_dir, args):
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd import pointnet2_utils as pu, radarflow_util as ru
+    g = _load(golden_dir, case)
+    net = CMFlow(args)
+    net.load_state_dict(_weights(manifest, golden_dir))
+    net = net.to(dev).eval()
+    # record what crosses the op boundary, in call order
+    bq, knn = [], []
+    bq0, knn0 = pu.ball_query, ru.knn_point
+    pu.ball_query = lambda *a: (bq.append(bq0(*a)) or bq[-1])
+    ru.knn_point = lambda *a, **k: (knn.append(knn0(*a, **k)) or knn[-1])
+    try:
+        t = lambda k: torch.from_numpy(g[k]).to(dev)
+        with torch.no_grad():
+            sf, cls, trans, mask = net(t("pc1"), t("pc2"), t("ft1"), t("ft2"), None, "test")
+    finally:
+        pu.ball_query, ru.knn_point = bq0, knn0
+    keys = sorted(k for k in g if k.startswith("bq"))
+    assert len(bq) == 12
+    for k, idx in zip(keys, bq):
+        assert np.array_equal(g[k], idx.cpu().numpy()), k                     # a1 bit-exact
+    from test_oracle import same_neighbours
+    assert same_neighbours(g["pc2"], knn[0].cpu().numpy(), g["knn_cross_sorted"])   # a7 sets
+    assert same_neighbours(g["pc1"], knn[1].cpu().numpy(), g["knn_self_sorted"])
+    for k in ("pc1_features", "pc2_features", "cor_features", "prop_features"):
+        # fp32 summation-order noise scales with the tensor's magnitude (cor_features reaches ~1e3)
+        np.testing.assert_allclose(net.last[k][0, ::4].cpu().numpy(), g[k], rtol=1e-4,
+                                   atol=1e-5 * max(1.0, float(np.abs(g[k]).max())), err_msg=k)
+    assert np.array_equal(mask.cpu().numpy(), g["mask"])
+    np.testing.assert_allclose(cls.cpu().numpy(), g["stat_cls"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(trans.cpu().numpy(), g["pre_trans"], rtol=0, atol=1e-4)
+    assert _epe(sf.cpu().numpy(), g["sf_agg"]) < 1e-4
+
+
+def test_query_and_group_slice(dev, golden_dir):
+    """Row a4 against the reference's own QueryAndGroup output (bit-exact: gather + subtract)."""
+    from cmflow_amd.pointnet2_utils import QueryAndGroup
+    g = _load(golden_dir, "cmflow_eval_synth_b2")
+    xyz_t = torch.from_numpy(g["pc1"]).permute(0, 2, 1).contiguous().to(dev)
+    out = QueryAndGroup(4.0, 8)(xyz_t, xyz_t, torch.from_numpy(g["ft1"]).to(dev))
+    assert np.array_equal(out[0].cpu().numpy(), g["qg_scale1_b0"])
+
+
+def test_cmflow_t_matches_reference_golden(dev, manifest_t, golden_dir, args):
+    from cmflow_amd.cmflow import CMFlow_T
+    g = _load(golden_dir, "cmflow_t_eval_synth_b2")
+    net = CMFlow_T(args)
+    net.load_state_dict(_weights(manifest_t, golden_dir, t=True))
+    net = net.to(dev).eval()
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    with torch.no_grad():
+        o1 = net(t("a_pc1"), t("a_pc2"), t("a_ft1"), t("a_ft2"), None, "test", None)
+        o2 = net(t("b_pc1"), t("b_pc2"), t("b_ft1"), t("b_ft2"), None, "test", o1[4])
+    for tag, o in (("a", o1), ("b", o2)):
+        assert np.array_equal(o[3].cpu().numpy(), g[tag + "_mask"])
+        assert _epe(o[0].cpu().numpy(), g[tag + "_sf_agg"]) < 1e-4
+        np.testing.assert_allclose(o[1].cpu().numpy(), g[tag + "_stat_cls"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o[2].cpu().numpy(), g[tag + "_pre_trans"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o[4].cpu().numpy(), g[tag + "_gfeat"], rtol=0, atol=1e-4)
+
+
+def test_forward_matches_oracle_fresh_inputs(dev, manifest, golden_dir, args):
+    """Same seeded inputs through the HIP path and the CPU oracle (B=8, not in the goldens)."""
+    from cmflow_amd.cmflow import CMFlow
+    sd = _weights(manifest, golden_dir)
+    ref = O.CMFlow(args)
+    ref.load_state_dict(sd)
+    ref.eval()
+    net = CMFlow(args)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    b = synth.make_batch(8, seed=2024)
+    with torch.no_grad():
+        r = ref(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+        o = net(*(b[k].to(dev) for k in ("pc1", "pc2", "ft1", "ft2")), None, "test")
+    assert torch.equal(o[3].cpu(), r[3])
+    assert _epe(o[0].cpu().numpy(), r[0].numpy()) < 1e-4
+    np.testing.assert_allclose(o[1].cpu().numpy(), r[1].numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(o[2].cpu().numpy(), r[2].numpy(), rtol=0, atol=1e-4)
+
+
+def test_train_step_matches_reference_golden(dev, manifest, golden_dir, args):
+    """Rows a3 + a15('train') + losses + Adam against the reference's own train step
+    (main_util.py:63-76 run behind the shims, tests/golden/make_golden.py)."""
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.train import TrainStep
+    g = _load(golden_dir, "cmflow_train_synth_b4")
+    net = CMFlow(args)
+    net.load_state_dict(_weights(manifest, golden_dir))
+    net = net.to(dev).train()
+    batch = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc1", "pc2", "ft1", "ft2", "gt_trans", "flow_label", "fg_mask",
+                                                            "interval", "radar_u", "radar_v", "opt_flow")}
+    step = TrainStep(net, vr_thres=args.vr_thres)
+    loss, items, outs, (dyn, mseg) = step.forward_loss(batch)
+    step.bucket.zero()
+    loss.backward()
+    assert np.array_equal(dyn.cpu().numpy(), g["dyn_mask"]) and np.array_equal(mseg.cpu().numpy(), g["mseg_gt"])
+    assert abs(loss.item() - float(g["loss"])) < 2e-4
+    for k, v in items.items():
+        assert abs(v.item() - float(g["item_" + k])) < 2e-4, k
+    assert _epe(outs[0].detach().cpu().numpy(), g["sf_agg"]) < 1e-4
+    np.testing.assert_allclose(outs[2].detach().cpu().numpy(), g["pre_trans"], rtol=0, atol=1e-4)
+    params = dict(net.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        p = params[str(name)]
+        if ref < 0:
+            assert p.grad is None, name
+        else:   # fp32 gradient noise floor of this net is ~1e-3 relative
+            assert abs(float(p.grad.norm()) - ref) <= 1e-2 * max(ref, 1e-3), (name, float(p.grad.norm()), ref)
+    for k in g:
+        if k.startswith("grad::"):
+            got = params[k[6:]].grad.reshape(-1)[:64].cpu().numpy()
+            np.testing.assert_allclose(got, g[k], rtol=1e-2, atol=1e-2 * np.abs(g[k]).max(), err_msg=k)
+    step.opt.step()
+    sd = net.state_dict()
+    for k in g:
+        if k.startswith("after::"):
+            np.testing.assert_allclose(sd[k[7:]].reshape(-1)[:64].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+def test_full_size_properties(dev, manifest, golden_dir, args):
+    """BASELINE.json sizes (B=64, N=256): size-independent properties instead of the (slow) oracle:
+    per-sample independence (a batch of 64 equals 64/8 batches of 8 in eval mode), rigid part of the
+    output is a proper rotation, indices within range."""
+    from cmflow_amd.cmflow import CMFlow
+    net = CMFlow(args)
+    net.load_state_dict(_weights(manifest, golden_dir))
+    net = net.to(dev).eval()
+    b = {k: v.to(dev) for k, v in synth.make_batch(64, seed=77).items()}
+    with torch.no_grad():
+        full = net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+        parts = [net(*(b[k][i:i + 8] for k in ("pc1", "pc2", "ft1", "ft2")), None, "test") for i in range(0, 64, 8)]
+    for j in range(4):
+        cat = torch.cat([p[j] for p in parts], dim=0)
+        if cat.dtype == torch.bool:
+            assert torch.equal(cat, full[j])
+        else:
+            np.testing.assert_allclose(cat.cpu().numpy(), full[j].cpu().numpy(), rtol=0, atol=1e-4)
+    R = full[2][:, :3, :3].double()
+    eye = torch.eye(3, dtype=torch.float64, device=dev).expand(64, 3, 3)
+    assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-5)
+    assert torch.all(torch.abs(torch.linalg.det(R).abs() - 1) < 1e-5)
