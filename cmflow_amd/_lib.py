@@ -22,6 +22,9 @@ SIGNATURES = {
     "cmf_knn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch_grad": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_group_rows": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_build_inverse": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_group_rows_grad": [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
 }
 
 
@@ -75,3 +78,40 @@ def dev_ptr(t, dtype):
 def check(err, what):
     if err != 0:
         raise RuntimeError("%s failed: hipError_t %d" % (what, err))
+
+
+# ---- live per-kernel timing for bench.py's `roofline` object ---------------------------------
+# HIP events recorded on the launch stream (torch's current stream) around every launch of ONE
+# tracked kernel inside the timed region.  `units` = algorithmic bytes (bound "hbm") or flops
+# (bound "mfma") of that launch, as defined in DESIGN.md.
+TRACKED_KERNEL = ("cmf_group_points", "hbm")
+_prof = None
+
+
+def profile_begin(kernel=None, bound=None):
+    global _prof
+    k, b = TRACKED_KERNEL
+    _prof = {"kernel": kernel or k, "bound": bound or b, "events": [], "units": 0.0}
+
+
+def profile_end():
+    global _prof
+    p, _prof = _prof, None
+    if p is None:
+        return None
+    torch.cuda.synchronize()
+    ms = sum(s.elapsed_time(e) for s, e in p["events"])
+    return {"kernel": p["kernel"], "bound": p["bound"], "launches": len(p["events"]), "ms": ms, "units": p["units"]}
+
+
+def tracked(name, units, fn):
+    """Run fn() (one kernel launch); time it with a HIP event pair if `name` is the tracked kernel."""
+    if _prof is None or name != _prof["kernel"]:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    _prof["events"].append((s, e))
+    _prof["units"] += units
+    return r

@@ -16,6 +16,10 @@ from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScale
 
 class CMFlow(nn.Module):
     score_eps = 1e-4            # models/cmflow.py:105; CMFlow_T has none (cmflow_t.py:119)
+    # "pm": point-major fused path (default).  "ref": the reference's op sequence in its own
+    # (B,C,N,ns) layout over the drop-in kernels (QueryAndGroup + 1x1 convs) -- kept as the
+    # unfused roofline/parity reference.
+    path = "pm"
 
     def __init__(self, args):
         super().__init__()
@@ -54,6 +58,8 @@ class CMFlow(nn.Module):
 
     def _propagate(self, pc1, pc2, feature1, feature2):
         """cmflow.py:59-88: everything of Backbone up to prop_features."""
+        if self.path == "pm":
+            return self._propagate_pm(pc1, pc2, feature1, feature2)
         N = pc1.size(2)
         pc1_features = self.mse_layer(pc1, feature1)
         pc2_features = self.mse_layer(pc2, feature2)
@@ -67,6 +73,20 @@ class CMFlow(nn.Module):
         self.last = {"pc1_features": pc1_features[:, :256], "pc2_features": pc2_features[:, :256],
                      "cor_features": cor_features, "prop_features": prop_features}
         return prop_features
+
+    def _propagate_pm(self, pc1, pc2, feature1, feature2):
+        """Same computation in point-major layout; returns prop_features as (B,256,N)."""
+        x1, x2 = pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous()       # (B,N,3)
+        a1, a2 = feature1.transpose(1, 2).contiguous(), feature2.transpose(1, 2).contiguous()
+        f1 = self.mse_layer.forward_pm(x1, a1)                                             # (B,N,256)
+        f2 = self.mse_layer.forward_pm(x2, a2)
+        f1 = torch.cat((f1, f1.max(dim=1, keepdim=True)[0].expand(-1, f1.shape[1], -1)), dim=2)
+        f2 = torch.cat((f2, f2.max(dim=1, keepdim=True)[0].expand(-1, f2.shape[1], -1)), dim=2)
+        cor = self.fc_layer.forward_pm(x1, x2, f1, f2)                                     # (B,N,512)
+        prop = self.mse_layer2.forward_pm(x1, torch.cat((a1, f1, cor), dim=2))             # (B,N,256)
+        self.last = {"pc1_features": f1[:, :, :256].transpose(1, 2), "pc2_features": f2[:, :, :256].transpose(1, 2),
+                     "cor_features": cor.transpose(1, 2), "prop_features": prop.transpose(1, 2)}
+        return prop.transpose(1, 2)
 
     def Backbone(self, pc1, pc2, feature1, feature2):
         prop_features = self._propagate(pc1, pc2, feature1, feature2)
@@ -90,8 +110,13 @@ class CMFlow(nn.Module):
         return weighted_kabsch(A, B, W)
 
     def _heads(self, final_features, pc1, label_m, mode):
-        output = self.fp(final_features)
-        stat_cls = self.mp(final_features)
+        if self.path == "pm":
+            ff = final_features.transpose(1, 2)                       # (B,N,512) view
+            output = self.fp.forward_pm(ff).transpose(1, 2)
+            stat_cls = self.mp.forward_pm(ff).transpose(1, 2)
+        else:
+            output = self.fp(final_features)
+            stat_cls = self.mp(final_features)
         if (mode == 'train') and (label_m is not None):
             scores = label_m.unsqueeze(1)
         else:

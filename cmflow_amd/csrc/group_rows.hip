@@ -1,0 +1,167 @@
+// Point-major grouping: the layout the fused CMFlow path computes in.
+//
+// The reference groups (B,C,N) tensors channel by channel (lib/src/group_points_gpu.cu:47-66):
+// an uncoalesced 4-byte gather per output float.  In point-major layout (B,N,C) a neighbour's
+// feature vector is one contiguous row, so grouping is a ROW gather with fully coalesced 16-byte
+// loads and stores:      out[b, e, :] = feat[b, idx[b, e], :]      e = p*nsample + s.
+//
+// Backward is a deterministic gather over an inverse index (CSR per sample) instead of the
+// reference's 538 M fp32 atomics (group_points_gpu.cu:8-25): for every source point j the list
+// of entries e with idx[e] == j, in ascending e, so the sum order is fixed (bit-reproducible)
+// and equals the CPU oracle's scan order.
+#include <algorithm>
+#include "cmf_common.h"
+#include "../../include/cmflow_hip.h"
+
+constexpr int GR_THREADS = 256;
+
+// feat: (b, n, ldf) rows of c floats; out: (b, entries, c) dense.
+template <int VEC>
+__global__ __launch_bounds__(GR_THREADS) void group_rows_kernel(
+    int n, int c, int ldf, int entries, long long total_vec,
+    const float *__restrict__ feat, const int *__restrict__ idx, float *__restrict__ out)
+{
+    const int cv = c / VEC;
+    for (long long i = (long long)blockIdx.x * GR_THREADS + threadIdx.x; i < total_vec;
+         i += (long long)gridDim.x * GR_THREADS) {
+        const long long row = i / cv;               // b*entries + e
+        const int col = (int)(i - row * cv) * VEC;
+        const int bs = (int)(row / entries);
+        const int j = idx[row];
+        const float *src = feat + ((size_t)bs * n + j) * ldf + col;
+        float *dst = out + (size_t)row * c + col;
+        if (VEC == 4) *reinterpret_cast<float4 *>(dst) = *reinterpret_cast<const float4 *>(src);
+        else *dst = *src;
+    }
+}
+
+extern "C" int cmf_group_rows(int b, int n, int c, int ldf, int entries,
+                              const float *feat, const int *idx, float *out, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && ldf >= c && entries >= 0);
+    if (b == 0 || entries == 0) return 0;
+    CMF_CHECK_ARG(feat && idx && out);
+    const bool v4 = (c % 4 == 0) && (ldf % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+    const long long total = (long long)b * entries * (v4 ? c / 4 : c);
+    const int grid = (int)std::min<long long>((total + GR_THREADS - 1) / GR_THREADS, 256 * 32);
+    if (v4) hipLaunchKernelGGL(group_rows_kernel<4>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                               n, c, ldf, entries, total, feat, idx, out);
+    else hipLaunchKernelGGL(group_rows_kernel<1>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                            n, c, ldf, entries, total, feat, idx, out);
+    return cmf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse index: per sample, offsets[n+1] and the entry list sorted by (target point, entry).
+// One workgroup per sample; thread j owns target point j and scans the sample's idx (staged in
+// LDS, all lanes read the same word -> broadcast) twice: count, then fill.
+// ---------------------------------------------------------------------------------------------
+constexpr int INV_THREADS = 256;
+constexpr int INV_TILE = 8192;          // idx entries per LDS tile (32 KiB)
+
+__global__ __launch_bounds__(INV_THREADS) void build_inverse_kernel(
+    int n, int entries, const int *__restrict__ idx, int *__restrict__ offsets, int *__restrict__ inv)
+{
+    __shared__ int tile[INV_TILE];
+    __shared__ int scan[INV_THREADS + 1];
+    const int bs = blockIdx.x;
+    const int *ix = idx + (size_t)bs * entries;
+    int *off = offsets + (size_t)bs * (n + 1);
+    int *lst = inv + (size_t)bs * entries;
+    // targets are processed in chunks of INV_THREADS points
+    int base_count = 0;                  // entries consumed by earlier chunks
+    for (int j0 = 0; j0 < n; j0 += INV_THREADS) {
+        const int j = j0 + threadIdx.x;
+        int cnt = 0;
+        for (int e0 = 0; e0 < entries; e0 += INV_TILE) {
+            const int len = min(INV_TILE, entries - e0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < len; i += INV_THREADS) tile[i] = ix[e0 + i];
+            __syncthreads();
+            if (j < n) for (int i = 0; i < len; ++i) cnt += (tile[i] == j);
+        }
+        // exclusive scan of cnt over the chunk (serial in LDS: 256 items, negligible)
+        __syncthreads();
+        scan[threadIdx.x + 1] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            scan[0] = base_count;
+            for (int i = 1; i <= INV_THREADS; ++i) scan[i] += scan[i - 1];
+        }
+        __syncthreads();
+        int pos = scan[threadIdx.x];
+        if (j < n) off[j] = pos;
+        base_count = scan[INV_THREADS];
+        for (int e0 = 0; e0 < entries; e0 += INV_TILE) {
+            const int len = min(INV_TILE, entries - e0);
+            __syncthreads();
+            for (int i = threadIdx.x; i < len; i += INV_THREADS) tile[i] = ix[e0 + i];
+            __syncthreads();
+            if (j < n) for (int i = 0; i < len; ++i) if (tile[i] == j) lst[pos++] = e0 + i;
+        }
+    }
+    if (threadIdx.x == 0) off[n] = base_count;
+}
+
+extern "C" int cmf_build_inverse(int b, int n, int entries, const int *idx, int *offsets, int *inv, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && entries >= 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(idx && offsets && inv);
+    hipLaunchKernelGGL(build_inverse_kernel, dim3(b), dim3(INV_THREADS), 0, (hipStream_t)stream,
+                       n, entries, idx, offsets, inv);
+    return cmf_launch_status();
+}
+
+// grad_feat[b, j, :] (ld = ldg) (+)= sum over entries e in inv(j) of grad_out[b, e, :]
+template <int VEC>
+__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_kernel(
+    int n, int c, int ldg, int entries, int accumulate, int total_waves,
+    const float *__restrict__ grad_out, const int *__restrict__ offsets, const int *__restrict__ inv,
+    float *__restrict__ grad_feat)
+{
+    // one wave per (sample, point): lanes stride over channels
+    const int wave = (blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
+    if (wave >= total_waves) return;
+    const int lane = threadIdx.x % CMF_WAVE;
+    const int bs = wave / n, j = wave - bs * n;
+    const int *off = offsets + (size_t)bs * (n + 1);
+    const int beg = off[j], end = off[j + 1];
+    const int *lst = inv + (size_t)bs * entries;
+    const float *g = grad_out + (size_t)bs * entries * c;
+    float *dst = grad_feat + ((size_t)bs * n + j) * ldg;
+    for (int col = lane * VEC; col < c; col += CMF_WAVE * VEC) {
+        if (VEC == 4) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = beg; t < end; ++t) {
+                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)lst[t] * c + col);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            float4 *d = reinterpret_cast<float4 *>(dst + col);
+            if (accumulate) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+            *d = acc;
+        } else {
+            float acc = 0.f;
+            for (int t = beg; t < end; ++t) acc += g[(size_t)lst[t] * c + col];
+            if (accumulate) acc += dst[col];
+            dst[col] = acc;
+        }
+    }
+}
+
+extern "C" int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, int accumulate,
+                                   const float *grad_out, const int *offsets, const int *inv,
+                                   float *grad_feat, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && ldg >= c && entries >= 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(grad_out && offsets && inv && grad_feat);
+    const bool v4 = (c % 4 == 0) && (ldg % 4 == 0) && (((uintptr_t)grad_out | (uintptr_t)grad_feat) % 16 == 0);
+    const long long waves = (long long)b * n;
+    const int grid = (int)((waves * CMF_WAVE + GR_THREADS - 1) / GR_THREADS);
+    if (v4) hipLaunchKernelGGL(group_rows_grad_kernel<4>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                               n, c, ldg, entries, accumulate, (int)waves, grad_out, offsets, inv, grad_feat);
+    else hipLaunchKernelGGL(group_rows_grad_kernel<1>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                            n, c, ldg, entries, accumulate, (int)waves, grad_out, offsets, inv, grad_feat);
+    return cmf_launch_status();
+}

@@ -1,0 +1,99 @@
+"""Point-major ("channels-last") primitives of the fused CMFlow path.
+
+The reference keeps features as (B,C,N) and materialises (B,3+C,N,ns) grouped tensors for 1x1
+convolutions (utils/model_utils/radarflow_util.py:144-162).  On MI355X the same arithmetic is
+laid out as row-major matrices [positions, channels]:
+
+* grouping a neighbour is a contiguous row copy (cmf_group_rows), its backward a deterministic
+  segmented sum over an inverse index (cmf_build_inverse + cmf_group_rows_grad);
+* every 1x1 conv is a GEMM  X[M,K] @ W[out,K]^T  on the conv weight viewed as (out,in);
+* the first conv of a set-conv / cost-volume block is linear, so it is applied ONCE per point
+  before grouping (W_f f)[idx] + W_xyz (x_j - x_i) instead of once per neighbour
+  (exact algebra; only fp32 summation order differs) -- 63 % fewer model FLOPs.
+"""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _lib
+
+_f32, _i32 = torch.float32, torch.int32
+
+
+class Neighbors:
+    """idx (B,P,S) int32 into N points per sample, plus its lazily built inverse index."""
+
+    def __init__(self, idx: torch.Tensor, n: int):
+        assert idx.dtype == _i32 and idx.is_contiguous()
+        self.idx, self.n = idx, n
+        self.B, self.P, self.S = idx.shape
+        self._inv = None
+
+    def inverse(self):
+        if self._inv is None:
+            entries = self.P * self.S
+            off = torch.empty(self.B, self.n + 1, dtype=_i32, device=self.idx.device)
+            inv = torch.empty(self.B, entries, dtype=_i32, device=self.idx.device)
+            err = _lib.lib().cmf_build_inverse(self.B, self.n, entries, _lib.dev_ptr(self.idx, _i32),
+                                               _lib.dev_ptr(off, _i32), _lib.dev_ptr(inv, _i32), _lib.stream_ptr())
+            _lib.check(err, "cmf_build_inverse")
+            self._inv = (off, inv)
+        return self._inv
+
+
+def _rows_view(t):
+    """(B,N,C) tensor whose rows are contiguous; returns (ptr-tensor, ld)."""
+    B, N, C = t.shape
+    if t.stride(2) != 1 or t.stride(0) != N * t.stride(1) or t.stride(1) < C:
+        t = t.contiguous()
+    return t, t.stride(1)
+
+
+class _GroupRows(Function):
+    @staticmethod
+    def forward(ctx, feat, nbr: Neighbors):
+        feat, ld = _rows_view(feat)
+        B, N, C = feat.shape
+        assert N == nbr.n and B == nbr.B
+        out = torch.empty(B, nbr.P, nbr.S, C, dtype=_f32, device=feat.device)
+        if not feat.is_cuda:
+            raise RuntimeError("cmflow_amd HIP op got a %s tensor: the product path runs on the GPU only" % feat.device)
+        err = _lib.lib().cmf_group_rows(B, N, C, ld, nbr.P * nbr.S, feat.data_ptr(), _lib.dev_ptr(nbr.idx, _i32),
+                                        _lib.dev_ptr(out, _f32), _lib.stream_ptr())
+        _lib.check(err, "cmf_group_rows")
+        ctx.nbr, ctx.shape = nbr, (B, N, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        nbr = ctx.nbr
+        B, N, C = ctx.shape
+        off, inv = nbr.inverse()
+        grad_out = grad_out.contiguous()
+        g = torch.empty(B, N, C, dtype=_f32, device=grad_out.device)
+        err = _lib.lib().cmf_group_rows_grad(B, N, C, C, nbr.P * nbr.S, 0, _lib.dev_ptr(grad_out, _f32),
+                                             _lib.dev_ptr(off, _i32), _lib.dev_ptr(inv, _i32),
+                                             _lib.dev_ptr(g, _f32), _lib.stream_ptr())
+        _lib.check(err, "cmf_group_rows_grad")
+        return g, None
+
+
+def group_rows(feat, nbr: Neighbors):
+    """feat (B,N,C) -> (B,P,S,C): out[b,p,s,:] = feat[b, idx[b,p,s], :]."""
+    return _GroupRows.apply(feat, nbr)
+
+
+def bn_pm(bn, x):
+    """BatchNorm2d semantics on a point-major tensor (..., C): statistics over every leading
+    position (= over (B, N, ns) of the reference's (B,C,N,ns) tensor)."""
+    shape = x.shape
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    y = F.batch_norm(x.reshape(-1, shape[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                     bn.training, bn.momentum, bn.eps)
+    return y.view(shape)
+
+
+def w2d(conv):
+    """1x1 conv weight (out,in,1,1) as the (out,in) matrix of the equivalent GEMM."""
+    return conv.weight.view(conv.weight.shape[0], conv.weight.shape[1])

@@ -16,6 +16,7 @@ from torch.autograd import Function
 
 from . import _lib
 from . import pointnet2_utils as pointutils
+from .fused import Neighbors, bn_pm, group_rows, w2d
 
 _f32, _i32 = torch.float32, torch.int32
 
@@ -100,6 +101,15 @@ class MultiScaleEncoder(nn.Module):
     def forward(self, xyz, features):
         return torch.cat([sa(xyz, features) for sa in self.ms_ls], dim=1)
 
+    def forward_pm(self, xyz_t, feats):
+        """Point-major: xyz_t (B,N,3), feats (B,N,C) -> (B,N,4*64).  The feature half of the four
+        scales' first convs is ONE GEMM over the shared input (W_f of all scales stacked)."""
+        o1 = self.ms_ls[0].mlp_convs[0].weight.shape[0]
+        wf_all = torch.cat([w2d(sa.mlp_convs[0])[:, 3:] for sa in self.ms_ls], dim=0)
+        y_all = F.linear(feats, wf_all)                                   # (B,N,4*o1)
+        outs = [sa.forward_pm(xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
+        return torch.cat(outs, dim=2)
+
 
 class PointLocalFeature(nn.Module):
     """radarflow_util.py:121-162 -- set-conv: group -> (conv1x1+BN+ReLU)x3 -> max over the ball
@@ -135,6 +145,23 @@ class PointLocalFeature(nn.Module):
             new_points = F.relu(bn(conv(new_points)))
         return new_points.squeeze(2)
 
+    def forward_pm(self, xyz_t, y):
+        """Point-major set-conv.  xyz_t (B,N,3); y (B,N,O1) = feats @ W_f^T, the feature half of
+        the first conv already applied per point (conv is linear: W [dxyz; f[idx]] =
+        W_xyz dxyz + (W_f f)[idx]).  -> (B,N,64)."""
+        B, N, _ = xyz_t.shape
+        idx = pointutils.ball_query(self.radius, self.nsample, xyz_t, xyz_t)
+        nbr = Neighbors(idx, N)
+        dxyz = group_rows(xyz_t, nbr) - xyz_t.unsqueeze(2)                # (B,N,ns,3) relative xyz
+        x = group_rows(y, nbr) + F.linear(dxyz, w2d(self.mlp_convs[0])[:, :3])
+        x = F.relu(bn_pm(self.mlp_bns[0], x))
+        for conv, bn in zip(list(self.mlp_convs)[1:], list(self.mlp_bns)[1:]):
+            x = F.relu(bn_pm(bn, F.linear(x, w2d(conv))))
+        x = torch.max(x, dim=2)[0]                                        # over the ball
+        for conv, bn in zip(self.mlp2_convs, self.mlp2_bns):
+            x = F.relu(bn_pm(bn, F.linear(x, w2d(conv))))
+        return x
+
 
 class WeightNet(nn.Module):
     """radarflow_util.py:287-318 (bn=False: the BN modules exist for the state_dict only)."""
@@ -157,6 +184,14 @@ class WeightNet(nn.Module):
         for i, conv in enumerate(self.mlp_convs):
             weights = F.relu(self.mlp_bns[i](conv(weights))) if self.bn else F.relu(conv(weights))
         return weights
+
+    def forward_pm(self, dxyz):
+        """dxyz (B,N,K,3) -> (B,N,K,out)"""
+        assert not self.bn
+        w = dxyz
+        for conv in self.mlp_convs:
+            w = F.relu(F.linear(w, w2d(conv), conv.bias))
+        return w
 
 
 class FeatureCorrelator(nn.Module):
@@ -205,6 +240,32 @@ class FeatureCorrelator(nn.Module):
         grouped = index_points_group(point_to_patch_cost.permute(0, 2, 1), knn_idx)
         return torch.sum(weights * grouped.permute(0, 3, 2, 1), dim=2)
 
+    def forward_pm(self, xyz1_t, xyz2_t, f1, f2):
+        """Point-major cost volume.  xyz*_t (B,N,3), f1/f2 (B,N,D) -> (B,N,512).  The first conv
+        over cat[f1, f2[idx], dxyz] is split by linearity into per-point GEMMs."""
+        assert not self.bn
+        B, N1, _ = xyz1_t.shape
+        D1, D2 = f1.shape[2], f2.shape[2]
+        K = self.nsample
+        act = self.relu
+        w0 = w2d(self.mlp_convs[0])
+        # point-to-patch
+        nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])
+        dxyz = group_rows(xyz2_t, nbr) - xyz1_t.unsqueeze(2)                               # (B,N1,K,3)
+        p1 = F.linear(f1, w0[:, :D1], self.mlp_convs[0].bias)                              # (B,N1,512)
+        p2 = F.linear(f2, w0[:, D1:D1 + D2])                                               # (B,N2,512)
+        x = p1.unsqueeze(2) + group_rows(p2, nbr) + F.linear(dxyz, w0[:, D1 + D2:])
+        x = act(x)
+        for conv in list(self.mlp_convs)[1:]:
+            x = act(F.linear(x, w2d(conv), conv.bias))
+        weights = self.weightnet1.forward_pm(dxyz)
+        p2p = torch.sum(weights * x, dim=2)                                                # (B,N1,512)
+        # patch-to-patch
+        nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), N1)
+        dxyz = group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2)
+        weights = self.weightnet2.forward_pm(dxyz)
+        return torch.sum(weights * group_rows(p2p, nbr), dim=2)
+
 
 class FlowHead(nn.Module):
     """radarflow_util.py:240-261"""
@@ -224,6 +285,12 @@ class FlowHead(nn.Module):
         for conv in self.sf_mlp:
             feat = conv(feat)
         return self.conv2(feat).squeeze(3)
+
+    def forward_pm(self, feat):
+        """feat (B,N,512) -> (B,N,3)"""
+        for blk in self.sf_mlp:
+            feat = F.relu(bn_pm(blk[1], F.linear(feat, w2d(blk[0]))))
+        return F.linear(feat, w2d(self.conv2))
 
 
 class MotionHead(nn.Module):
@@ -245,3 +312,9 @@ class MotionHead(nn.Module):
         for conv in self.sf_mlp:
             feat = conv(feat)
         return self.m(self.conv2(feat)).squeeze(3)
+
+    def forward_pm(self, feat):
+        """feat (B,N,512) -> (B,N,1)"""
+        for blk in self.sf_mlp:
+            feat = F.relu(bn_pm(blk[1], F.linear(feat, w2d(blk[0]))))
+        return torch.sigmoid(F.linear(feat, w2d(self.conv2)))

@@ -63,6 +63,26 @@ int cmf_weighted_kabsch_grad(int b, int n, const float *A, const float *Bm, cons
                              const double *aux, const float *grad_trans,
                              float *grad_A, float *grad_B, float *grad_W, void *stream);
 
+/* ---- point-major grouping (the layout the fused path computes in) ------------------------------ */
+
+/* Row gather: feat (b,n,ldf) rows of c floats, idx (b,entries) -> out (b,entries,c) with
+ * out[b,e,:] = feat[b,idx[b,e],:].  Same operation as cmf_group_points on the transposed layout
+ * (reference: lib/src/group_points_gpu.cu:47-66 via utils/model_utils/radarflow_util.py:52-63),
+ * with coalesced 16-byte accesses instead of a 4-byte gather. */
+int cmf_group_rows(int b, int n, int c, int ldf, int entries,
+                   const float *feat, const int *idx, float *out, void *stream);
+
+/* Inverse index of idx (b,entries) with values in [0,n): offsets (b,n+1), inv (b,entries) --
+ * for each target point the entries that reference it, ascending.  Feeds cmf_group_rows_grad. */
+int cmf_build_inverse(int b, int n, int entries, const int *idx, int *offsets, int *inv, void *stream);
+
+/* Backward of cmf_group_rows as a deterministic segmented sum (replaces the fp32 atomics of
+ * lib/src/group_points_gpu.cu:8-25): grad_feat[b,j,:] (row stride ldg) = (accumulate ? old : 0) +
+ * sum_{e in inv(j)} grad_out[b,e,:], summed in ascending e. */
+int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, int accumulate,
+                        const float *grad_out, const int *offsets, const int *inv,
+                        float *grad_feat, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 

@@ -39,12 +39,14 @@ def _epe(a, b):
     return float(np.linalg.norm(a - b, axis=1).mean())
 
 
+@pytest.mark.parametrize("path", ["pm", "ref"])
 @pytest.mark.parametrize("case", EVAL_CASES)
-def test_forward_matches_reference_golden(case, dev, manifest, golden_dir, args):
+def test_forward_matches_reference_golden(case, path, dev, manifest, golden_dir, args):
     from cmflow_amd.cmflow import CMFlow
     from cmflow_amd import pointnet2_utils as pu, radarflow_util as ru
     g = _load(golden_dir, case)
     net = CMFlow(args)
+    net.path = path
     net.load_state_dict(_weights(manifest, golden_dir))
     net = net.to(dev).eval()
     # record what crosses the op boundary, in call order
@@ -122,13 +124,15 @@ def test_forward_matches_oracle_fresh_inputs(dev, manifest, golden_dir, args):
     np.testing.assert_allclose(o[2].cpu().numpy(), r[2].numpy(), rtol=0, atol=1e-4)
 
 
-def test_train_step_matches_reference_golden(dev, manifest, golden_dir, args):
+@pytest.mark.parametrize("path", ["pm", "ref"])
+def test_train_step_matches_reference_golden(path, dev, manifest, golden_dir, args):
     """Rows a3 + a15('train') + losses + Adam against the reference's own train step
     (main_util.py:63-76 run behind the shims, tests/golden/make_golden.py)."""
     from cmflow_amd.cmflow import CMFlow
     from cmflow_amd.train import TrainStep
     g = _load(golden_dir, "cmflow_train_synth_b4")
     net = CMFlow(args)
+    net.path = path
     net.load_state_dict(_weights(manifest, golden_dir))
     net = net.to(dev).train()
     batch = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc1", "pc2", "ft1", "ft2", "gt_trans", "flow_label", "fg_mask",

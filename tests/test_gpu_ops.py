@@ -131,6 +131,32 @@ def test_kabsch_kat_and_grad(dev, golden_dir):
         np.testing.assert_allclose(got_g.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * scale, err_msg=name)
 
 
+@pytest.mark.parametrize("B,N,C,P,S,ld", [(4, 256, 512, 256, 32, 2048), (2, 256, 32, 256, 4, 32), (2, 100, 3, 100, 8, 3),
+                                          (1, 300, 64, 50, 5, 64), (2, 256, 1027, 256, 8, 1027)])
+def test_group_rows_and_grad(dev, B, N, C, P, S, ld):
+    """Point-major grouping: bit-exact copy forward; backward is a deterministic segmented sum in
+    ascending entry order == the oracle's scan-order scatter (bit-exact, unlike atomics)."""
+    from cmflow_amd.fused import Neighbors, group_rows
+    g = torch.Generator().manual_seed(B * N + C)
+    big = torch.randn(B, N, ld, generator=g)
+    col0 = (ld - C) // 2
+    idx = torch.randint(0, N, (B, P, S), generator=g, dtype=torch.int32)
+    idx[:, :, 0] = torch.arange(P).remainder(N).int()               # every point referenced, some hubs
+    feat = big.to(dev)[:, :, col0:col0 + C].requires_grad_(True)    # strided row view, like y_all slices
+    nbr = Neighbors(idx.to(dev), N)
+    out = group_rows(feat, nbr)
+    ref_in = big[:, :, col0:col0 + C].permute(0, 2, 1).contiguous()          # (B,C,N) for the oracle
+    ref = orc.group_points(ref_in, idx).permute(0, 2, 3, 1)                  # (B,P,S,C)
+    assert torch.equal(out.cpu(), ref)
+    go = torch.randn(B, P, S, C, generator=g)
+    out.backward(go.to(dev))
+    ref_g = orc.group_points_grad(go.permute(0, 3, 1, 2).contiguous(), idx, N).permute(0, 2, 1)   # (B,N,C)
+    assert torch.equal(feat.grad.cpu(), ref_g)
+    feat.grad = None
+    group_rows(feat, nbr).backward(go.to(dev))                       # reproducible run to run
+    assert torch.equal(feat.grad.cpu(), ref_g)
+
+
 def test_product_refuses_cpu_tensors():
     """No CPU fallback: the product ops raise on CPU tensors instead of computing elsewhere."""
     from cmflow_amd.pointnet2_utils import ball_query
