@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "libcmflow_hip.so")
 
-_vp, _ci, _cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_vp, _ci, _cf, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 
 # name -> argtypes (restype is int = hipError_t unless noted); mirrors include/cmflow_hip.h
 SIGNATURES = {
@@ -25,6 +25,9 @@ SIGNATURES = {
     "cmf_group_rows": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_build_inverse": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_group_rows_grad": [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
+                 _ci, _vp, _ll, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
+    "cmf_gemm_tiles_m": [_ci],
 }
 
 

@@ -1,0 +1,415 @@
+// fp32 MFMA GEMM for the point-major CMFlow path (every 1x1 conv of the reference is a GEMM on
+// [positions, channels] matrices; utils/model_utils/radarflow_util.py:151-159,215-221,253-285).
+//
+//     C[M,N] = epi( pro(A)[M,K] * B[K,N] )
+//
+// * v_mfma_f32_32x32x2_f32: exact fp32 (bit-equal to an fmaf chain), 64 FLOP/clk/SIMD = the chip's
+//   157 TF fp32 peak (no TF32/xf32 on gfx950; bf16 would break the 1e-4 parity bound).
+// * 256 threads = 4 wavefronts; block tile BM x BN x 32; operands staged global -> registers ->
+//   LDS (double buffered, one barrier per K-chunk); LDS rows padded to 36 floats so the
+//   ds_read_b128 fragment loads are bank-conflict free.
+// * K-permutation trick: a lane reads 4 consecutive k of its row with ONE ds_read_b128 (lanes
+//   0-31 take k0..k0+3, lanes 32-63 take k0+4..k0+7) and feeds them to 4 MFMAs; step t of the 4
+//   contracts k in {k0+t, k0+4+t}.  A and B use the same map, so the sum is just reordered.
+// * prologue (fused BN+ReLU of the producer layer): A'[m,k] = relu(pa[k]*A[m,k] + pc[k]).
+// * epilogues: +bias[n]; relu / leaky(0.1) / sigmoid; per-column (sum, sum of squares) partials
+//   per row tile for train-mode BatchNorm; backward masks (see cmf_gemm docs in cmflow_hip.h).
+// * XCD-aware tile order: the column tiles that share an A row-panel run back to back on ONE XCD
+//   (blockIdx -> XCD is round-robin), so the panel is fetched from HBM once and re-read from L2.
+#include <algorithm>
+#include "cmf_common.h"
+#include "../../include/cmflow_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int G_THREADS = 256;
+constexpr int G_BK = 32;
+constexpr int G_LDS_LD = G_BK + 4;      // 36 floats = 144 B row stride (conflict-free b128 reads)
+
+struct GemmArgs {
+    int M, N, K;                // C is MxN, contraction length K (this split's range is [k_begin,k_end))
+    const float *A; long long lda;
+    const float *B; long long ldb;
+    float *C; long long ldc;
+    // prologue on A (A_MK only): per-contraction-index affine + relu
+    const float *pro_a, *pro_c;
+    // prologue on B by output column (used by the weight-gradient GEMM: B = activated layer input)
+    const float *prob_a, *prob_c;
+    // epilogue
+    const float *bias;          // [N] or null
+    int act;                    // 0 none, 1 relu, 2 leaky(0.1), 3 sigmoid
+    float *stats;               // [tiles_m][2][N] partial (sum, sumsq) of the STORED values, or null
+    // backward epilogue: multiply by the activation derivative of the producer layer
+    //   mode 1 (BN+ReLU):  dU = acc * [ea[n]*Z[m,n] + ec[n] > 0];  partials s1 = sum dU,
+    //                      s2 = sum dU * (Z - mean[n]) * invstd[n]  -> stats[tiles_m][2][N]
+    //   mode 2 (leaky):    dZ = acc * (Z[m,n] > 0 ? 1 : 0.1)
+    //   mode 3 (relu on stored activation Z>0)
+    int bwd_mode;
+    const float *Z; long long ldz;
+    const float *ea, *ec, *emean, *einvstd;
+    int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
+    int accumulate;             // C += result (beta = 1)
+};
+
+__device__ __forceinline__ float act_fn(float v, int act)
+{
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : 0.1f * v;
+    if (act == 3) return 1.0f / (1.0f + __expf(-v));
+    return v;
+}
+
+// A_T: A stored [K][M] (contraction-major) instead of [M][K].  B_T: B stored [N][K] (i.e. W[out][in],
+// the forward layout) instead of [K][N].
+template <int BM, int BN, bool A_T, bool B_T>
+__global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
+{
+    constexpr int WARPS_N = (BN >= 128) ? 2 : 1;
+    constexpr int WARPS_M = 4 / WARPS_N;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;     // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;               // 32x32 MFMA tiles per wave
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                                       // [2][BM][G_LDS_LD]
+    float *Bs = smem + 2 * BM * G_LDS_LD;                   // [2][BN][G_LDS_LD]
+
+    // ---- XCD-aware tile mapping ----
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    int tm, tn;
+    {
+        const int id = blockIdx.x, nx = 8;
+        const int per = (tiles_m + nx - 1) / nx;            // row panels per XCD
+        const int xcd = id % nx, slot = id / nx;
+        tm = xcd * per + slot / tiles_n;
+        tn = slot % tiles_n;
+        if (tm >= tiles_m || slot / tiles_n >= per) return;
+    }
+    const int split = blockIdx.y;
+    const int kchunks_total = (p.K + G_BK - 1) / G_BK;
+    const int kchunks_per = (kchunks_total + p.split_k - 1) / p.split_k;
+    const int kc_begin = split * kchunks_per;
+    const int kc_end = min(kchunks_total, kc_begin + kchunks_per);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WARPS_N, wn = wid % WARPS_N;
+
+    // ---- staging maps ----
+    // non-transposed operand (rows of 32 contiguous k): thread -> (row = tid/8 + 32*i, k4 = (tid%8)*4)
+    // transposed operand   (rows of contiguous m/n for one k): thread -> (k = tid/32 + 8*i, x4 = (tid%32)*4)
+    // transposed staging: TPR threads cover one k-row (BM or BN contiguous floats), RPI rows per pass
+    constexpr int A_TPR = BM / 4, A_RPI = G_THREADS / A_TPR;
+    constexpr int B_TPR = BN / 4, B_RPI = G_THREADS / B_TPR;
+    constexpr int A_IT = A_T ? (G_BK / A_RPI) : (BM / 32);
+    constexpr int B_IT = B_T ? (BN / 32) : (G_BK / B_RPI);
+    float4 ra[A_IT], rb[B_IT];
+    float4 psa = make_float4(1.f, 1.f, 1.f, 1.f), psc = make_float4(0.f, 0.f, 0.f, 0.f);   // A prologue (per chunk)
+    float4 qsa = make_float4(1.f, 1.f, 1.f, 1.f), qsc = make_float4(0.f, 0.f, 0.f, 0.f);   // B prologue (per thread)
+    unsigned kmask = 0xF;                               // which of this thread's 4 k are < K (edge chunks)
+    const bool proA = !A_T && p.pro_a != nullptr;
+    const bool proB = !B_T && p.prob_a != nullptr;
+    const bool edge_mn = (m0 + BM > p.M) || (n0 + BN > p.N);
+    if (proB) {
+        const int n = n0 + (tid % B_TPR) * 4;
+        float t[8] = {1, 1, 1, 1, 0, 0, 0, 0};
+        for (int j = 0; j < 4; ++j) if (n + j < p.N) { t[j] = p.prob_a[n + j]; t[4 + j] = p.prob_c[n + j]; }
+        qsa = make_float4(t[0], t[1], t[2], t[3]); qsc = make_float4(t[4], t[5], t[6], t[7]);
+    }
+
+    // Loads only ISSUE here (no arithmetic on the results), so all of a chunk's global loads are
+    // in flight together under the MFMAs of the previous chunk; the prologue math runs in store_*.
+    auto load_tiles = [&](int kc) {
+        const int k0 = kc * G_BK;
+        const bool fast = !edge_mn && (k0 + G_BK <= p.K);
+        if (fast) {
+            if (!A_T) {
+                const int kk = k0 + (tid & 7) * 4;
+                if (proA) { psa = *(const float4 *)(p.pro_a + kk); psc = *(const float4 *)(p.pro_c + kk); }
+                const float *src = p.A + (long long)(m0 + (tid >> 3)) * p.lda + kk;
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) ra[i] = *(const float4 *)(src + (long long)32 * i * p.lda);
+            } else {
+                const float *src = p.A + (long long)(k0 + tid / A_TPR) * p.lda + m0 + (tid % A_TPR) * 4;
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) ra[i] = *(const float4 *)(src + (long long)A_RPI * i * p.lda);
+            }
+            if (B_T) {
+                const float *src = p.B + (long long)(n0 + (tid >> 3)) * p.ldb + k0 + (tid & 7) * 4;
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) rb[i] = *(const float4 *)(src + (long long)32 * i * p.ldb);
+            } else {
+                const float *src = p.B + (long long)(k0 + tid / B_TPR) * p.ldb + n0 + (tid % B_TPR) * 4;
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) rb[i] = *(const float4 *)(src + (long long)B_RPI * i * p.ldb);
+            }
+            kmask = 0xF;
+            return;
+        }
+        // ---- edge path: bounds-checked, zero-filled ----
+        auto ld4 = [&](const float *src, int valid) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            if (valid >= 4) return *(const float4 *)src;
+            for (int j = 0; j < 4; ++j) if (j < valid) t[j] = src[j];
+            return make_float4(t[0], t[1], t[2], t[3]);
+        };
+        if (!A_T) {
+            const int kk = k0 + (tid & 7) * 4;
+            const int kv = max(0, min(4, p.K - kk));
+            kmask = (1u << kv) - 1u;
+            if (proA) { psa = ld4(p.pro_a + kk, kv); psc = ld4(p.pro_c + kk, kv); }
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int m = m0 + (tid >> 3) + 32 * i;
+                ra[i] = (m < p.M && kv > 0) ? ld4(p.A + (long long)m * p.lda + kk, kv) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m >= p.M) ra[i].x = __builtin_nanf("");            // marks a row that must store zeros
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int k = k0 + tid / A_TPR + A_RPI * i, m = m0 + (tid % A_TPR) * 4;
+                ra[i] = (k < p.K && m < p.M) ? ld4(p.A + (long long)k * p.lda + m, p.M - m) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        if (B_T) {
+            const int kk = k0 + (tid & 7) * 4;
+            const int kv = max(0, min(4, p.K - kk));
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int n = n0 + (tid >> 3) + 32 * i;
+                rb[i] = (n < p.N && kv > 0) ? ld4(p.B + (long long)n * p.ldb + kk, kv) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int k = k0 + tid / B_TPR + B_RPI * i, n = n0 + (tid % B_TPR) * 4;
+                rb[i] = (k < p.K && n < p.N) ? ld4(p.B + (long long)k * p.ldb + n, p.N - n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!(k < p.K)) rb[i].x = __builtin_nanf("");          // out-of-range k row: must store zeros
+            }
+        }
+    };
+    auto pro4 = [&](float4 v, const float4 &sa, const float4 &sc) {
+        v.x = fmaxf(fmaf(sa.x, v.x, sc.x), 0.f); v.y = fmaxf(fmaf(sa.y, v.y, sc.y), 0.f);
+        v.z = fmaxf(fmaf(sa.z, v.z, sc.z), 0.f); v.w = fmaxf(fmaf(sa.w, v.w, sc.w), 0.f);
+        return v;
+    };
+    auto store_A = [&](int buf) {
+        float *dst = As + buf * BM * G_LDS_LD;
+        if (!A_T) {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                float4 v = ra[i];
+                if (proA) {
+                    const bool dead = v.x != v.x;                   // NaN marker from the edge path
+                    v = pro4(v, psa, psc);
+                    if (dead) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kmask != 0xF) { if (!(kmask & 1)) v.x = 0.f; if (!(kmask & 2)) v.y = 0.f;
+                                        if (!(kmask & 4)) v.z = 0.f; if (!(kmask & 8)) v.w = 0.f; }
+                } else if (v.x != v.x && edge_mn) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *(float4 *)(dst + ((tid >> 3) + 32 * i) * G_LDS_LD + (tid & 7) * 4) = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int k = tid / A_TPR + A_RPI * i, m = (tid % A_TPR) * 4;
+                dst[(m + 0) * G_LDS_LD + k] = ra[i].x; dst[(m + 1) * G_LDS_LD + k] = ra[i].y;
+                dst[(m + 2) * G_LDS_LD + k] = ra[i].z; dst[(m + 3) * G_LDS_LD + k] = ra[i].w;
+            }
+        }
+    };
+    auto store_B = [&](int buf) {
+        float *dst = Bs + buf * BN * G_LDS_LD;
+        if (B_T) {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                *(float4 *)(dst + ((tid >> 3) + 32 * i) * G_LDS_LD + (tid & 7) * 4) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i) {
+                const int k = tid / B_TPR + B_RPI * i, n = (tid % B_TPR) * 4;
+                float4 v = rb[i];
+                if (proB) {
+                    const bool dead = v.x != v.x;
+                    v = pro4(v, qsa, qsc);
+                    if (dead) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    // columns n >= N hold relu(qsc)=0-filled scale (qsa=1,qsc=0 -> relu(0)=0): already zero
+                } else if (v.x != v.x) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[(n + 0) * G_LDS_LD + k] = v.x; dst[(n + 1) * G_LDS_LD + k] = v.y;
+                dst[(n + 2) * G_LDS_LD + k] = v.z; dst[(n + 3) * G_LDS_LD + k] = v.w;
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kc_begin < kc_end) {
+        load_tiles(kc_begin);
+        store_A(0); store_B(0);
+        __syncthreads();
+        int buf = 0;
+        const int frow = lane & 31, fk = (lane >> 5) * 4;
+        for (int kc = kc_begin; kc < kc_end; ++kc) {
+            const bool more = kc + 1 < kc_end;
+            if (more) load_tiles(kc + 1);                           // global loads in flight under the MFMAs
+            const float *a_s = As + buf * BM * G_LDS_LD + (wm * WM + frow) * G_LDS_LD + fk;
+            const float *b_s = Bs + buf * BN * G_LDS_LD + (wn * WN + frow) * G_LDS_LD + fk;
+#pragma unroll
+            for (int k8 = 0; k8 < G_BK; k8 += 8) {
+                float4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *(const float4 *)(a_s + i * 32 * G_LDS_LD + k8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *(const float4 *)(b_s + j * 32 * G_LDS_LD + k8);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+            if (more) { store_A(buf ^ 1); store_B(buf ^ 1); }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue ----  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float *Cout = p.C + (p.split_k > 1 ? (long long)split * p.M * p.ldc : 0);
+    const bool want_stats = p.stats != nullptr && p.split_k == 1;
+    float *red = smem;                              // reuse LDS for the cross-wave column reduction
+    if (want_stats) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        const bool n_ok = n < p.N;
+        float bias = 0.f, ea = 0.f, ec = 0.f, emean = 0.f, einv = 0.f;
+        if (n_ok) {
+            if (p.bias) bias = p.bias[n];
+            if (p.bwd_mode == 1) { ea = p.ea[n]; ec = p.ec[n]; emean = p.emean[n]; einv = p.einvstd[n]; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n_ok) {
+                    float v = acc[i][j][r];
+                    if (p.split_k == 1) {
+                        v = act_fn(v + bias, p.act);
+                        if (p.bwd_mode) {
+                            const float z = p.Z[(long long)m * p.ldz + n];
+                            if (p.bwd_mode == 1) {
+                                v = (fmaf(ea, z, ec) > 0.f) ? v : 0.f;
+                                s1 += v; s2 += v * ((z - emean) * einv);
+                            } else if (p.bwd_mode == 2) v = z > 0.f ? v : 0.1f * v;
+                            else v = z > 0.f ? v : 0.f;
+                        } else if (want_stats) { s1 += v; s2 += v * v; }
+                    }
+                    float *dst = Cout + (long long)m * p.ldc + n;
+                    if (p.accumulate && p.split_k == 1) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int col = wn * WN + j * 32 + lane;         // column within the block tile
+                red[(wm * 2 + 0) * BN + col] = s1;
+                red[(wm * 2 + 1) * BN + col] = s2;
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        for (int c = tid; c < BN; c += G_THREADS) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WARPS_M; ++w) { s1 += red[(w * 2 + 0) * BN + c]; s2 += red[(w * 2 + 1) * BN + c]; }
+            if (n0 + c < p.N) {
+                p.stats[((long long)tm * 2 + 0) * p.N + n0 + c] = s1;
+                p.stats[((long long)tm * 2 + 1) * p.N + n0 + c] = s2;
+            }
+        }
+    }
+}
+
+// Sum split-K slabs: C[m,n] (+)= sum_s P[s][m][n]   (deterministic order)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(long long total, int splits, int N, long long ldc, int accumulate,
+                                                            const float *__restrict__ P, float *__restrict__ C)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += P[(long long)k * total + i];
+        const long long m = i / N, n = i - m * N;
+        float *dst = C + m * ldc + n;
+        *dst = accumulate ? *dst + s : s;
+    }
+}
+
+template <int BM, int BN, bool A_T, bool B_T>
+static int launch(const GemmArgs &a, hipStream_t st)
+{
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const int per = (tiles_m + 7) / 8;
+    dim3 grid(8 * per * tiles_n, a.split_k);
+    const size_t lds = (size_t)2 * (BM + BN) * G_LDS_LD * sizeof(float);
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T>), grid, dim3(G_THREADS), lds, st, a);
+    return cmf_launch_status();
+}
+
+extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
+                        const float *A, long long lda, const float *B, long long ldb, float *C, long long ldc,
+                        const float *pro_a, const float *pro_c, const float *prob_a, const float *prob_c,
+                        const float *bias, int act, float *stats,
+                        int bwd_mode, const float *Z, long long ldz,
+                        const float *ea, const float *ec, const float *emean, const float *einvstd,
+                        int split_k, float *workspace, int accumulate, void *stream)
+{
+    CMF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && split_k >= 1);
+    if (M == 0 || N == 0) return 0;
+    CMF_CHECK_ARG(A && B && C);
+    CMF_CHECK_ARG(!(a_t && pro_a));                                  // A prologue needs the [M][K] layout
+    CMF_CHECK_ARG(!(b_t && prob_a));
+    CMF_CHECK_ARG(split_k == 1 || (workspace && !stats && !bwd_mode && !bias && !act));
+    // 16-byte vector loads need aligned rows
+    CMF_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0));
+    CMF_CHECK_ARG(!pro_a || (((uintptr_t)pro_a | (uintptr_t)pro_c) % 16 == 0));
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
+    g.C = split_k > 1 ? workspace : C; g.ldc = split_k > 1 ? N : ldc;
+    g.pro_a = pro_a; g.pro_c = pro_c; g.prob_a = prob_a; g.prob_c = prob_c;
+    g.bias = bias; g.act = act; g.stats = stats; g.bwd_mode = bwd_mode; g.Z = Z; g.ldz = ldz;
+    g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.split_k = split_k;
+    g.accumulate = split_k > 1 ? 0 : accumulate;
+    int err;
+    const bool wide = N > 64;
+    if (!a_t && b_t)       err = wide ? launch<128, 128, false, true>(g, st)  : launch<128, 64, false, true>(g, st);
+    else if (!a_t && !b_t) err = wide ? launch<128, 128, false, false>(g, st) : launch<128, 64, false, false>(g, st);
+    else if (a_t && !b_t)  err = wide ? launch<128, 128, true, false>(g, st)  : launch<128, 64, true, false>(g, st);
+    else                   err = wide ? launch<128, 128, true, true>(g, st)   : launch<128, 64, true, true>(g, st);
+    if (err) return err;
+    if (split_k > 1) {
+        const long long total = (long long)M * N;
+        const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, total, split_k, N, ldc, accumulate, workspace, C);
+        return cmf_launch_status();
+    }
+    return 0;
+}
+
+// tiles_m of the forward tile config for (M): the caller sizes the stats partial buffer with it
+extern "C" int cmf_gemm_tiles_m(int M) { return (M + 127) / 128; }

@@ -97,3 +97,39 @@ def bn_pm(bn, x):
 def w2d(conv):
     """1x1 conv weight (out,in,1,1) as the (out,in) matrix of the equivalent GEMM."""
     return conv.weight.view(conv.weight.shape[0], conv.weight.shape[1])
+
+
+# ---- fp32 MFMA GEMM (cmf_gemm) ---------------------------------------------------------------
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(A, B, *, a_t=False, b_t=True, out=None, pro=None, prob=None, bias=None, act=0, stats=False,
+         bwd=None, split_k=1, accumulate=False):
+    """C = epi(pro(A) @ B) through cmf_gemm.  A: (M,K) [or (K,M) if a_t]; B: (K,N) [or (N,K) if b_t]
+    -- both may be row-strided 2-D views.  Returns C, or (C, stats_partials) with stats=True."""
+    assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1
+    M, K = (A.shape[1], A.shape[0]) if a_t else A.shape
+    N = B.shape[0] if b_t else B.shape[1]
+    assert (B.shape[1] if b_t else B.shape[0]) == K, (A.shape, B.shape, a_t, b_t)
+    dev = A.device
+    if out is None:
+        out = torch.empty(M, N, dtype=_f32, device=dev)
+    assert out.stride(1) == 1 and out.shape == (M, N)
+    st = None
+    if stats or (bwd is not None and bwd[0] == 1):
+        st = torch.empty(_lib.lib().cmf_gemm_tiles_m(M), 2, N, dtype=_f32, device=dev)
+    ws = torch.empty(split_k, M, N, dtype=_f32, device=dev) if split_k > 1 else None
+    mode, Z, ea, ec, em, ei = 0, None, None, None, None, None
+    if bwd is not None:
+        mode, Z = bwd[0], bwd[1]
+        if mode == 1:
+            ea, ec, em, ei = bwd[2:6]
+    units = 2.0 * M * N * K
+    err = _lib.tracked("cmf_gemm", units, lambda: _lib.lib().cmf_gemm(
+        M, N, K, int(a_t), int(b_t), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0),
+        _p(pro[0]) if pro else None, _p(pro[1]) if pro else None, _p(prob[0]) if prob else None,
+        _p(prob[1]) if prob else None, _p(bias), act, _p(st), mode, _p(Z), Z.stride(0) if Z is not None else 0,
+        _p(ea), _p(ec), _p(em), _p(ei), split_k, _p(ws), int(accumulate), _lib.stream_ptr()))
+    _lib.check(err, "cmf_gemm")
+    return (out, st) if st is not None else out

@@ -83,6 +83,30 @@ int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, int accumulat
                         const float *grad_out, const int *offsets, const int *inv,
                         float *grad_feat, void *stream);
 
+/* ---- fp32 MFMA GEMM with fused BatchNorm/activation prologue and epilogues ---------------------- *
+ * Every 1x1 Conv2d of the reference (utils/model_utils/radarflow_util.py:132-139,174,246-251,
+ * 299-305) is  C[M,N] = epi( pro(A)[M,K] * B[K,N] )  on point-major matrices.
+ *   a_t: A is stored [K][M] (lda = row stride) instead of [M][K];  b_t: B is stored [N][K]
+ *        (a conv weight (out,in)) instead of [K][N].
+ *   pro_a/pro_c [K]  (a_t == 0 only): A' = relu(pro_a[k]*A + pro_c[k])   -- producer's BN+ReLU
+ *   prob_a/prob_c [N] (b_t == 0 only): B' = relu(prob_a[n]*B + prob_c[n])
+ *   bias [N], act: 0 none / 1 relu / 2 leaky(0.1) / 3 sigmoid
+ *   stats: [ceil(M/128)][2][N] per-row-tile partial (sum, sum of squares) of the stored C
+ *   bwd_mode 1: C = acc * [ea[n]*Z + ec[n] > 0], stats <- partial (sum C, sum C*(Z-emean)*einvstd)
+ *   bwd_mode 2: C = acc * (Z > 0 ? 1 : 0.1)        bwd_mode 3: C = acc * [Z > 0]
+ *   split_k > 1: contraction split over split_k slabs in `workspace` ([split_k][M][N] floats),
+ *                summed in a fixed order by a second kernel (deterministic weight gradients)
+ *   accumulate: C += result
+ * Row strides (lda, ldb) must be multiples of 4 floats and A, B 16-byte aligned. */
+int cmf_gemm(int M, int N, int K, int a_t, int b_t,
+             const float *A, long long lda, const float *B, long long ldb, float *C, long long ldc,
+             const float *pro_a, const float *pro_c, const float *prob_a, const float *prob_c,
+             const float *bias, int act, float *stats,
+             int bwd_mode, const float *Z, long long ldz,
+             const float *ea, const float *ec, const float *emean, const float *einvstd,
+             int split_k, float *workspace, int accumulate, void *stream);
+int cmf_gemm_tiles_m(int M);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 

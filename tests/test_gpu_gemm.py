@@ -1,0 +1,125 @@
+"""GPU: the fp32 MFMA GEMM (cmf_gemm) against a torch fp32/fp64 reference of the same op.
+
+Floating-point kernel => tolerance, stated per check: fp32 MFMA is an exact fmaf chain, the only
+difference to torch is summation order: |err| <= 2e-6 * sum|a*b| (checked against an fp64 product).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    return torch.device("cuda:0")
+
+
+def _check(C, ref64, absprod64, tol=2e-6):
+    err = (C.double() - ref64).abs()
+    bound = tol * absprod64 + 1e-6
+    assert bool((err <= bound).all()), float((err / bound).max())
+
+
+SHAPES = [(256, 128, 64), (1000, 192, 100), (128, 64, 32), (130, 32, 1027 + 1), (4096, 256, 512), (77, 40, 8),
+          (16384, 512, 1028), (300, 2048, 96)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("a_t,b_t", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_layouts(dev, M, N, K, a_t, b_t):
+    from cmflow_amd.fused import gemm
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    ldk = (K + 3) // 4 * 4 + 4                      # padded row strides (multiples of 4)
+    ldm = (M + 3) // 4 * 4
+    ldn = (N + 3) // 4 * 4 + 8
+    A = torch.randn(M, K, generator=g).to(dev)
+    B = torch.randn(K, N, generator=g).to(dev)      # asymmetric operands: a transposed write cannot pass
+    if a_t:
+        Abuf = torch.zeros(K, ldm, device=dev); Abuf[:, :M] = A.t(); Aarg = Abuf[:, :M]
+    else:
+        Abuf = torch.zeros(M, ldk, device=dev); Abuf[:, :K] = A; Aarg = Abuf[:, :K]
+    if b_t:
+        Bbuf = torch.zeros(N, ldk, device=dev); Bbuf[:, :K] = B.t(); Barg = Bbuf[:, :K]
+    else:
+        Bbuf = torch.zeros(K, ldn, device=dev); Bbuf[:, :N] = B; Barg = Bbuf[:, :N]
+    C = gemm(Aarg, Barg, a_t=a_t, b_t=b_t)
+    _check(C, A.double() @ B.double(), A.double().abs() @ B.double().abs())
+
+
+def test_gemm_prologue_epilogue_stats(dev):
+    from cmflow_amd.fused import gemm
+    g = torch.Generator().manual_seed(0)
+    M, N, K = 1000, 192, 96
+    A, W = torch.randn(M, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev)
+    pa, pc = (torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    Ap = torch.relu(A * pa + pc)
+    for act, fn in ((0, lambda x: x), (1, torch.relu), (2, lambda x: torch.nn.functional.leaky_relu(x, 0.1)),
+                    (3, torch.sigmoid)):
+        C, st = gemm(A, W, pro=(pa, pc), bias=bias, act=act, stats=True)
+        ref = fn(Ap.double() @ W.double().t() + bias.double())
+        np.testing.assert_allclose(C.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+        s = st.double().sum(dim=0)                   # reduce the per-row-tile partials
+        np.testing.assert_allclose(s[0].cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(s[1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # write into a column slice of a wider buffer (concat without a copy) and accumulate
+    wide = torch.zeros(M, 3 * N, device=dev)
+    gemm(A, W, out=wide[:, N:2 * N])
+    gemm(A, W, out=wide[:, N:2 * N], accumulate=True)
+    np.testing.assert_allclose(wide[:, N:2 * N].cpu().numpy(), 2 * (A @ W.t()).cpu().numpy(), rtol=2e-5, atol=2e-4)
+    assert float(wide[:, :N].abs().max()) == 0 and float(wide[:, 2 * N:].abs().max()) == 0
+
+
+def test_gemm_backward_modes_and_splitk(dev):
+    from cmflow_amd.fused import gemm
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 2048, 128, 256
+    dZ = torch.randn(M, N, generator=g).to(dev)          # grad wrt layer output
+    W = torch.randn(N, K, generator=g).to(dev)           # layer weight (out=N, in=K)
+    Zp = torch.randn(M, K, generator=g).to(dev)          # producer layer's pre-BN output
+    ea, ec = (torch.rand(K, generator=g) + 0.5).to(dev), (0.3 * torch.randn(K, generator=g)).to(dev)
+    mean, invstd = torch.randn(K, generator=g).to(dev), (torch.rand(K, generator=g) + 0.5).to(dev)
+    # dX = dZ @ W masked by the producer's BN+ReLU, with the two BN-backward column sums
+    dU, st = gemm(dZ, W, b_t=False, bwd=(1, Zp, ea, ec, mean, invstd))
+    ref = (dZ.double() @ W.double()) * ((ea * Zp + ec) > 0)
+    np.testing.assert_allclose(dU.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    s = st.double().sum(0)
+    np.testing.assert_allclose(s[0].cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(s[1].cpu().numpy(), (ref * ((Zp - mean) * invstd).double()).sum(0).cpu().numpy(),
+                               rtol=1e-4, atol=5e-3)
+    dL = gemm(dZ, W, b_t=False, bwd=(2, Zp))
+    ref2 = (dZ.double() @ W.double()) * torch.where(Zp > 0, 1.0, 0.1)
+    np.testing.assert_allclose(dL.cpu().numpy(), ref2.float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    # dW = dZ^T @ relu(a*Zp + c): contraction over M, split-K, activated B operand
+    X = torch.relu(ea * Zp + ec)
+    ref3 = dZ.double().t() @ X.double()
+    for split in (1, 4, 16):
+        dW = gemm(dZ, Zp, a_t=True, b_t=False, prob=(ea, ec), split_k=split)
+        _check(dW, ref3, dZ.double().abs().t() @ X.double().abs(), tol=4e-6)
+    dW2 = gemm(dZ, Zp, a_t=True, b_t=False, prob=(ea, ec), split_k=8)
+    assert torch.equal(dW, dW) and torch.equal(dW2, gemm(dZ, Zp, a_t=True, b_t=False, prob=(ea, ec), split_k=8))
+
+
+def test_gemm_throughput_report(dev):
+    """Not a pass/fail perf gate: prints achieved TFLOP/s for the model's dominant shapes."""
+    from cmflow_amd.fused import gemm
+    for M, N, K in ((524288, 256, 512), (16384, 2048, 1028), (131072, 512, 512), (524288, 64, 256)):
+        A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
+        gemm(A, W)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            gemm(A, W)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        e0.record()
+        for _ in range(5):
+            torch.matmul(A, W.t())
+        e1.record(); torch.cuda.synchronize()
+        ms_t = e0.elapsed_time(e1) / 5
+        print("gemm M=%d N=%d K=%d: %.3f ms = %.1f TFLOP/s (torch/hipBLASLt %.3f ms = %.1f)" %
+              (M, N, K, ms, 2e-9 * M * N * K / ms, ms_t, 2e-9 * M * N * K / ms_t))
