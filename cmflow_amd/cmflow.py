@@ -16,10 +16,16 @@ from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScale
 
 class CMFlow(nn.Module):
     score_eps = 1e-4            # models/cmflow.py:105; CMFlow_T has none (cmflow_t.py:119)
-    # "pm": point-major fused path (default).  "ref": the reference's op sequence in its own
-    # (B,C,N,ns) layout over the drop-in kernels (QueryAndGroup + 1x1 convs) -- kept as the
-    # unfused roofline/parity reference.
+    # "pm": point-major fused path on the hand-written GEMM / BN / pooling kernels (default).
+    # "pm_torch": same layout and hoisting, dense math through torch (debug reference).
+    # "ref": the reference's op sequence in its own (B,C,N,ns) layout over the drop-in kernels
+    # (QueryAndGroup + 1x1 convs) -- kept as the unfused roofline/parity reference.
     path = "pm"
+
+    def _set_blocks(self, on):
+        for m in self.modules():
+            if hasattr(m, "use_blocks"):
+                m.use_blocks = on
 
     def __init__(self, args):
         super().__init__()
@@ -58,7 +64,8 @@ class CMFlow(nn.Module):
 
     def _propagate(self, pc1, pc2, feature1, feature2):
         """cmflow.py:59-88: everything of Backbone up to prop_features."""
-        if self.path == "pm":
+        if self.path in ("pm", "pm_torch"):
+            self._set_blocks(self.path == "pm")
             return self._propagate_pm(pc1, pc2, feature1, feature2)
         N = pc1.size(2)
         pc1_features = self.mse_layer(pc1, feature1)
@@ -83,7 +90,10 @@ class CMFlow(nn.Module):
         f1 = torch.cat((f1, f1.max(dim=1, keepdim=True)[0].expand(-1, f1.shape[1], -1)), dim=2)
         f2 = torch.cat((f2, f2.max(dim=1, keepdim=True)[0].expand(-1, f2.shape[1], -1)), dim=2)
         cor = self.fc_layer.forward_pm(x1, x2, f1, f2)                                     # (B,N,512)
-        prop = self.mse_layer2.forward_pm(x1, torch.cat((a1, f1, cor), dim=2))             # (B,N,256)
+        # embeddings (B,N,1027) with one zero column so rows are 16-byte aligned for the GEMM (K = 1028)
+        emb = torch.cat((a1, f1, cor, torch.zeros_like(a1[:, :, :1])), dim=2) if self.path == "pm" else \
+            torch.cat((a1, f1, cor), dim=2)
+        prop = self.mse_layer2.forward_pm(x1, emb)                                         # (B,N,256)
         self.last = {"pc1_features": f1[:, :, :256].transpose(1, 2), "pc2_features": f2[:, :, :256].transpose(1, 2),
                      "cor_features": cor.transpose(1, 2), "prop_features": prop.transpose(1, 2)}
         return prop.transpose(1, 2)
@@ -110,7 +120,7 @@ class CMFlow(nn.Module):
         return weighted_kabsch(A, B, W)
 
     def _heads(self, final_features, pc1, label_m, mode):
-        if self.path == "pm":
+        if self.path in ("pm", "pm_torch"):
             ff = final_features.transpose(1, 2)                       # (B,N,512) view
             output = self.fp.forward_pm(ff).transpose(1, 2)
             stat_cls = self.mp.forward_pm(ff).transpose(1, 2)

@@ -64,14 +64,21 @@ __device__ __forceinline__ float act_fn(float v, int act)
 template <int BM, int BN, bool A_T, bool B_T>
 __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
 {
-    constexpr int WARPS_N = (BN >= 128) ? 2 : 1;
-    constexpr int WARPS_M = 4 / WARPS_N;
+    constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
+    constexpr int WARPS_N = 4 / WARPS_M;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;     // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;               // 32x32 MFMA tiles per wave
     static_assert(TM >= 1 && TN >= 1, "tile");
+    // LDS images.  An operand whose global rows run along the contraction index (A[M][K], B[N][K]) is
+    // kept row-major [rows][36] and read with one ds_read_b128 per 4 k.  An operand stored
+    // contraction-major in global memory (A[K][M], B[K][N]) keeps that order in LDS, [32][rows+4]:
+    // its staging stores are then contiguous ds_write_b128 (a transposing store would be a 16-way bank
+    // conflict) and fragments are read with conflict-free ds_read_b32 (32 consecutive floats per k).
+    constexpr int A_LD = A_T ? BM + 4 : G_LDS_LD, A_SZ = A_T ? G_BK * (BM + 4) : BM * G_LDS_LD;
+    constexpr int B_LD = B_T ? G_LDS_LD : BN + 4, B_SZ = B_T ? BN * G_LDS_LD : G_BK * (BN + 4);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                                       // [2][BM][G_LDS_LD]
-    float *Bs = smem + 2 * BM * G_LDS_LD;                   // [2][BN][G_LDS_LD]
+    float *As = smem;                                       // [2][A_SZ]
+    float *Bs = smem + 2 * A_SZ;                            // [2][B_SZ]
 
     // ---- XCD-aware tile mapping ----
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         return v;
     };
     auto store_A = [&](int buf) {
-        float *dst = As + buf * BM * G_LDS_LD;
+        float *dst = As + buf * A_SZ;
         if (!A_T) {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
@@ -210,13 +217,12 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int k = tid / A_TPR + A_RPI * i, m = (tid % A_TPR) * 4;
-                dst[(m + 0) * G_LDS_LD + k] = ra[i].x; dst[(m + 1) * G_LDS_LD + k] = ra[i].y;
-                dst[(m + 2) * G_LDS_LD + k] = ra[i].z; dst[(m + 3) * G_LDS_LD + k] = ra[i].w;
+                *(float4 *)(dst + k * A_LD + m) = ra[i];
             }
         }
     };
     auto store_B = [&](int buf) {
-        float *dst = Bs + buf * BN * G_LDS_LD;
+        float *dst = Bs + buf * B_SZ;
         if (B_T) {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
@@ -232,8 +238,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                     if (dead) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     // columns n >= N hold relu(qsc)=0-filled scale (qsa=1,qsc=0 -> relu(0)=0): already zero
                 } else if (v.x != v.x) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[(n + 0) * G_LDS_LD + k] = v.x; dst[(n + 1) * G_LDS_LD + k] = v.y;
-                dst[(n + 2) * G_LDS_LD + k] = v.z; dst[(n + 3) * G_LDS_LD + k] = v.w;
+                *(float4 *)(dst + k * B_LD + n) = v;
             }
         }
     };
@@ -255,15 +260,23 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         for (int kc = kc_begin; kc < kc_end; ++kc) {
             const bool more = kc + 1 < kc_end;
             if (more) load_tiles(kc + 1);                           // global loads in flight under the MFMAs
-            const float *a_s = As + buf * BM * G_LDS_LD + (wm * WM + frow) * G_LDS_LD + fk;
-            const float *b_s = Bs + buf * BN * G_LDS_LD + (wn * WN + frow) * G_LDS_LD + fk;
+            const float *a_s = As + buf * A_SZ + (A_T ? fk * A_LD + wm * WM + frow : (wm * WM + frow) * A_LD + fk);
+            const float *b_s = Bs + buf * B_SZ + (B_T ? (wn * WN + frow) * B_LD + fk : fk * B_LD + wn * WN + frow);
 #pragma unroll
             for (int k8 = 0; k8 < G_BK; k8 += 8) {
                 float4 af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *(const float4 *)(a_s + i * 32 * G_LDS_LD + k8);
+                for (int i = 0; i < TM; ++i) {
+                    if (!A_T) af[i] = *(const float4 *)(a_s + i * 32 * A_LD + k8);
+                    else { const float *q = a_s + k8 * A_LD + i * 32;
+                           af[i] = make_float4(q[0], q[A_LD], q[2 * A_LD], q[3 * A_LD]); }
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *(const float4 *)(b_s + j * 32 * G_LDS_LD + k8);
+                for (int j = 0; j < TN; ++j) {
+                    if (B_T) bf[j] = *(const float4 *)(b_s + j * 32 * B_LD + k8);
+                    else { const float *q = b_s + k8 * B_LD + j * 32;
+                           bf[j] = make_float4(q[0], q[B_LD], q[2 * B_LD], q[3 * B_LD]); }
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -343,10 +356,26 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     }
 }
 
-// Sum split-K slabs: C[m,n] (+)= sum_s P[s][m][n]   (deterministic order)
+// Sum split-K slabs: C[m,n] (+)= sum_s P[s][m][n]   (fixed order -> deterministic weight gradients)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(long long total, int splits, int N, long long ldc, int accumulate,
                                                             const float *__restrict__ P, float *__restrict__ C)
 {
+    const bool v4 = (N % 4 == 0) && (ldc % 4 == 0);
+    if (v4) {
+        const long long total4 = total / 4;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < splits; ++k) {
+                const float4 v = *(const float4 *)(P + (long long)k * total + i * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            const long long e = i * 4, m = e / N, n = e - m * N;
+            float4 *dst = (float4 *)(C + m * ldc + n);
+            if (accumulate) { const float4 o = *dst; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+            *dst = s;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += P[(long long)k * total + i];
@@ -362,7 +391,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per = (tiles_m + 7) / 8;
     dim3 grid(8 * per * tiles_n, a.split_k);
-    const size_t lds = (size_t)2 * (BM + BN) * G_LDS_LD * sizeof(float);
+    const size_t lds = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
@@ -396,11 +425,15 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.split_k = split_k;
     g.accumulate = split_k > 1 ? 0 : accumulate;
     int err;
-    const bool wide = N > 64;
-    if (!a_t && b_t)       err = wide ? launch<128, 128, false, true>(g, st)  : launch<128, 64, false, true>(g, st);
-    else if (!a_t && !b_t) err = wide ? launch<128, 128, false, false>(g, st) : launch<128, 64, false, false>(g, st);
-    else if (a_t && !b_t)  err = wide ? launch<128, 128, true, false>(g, st)  : launch<128, 64, true, false>(g, st);
-    else                   err = wide ? launch<128, 128, true, true>(g, st)   : launch<128, 64, true, true>(g, st);
+    const bool wide = N > 64, tall = M > 64;
+#define CMF_PICK(AT, BT)                                                                                   \
+    (tall ? (wide ? launch<128, 128, AT, BT>(g, st) : launch<128, 64, AT, BT>(g, st))                      \
+          : (wide ? launch<64, 128, AT, BT>(g, st) : launch<64, 64, AT, BT>(g, st)))
+    if (!a_t && b_t)       err = CMF_PICK(false, true);
+    else if (!a_t && !b_t) err = CMF_PICK(false, false);
+    else if (a_t && !b_t)  err = CMF_PICK(true, false);
+    else                   err = CMF_PICK(true, true);
+#undef CMF_PICK
     if (err) return err;
     if (split_k > 1) {
         const long long total = (long long)M * N;
@@ -412,4 +445,4 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
 }
 
 // tiles_m of the forward tile config for (M): the caller sizes the stats partial buffer with it
-extern "C" int cmf_gemm_tiles_m(int M) { return (M + 127) / 128; }
+extern "C" int cmf_gemm_tiles_m(int M) { return M > 64 ? (M + 127) / 128 : 1; }

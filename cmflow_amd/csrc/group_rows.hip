@@ -59,56 +59,59 @@ extern "C" int cmf_group_rows(int b, int n, int c, int ldf, int entries,
 constexpr int INV_THREADS = 256;
 constexpr int INV_TILE = 8192;          // idx entries per LDS tile (32 KiB)
 
-__global__ __launch_bounds__(INV_THREADS) void build_inverse_kernel(
-    int n, int entries, const int *__restrict__ idx, int *__restrict__ offsets, int *__restrict__ inv)
+// pass 1: offsets[b][0..n] = exclusive scan of the per-target counts (LDS integer histogram: the counts
+// are order independent, so atomics are deterministic here)
+__global__ __launch_bounds__(INV_THREADS) void inverse_count_kernel(
+    int n, int entries, const int *__restrict__ idx, int *__restrict__ offsets)
 {
-    __shared__ int tile[INV_TILE];
-    __shared__ int scan[INV_THREADS + 1];
+    extern __shared__ int hist[];        // [n + 1]
     const int bs = blockIdx.x;
     const int *ix = idx + (size_t)bs * entries;
-    int *off = offsets + (size_t)bs * (n + 1);
-    int *lst = inv + (size_t)bs * entries;
-    // targets are processed in chunks of INV_THREADS points
-    int base_count = 0;                  // entries consumed by earlier chunks
-    for (int j0 = 0; j0 < n; j0 += INV_THREADS) {
-        const int j = j0 + threadIdx.x;
-        int cnt = 0;
-        for (int e0 = 0; e0 < entries; e0 += INV_TILE) {
-            const int len = min(INV_TILE, entries - e0);
-            __syncthreads();
-            for (int i = threadIdx.x; i < len; i += INV_THREADS) tile[i] = ix[e0 + i];
-            __syncthreads();
-            if (j < n) for (int i = 0; i < len; ++i) cnt += (tile[i] == j);
-        }
-        // exclusive scan of cnt over the chunk (serial in LDS: 256 items, negligible)
-        __syncthreads();
-        scan[threadIdx.x + 1] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            scan[0] = base_count;
-            for (int i = 1; i <= INV_THREADS; ++i) scan[i] += scan[i - 1];
-        }
-        __syncthreads();
-        int pos = scan[threadIdx.x];
-        if (j < n) off[j] = pos;
-        base_count = scan[INV_THREADS];
-        for (int e0 = 0; e0 < entries; e0 += INV_TILE) {
-            const int len = min(INV_TILE, entries - e0);
-            __syncthreads();
-            for (int i = threadIdx.x; i < len; i += INV_THREADS) tile[i] = ix[e0 + i];
-            __syncthreads();
-            if (j < n) for (int i = 0; i < len; ++i) if (tile[i] == j) lst[pos++] = e0 + i;
-        }
+    for (int i = threadIdx.x; i <= n; i += INV_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < entries; e += INV_THREADS) atomicAdd(&hist[ix[e]], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {              // n is a few hundred to a few thousand: a serial scan is negligible
+        int run = 0;
+        for (int i = 0; i < n; ++i) { const int c = hist[i]; hist[i] = run; run += c; }
+        hist[n] = run;
     }
-    if (threadIdx.x == 0) off[n] = base_count;
+    __syncthreads();
+    int *off = offsets + (size_t)bs * (n + 1);
+    for (int i = threadIdx.x; i <= n; i += INV_THREADS) off[i] = hist[i];
+}
+
+// pass 2: one lane per target point scans the sample's idx (LDS broadcast reads) and appends the entries
+// that reference it in ascending order -> the list order (hence every later sum) is deterministic.
+// grid (b, ceil(n/64)): 64 targets per wavefront so the scan spreads over the whole chip.
+__global__ __launch_bounds__(CMF_WAVE) void inverse_fill_kernel(
+    int n, int entries, const int *__restrict__ idx, const int *__restrict__ offsets, int *__restrict__ inv)
+{
+    __shared__ int tile[INV_TILE];
+    const int bs = blockIdx.x;
+    const int j = blockIdx.y * CMF_WAVE + threadIdx.x;
+    const int *ix = idx + (size_t)bs * entries;
+    int *lst = inv + (size_t)bs * entries;
+    int pos = (j < n) ? offsets[(size_t)bs * (n + 1) + j] : 0;
+    for (int e0 = 0; e0 < entries; e0 += INV_TILE) {
+        const int len = min(INV_TILE, entries - e0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < len; i += CMF_WAVE) tile[i] = ix[e0 + i];
+        __syncthreads();
+        if (j < n)
+            for (int i = 0; i < len; ++i)
+                if (tile[i] == j) lst[pos++] = e0 + i;
+    }
 }
 
 extern "C" int cmf_build_inverse(int b, int n, int entries, const int *idx, int *offsets, int *inv, void *stream)
 {
-    CMF_CHECK_ARG(b >= 0 && n > 0 && entries >= 0);
+    CMF_CHECK_ARG(b >= 0 && n > 0 && entries >= 0 && n < 40000);
     if (b == 0) return 0;
     CMF_CHECK_ARG(idx && offsets && inv);
-    hipLaunchKernelGGL(build_inverse_kernel, dim3(b), dim3(INV_THREADS), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(inverse_count_kernel, dim3(b), dim3(INV_THREADS), (size_t)(n + 1) * sizeof(int), (hipStream_t)stream,
+                       n, entries, idx, offsets);
+    hipLaunchKernelGGL(inverse_fill_kernel, dim3(b, cmf_divup(n, CMF_WAVE)), dim3(CMF_WAVE), 0, (hipStream_t)stream,
                        n, entries, idx, offsets, inv);
     return cmf_launch_status();
 }

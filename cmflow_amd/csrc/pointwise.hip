@@ -1,0 +1,383 @@
+// Elementwise / reduction kernels around the GEMMs of the point-major path: BatchNorm statistics
+// and folding, the set-conv gather (first conv hoisted per point), BN+ReLU+max over the ball,
+// and their backward passes.  All are HBM-bound streams over [positions, channels] matrices with
+// 16-byte accesses; per-channel reductions are tree-reduced per 128-row tile into a partial buffer
+// [tiles][2][C] (deterministic: no atomics) and finished by cmf_bn_finalize / cmf_colsum_finalize.
+#include <algorithm>
+#include "cmf_common.h"
+#include "../../include/cmflow_hip.h"
+
+constexpr int PW_THREADS = 256;
+constexpr int PW_ROWS = 128;        // rows per tile == cmf_gemm's BM, so partial buffers are interchangeable
+
+// ---------------------------------------------------------------------------------------------
+// BN finalize.  partial [tiles][2][C] (sum, sumsq) over `count` rows ->
+//   train: mean, invstd (biased var), running stats update (unbiased var, momentum), a = g*invstd,
+//          c = b - mean*a.        eval (tiles == 0): a, c from the running statistics.
+// ---------------------------------------------------------------------------------------------
+// Cross-tile reduction shared by the two finalize kernels: a 256-thread workgroup owns 16 columns of
+// the [tiles][ncols] partial matrix; 16 tile-lanes stride over the tiles (coalesced 64-byte reads),
+// accumulate in double, and are combined through LDS in a fixed order (deterministic).
+constexpr int FIN_COLS = 16, FIN_LANES = 16;
+__device__ __forceinline__ double fin_reduce(int tiles, int ncols, int col, const float *__restrict__ partial, double *sh)
+{
+    const int cl = threadIdx.x % FIN_COLS, tl = threadIdx.x / FIN_COLS;
+    double s = 0.0;
+    if (col < ncols)
+        for (int t = tl; t < tiles; t += FIN_LANES) s += (double)partial[(size_t)t * ncols + col];
+    sh[tl * FIN_COLS + cl] = s;
+    __syncthreads();
+    double r = 0.0;
+    if (tl == 0)
+        for (int l = 0; l < FIN_LANES; ++l) r += sh[l * FIN_COLS + cl];
+    __syncthreads();
+    return r;          // valid for tl == 0
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    int tiles, int C, double count, const float *__restrict__ partial,
+    const float *__restrict__ gamma, const float *__restrict__ beta,
+    float eps, float momentum, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float *__restrict__ mean_out,
+    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out)
+{
+    __shared__ double sh[FIN_COLS * FIN_LANES];
+    const int ch = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+    double mean = 0.0, var = 1.0;
+    if (tiles > 0) {
+        const double s1 = fin_reduce(tiles, 2 * C, ch, partial, sh);                 // row layout [2][C]: sums
+        const double s2 = fin_reduce(tiles, 2 * C, C + ch, partial, sh);             // then sums of squares
+        mean = s1 / count;
+        var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+    }
+    if (threadIdx.x >= FIN_COLS || ch >= C) return;
+    if (tiles > 0) {
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+            running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+        }
+    } else { mean = running_mean[ch]; var = running_var[ch]; }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (gamma ? (double)gamma[ch] : 1.0) * invstd;
+    if (mean_out) mean_out[ch] = (float)mean;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    a_out[ch] = (float)a;
+    c_out[ch] = (float)((beta ? (double)beta[ch] : 0.0) - mean * a);
+}
+
+extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *partial, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean,
+                               float *running_var, float *mean_out, float *invstd_out, float *a_out,
+                               float *c_out, void *stream)
+{
+    CMF_CHECK_ARG(C > 0 && a_out && c_out && (tiles == 0 ? (running_mean && running_var) : partial != nullptr));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cmf_divup(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, tiles, C, count,
+                       partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out);
+    return cmf_launch_status();
+}
+
+// column sums of the partial buffer: out[2][C] = sum_t partial[t][2][C]  (dbeta, dgamma in backward)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out)
+{
+    __shared__ double sh[FIN_COLS * FIN_LANES];
+    const int col = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+    const double s = fin_reduce(tiles, C2, col, partial, sh);
+    if (threadIdx.x < FIN_COLS && col < C2) out[col] = (float)s;
+}
+
+extern "C" int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void *stream)
+{
+    CMF_CHECK_ARG(tiles > 0 && C > 0 && partial && out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(2 * C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
+                       tiles, 2 * C, partial, out);
+    return cmf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile-shaped streaming helper: a workgroup owns PW_ROWS rows x all C columns; thread t owns the
+// float4 column group (t % CG) and the rows (t / CG) + k*RL.  Column partial sums are reduced over
+// the RL row-lanes through LDS and written to partial[tile][2][C].
+// ---------------------------------------------------------------------------------------------
+struct TileMap { int cg, rl, col, r0; };
+__device__ __forceinline__ TileMap tile_map(int C)
+{
+    TileMap t;
+    t.cg = C / 4; t.rl = PW_THREADS / t.cg; t.col = (threadIdx.x % t.cg) * 4; t.r0 = threadIdx.x / t.cg;
+    return t;
+}
+__device__ __forceinline__ void tile_reduce_store(float4 s1, float4 s2, const TileMap &tm, int C, float *partial, float *red)
+{
+    // red: [rl][2][C]
+    float *r = red + (size_t)tm.r0 * 2 * C;
+    *(float4 *)(r + tm.col) = s1;
+    *(float4 *)(r + C + tm.col) = s2;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += PW_THREADS) {
+        float s = 0.f;
+        for (int l = 0; l < tm.rl; ++l) s += red[(size_t)l * 2 * C + i];
+        partial[(size_t)blockIdx.x * 2 * C + i] = s;
+    }
+}
+static inline bool tile_ok(int C) { return C % 4 == 0 && C >= 4 && C / 4 <= PW_THREADS && PW_THREADS % (C / 4) == 0; }
+static inline size_t tile_lds(int C) { return (size_t)(PW_THREADS / (C / 4)) * 2 * C * sizeof(float); }
+
+// ---------------------------------------------------------------------------------------------
+// Set-conv / cost-volume gather with the first conv hoisted:
+//   z[b,p,s,:] = act( ysrc[b, idx[b,p,s], :] + (yctr ? yctr[b,p,:] : 0) + Wx (xyz_src[idx] - xyz_ctr[p]) )
+// plus BN partial statistics of z, and the relative coordinates dxyz (B,P,S,4) (4th lane 0) that the
+// WeightNet and the weight-gradient GEMM consume.   (radarflow_util.py:148-151 / :207-214)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
+    int n_src, int P, int S, int C, long long rows,
+    const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr, int ld_ctr,
+    const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
+    const float *__restrict__ Wx, int ldw, const int *__restrict__ idx, int act,
+    float *__restrict__ z, float *__restrict__ dxyz, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const TileMap tm = tile_map(C);
+    float wx[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wx[j][k] = Wx[(size_t)(tm.col + j) * ldw + k];
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const long long row0 = (long long)blockIdx.x * PW_ROWS;
+    for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
+        const long long row = row0 + r;                 // (b*P + p)*S + s
+        if (row >= rows) break;
+        const long long bp = row / S;
+        const int b = (int)(bp / P);
+        const int j = idx[row];
+        const float *xs = xyz_src + ((size_t)b * n_src + j) * 3;
+        const float *xc = xyz_ctr + (size_t)bp * 3;
+        const float dx = xs[0] - xc[0], dy = xs[1] - xc[1], dz = xs[2] - xc[2];
+        float4 v = *(const float4 *)(ysrc + ((size_t)b * n_src + j) * ld_src + tm.col);
+        if (yctr) { const float4 c = *(const float4 *)(yctr + (size_t)bp * ld_ctr + tm.col); v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
+        v.x += fmaf(wx[0][2], dz, fmaf(wx[0][1], dy, wx[0][0] * dx));
+        v.y += fmaf(wx[1][2], dz, fmaf(wx[1][1], dy, wx[1][0] * dx));
+        v.z += fmaf(wx[2][2], dz, fmaf(wx[2][1], dy, wx[2][0] * dx));
+        v.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
+        if (act == 2) { v.x = v.x > 0.f ? v.x : 0.1f * v.x; v.y = v.y > 0.f ? v.y : 0.1f * v.y;
+                        v.z = v.z > 0.f ? v.z : 0.1f * v.z; v.w = v.w > 0.f ? v.w : 0.1f * v.w; }
+        *(float4 *)(z + (size_t)row * C + tm.col) = v;
+        if (dxyz && tm.col == 0) *(float4 *)(dxyz + (size_t)row * 4) = make_float4(dx, dy, dz, 0.f);
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    }
+    if (partial) tile_reduce_store(s1, s2, tm, C, partial, red);
+}
+
+extern "C" int cmf_group_affine(int b, int n_src, int P, int S, int C,
+                                const float *ysrc, int ld_src, const float *yctr, int ld_ctr,
+                                const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
+                                const int *idx, int act, float *z, float *dxyz, float *partial, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n_src > 0 && P > 0 && S > 0 && tile_ok(C));
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(ysrc && xyz_src && xyz_ctr && Wx && idx && z && ld_src % 4 == 0 && (!yctr || ld_ctr % 4 == 0));
+    const long long rows = (long long)b * P * S;
+    const int tiles = cmf_divup(rows, PW_ROWS);
+    hipLaunchKernelGGL(group_affine_kernel, dim3(tiles), dim3(PW_THREADS), partial ? tile_lds(C) : 0, (hipStream_t)stream,
+                       n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial);
+    return cmf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[p, :] = max_s relu(a*z[p,s,:] + c)   (radarflow_util.py:151-155 fused: BN + ReLU + max over the ball)
+// argmax (uint8, first maximum) is kept for the backward pass.  out may be a column slice (ldo).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_kernel(
+    long long P, int S, int C, const float *__restrict__ z, const float *__restrict__ a, const float *__restrict__ c,
+    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax)
+{
+    const int cg = C / 4;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < P * cg; i += (long long)gridDim.x * PW_THREADS) {
+        const long long p = i / cg;
+        const int col = (int)(i - p * cg) * 4;
+        const float4 sa = *(const float4 *)(a + col), sc = *(const float4 *)(c + col);
+        float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);
+        uchar4 bi = make_uchar4(0, 0, 0, 0);
+        const float *src = z + (size_t)p * S * C + col;
+        for (int s = 0; s < S; ++s) {
+            const float4 v = *(const float4 *)(src + (size_t)s * C);
+            const float x = fmaxf(fmaf(sa.x, v.x, sc.x), 0.f), y = fmaxf(fmaf(sa.y, v.y, sc.y), 0.f);
+            const float zz = fmaxf(fmaf(sa.z, v.z, sc.z), 0.f), w = fmaxf(fmaf(sa.w, v.w, sc.w), 0.f);
+            if (x > best.x) { best.x = x; bi.x = (unsigned char)s; }
+            if (y > best.y) { best.y = y; bi.y = (unsigned char)s; }
+            if (zz > best.z) { best.z = zz; bi.z = (unsigned char)s; }
+            if (w > best.w) { best.w = w; bi.w = (unsigned char)s; }
+        }
+        *(float4 *)(out + (size_t)p * ldo + col) = best;
+        if (argmax) *(uchar4 *)(argmax + (size_t)p * C + col) = bi;
+    }
+}
+
+extern "C" int cmf_bn_relu_maxpool(long long P, int S, int C, const float *z, const float *a, const float *c,
+                                   float *out, long long ldo, unsigned char *argmax, void *stream)
+{
+    CMF_CHECK_ARG(P >= 0 && S > 0 && S <= 255 && C % 4 == 0 && ldo % 4 == 0);
+    if (P == 0) return 0;
+    CMF_CHECK_ARG(z && a && c && out);
+    const int grid = (int)std::min<long long>((P * (C / 4) + PW_THREADS - 1) / PW_THREADS, 8192);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid), dim3(PW_THREADS), 0, (hipStream_t)stream, P, S, C, z, a, c, out, ldo, argmax);
+    return cmf_launch_status();
+}
+
+// Backward of the fused BN+ReLU+max:  dU[p,s,:] = (s == argmax[p,:] && a*z+c > 0) ? dout[p,:] : 0, with the
+// BN-backward partial sums  s1 = sum dU,  s2 = sum dU * (z - mean) * invstd.
+__global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_kernel(
+    long long rows, int S, int C, const float *__restrict__ dout, long long ldd, const float *__restrict__ z,
+    const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const unsigned char *__restrict__ argmax, float *__restrict__ dU,
+    float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const TileMap tm = tile_map(C);
+    const float4 sa = *(const float4 *)(a + tm.col), sc = *(const float4 *)(c + tm.col);
+    const float4 mu = *(const float4 *)(mean + tm.col), is = *(const float4 *)(invstd + tm.col);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const long long row0 = (long long)blockIdx.x * PW_ROWS;
+    for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
+        const long long row = row0 + r;
+        if (row >= rows) break;
+        const long long p = row / S;
+        const int s = (int)(row - p * S);
+        const uchar4 am = *(const uchar4 *)(argmax + (size_t)p * C + tm.col);
+        const float4 g = *(const float4 *)(dout + (size_t)p * ldd + tm.col);
+        const float4 v = *(const float4 *)(z + (size_t)row * C + tm.col);
+        float4 d;
+        d.x = (am.x == s && fmaf(sa.x, v.x, sc.x) > 0.f) ? g.x : 0.f;
+        d.y = (am.y == s && fmaf(sa.y, v.y, sc.y) > 0.f) ? g.y : 0.f;
+        d.z = (am.z == s && fmaf(sa.z, v.z, sc.z) > 0.f) ? g.z : 0.f;
+        d.w = (am.w == s && fmaf(sa.w, v.w, sc.w) > 0.f) ? g.w : 0.f;
+        *(float4 *)(dU + (size_t)row * C + tm.col) = d;
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x += d.x * ((v.x - mu.x) * is.x); s2.y += d.y * ((v.y - mu.y) * is.y);
+        s2.z += d.z * ((v.z - mu.z) * is.z); s2.w += d.w * ((v.w - mu.w) * is.w);
+    }
+    tile_reduce_store(s1, s2, tm, C, partial, red);
+}
+
+extern "C" int cmf_maxpool_bwd(long long P, int S, int C, const float *dout, long long ldd, const float *z,
+                               const float *a, const float *c, const float *mean, const float *invstd,
+                               const unsigned char *argmax, float *dU, float *partial, void *stream)
+{
+    CMF_CHECK_ARG(P >= 0 && S > 0 && tile_ok(C) && ldd % 4 == 0);
+    if (P == 0) return 0;
+    CMF_CHECK_ARG(dout && z && a && c && mean && invstd && argmax && dU && partial);
+    const long long rows = P * S;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(cmf_divup(rows, PW_ROWS)), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
+                       rows, S, C, dout, ldd, z, a, c, mean, invstd, argmax, dU, partial);
+    return cmf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = relu(a*z + c) materialised (chain ends; out may be a column slice of a concat buffer)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PW_THREADS) void affine_relu_kernel(long long M, int C, const float *__restrict__ z, long long ldz,
+                                                                 const float *__restrict__ a, const float *__restrict__ c,
+                                                                 float *__restrict__ out, long long ldo)
+{
+    const int cg = C / 4;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < M * cg; i += (long long)gridDim.x * PW_THREADS) {
+        const long long m = i / cg;
+        const int col = (int)(i - m * cg) * 4;
+        const float4 sa = *(const float4 *)(a + col), sc = *(const float4 *)(c + col);
+        float4 v = *(const float4 *)(z + (size_t)m * ldz + col);
+        v.x = fmaxf(fmaf(sa.x, v.x, sc.x), 0.f); v.y = fmaxf(fmaf(sa.y, v.y, sc.y), 0.f);
+        v.z = fmaxf(fmaf(sa.z, v.z, sc.z), 0.f); v.w = fmaxf(fmaf(sa.w, v.w, sc.w), 0.f);
+        *(float4 *)(out + (size_t)m * ldo + col) = v;
+    }
+}
+
+extern "C" int cmf_affine_relu(long long M, int C, const float *z, long long ldz, const float *a, const float *c,
+                               float *out, long long ldo, void *stream)
+{
+    CMF_CHECK_ARG(M >= 0 && C % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0);
+    if (M == 0) return 0;
+    CMF_CHECK_ARG(z && a && c && out);
+    const int grid = (int)std::min<long long>((M * (C / 4) + PW_THREADS - 1) / PW_THREADS, 8192);
+    hipLaunchKernelGGL(affine_relu_kernel, dim3(grid), dim3(PW_THREADS), 0, (hipStream_t)stream, M, C, z, ldz, a, c, out, ldo);
+    return cmf_launch_status();
+}
+
+// dU = dY * [a*z + c > 0] with the BN-backward partial sums (stand-alone form of cmf_gemm's bwd_mode 1,
+// for gradients that do not come out of a GEMM: concat slices, global max, ...).
+__global__ __launch_bounds__(PW_THREADS) void act_bwd_stats_kernel(
+    long long rows, int C, const float *__restrict__ dY, long long ldy, const float *__restrict__ z, long long ldz,
+    const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ dU, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const TileMap tm = tile_map(C);
+    const float4 sa = *(const float4 *)(a + tm.col), sc = *(const float4 *)(c + tm.col);
+    const float4 mu = *(const float4 *)(mean + tm.col), is = *(const float4 *)(invstd + tm.col);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const long long row0 = (long long)blockIdx.x * PW_ROWS;
+    for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
+        const long long row = row0 + r;
+        if (row >= rows) break;
+        const float4 g = *(const float4 *)(dY + (size_t)row * ldy + tm.col);
+        const float4 v = *(const float4 *)(z + (size_t)row * ldz + tm.col);
+        float4 d;
+        d.x = fmaf(sa.x, v.x, sc.x) > 0.f ? g.x : 0.f; d.y = fmaf(sa.y, v.y, sc.y) > 0.f ? g.y : 0.f;
+        d.z = fmaf(sa.z, v.z, sc.z) > 0.f ? g.z : 0.f; d.w = fmaf(sa.w, v.w, sc.w) > 0.f ? g.w : 0.f;
+        *(float4 *)(dU + (size_t)row * C + tm.col) = d;
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x += d.x * ((v.x - mu.x) * is.x); s2.y += d.y * ((v.y - mu.y) * is.y);
+        s2.z += d.z * ((v.z - mu.z) * is.z); s2.w += d.w * ((v.w - mu.w) * is.w);
+    }
+    tile_reduce_store(s1, s2, tm, C, partial, red);
+}
+
+extern "C" int cmf_act_bwd_stats(long long M, int C, const float *dY, long long ldy, const float *z, long long ldz,
+                                 const float *a, const float *c, const float *mean, const float *invstd,
+                                 float *dU, float *partial, void *stream)
+{
+    CMF_CHECK_ARG(M >= 0 && tile_ok(C) && ldy % 4 == 0 && ldz % 4 == 0);
+    if (M == 0) return 0;
+    CMF_CHECK_ARG(dY && z && a && c && mean && invstd && dU && partial);
+    hipLaunchKernelGGL(act_bwd_stats_kernel, dim3(cmf_divup(M, PW_ROWS)), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
+                       M, C, dY, ldy, z, ldz, a, c, mean, invstd, dU, partial);
+    return cmf_launch_status();
+}
+
+// Train-mode BatchNorm backward, in place:  dZ = a * (dU - s1/M - zhat * s2/M),  zhat = (z-mean)*invstd,
+// (s1, s2) = sums[2][C].  Eval mode (sums == nullptr): dZ = a * dU.
+__global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_kernel(
+    long long M, int C, float *__restrict__ dU, const float *__restrict__ z, long long ldz, const float *__restrict__ a,
+    const float *__restrict__ mean, const float *__restrict__ invstd, const float *__restrict__ sums, float inv_count)
+{
+    const int cg = C / 4;
+    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < M * cg; i += (long long)gridDim.x * PW_THREADS) {
+        const long long m = i / cg;
+        const int col = (int)(i - m * cg) * 4;
+        const float4 sa = *(const float4 *)(a + col);
+        float4 d = *(float4 *)(dU + (size_t)m * C + col);
+        if (sums) {
+            const float4 mu = *(const float4 *)(mean + col), is = *(const float4 *)(invstd + col);
+            const float4 t1 = *(const float4 *)(sums + col), t2 = *(const float4 *)(sums + C + col);
+            const float4 v = *(const float4 *)(z + (size_t)m * ldz + col);
+            d.x = sa.x * (d.x - t1.x * inv_count - (v.x - mu.x) * is.x * (t2.x * inv_count));
+            d.y = sa.y * (d.y - t1.y * inv_count - (v.y - mu.y) * is.y * (t2.y * inv_count));
+            d.z = sa.z * (d.z - t1.z * inv_count - (v.z - mu.z) * is.z * (t2.z * inv_count));
+            d.w = sa.w * (d.w - t1.w * inv_count - (v.w - mu.w) * is.w * (t2.w * inv_count));
+        } else { d.x *= sa.x; d.y *= sa.y; d.z *= sa.z; d.w *= sa.w; }
+        *(float4 *)(dU + (size_t)m * C + col) = d;
+    }
+}
+
+extern "C" int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, long long ldz, const float *a,
+                                const float *mean, const float *invstd, const float *sums, void *stream)
+{
+    CMF_CHECK_ARG(M >= 0 && C % 4 == 0 && ldz % 4 == 0);
+    if (M == 0) return 0;
+    CMF_CHECK_ARG(dU && a && (!sums || (z && mean && invstd)));
+    const int grid = (int)std::min<long long>((M * (C / 4) + PW_THREADS - 1) / PW_THREADS, 8192);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       M, C, dU, z, ldz, a, mean, invstd, sums, (float)(1.0 / (double)M));
+    return cmf_launch_status();
+}

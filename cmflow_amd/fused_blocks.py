@@ -1,0 +1,408 @@
+"""Fused blocks of the point-major CMFlow path: hand-written forward AND backward over the HIP
+kernels (cmf_gemm, cmf_group_affine, cmf_bn_*, cmf_*maxpool*), wrapped as autograd Functions.
+
+Design (DESIGN.md "Fused path"):
+* activations between layers stay as the PRE-BatchNorm GEMM output Z; the BatchNorm affine and
+  the ReLU of layer l are applied by the consumer (GEMM prologue / max-pool / materialise kernel),
+  so no normalised or activated tensor of the big grouped shape is ever written;
+* train-mode BatchNorm statistics come out of the producing kernel's epilogue as per-tile partials
+  (deterministic, no atomics) and are folded by cmf_bn_finalize into (a, c) = (gamma*invstd,
+  beta - mean*a), which also updates running_mean / running_var exactly like nn.BatchNorm2d;
+* backward: dX-GEMMs apply the producer's ReLU mask and emit the two BN-backward column sums in
+  their epilogue; weight-gradient GEMMs contract over the positions with deterministic split-K and
+  re-apply the producer's BN+ReLU to the saved Z in their B-operand prologue.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from . import pointnet2_utils as pointutils
+from .fused import Neighbors, gemm, group_rows  # noqa: F401
+
+_f32, _i32 = torch.float32, torch.int32
+L = _lib.lib
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _tiles(M):
+    return (M + 127) // 128
+
+
+# ---- thin wrappers ---------------------------------------------------------------------------
+class BNState:
+    """Folded BatchNorm of one layer: y = relu(a*z + c); mean/invstd for the backward pass."""
+    __slots__ = ("a", "c", "mean", "invstd", "training", "count")
+
+
+def bn_fold(bn, partial, count):
+    """partial [tiles][2][C] or None (eval).  Updates bn.running_* / num_batches_tracked in train mode."""
+    C = bn.num_features
+    dev = bn.weight.device
+    st = BNState()
+    buf = torch.empty(4, C, dtype=_f32, device=dev)
+    st.mean, st.invstd, st.a, st.c = buf[0], buf[1], buf[2], buf[3]
+    st.training = partial is not None
+    st.count = count
+    if st.training:
+        if bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        err = L().cmf_bn_finalize(partial.shape[0], C, float(count), _p(partial), _p(bn.weight), _p(bn.bias),
+                                  bn.eps, mom, _p(bn.running_mean) if bn.track_running_stats else None,
+                                  _p(bn.running_var) if bn.track_running_stats else None,
+                                  _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), _lib.stream_ptr())
+    else:
+        err = L().cmf_bn_finalize(0, C, 1.0, None, _p(bn.weight), _p(bn.bias), bn.eps, 0.0, _p(bn.running_mean),
+                                  _p(bn.running_var), _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), _lib.stream_ptr())
+    _lib.check(err, "cmf_bn_finalize")
+    return st
+
+
+def colsum(partial):
+    C = partial.shape[2]
+    out = torch.empty(2, C, dtype=_f32, device=partial.device)
+    _lib.check(L().cmf_colsum_finalize(partial.shape[0], C, _p(partial), _p(out), _lib.stream_ptr()), "cmf_colsum_finalize")
+    return out
+
+
+def group_affine(ysrc, yctr, xyz_src, xyz_ctr, wx, idx, act=0, stats=True, want_dxyz=True):
+    """-> z (B,P,S,C), dxyz (B,P,S,4) or None, partial or None.  ysrc (B,n_src,C) row-strided view."""
+    B, n_src, C = ysrc.shape
+    _, P, S = idx.shape
+    assert ysrc.stride(2) == 1 and ysrc.stride(0) == n_src * ysrc.stride(1)
+    dev = ysrc.device
+    z = torch.empty(B, P, S, C, dtype=_f32, device=dev)
+    dxyz = torch.empty(B, P, S, 4, dtype=_f32, device=dev) if want_dxyz else None
+    part = torch.empty(_tiles(B * P * S), 2, C, dtype=_f32, device=dev) if stats else None
+    wx = wx.contiguous()
+    err = L().cmf_group_affine(B, n_src, P, S, C, ysrc.data_ptr(), ysrc.stride(1),
+                               _p(yctr), yctr.stride(1) if yctr is not None else 0,
+                               _p(xyz_src), _p(xyz_ctr), _p(wx), wx.stride(0), _p(idx), act,
+                               _p(z), _p(dxyz), _p(part), _lib.stream_ptr())
+    _lib.check(err, "cmf_group_affine")
+    return z, dxyz, part
+
+
+def bn_relu_maxpool(z, st, out=None):
+    """z (P,S,C) -> out (P,C), argmax (P,C) uint8"""
+    P, S, C = z.shape
+    if out is None:
+        out = torch.empty(P, C, dtype=_f32, device=z.device)
+    am = torch.empty(P, C, dtype=torch.uint8, device=z.device)
+    err = L().cmf_bn_relu_maxpool(P, S, C, _p(z), _p(st.a), _p(st.c), out.data_ptr(), out.stride(0), _p(am), _lib.stream_ptr())
+    _lib.check(err, "cmf_bn_relu_maxpool")
+    return out, am
+
+
+def maxpool_bwd(dout, z, st, am):
+    P, S, C = z.shape
+    dU = torch.empty(P * S, C, dtype=_f32, device=z.device)
+    part = torch.empty(_tiles(P * S), 2, C, dtype=_f32, device=z.device)
+    err = L().cmf_maxpool_bwd(P, S, C, dout.data_ptr(), dout.stride(0), _p(z), _p(st.a), _p(st.c), _p(st.mean),
+                              _p(st.invstd), _p(am), _p(dU), _p(part), _lib.stream_ptr())
+    _lib.check(err, "cmf_maxpool_bwd")
+    return dU, part
+
+
+def affine_relu(z, st, out=None):
+    M, C = z.shape
+    if out is None:
+        out = torch.empty(M, C, dtype=_f32, device=z.device)
+    err = L().cmf_affine_relu(M, C, z.data_ptr(), z.stride(0), _p(st.a), _p(st.c), out.data_ptr(), out.stride(0), _lib.stream_ptr())
+    _lib.check(err, "cmf_affine_relu")
+    return out
+
+
+def act_bwd_stats(dY, z, st):
+    M, C = z.shape
+    dU = torch.empty(M, C, dtype=_f32, device=z.device)
+    part = torch.empty(_tiles(M), 2, C, dtype=_f32, device=z.device)
+    err = L().cmf_act_bwd_stats(M, C, dY.data_ptr(), dY.stride(0), z.data_ptr(), z.stride(0), _p(st.a), _p(st.c),
+                                _p(st.mean), _p(st.invstd), _p(dU), _p(part), _lib.stream_ptr())
+    _lib.check(err, "cmf_act_bwd_stats")
+    return dU, part
+
+
+def bn_backward(dU, part, z, st):
+    """dU (M,C) masked upstream gradient + its partial sums -> dZ (in place), dgamma, dbeta."""
+    sums = colsum(part)                                   # [0] = sum dU = dbeta, [1] = sum dU*zhat = dgamma
+    M, C = dU.shape
+    err = L().cmf_bn_bwd_apply(M, C, _p(dU), z.data_ptr(), z.stride(0), _p(st.a), _p(st.mean), _p(st.invstd),
+                               _p(sums) if st.training else None, _lib.stream_ptr())
+    _lib.check(err, "cmf_bn_bwd_apply")
+    return dU, sums[1], sums[0]
+
+
+def gemm_dw(dZ, X, prob=None):
+    """Weight gradient dW[N,K] = dZ[M,N]^T @ act(X)[M,K]; contraction over the positions, split-K so that
+    the launch fills the chip, slabs summed in fixed order (deterministic)."""
+    M, N = dZ.shape
+    K = X.shape[1]
+    tiles = ((N + 127) // 128 if N > 64 else 1) * ((K + 127) // 128 if K > 64 else 1)
+    chunks = (M + 31) // 32
+    # ~2 workgroups per CU; every slab costs an extra N*K*4-byte round trip in the reduction
+    split = max(1, min(chunks // 16, (512 + tiles - 1) // tiles))
+    return gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split)
+
+
+class LinBN:
+    """One (1x1 conv, BatchNorm2d) pair viewed as GEMM weight + BN module."""
+
+    def __init__(self, conv, bn):
+        self.conv, self.bn = conv, bn
+
+    @property
+    def w(self):
+        w = self.conv.weight
+        return w.view(w.shape[0], w.shape[1])
+
+
+def _fwd_layer(x, x_st, w, bn, training):
+    """Z = act(x) @ w^T with train-mode statistics; x_st None => x is already activated."""
+    pro = (x_st.a, x_st.c) if x_st is not None else None
+    if training:
+        z, part = gemm(x, w, pro=pro, stats=True)
+        return z, bn_fold(bn, part, x.shape[0])
+    return gemm(x, w, pro=pro), bn_fold(bn, None, x.shape[0])
+
+
+def _bwd_layer(dZ, x, x_st, w, need_dx=True):
+    """Given dZ of Z = act(x) @ w^T: -> dW, and (dU_x, partial) = gradient wrt x's PRE-activation, masked by
+    x's ReLU with the BN-backward sums of layer x (x_st given), or the plain dX (x_st None)."""
+    dW = gemm_dw(dZ, x, prob=(x_st.a, x_st.c) if x_st is not None else None)
+    if not need_dx:
+        return dW, None, None
+    if x_st is None:
+        return dW, gemm(dZ, w, b_t=False), None
+    dU, part = gemm(dZ, w, b_t=False, bwd=(1, x, x_st.a, x_st.c, x_st.mean, x_st.invstd))
+    return dW, dU, part
+
+
+# ---- plain linear layer on own GEMM ------------------------------------------------------------
+class LinearFn(Function):
+    """y = act(x @ w^T + bias), x (M,K) row-strided, w (N,K).  act: 0 none / 1 relu / 2 leaky(0.1) / 3 sigmoid.
+    Operands whose row stride is not a multiple of 4 floats are copied into padded buffers."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, act):
+        ok = x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[1] % 4 == 0
+        x2 = x if ok else _pad_cols(x)
+        w2 = _pad_cols(w)
+        y = gemm(x2, w2, bias=bias, act=act)
+        ctx.save_for_backward(x2, w2, y if act else None)
+        ctx.act, ctx.has_bias, ctx.shape = act, bias is not None, (w.shape[0], w.shape[1])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w2, y = ctx.saved_tensors
+        N, K = ctx.shape
+        dy = dy.contiguous()
+        if ctx.act == 1:
+            dy = dy * (y > 0)
+        elif ctx.act == 2:
+            dy = torch.where(y > 0, dy, 0.1 * dy)
+        elif ctx.act == 3:
+            dy = dy * y * (1 - y)
+        dx = dw = db = None
+        dyp = _pad_cols(dy)                                             # (M, N4)
+        if ctx.needs_input_grad[0]:
+            wp = w2 if dyp.shape[1] == N else torch.nn.functional.pad(w2, (0, 0, 0, dyp.shape[1] - N))
+            dx = gemm(dyp, wp, b_t=False)[:, :K]
+        if ctx.needs_input_grad[1]:
+            dw = gemm_dw(dyp, x2)[:N, :K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db, None
+
+
+def _pad_k(t):
+    """Copy a 2-D tensor into a buffer whose row stride is a multiple of 4 floats (zero padded); returns the
+    (rows, K) view of it."""
+    r, k = t.shape
+    ld = (k + 3) // 4 * 4
+    buf = torch.zeros(r, ld, dtype=t.dtype, device=t.device)
+    buf[:, :k] = t
+    return buf[:, :k]
+
+
+def _pad_cols(t):
+    """Like _pad_k but returns the padded (rows, ld) tensor (extra zero columns participate harmlessly)."""
+    r, k = t.shape
+    ld = (k + 3) // 4 * 4
+    if ld == k and t.is_contiguous():
+        return t
+    buf = torch.zeros(r, ld, dtype=t.dtype, device=t.device)
+    buf[:, :k] = t
+    return buf
+
+
+def linear(x, w, bias=None, act=0):
+    """(..., K) -> (..., N) through cmf_gemm"""
+    shp = x.shape
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), w, bias, act)
+    return y.view(*shp[:-1], w.shape[0])
+
+
+# ---- [linear + BN + ReLU] x L on a materialised input -------------------------------------------
+class MLPChainFn(Function):
+    """x (M,K) activated -> relu(bn_L(... relu(bn_1(x w_1^T)) ...)) materialised (M, C_L).
+    params: w_1, gamma_1, beta_1, ..., w_L, gamma_L, beta_L; bns: the BatchNorm modules (running stats)."""
+
+    @staticmethod
+    def forward(ctx, x, bns, training, *params):
+        x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0) else x.contiguous()
+        zs, sts = [], []
+        cur, cur_st = x, None
+        for i, bn in enumerate(bns):
+            w = params[3 * i].contiguous()
+            z, st = _fwd_layer(cur, cur_st, w, bn, training)
+            zs.append(z)
+            sts.append(st)
+            cur, cur_st = z, st
+        y = affine_relu(cur, cur_st)
+        ctx.x, ctx.zs, ctx.sts, ctx.ws = x, zs, sts, [params[3 * i].contiguous() for i in range(len(bns))]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, zs, sts, ws = ctx.x, ctx.zs, ctx.sts, ctx.ws
+        Lr = len(zs)
+        grads = [None] * (3 * Lr)
+        dU, part = act_bwd_stats(dy, zs[-1], sts[-1])
+        dx = None
+        for i in range(Lr - 1, -1, -1):
+            dZ, dg, db = bn_backward(dU, part, zs[i], sts[i])
+            grads[3 * i + 1], grads[3 * i + 2] = dg, db
+            if i > 0:
+                grads[3 * i], dU, part = _bwd_layer(dZ, zs[i - 1], sts[i - 1], ws[i])
+            else:
+                grads[0], dx, _ = _bwd_layer(dZ, x, None, ws[0], need_dx=ctx.needs_input_grad[0])
+        return (dx, None, None, *grads)
+
+
+def mlp_chain(x, layers, training):
+    """layers: list of (conv, bn) modules.  x (..., K) -> (..., C_L)."""
+    shp = x.shape
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight.view(conv.weight.shape[0], conv.weight.shape[1]), bn.weight, bn.bias]
+    y = MLPChainFn.apply(x.reshape(-1, shp[-1]), [bn for _, bn in layers], training, *params)
+    return y.view(*shp[:-1], y.shape[-1])
+
+
+# ---- the set-conv block (PointLocalFeature) -------------------------------------------------------
+class SetConvFn(Function):
+    """utils/model_utils/radarflow_util.py:144-162 in one fused forward/backward.
+    xyz_t (B,N,3); y (B,N,O1) = feats @ W_f^T (the feature half of the first conv, applied per point);
+    params: wx (O1,3), g1,b1, w2,g2,b2, w3,g3,b3, w4,g4,b4, w5,g5,b5, w6,g6,b6.   -> (B,N,C6)."""
+
+    @staticmethod
+    def forward(ctx, xyz_t, y, radius, nsample, bns, training, *params):
+        B, N, _ = xyz_t.shape
+        wx, g1, b1, w2, g2, b2, w3, g3, b3, w4, g4, b4, w5, g5, b5, w6, g6, b6 = params
+        idx = pointutils.ball_query(radius, nsample, xyz_t, xyz_t)
+        nbr = Neighbors(idx, N)
+        z1, dxyz, part = group_affine(y, None, xyz_t, xyz_t, wx, idx, act=0, stats=training)
+        M = B * N * nsample
+        z1 = z1.view(M, -1)
+        st1 = bn_fold(bns[0], part, M)
+        w2, w3, w4, w5, w6 = (t.contiguous() for t in (w2, w3, w4, w5, w6))
+        z2, st2 = _fwd_layer(z1, st1, w2, bns[1], training)
+        z3, st3 = _fwd_layer(z2, st2, w3, bns[2], training)
+        x, am = bn_relu_maxpool(z3.view(B * N, nsample, -1), st3)
+        z4, st4 = _fwd_layer(x, None, w4, bns[3], training)
+        z5, st5 = _fwd_layer(z4, st4, w5, bns[4], training)
+        z6, st6 = _fwd_layer(z5, st5, w6, bns[5], training)
+        res = affine_relu(z6, st6)
+        ctx.saved = (nbr, dxyz, z1, z2, z3, am, x, z4, z5, z6, (st1, st2, st3, st4, st5, st6), (w2, w3, w4, w5, w6),
+                     (B, N, nsample), y.shape[2])
+        return res.view(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        nbr, dxyz, z1, z2, z3, am, x, z4, z5, z6, sts, ws, (B, N, S), O1 = ctx.saved
+        st1, st2, st3, st4, st5, st6 = sts
+        w2, w3, w4, w5, w6 = ws
+        dout = dout.reshape(B * N, -1)
+        g = {}
+        dU, part = act_bwd_stats(dout, z6, st6)
+        dZ6, g["g6"], g["b6"] = bn_backward(dU, part, z6, st6)
+        g["w6"], dU, part = _bwd_layer(dZ6, z5, st5, w6)
+        dZ5, g["g5"], g["b5"] = bn_backward(dU, part, z5, st5)
+        g["w5"], dU, part = _bwd_layer(dZ5, z4, st4, w5)
+        dZ4, g["g4"], g["b4"] = bn_backward(dU, part, z4, st4)
+        g["w4"], dx, _ = _bwd_layer(dZ4, x, None, w4)
+        dU, part = maxpool_bwd(dx, z3.view(B * N, S, -1), st3, am)
+        dZ3, g["g3"], g["b3"] = bn_backward(dU, part, z3, st3)
+        g["w3"], dU, part = _bwd_layer(dZ3, z2, st2, w3)
+        dZ2, g["g2"], g["b2"] = bn_backward(dU, part, z2, st2)
+        g["w2"], dU, part = _bwd_layer(dZ2, z1, st1, w2)
+        dZ1, g["g1"], g["b1"] = bn_backward(dU, part, z1, st1)
+        # z1 = y[idx] + wx . dxyz
+        dwx = gemm_dw(dZ1, dxyz.view(-1, 4))[:, :3]
+        dy = None
+        if ctx.needs_input_grad[1]:
+            off, inv = nbr.inverse()
+            dy = torch.empty(B, N, O1, dtype=_f32, device=dZ1.device)
+            err = L().cmf_group_rows_grad(B, N, O1, O1, N * S, 0, _p(dZ1), _p(off), _p(inv), _p(dy), _lib.stream_ptr())
+            _lib.check(err, "cmf_group_rows_grad")
+        return (None, dy, None, None, None, None, dwx, g["g1"], g["b1"], g["w2"], g["g2"], g["b2"], g["w3"], g["g3"],
+                g["b3"], g["w4"], g["g4"], g["b4"], g["w5"], g["g5"], g["b5"], g["w6"], g["g6"], g["b6"])
+
+
+def set_conv(module, xyz_t, y):
+    """module: PointLocalFeature; y: (B,N,O1) view of the hoisted first-conv features."""
+    w2d = lambda conv: conv.weight.view(conv.weight.shape[0], conv.weight.shape[1])
+    c, b = module.mlp_convs, module.mlp_bns
+    c2, b2 = module.mlp2_convs, module.mlp2_bns
+    params = [w2d(c[0])[:, :3], b[0].weight, b[0].bias, w2d(c[1]), b[1].weight, b[1].bias, w2d(c[2]), b[2].weight, b[2].bias,
+              w2d(c2[0]), b2[0].weight, b2[0].bias, w2d(c2[1]), b2[1].weight, b2[1].bias, w2d(c2[2]), b2[2].weight, b2[2].bias]
+    bns = [b[0], b[1], b[2], b2[0], b2[1], b2[2]]
+    return SetConvFn.apply(xyz_t, y, module.radius, module.nsample, bns, b[0].training, *params)
+
+
+# ---- cost volume (FeatureCorrelator) --------------------------------------------------------------
+class CostVolumeMLPFn(Function):
+    """Point-to-patch MLP of radarflow_util.py:207-221 with the first conv hoisted:
+        x1 = leaky(p1[n] + p2[idx] + w3 . dxyz)   (p1 carries the bias),  x2 = leaky(x1 W2^T + b2),
+        x3 = leaky(x2 W3^T + b3)                  -> x3 (B,N,K,C), dxyz (B,N,K,4)
+    p1 (B,N1,C), p2 (B,N2,C) per-point GEMM outputs; wd (C,3) the direction columns of the first conv."""
+
+    @staticmethod
+    def forward(ctx, xyz1_t, xyz2_t, p1, p2, nbr, wd, w2, b2, w3, b3):
+        B, N1, C = p1.shape
+        K = nbr.S
+        p1c, p2c = p1.contiguous(), p2.contiguous()
+        x1, dxyz, _ = group_affine(p2c, p1c, xyz2_t, xyz1_t, wd, nbr.idx, act=2, stats=False)
+        M = B * N1 * K
+        x1 = x1.view(M, C)
+        w2, w3 = w2.contiguous(), w3.contiguous()
+        x2 = gemm(x1, w2, bias=b2, act=2)
+        x3 = gemm(x2, w3, bias=b3, act=2)
+        ctx.saved = (nbr, dxyz, x1, x2, x3, w2, w3, (B, N1, K, C), p2.shape[1])
+        ctx.mark_non_differentiable(dxyz)
+        return x3.view(B, N1, K, -1), dxyz
+
+    @staticmethod
+    def backward(ctx, dx3, _ddxyz):
+        nbr, dxyz, x1, x2, x3, w2, w3, (B, N1, K, C), N2 = ctx.saved
+        M = B * N1 * K
+        dx3 = dx3.reshape(M, -1)
+        dz3 = torch.where(x3 > 0, dx3, 0.1 * dx3)                 # leaky'(z) has the sign of the stored activation
+        db3 = dz3.sum(0)
+        dw3 = gemm_dw(dz3, x2)
+        dz2 = gemm(dz3, w3, b_t=False, bwd=(2, x2))
+        db2 = dz2.sum(0)
+        dw2 = gemm_dw(dz2, x1)
+        dz1 = gemm(dz2, w2, b_t=False, bwd=(2, x1))
+        dwd = gemm_dw(dz1, dxyz.view(-1, 4))[:, :3]
+        dp1 = dz1.view(B, N1, K, C).sum(dim=2)
+        off, inv = nbr.inverse()
+        dp2 = torch.empty(B, N2, C, dtype=_f32, device=dz1.device)
+        err = L().cmf_group_rows_grad(B, N2, C, C, N1 * K, 0, _p(dz1), _p(off), _p(inv), _p(dp2), _lib.stream_ptr())
+        _lib.check(err, "cmf_group_rows_grad")
+        return None, None, dp1, dp2, None, dwd, dw2, db2, dw3, db3

@@ -17,6 +17,7 @@ from torch.autograd import Function
 from . import _lib
 from . import pointnet2_utils as pointutils
 from .fused import Neighbors, bn_pm, group_rows, w2d
+from . import fused_blocks as FB
 
 _f32, _i32 = torch.float32, torch.int32
 
@@ -106,9 +107,18 @@ class MultiScaleEncoder(nn.Module):
         scales' first convs is ONE GEMM over the shared input (W_f of all scales stacked)."""
         o1 = self.ms_ls[0].mlp_convs[0].weight.shape[0]
         wf_all = torch.cat([w2d(sa.mlp_convs[0])[:, 3:] for sa in self.ms_ls], dim=0)
-        y_all = F.linear(feats, wf_all)                                   # (B,N,4*o1)
-        outs = [sa.forward_pm(xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
+        if not self.use_blocks:
+            y_all = F.linear(feats, wf_all)                               # (B,N,4*o1)
+            outs = [sa.forward_pm(xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
+            return torch.cat(outs, dim=2)
+        kpad = feats.shape[2] - wf_all.shape[1]            # caller may hand over K zero-padded to a multiple of 4
+        if kpad:
+            wf_all = F.pad(wf_all, (0, kpad))
+        y_all = FB.linear(feats, wf_all)
+        outs = [FB.set_conv(sa, xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
         return torch.cat(outs, dim=2)
+
+    use_blocks = True
 
 
 class PointLocalFeature(nn.Module):
@@ -185,12 +195,12 @@ class WeightNet(nn.Module):
             weights = F.relu(self.mlp_bns[i](conv(weights))) if self.bn else F.relu(conv(weights))
         return weights
 
-    def forward_pm(self, dxyz):
+    def forward_pm(self, dxyz, use_blocks=False):
         """dxyz (B,N,K,3) -> (B,N,K,out)"""
         assert not self.bn
         w = dxyz
         for conv in self.mlp_convs:
-            w = F.relu(F.linear(w, w2d(conv), conv.bias))
+            w = FB.linear(w, w2d(conv), conv.bias, act=1) if use_blocks else F.relu(F.linear(w, w2d(conv), conv.bias))
         return w
 
 
@@ -244,6 +254,8 @@ class FeatureCorrelator(nn.Module):
         """Point-major cost volume.  xyz*_t (B,N,3), f1/f2 (B,N,D) -> (B,N,512).  The first conv
         over cat[f1, f2[idx], dxyz] is split by linearity into per-point GEMMs."""
         assert not self.bn
+        if self.use_blocks:
+            return self._forward_blocks(xyz1_t, xyz2_t, f1, f2)
         B, N1, _ = xyz1_t.shape
         D1, D2 = f1.shape[2], f2.shape[2]
         K = self.nsample
@@ -267,6 +279,28 @@ class FeatureCorrelator(nn.Module):
         return torch.sum(weights * group_rows(p2p, nbr), dim=2)
 
 
+def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
+    """FeatureCorrelator on the fused blocks (own GEMMs, hoisted first conv, fused grouping)."""
+    D1, D2 = f1.shape[2], f2.shape[2]
+    K = self.nsample
+    c0, c1, c2 = self.mlp_convs
+    w0 = w2d(c0)
+    nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])
+    p1 = FB.linear(f1, w0[:, :D1], c0.bias)
+    p2 = FB.linear(f2, w0[:, D1:D1 + D2])
+    x, dxyz = FB.CostVolumeMLPFn.apply(xyz1_t, xyz2_t, p1, p2, nbr, w0[:, D1 + D2:], w2d(c1), c1.bias, w2d(c2), c2.bias)
+    weights = self.weightnet1.forward_pm(dxyz, use_blocks=True)
+    p2p = torch.sum(weights * x, dim=2)
+    nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
+    dxyz2 = F.pad(group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2), (0, 1))
+    weights = self.weightnet2.forward_pm(dxyz2, use_blocks=True)
+    return torch.sum(weights * group_rows(p2p, nbr), dim=2)
+
+
+FeatureCorrelator._forward_blocks = _fc_blocks
+FeatureCorrelator.use_blocks = True
+
+
 class FlowHead(nn.Module):
     """radarflow_util.py:240-261"""
 
@@ -288,9 +322,14 @@ class FlowHead(nn.Module):
 
     def forward_pm(self, feat):
         """feat (B,N,512) -> (B,N,3)"""
+        if self.use_blocks:
+            feat = FB.mlp_chain(feat, [(blk[0], blk[1]) for blk in self.sf_mlp], self.sf_mlp[0][1].training)
+            return FB.linear(feat, w2d(self.conv2))
         for blk in self.sf_mlp:
             feat = F.relu(bn_pm(blk[1], F.linear(feat, w2d(blk[0]))))
         return F.linear(feat, w2d(self.conv2))
+
+    use_blocks = True
 
 
 class MotionHead(nn.Module):
@@ -315,6 +354,11 @@ class MotionHead(nn.Module):
 
     def forward_pm(self, feat):
         """feat (B,N,512) -> (B,N,1)"""
+        if self.use_blocks:
+            feat = FB.mlp_chain(feat, [(blk[0], blk[1]) for blk in self.sf_mlp], self.sf_mlp[0][1].training)
+            return FB.linear(feat, w2d(self.conv2), None, act=3)
         for blk in self.sf_mlp:
             feat = F.relu(bn_pm(blk[1], F.linear(feat, w2d(blk[0]))))
         return torch.sigmoid(F.linear(feat, w2d(self.conv2)))
+
+    use_blocks = True

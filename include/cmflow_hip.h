@@ -107,6 +107,49 @@ int cmf_gemm(int M, int N, int K, int a_t, int b_t,
              int split_k, float *workspace, int accumulate, void *stream);
 int cmf_gemm_tiles_m(int M);
 
+/* ---- BatchNorm / activation / pooling kernels around the GEMMs (point-major) ---------------------- *
+ * Per-channel reductions use a partial buffer [ceil(rows/128)][2][C] (no atomics, fixed order). */
+
+/* partial (sum, sumsq) over `count` rows -> mean, invstd (biased variance), running-stat update
+ * (momentum, unbiased variance: torch BatchNorm2d train semantics, radarflow_util.py:133-139), and the
+ * folded affine a = gamma*invstd, c = beta - mean*a.  tiles == 0: eval mode, fold the running stats. */
+int cmf_bn_finalize(int tiles, int C, double count, const float *partial, const float *gamma,
+                    const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                    float *mean_out, float *invstd_out, float *a_out, float *c_out, void *stream);
+/* out[2][C] = sum over tiles of partial[t][2][C] */
+int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void *stream);
+
+/* Set-conv / cost-volume grouping with the first 1x1 conv hoisted per point
+ * (QueryAndGroup + first Conv2d, lib/pointnet2_utils.py:277-285 + radarflow_util.py:151;
+ *  cost volume radarflow_util.py:207-216):
+ *   z[b,p,s,:] = act( ysrc[b,idx[b,p,s],:] + (yctr ? yctr[b,p,:] : 0) + Wx (xyz_src[b,idx] - xyz_ctr[b,p]) )
+ * ysrc (b,n_src,ld_src), yctr (b,P,ld_ctr) or NULL, Wx (C,3) with row stride ldw, idx (b,P,S);
+ * act 0 none / 2 leaky(0.1); z (b,P,S,C); dxyz (b,P,S,4) relative coordinates (optional);
+ * partial: BN statistics of z (optional). */
+int cmf_group_affine(int b, int n_src, int P, int S, int C,
+                     const float *ysrc, int ld_src, const float *yctr, int ld_ctr,
+                     const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
+                     const int *idx, int act, float *z, float *dxyz, float *partial, void *stream);
+
+/* out[p,:] = max_s relu(a*z[p,s,:] + c): BN + ReLU + max over the ball (radarflow_util.py:151-155);
+ * argmax (P,C) uint8 optional. */
+int cmf_bn_relu_maxpool(long long P, int S, int C, const float *z, const float *a, const float *c,
+                        float *out, long long ldo, unsigned char *argmax, void *stream);
+int cmf_maxpool_bwd(long long P, int S, int C, const float *dout, long long ldd, const float *z,
+                    const float *a, const float *c, const float *mean, const float *invstd,
+                    const unsigned char *argmax, float *dU, float *partial, void *stream);
+
+/* out = relu(a*z + c) (row strides ldz / ldo: out may be a column slice of a concat buffer) */
+int cmf_affine_relu(long long M, int C, const float *z, long long ldz, const float *a, const float *c,
+                    float *out, long long ldo, void *stream);
+/* dU = dY * [a*z + c > 0] + partial (sum dU, sum dU*(z-mean)*invstd) */
+int cmf_act_bwd_stats(long long M, int C, const float *dY, long long ldy, const float *z, long long ldz,
+                      const float *a, const float *c, const float *mean, const float *invstd,
+                      float *dU, float *partial, void *stream);
+/* in place: dZ = a*(dU - s1/M - zhat*s2/M) with sums = {s1[C], s2[C]}; sums == NULL: dZ = a*dU (eval BN) */
+int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, long long ldz, const float *a,
+                     const float *mean, const float *invstd, const float *sums, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 

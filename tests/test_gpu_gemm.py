@@ -123,3 +123,20 @@ def test_gemm_throughput_report(dev):
         ms_t = e0.elapsed_time(e1) / 5
         print("gemm M=%d N=%d K=%d: %.3f ms = %.1f TFLOP/s (torch/hipBLASLt %.3f ms = %.1f)" %
               (M, N, K, ms, 2e-9 * M * N * K / ms, ms_t, 2e-9 * M * N * K / ms_t))
+
+
+def test_gemm_backward_throughput_report(dev):
+    """Prints TFLOP/s of the two backward GEMM forms on the dominant shapes."""
+    from cmflow_amd.fused import gemm
+    from cmflow_amd.fused_blocks import gemm_dw
+    for M, N, K in ((524288, 256, 512), (131072, 512, 512)):
+        dZ = torch.randn(M, N, device=dev); W = torch.randn(N, K, device=dev); X = torch.randn(M, K, device=dev)
+        for name, fn in (("dX = dZ @ W", lambda: gemm(dZ, W, b_t=False)), ("dW = dZ^T @ X", lambda: gemm_dw(dZ, X))):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            print("%s M=%d N=%d K=%d: %.3f ms = %.1f TFLOP/s" % (name, M, N, K, ms, 2e-9 * M * N * K / ms))

@@ -39,7 +39,7 @@ def _epe(a, b):
     return float(np.linalg.norm(a - b, axis=1).mean())
 
 
-@pytest.mark.parametrize("path", ["pm", "ref"])
+@pytest.mark.parametrize("path", ["pm", "pm_torch", "ref"])
 @pytest.mark.parametrize("case", EVAL_CASES)
 def test_forward_matches_reference_golden(case, path, dev, manifest, golden_dir, args):
     from cmflow_amd.cmflow import CMFlow
@@ -124,7 +124,7 @@ def test_forward_matches_oracle_fresh_inputs(dev, manifest, golden_dir, args):
     np.testing.assert_allclose(o[2].cpu().numpy(), r[2].numpy(), rtol=0, atol=1e-4)
 
 
-@pytest.mark.parametrize("path", ["pm", "ref"])
+@pytest.mark.parametrize("path", ["pm", "pm_torch", "ref"])
 def test_train_step_matches_reference_golden(path, dev, manifest, golden_dir, args):
     """Rows a3 + a15('train') + losses + Adam against the reference's own train step
     (main_util.py:63-76 run behind the shims, tests/golden/make_golden.py)."""
