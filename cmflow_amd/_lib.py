@@ -24,6 +24,7 @@ SIGNATURES = {
     "cmf_weighted_kabsch_grad": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_rows": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_build_inverse": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_build_inverse_ps": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_group_rows_grad": [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],

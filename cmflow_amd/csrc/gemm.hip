@@ -81,17 +81,29 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     float *Bs = smem + 2 * A_SZ;                            // [2][B_SZ]
 
     // ---- XCD-aware tile mapping ----
+    // Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  split_k == 1: the
+    // column tiles sharing an A row-panel run back to back on ONE XCD.  split_k > 1 (weight gradients:
+    // huge contraction, few output tiles): ALL output tiles of one K-slab run on one XCD, so both
+    // operand slabs are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    int tm, tn;
+    int tm, tn, split;
     {
         const int id = blockIdx.x, nx = 8;
-        const int per = (tiles_m + nx - 1) / nx;            // row panels per XCD
         const int xcd = id % nx, slot = id / nx;
-        tm = xcd * per + slot / tiles_n;
-        tn = slot % tiles_n;
-        if (tm >= tiles_m || slot / tiles_n >= per) return;
+        if (p.split_k > 1) {
+            const int tiles = tiles_m * tiles_n;
+            split = xcd + nx * (slot / tiles);
+            const int t = slot % tiles;
+            tm = t / tiles_n; tn = t % tiles_n;
+            if (split >= p.split_k) return;
+        } else {
+            const int per = (tiles_m + nx - 1) / nx;            // row panels per XCD
+            split = 0;
+            tm = xcd * per + slot / tiles_n;
+            tn = slot % tiles_n;
+            if (tm >= tiles_m || slot / tiles_n >= per) return;
+        }
     }
-    const int split = blockIdx.y;
     const int kchunks_total = (p.K + G_BK - 1) / G_BK;
     const int kchunks_per = (kchunks_total + p.split_k - 1) / p.split_k;
     const int kc_begin = split * kchunks_per;
@@ -390,7 +402,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
 {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per = (tiles_m + 7) / 8;
-    dim3 grid(8 * per * tiles_n, a.split_k);
+    dim3 grid(a.split_k > 1 ? 8 * ((a.split_k + 7) / 8) * tiles_m * tiles_n : 8 * per * tiles_n);
     const size_t lds = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T>,

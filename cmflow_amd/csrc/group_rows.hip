@@ -13,6 +13,8 @@
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
+int cmf_build_inverse_rows(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream, int entries);
+
 constexpr int GR_THREADS = 256;
 
 // feat: (b, n, ldf) rows of c floats; out: (b, entries, c) dense.
@@ -104,11 +106,82 @@ __global__ __launch_bounds__(CMF_WAVE) void inverse_fill_kernel(
     }
 }
 
+// Fast path for the model's sizes (rows P <= 256, targets n with P*(n+1)*2 bytes of LDS): a P x n matrix
+// of uint16 multiplicities cnt[p][j] in LDS gives every entry its rank without scanning:
+//   A) thread p walks its row: rank_in_row = cnt[p][j]++            (one owner per row: no atomics)
+//   B) thread j turns column j into an exclusive prefix over p; column totals -> offsets (scan over j)
+//   C) thread p writes entry (p,s) to offsets[j] + prefix[p][j] + rank_in_row  => ascending entry order.
+// O(P*S + P*n/threads) work per sample instead of O(n * P*S).
+constexpr int INVM_THREADS = 256;
+__global__ __launch_bounds__(INVM_THREADS) void inverse_matrix_kernel(
+    int n, int P, int S, const int *__restrict__ idx, int *__restrict__ offsets, int *__restrict__ inv)
+{
+    extern __shared__ unsigned short cnt[];             // [P][ld], ld = n + 1 (odd stride spreads the banks)
+    __shared__ int tot[INVM_THREADS + 1];
+    const int ld = n | 1;
+    const int bs = blockIdx.x, t = threadIdx.x;
+    const int entries = P * S;
+    const int *ix = idx + (size_t)bs * entries;
+    int *off = offsets + (size_t)bs * (n + 1);
+    int *lst = inv + (size_t)bs * entries;
+    for (int i = t; i < P * ld; i += INVM_THREADS) cnt[i] = 0;
+    __syncthreads();
+    // A: within-row ranks, kept packed in registers (S <= 64 -> 8 bits each would do; use a local array)
+    unsigned char rank[64];
+    if (t < P)
+        for (int s = 0; s < S; ++s) { const int j = ix[t * S + s]; rank[s] = (unsigned char)(cnt[t * ld + j]++); }
+    __syncthreads();
+    // B: column prefix over rows; handles n > 256 by striding columns
+    for (int j0 = 0; j0 < n; j0 += INVM_THREADS) {
+        const int j = j0 + t;
+        int run = 0;
+        if (j < n)
+            for (int p = 0; p < P; ++p) { const int c = cnt[p * ld + j]; cnt[p * ld + j] = (unsigned short)run; run += c; }
+        // exclusive scan of the column totals of this chunk (serial over <= 256 items)
+        tot[t + 1] = (j < n) ? run : 0;
+        __syncthreads();
+        if (t == 0) { tot[0] = (j0 == 0) ? 0 : off[j0]; for (int i = 1; i <= INVM_THREADS; ++i) tot[i] += tot[i - 1]; }
+        __syncthreads();
+        if (j < n) off[j] = tot[t];
+        if (t == 0) off[min(j0 + INVM_THREADS, n)] = tot[min(INVM_THREADS, n - j0)];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // C: scatter the entries to their slots
+    if (t < P)
+        for (int s = 0; s < S; ++s) {
+            const int j = ix[t * S + s];
+            lst[off[j] + cnt[t * ld + j] + rank[s]] = t * S + s;
+        }
+}
+
 extern "C" int cmf_build_inverse(int b, int n, int entries, const int *idx, int *offsets, int *inv, void *stream)
 {
     CMF_CHECK_ARG(b >= 0 && n > 0 && entries >= 0 && n < 40000);
     if (b == 0) return 0;
     CMF_CHECK_ARG(idx && offsets && inv);
+    return cmf_build_inverse_rows(b, n, 0, 0, idx, offsets, inv, stream, entries);
+}
+
+// rows/S known (idx is (b,P,S)): enables the matrix fast path
+extern "C" int cmf_build_inverse_ps(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && P >= 0 && S >= 0 && n < 40000);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(idx && offsets && inv);
+    return cmf_build_inverse_rows(b, n, P, S, idx, offsets, inv, stream, P * S);
+}
+
+int cmf_build_inverse_rows(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream, int entries)
+{
+    const size_t mat = (size_t)P * (n | 1) * sizeof(unsigned short);
+    if (P > 0 && P <= INVM_THREADS && S <= 64 && mat <= 150 * 1024) {
+        static bool set = false;
+        if (!set) { (void)hipFuncSetAttribute((const void *)inverse_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+        hipLaunchKernelGGL(inverse_matrix_kernel, dim3(b), dim3(INVM_THREADS), mat, (hipStream_t)stream, n, P, S, idx, offsets, inv);
+        return cmf_launch_status();
+    }
     hipLaunchKernelGGL(inverse_count_kernel, dim3(b), dim3(INV_THREADS), (size_t)(n + 1) * sizeof(int), (hipStream_t)stream,
                        n, entries, idx, offsets);
     hipLaunchKernelGGL(inverse_fill_kernel, dim3(b, cmf_divup(n, CMF_WAVE)), dim3(CMF_WAVE), 0, (hipStream_t)stream,

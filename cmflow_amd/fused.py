@@ -34,9 +34,9 @@ class Neighbors:
             entries = self.P * self.S
             off = torch.empty(self.B, self.n + 1, dtype=_i32, device=self.idx.device)
             inv = torch.empty(self.B, entries, dtype=_i32, device=self.idx.device)
-            err = _lib.lib().cmf_build_inverse(self.B, self.n, entries, _lib.dev_ptr(self.idx, _i32),
-                                               _lib.dev_ptr(off, _i32), _lib.dev_ptr(inv, _i32), _lib.stream_ptr())
-            _lib.check(err, "cmf_build_inverse")
+            err = _lib.lib().cmf_build_inverse_ps(self.B, self.n, self.P, self.S, _lib.dev_ptr(self.idx, _i32),
+                                                  _lib.dev_ptr(off, _i32), _lib.dev_ptr(inv, _i32), _lib.stream_ptr())
+            _lib.check(err, "cmf_build_inverse_ps")
             self._inv = (off, inv)
         return self._inv
 

@@ -75,6 +75,8 @@ int cmf_group_rows(int b, int n, int c, int ldf, int entries,
 /* Inverse index of idx (b,entries) with values in [0,n): offsets (b,n+1), inv (b,entries) --
  * for each target point the entries that reference it, ascending.  Feeds cmf_group_rows_grad. */
 int cmf_build_inverse(int b, int n, int entries, const int *idx, int *offsets, int *inv, void *stream);
+/* Same, for idx of shape (b,P,S): small P / n take an O(P*S) LDS-matrix path instead of a scan. */
+int cmf_build_inverse_ps(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream);
 
 /* Backward of cmf_group_rows as a deterministic segmented sum (replaces the fp32 atomics of
  * lib/src/group_points_gpu.cu:8-25): grad_feat[b,j,:] (row stride ldg) = (accumulate ? old : 0) +
