@@ -17,6 +17,7 @@
 // * XCD-aware tile order: the column tiles that share an A row-panel run back to back on ONE XCD
 //   (blockIdx -> XCD is round-robin), so the panel is fetched from HBM once and re-read from L2.
 #include <algorithm>
+#include <cstdlib>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -298,72 +299,95 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                     }
+                // stage the NEXT chunk into the other LDS buffer three quarters of the way through this
+                // chunk's MFMAs: its global loads have had ~3/4 of a chunk to land, and the LDS writes
+                // retire under the remaining MFMAs instead of in front of the barrier.
+                if (k8 == G_BK - 16 && more) { store_A(buf ^ 1); store_B(buf ^ 1); }
             }
-            if (more) { store_A(buf ^ 1); store_B(buf ^ 1); }
             __syncthreads();
             buf ^= 1;
         }
     }
 
-    // ---- epilogue ----  C/D map of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float *Cout = p.C + (p.split_k > 1 ? (long long)split * p.M * p.ldc : 0);
-    const bool want_stats = p.stats != nullptr && p.split_k == 1;
-    float *red = smem;                              // reuse LDS for the cross-wave column reduction
-    if (want_stats) __syncthreads();
+    // ---- epilogue ----
+    // The accumulators (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are
+    // transposed through LDS so that every global access of the epilogue is a coalesced 16-byte access:
+    // a lane-per-column store tail is store-ISSUE bound (64 dword stores + 64 dword loads per lane).
+    constexpr int T_LD = BN + 4;
+    float *tile = smem;                                  // [BM][T_LD], fits inside the staging buffers
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + (lane & 31);
-        const bool n_ok = n < p.N;
-        float bias = 0.f, ea = 0.f, ec = 0.f, emean = 0.f, einv = 0.f;
-        if (n_ok) {
-            if (p.bias) bias = p.bias[n];
-            if (p.bwd_mode == 1) { ea = p.ea[n]; ec = p.ec[n]; emean = p.emean[n]; einv = p.einvstd[n]; }
-        }
-        float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M && n_ok) {
-                    float v = acc[i][j][r];
-                    if (p.split_k == 1) {
-                        v = act_fn(v + bias, p.act);
-                        if (p.bwd_mode) {
-                            const float z = p.Z[(long long)m * p.ldz + n];
-                            if (p.bwd_mode == 1) {
-                                v = (fmaf(ea, z, ec) > 0.f) ? v : 0.f;
-                                s1 += v; s2 += v * ((z - emean) * einv);
-                            } else if (p.bwd_mode == 2) v = z > 0.f ? v : 0.1f * v;
-                            else v = z > 0.f ? v : 0.f;
-                        } else if (want_stats) { s1 += v; s2 += v * v; }
-                    }
-                    float *dst = Cout + (long long)m * p.ldc + n;
-                    if (p.accumulate && p.split_k == 1) v += *dst;
-                    *dst = v;
-                }
+                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = wn * WN + j * 32 + (lane & 31);
+                tile[row * T_LD + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    float *Cout = p.C + (p.split_k > 1 ? (long long)split * p.M * p.ldc : 0);
+    const bool want_stats = p.stats != nullptr && p.split_k == 1;
+    constexpr int TPR = BN / 4;                          // threads per tile row
+    constexpr int RPP = G_THREADS / TPR;                 // rows per pass
+    const int col = (tid % TPR) * 4, n = n0 + col;
+    const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)Cout) % 16 == 0) && (n + 3 < p.N) &&
+                     (!p.bwd_mode || (p.ldz % 4 == 0 && ((uintptr_t)p.Z) % 16 == 0));
+    float bias[4] = {0, 0, 0, 0}, ea[4] = {0, 0, 0, 0}, ec[4] = {0, 0, 0, 0}, em[4] = {0, 0, 0, 0}, ei[4] = {0, 0, 0, 0};
+    if (p.split_k == 1)
+        for (int q = 0; q < 4; ++q)
+            if (n + q < p.N) {
+                if (p.bias) bias[q] = p.bias[n + q];
+                if (p.bwd_mode == 1) { ea[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
+            }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int r0 = tid / TPR; r0 < BM; r0 += RPP) {
+        const int m = m0 + r0;
+        if (m >= p.M) break;
+        const float4 t4 = *(const float4 *)(tile + r0 * T_LD + col);
+        float v[4] = {t4.x, t4.y, t4.z, t4.w};
+        if (p.split_k == 1) {
+            float z[4] = {0, 0, 0, 0};
+            if (p.bwd_mode) {
+                const float *zp = p.Z + (long long)m * p.ldz + n;
+                if (vec) { const float4 z4 = *(const float4 *)zp; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w; }
+                else for (int q = 0; q < 4; ++q) if (n + q < p.N) z[q] = zp[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x = act_fn(v[q] + bias[q], p.act);
+                if (p.bwd_mode == 1) {
+                    x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
+                    s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
+                } else if (p.bwd_mode == 2) x = z[q] > 0.f ? x : 0.1f * x;
+                else if (p.bwd_mode == 3) x = z[q] > 0.f ? x : 0.f;
+                else if (want_stats) { s1[q] += x; s2[q] += x * x; }
+                v[q] = x;
             }
         }
-        if (want_stats) {
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                const int col = wn * WN + j * 32 + lane;         // column within the block tile
-                red[(wm * 2 + 0) * BN + col] = s1;
-                red[(wm * 2 + 1) * BN + col] = s2;
-            }
+        float *dst = Cout + (long long)m * p.ldc + n;
+        if (vec) {
+            float4 o = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.accumulate && p.split_k == 1) { const float4 c4 = *(const float4 *)dst; o.x += c4.x; o.y += c4.y; o.z += c4.z; o.w += c4.w; }
+            *(float4 *)dst = o;
+        } else {
+            for (int q = 0; q < 4; ++q)
+                if (n + q < p.N) dst[q] = (p.accumulate && p.split_k == 1) ? dst[q] + v[q] : v[q];
         }
     }
     if (want_stats) {
+        __syncthreads();                                 // all tile reads done: reuse LDS for the column reduction
+        float *red = smem;                               // [RPP][2][BN]
+        const int rg = tid / TPR;
+        *(float4 *)(red + (rg * 2 + 0) * BN + col) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *(float4 *)(red + (rg * 2 + 1) * BN + col) = make_float4(s2[0], s2[1], s2[2], s2[3]);
         __syncthreads();
-        for (int c = tid; c < BN; c += G_THREADS) {
-            float s1 = 0.f, s2 = 0.f;
+        for (int c = tid; c < 2 * BN; c += G_THREADS) {
+            const int which = c / BN, cc = c % BN;
+            float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < WARPS_M; ++w) { s1 += red[(w * 2 + 0) * BN + c]; s2 += red[(w * 2 + 1) * BN + c]; }
-            if (n0 + c < p.N) {
-                p.stats[((long long)tm * 2 + 0) * p.N + n0 + c] = s1;
-                p.stats[((long long)tm * 2 + 1) * p.N + n0 + c] = s2;
-            }
+            for (int g = 0; g < RPP; ++g) sum += red[(g * 2 + which) * BN + cc];
+            if (n0 + cc < p.N) p.stats[((long long)tm * 2 + which) * p.N + n0 + cc] = sum;
         }
     }
 }
