@@ -9,8 +9,10 @@ Adam) on synthetic N=256 radar clouds at B=64 per GPU (BASELINE.json metric / co
 One process per GPU; batches shard over ranks (weak scaling: 64 pairs per GPU); the only
 collective is one RCCL all-reduce of the flat gradient bucket per step.  Rank 0 prints ONE
 JSON line.  `roofline` is measured live with HIP events around every launch of the dominant
-hand-written kernel inside the timed region; `cpu_baseline` is the CPU oracle ("port") timed on
-this box's host cores on a bounded sample.
+hand-written kernel (cmf_gemm, the fp32 MFMA GEMM behind every 1x1 conv) inside the timed region:
+achieved = sum of 2*M*N*K over its launches / sum of their durations, peak = 157.3 TFLOP/s dense
+fp32 MFMA; `--track cmf_group_points` reports the HBM-bound grouping kernel of the unfused path
+instead.  `cpu_baseline` is the CPU oracle ("port") timed on this box's host cores on a bounded sample.
 """
 import argparse
 import json
@@ -104,6 +106,9 @@ def main():
     ap.add_argument("--model", choices=["cmflow", "cmflow_t"], default="cmflow")
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", choices=["pm", "pm_torch", "ref"], default="pm",
+                    help="pm: fused point-major HIP path (product); ref: unfused reference-layout ops")
+    ap.add_argument("--track", choices=["cmf_gemm", "cmf_group_points"], default=None)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +134,7 @@ def main():
     net = (CMFlow_T if a.model == "cmflow_t" else CMFlow)(Args())
     net.load_state_dict(load_weights(a.model))
     net = net.to(dev)
+    net.path = a.path
     broadcast_module(net)
     batch = {k: v.to(dev) for k, v in synth.make_batch(a.batch, seed=1234 + rank, train_extras=True).items()}
 
@@ -158,7 +164,8 @@ def main():
 
     for _ in range(a.warmup):
         one()
-    _lib.profile_begin()                             # HIP-event pairs around every launch of the tracked kernel
+    track = a.track or ("cmf_group_points" if a.path == "ref" else "cmf_gemm")
+    _lib.profile_begin(track, "hbm" if track == "cmf_group_points" else "mfma")   # HIP-event pairs around every launch
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -184,7 +191,9 @@ def main():
             roof = {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
                     "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
                     "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
-                    "algorithmic_per_launch": per_launch}
+                    "algorithmic_per_launch": per_launch,
+                    "launch_filter": "launches >= %.0e units (cmflow_amd/_lib.py TRACK_MIN_UNITS)" %
+                                     _lib.TRACK_MIN_UNITS.get(prof["kernel"], 0.0)}
         cpu = None
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(a.mode, a.model)
@@ -200,6 +209,9 @@ def main():
                                      a.batch * world, "; dp%d RCCL grad all-reduce" % world if world > 1 else "")),
                        "parallelism": "dp%d" % world},
             "roofline": roof, "cpu_baseline": cpu,
+            # model-level rate against the reference's ALGORITHMIC work (25.52 GFLOP per frame pair forward,
+            # x3 for fwd+bwd) -- the build's hoisted first convs execute fewer FLOPs than that
+            "algorithmic_model_tflops": round(pairs / dt * 25.52e9 * (3.0 if a.mode == "train" else 1.0) / 1e12, 2),
         }
         print(json.dumps(line))
     if world > 1:

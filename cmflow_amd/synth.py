@@ -24,16 +24,26 @@ T_CAMERA_RADAR = [[-0.013857, -0.9997468, 0.01772762, 0.05283124],
                   [0.0, 0.0, 0.0, 1.0]]
 
 
-def _mixture(g, B, N, centres, box_lo, box_hi, sigma):
-    """70 % clustered around `centres`, 30 % uniform in the box."""
-    n_c = centres.shape[1]
-    which = torch.randint(0, n_c, (B, N), generator=g)
-    c = torch.gather(centres, 1, which.unsqueeze(-1).expand(B, N, 3))
-    clustered = c + torch.randn(B, N, 3, generator=g) * sigma
-    uniform = box_lo + (box_hi - box_lo) * torch.rand(B, N, 3, generator=g)
-    pick = (torch.rand(B, N, 1, generator=g) < 0.7)
-    pts = torch.where(pick, clustered, uniform)
+def _mixture(g, B, N, scene, box_lo, box_hi, f_sub=0.5, f_reg=0.42):
+    """Two-level mixture calibrated to real VoD radar occupancy (mean points within r = 2/4/8/16 m of a
+    point: 6.9/16.4/40.7/91.5 measured on the reference's saved clouds; this generator gives
+    6.7/16.3/43.0/85.8): 50 % tight object-like sub-clusters, 42 % broad regions, 8 % uniform clutter."""
+    reg, sub, s_reg, s_sub = scene
+    n_reg, n_sub = reg.shape[1], sub.shape[1] // reg.shape[1]
+    wr = torch.randint(0, n_reg, (B, N), generator=g)
+    ws = wr * n_sub + torch.randint(0, n_sub, (B, N), generator=g)
+    pr = torch.gather(reg, 1, wr.unsqueeze(-1).expand(B, N, 3)) + torch.randn(B, N, 3, generator=g) * s_reg
+    ps = torch.gather(sub, 1, ws.unsqueeze(-1).expand(B, N, 3)) + torch.randn(B, N, 3, generator=g) * s_sub
+    pu = box_lo + (box_hi - box_lo) * torch.rand(B, N, 3, generator=g)
+    u = torch.rand(B, N, 1, generator=g)
+    pts = torch.where(u < f_sub, ps, torch.where(u < f_sub + f_reg, pr, pu))
     return torch.maximum(torch.minimum(pts, box_hi), box_lo)
+
+
+def _scene(g, B, lo, hi, n_reg, n_sub, s_reg, s_off, s_sub):
+    reg = lo + (hi - lo) * torch.rand(B, n_reg, 3, generator=g)
+    sub = (reg[:, :, None, :] + torch.randn(B, n_reg, n_sub, 3, generator=g) * torch.tensor(s_off)).reshape(B, n_reg * n_sub, 3)
+    return reg, sub, torch.tensor(s_reg), torch.tensor(s_sub)
 
 
 def rigid_transform(yaw_deg=0.5, t=(-0.5, 0.0, 0.0), B=1):
@@ -53,17 +63,15 @@ def make_batch(B, N=256, seed=1234, lidar=False, train_extras=False):
     (B,), radar_u/v (B,N), opt_flow (B,N,2) for the loss path (main_util.py:63-72).
     """
     g = torch.Generator().manual_seed(seed)
-    if lidar:   # config 5: LiDAR-like box
-        lo, hi, sig = torch.tensor([0.0, -40.0, -3.0]), torch.tensor([70.0, 40.0, 1.0]), torch.tensor([2.0, 2.0, 0.5])
-        n_c = 96
-    else:       # radar: calibrated to VoD occupancy (mean pts-in-ball ~7/16/41/91 at r=2/4/8/16)
-        lo, hi, sig = torch.tensor([2.0, -25.0, -3.0]), torch.tensor([90.0, 25.0, 3.0]), torch.tensor([1.5, 1.5, 0.5])
-        n_c = 24
-    centres = lo + (hi - lo) * torch.rand(B, n_c, 3, generator=g)
-    centres[..., 2] = centres[..., 2].clamp(-2.5, 2.5) if not lidar else centres[..., 2]
-    p1 = _mixture(g, B, N, centres, lo, hi, sig)
+    if lidar:   # config 5: LiDAR-like box, many more structures
+        lo, hi = torch.tensor([0.0, -40.0, -3.0]), torch.tensor([70.0, 40.0, 1.0])
+        scene = _scene(g, B, lo, hi, 24, 8, (6.0, 5.0, 0.6), (5.0, 5.0, 0.4), (0.8, 0.8, 0.3))
+    else:       # radar: calibrated to VoD occupancy
+        lo, hi = torch.tensor([2.0, -25.0, -3.0]), torch.tensor([90.0, 25.0, 3.0])
+        scene = _scene(g, B, lo, hi, 3, 6, (6.0, 5.0, 0.8), (5.0, 5.0, 0.6), (0.8, 0.8, 0.3))
+    p1 = _mixture(g, B, N, scene, lo, hi)
     T = rigid_transform(B=B)
-    p2 = _mixture(g, B, N, centres, lo, hi, sig)
+    p2 = _mixture(g, B, N, scene, lo, hi)
     p2 = torch.einsum("bij,bnj->bni", T[:, :3, :3], p2) + T[:, None, :3, 3]
     p2 = p2 + 0.05 * torch.randn(B, N, 3, generator=g)
 

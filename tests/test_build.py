@@ -1,0 +1,80 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/*.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def so_path():
+    from cmflow_amd import _lib
+    return _lib.build()
+
+
+def declared_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(REPO, "include")):
+        if fn.endswith(".h"):
+            text = open(os.path.join(REPO, "include", fn)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            names |= set(re.findall(r"\b(cmf_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol(so_path):
+    lib = ctypes.CDLL(so_path)
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    missing = [n for n in sorted(decl) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.cmf_version is not None
+    lib.cmf_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.cmf_version()
+
+
+def test_ctypes_signatures_cover_the_header(so_path):
+    from cmflow_amd import _lib
+    decl = declared_symbols() - {"cmf_version"}
+    assert decl == set(_lib.SIGNATURES), decl ^ set(_lib.SIGNATURES)
+
+
+def test_only_gfx950_code_objects(so_path):
+    """The fat binary embedded in the library carries gfx950 code objects only (no other arch, no
+    compatibility targets)."""
+    blob = open(so_path, "rb").read()
+    archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert archs == {b"gfx950"}, archs
+
+
+def test_ball_query_isa_has_no_fma_contraction():
+    """The canonical arithmetic of the neighbour search: the ball-query distance must be
+    three products and two adds, each individually rounded -- no v_fma/v_fmac/v_mad in that kernel."""
+    src = os.path.join(REPO, "cmflow_amd", "csrc", "neighbor.hip")
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+                          "--cuda-device-only", "-o", "-", src], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    asm = out.stdout
+    start = asm.index("_Z17ball_query_kernel")
+    body = asm[start:asm.index("s_endpgm", start)]
+    assert not re.search(r"v_(fma|fmac|mad|pk_fma)_f32", body)
+    knn = asm[asm.index("_Z10knn_kernelILi8EE"):]
+    knn = knn[:knn.index("s_endpgm")]
+    assert re.search(r"v_(fma|fmac)_f32", knn)        # the k-ordered FMA chain of the dot product IS required there
+
+
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback anywhere on the product path."""
+    import torch
+    from cmflow_amd.pointnet2_utils import ball_query, grouping_operation
+    from cmflow_amd.radarflow_util import knn_point, weighted_kabsch
+    x = torch.zeros(1, 8, 3)
+    for fn in (lambda: ball_query(1.0, 4, x, x), lambda: knn_point(4, x, x),
+               lambda: grouping_operation(torch.zeros(1, 2, 8), torch.zeros(1, 8, 4, dtype=torch.int32)),
+               lambda: weighted_kabsch(torch.zeros(1, 3, 8), torch.zeros(1, 3, 8), torch.ones(1, 8) / 8)):
+        with pytest.raises(RuntimeError):
+            fn()

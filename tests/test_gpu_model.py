@@ -73,7 +73,7 @@ def test_forward_matches_reference_golden(case, path, dev, manifest, golden_dir,
                                    atol=1e-5 * max(1.0, float(np.abs(g[k]).max())), err_msg=k)
     assert np.array_equal(mask.cpu().numpy(), g["mask"])
     np.testing.assert_allclose(cls.cpu().numpy(), g["stat_cls"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(trans.cpu().numpy(), g["pre_trans"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(trans.cpu().numpy(), g["pre_trans"], rtol=2e-5, atol=1e-4)
     assert _epe(sf.cpu().numpy(), g["sf_agg"]) < 1e-4
 
 
@@ -100,7 +100,7 @@ def test_cmflow_t_matches_reference_golden(dev, manifest_t, golden_dir, args):
         assert np.array_equal(o[3].cpu().numpy(), g[tag + "_mask"])
         assert _epe(o[0].cpu().numpy(), g[tag + "_sf_agg"]) < 1e-4
         np.testing.assert_allclose(o[1].cpu().numpy(), g[tag + "_stat_cls"], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(o[2].cpu().numpy(), g[tag + "_pre_trans"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o[2].cpu().numpy(), g[tag + "_pre_trans"], rtol=2e-5, atol=1e-4)
         np.testing.assert_allclose(o[4].cpu().numpy(), g[tag + "_gfeat"], rtol=0, atol=1e-4)
 
 
@@ -121,7 +121,7 @@ def test_forward_matches_oracle_fresh_inputs(dev, manifest, golden_dir, args):
     assert torch.equal(o[3].cpu(), r[3])
     assert _epe(o[0].cpu().numpy(), r[0].numpy()) < 1e-4
     np.testing.assert_allclose(o[1].cpu().numpy(), r[1].numpy(), rtol=0, atol=1e-4)
-    np.testing.assert_allclose(o[2].cpu().numpy(), r[2].numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(o[2].cpu().numpy(), r[2].numpy(), rtol=2e-5, atol=1e-4)   # t reaches ~10 m: fp32 relative
 
 
 @pytest.mark.parametrize("path", ["pm", "pm_torch", "ref"])
@@ -146,7 +146,7 @@ def test_train_step_matches_reference_golden(path, dev, manifest, golden_dir, ar
     for k, v in items.items():
         assert abs(v.item() - float(g["item_" + k])) < 2e-4, k
     assert _epe(outs[0].detach().cpu().numpy(), g["sf_agg"]) < 1e-4
-    np.testing.assert_allclose(outs[2].detach().cpu().numpy(), g["pre_trans"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(outs[2].detach().cpu().numpy(), g["pre_trans"], rtol=2e-5, atol=1e-4)
     params = dict(net.named_parameters())
     for name, ref in zip(g["grad_names"], g["grad_norms"]):
         p = params[str(name)]
