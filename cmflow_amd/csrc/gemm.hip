@@ -24,8 +24,13 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int G_THREADS = 256;
-constexpr int G_BK = 32;
-constexpr int G_LDS_LD = G_BK + 4;      // 36 floats = 144 B row stride (conflict-free b128 reads)
+#ifndef CMF_GEMM_BK
+#define CMF_GEMM_BK 16
+#endif
+constexpr int G_BK = CMF_GEMM_BK;
+constexpr int G_KT = G_BK / 4;            // threads covering one k-contiguous row of a chunk
+constexpr int G_RP = 256 / G_KT;          // rows staged per pass by the 256 threads
+constexpr int G_LDS_LD = G_BK + 4;      // 20 floats (BK=16) / 36 (BK=32): row strides whose 16-B slots tile all 64 banks -> conflict-free b128 reads
 
 struct GemmArgs {
     int M, N, K;                // C is MxN, contraction length K (this split's range is [k_begin,k_end))
@@ -119,8 +124,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     // transposed staging: TPR threads cover one k-row (BM or BN contiguous floats), RPI rows per pass
     constexpr int A_TPR = BM / 4, A_RPI = G_THREADS / A_TPR;
     constexpr int B_TPR = BN / 4, B_RPI = G_THREADS / B_TPR;
-    constexpr int A_IT = A_T ? (G_BK / A_RPI) : (BM / 32);
-    constexpr int B_IT = B_T ? (BN / 32) : (G_BK / B_RPI);
+    constexpr int A_IT = A_T ? (G_BK / A_RPI) : (BM / G_RP);
+    constexpr int B_IT = B_T ? (BN / G_RP) : (G_BK / B_RPI);
     float4 ra[A_IT], rb[B_IT];
     float4 psa = make_float4(1.f, 1.f, 1.f, 1.f), psc = make_float4(0.f, 0.f, 0.f, 0.f);   // A prologue (per chunk)
     float4 qsa = make_float4(1.f, 1.f, 1.f, 1.f), qsc = make_float4(0.f, 0.f, 0.f, 0.f);   // B prologue (per thread)
@@ -142,20 +147,20 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         const bool fast = !edge_mn && (k0 + G_BK <= p.K);
         if (fast) {
             if (!A_T) {
-                const int kk = k0 + (tid & 7) * 4;
+                const int kk = k0 + (tid % G_KT) * 4;
                 if (proA) { psa = *(const float4 *)(p.pro_a + kk); psc = *(const float4 *)(p.pro_c + kk); }
-                const float *src = p.A + (long long)(m0 + (tid >> 3)) * p.lda + kk;
+                const float *src = p.A + (long long)(m0 + (tid / G_KT)) * p.lda + kk;
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i) ra[i] = *(const float4 *)(src + (long long)32 * i * p.lda);
+                for (int i = 0; i < A_IT; ++i) ra[i] = *(const float4 *)(src + (long long)G_RP * i * p.lda);
             } else {
                 const float *src = p.A + (long long)(k0 + tid / A_TPR) * p.lda + m0 + (tid % A_TPR) * 4;
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) ra[i] = *(const float4 *)(src + (long long)A_RPI * i * p.lda);
             }
             if (B_T) {
-                const float *src = p.B + (long long)(n0 + (tid >> 3)) * p.ldb + k0 + (tid & 7) * 4;
+                const float *src = p.B + (long long)(n0 + (tid / G_KT)) * p.ldb + k0 + (tid % G_KT) * 4;
 #pragma unroll
-                for (int i = 0; i < B_IT; ++i) rb[i] = *(const float4 *)(src + (long long)32 * i * p.ldb);
+                for (int i = 0; i < B_IT; ++i) rb[i] = *(const float4 *)(src + (long long)G_RP * i * p.ldb);
             } else {
                 const float *src = p.B + (long long)(k0 + tid / B_TPR) * p.ldb + n0 + (tid % B_TPR) * 4;
 #pragma unroll
@@ -172,13 +177,13 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             return make_float4(t[0], t[1], t[2], t[3]);
         };
         if (!A_T) {
-            const int kk = k0 + (tid & 7) * 4;
+            const int kk = k0 + (tid % G_KT) * 4;
             const int kv = max(0, min(4, p.K - kk));
             kmask = (1u << kv) - 1u;
             if (proA) { psa = ld4(p.pro_a + kk, kv); psc = ld4(p.pro_c + kk, kv); }
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
-                const int m = m0 + (tid >> 3) + 32 * i;
+                const int m = m0 + (tid / G_KT) + G_RP * i;
                 ra[i] = (m < p.M && kv > 0) ? ld4(p.A + (long long)m * p.lda + kk, kv) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (m >= p.M) ra[i].x = __builtin_nanf("");            // marks a row that must store zeros
             }
@@ -190,11 +195,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             }
         }
         if (B_T) {
-            const int kk = k0 + (tid & 7) * 4;
+            const int kk = k0 + (tid % G_KT) * 4;
             const int kv = max(0, min(4, p.K - kk));
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
-                const int n = n0 + (tid >> 3) + 32 * i;
+                const int n = n0 + (tid / G_KT) + G_RP * i;
                 rb[i] = (n < p.N && kv > 0) ? ld4(p.B + (long long)n * p.ldb + kk, kv) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         } else {
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                     if (kmask != 0xF) { if (!(kmask & 1)) v.x = 0.f; if (!(kmask & 2)) v.y = 0.f;
                                         if (!(kmask & 4)) v.z = 0.f; if (!(kmask & 8)) v.w = 0.f; }
                 } else if (v.x != v.x && edge_mn) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *(float4 *)(dst + ((tid >> 3) + 32 * i) * G_LDS_LD + (tid & 7) * 4) = v;
+                *(float4 *)(dst + ((tid / G_KT) + G_RP * i) * G_LDS_LD + (tid % G_KT) * 4) = v;
             }
         } else {
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         if (B_T) {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
-                *(float4 *)(dst + ((tid >> 3) + 32 * i) * G_LDS_LD + (tid & 7) * 4) = rb[i];
+                *(float4 *)(dst + ((tid / G_KT) + G_RP * i) * G_LDS_LD + (tid % G_KT) * 4) = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) {
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                 // stage the NEXT chunk into the other LDS buffer three quarters of the way through this
                 // chunk's MFMAs: its global loads have had ~3/4 of a chunk to land, and the LDS writes
                 // retire under the remaining MFMAs instead of in front of the barrier.
-                if (k8 == G_BK - 16 && more) { store_A(buf ^ 1); store_B(buf ^ 1); }
+                if (k8 == (G_BK >= 32 ? G_BK - 16 : G_BK - 8) && more) { store_A(buf ^ 1); store_B(buf ^ 1); }
             }
             __syncthreads();
             buf ^= 1;
@@ -314,18 +319,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     // transposed through LDS so that every global access of the epilogue is a coalesced 16-byte access:
     // a lane-per-column store tail is store-ISSUE bound (64 dword stores + 64 dword loads per lane).
     constexpr int T_LD = BN + 4;
-    float *tile = smem;                                  // [BM][T_LD], fits inside the staging buffers
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int col = wn * WN + j * 32 + (lane & 31);
-                tile[row * T_LD + col] = acc[i][j][r];
-            }
-    __syncthreads();
+    float *tile = smem;                                  // [WM][T_LD]: one wave-row band per pass, fits inside the staging buffers
     float *Cout = p.C + (p.split_k > 1 ? (long long)split * p.M * p.ldc : 0);
     const bool want_stats = p.stats != nullptr && p.split_k == 1;
     constexpr int TPR = BN / 4;                          // threads per tile row
@@ -341,38 +335,55 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                 if (p.bwd_mode == 1) { ea[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
             }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    for (int r0 = tid / TPR; r0 < BM; r0 += RPP) {
-        const int m = m0 + r0;
-        if (m >= p.M) break;
-        const float4 t4 = *(const float4 *)(tile + r0 * T_LD + col);
-        float v[4] = {t4.x, t4.y, t4.z, t4.w};
-        if (p.split_k == 1) {
-            float z[4] = {0, 0, 0, 0};
-            if (p.bwd_mode) {
-                const float *zp = p.Z + (long long)m * p.ldz + n;
-                if (vec) { const float4 z4 = *(const float4 *)zp; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w; }
-                else for (int q = 0; q < 4; ++q) if (n + q < p.N) z[q] = zp[q];
-            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float x = act_fn(v[q] + bias[q], p.act);
-                if (p.bwd_mode == 1) {
-                    x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
-                    s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
-                } else if (p.bwd_mode == 2) x = z[q] > 0.f ? x : 0.1f * x;
-                else if (p.bwd_mode == 3) x = z[q] > 0.f ? x : 0.f;
-                else if (want_stats) { s1[q] += x; s2[q] += x * x; }
-                v[q] = x;
-            }
+    for (int band = 0; band < WARPS_M; ++band) {
+        if (band > 0) __syncthreads();                   // previous band fully consumed
+        if (wm == band) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        const int c = wn * WN + j * 32 + (lane & 31);
+                        tile[row * T_LD + c] = acc[i][j][r];
+                    }
         }
-        float *dst = Cout + (long long)m * p.ldc + n;
-        if (vec) {
-            float4 o = make_float4(v[0], v[1], v[2], v[3]);
-            if (p.accumulate && p.split_k == 1) { const float4 c4 = *(const float4 *)dst; o.x += c4.x; o.y += c4.y; o.z += c4.z; o.w += c4.w; }
-            *(float4 *)dst = o;
-        } else {
-            for (int q = 0; q < 4; ++q)
-                if (n + q < p.N) dst[q] = (p.accumulate && p.split_k == 1) ? dst[q] + v[q] : v[q];
+        __syncthreads();
+        for (int r0 = tid / TPR; r0 < WM; r0 += RPP) {
+            const int m = m0 + band * WM + r0;
+            if (m >= p.M) break;
+            const float4 t4 = *(const float4 *)(tile + r0 * T_LD + col);
+            float v[4] = {t4.x, t4.y, t4.z, t4.w};
+            if (p.split_k == 1) {
+                float z[4] = {0, 0, 0, 0};
+                if (p.bwd_mode) {
+                    const float *zp = p.Z + (long long)m * p.ldz + n;
+                    if (vec) { const float4 z4 = *(const float4 *)zp; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w; }
+                    else for (int q = 0; q < 4; ++q) if (n + q < p.N) z[q] = zp[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = act_fn(v[q] + bias[q], p.act);
+                    if (p.bwd_mode == 1) {
+                        x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
+                        s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
+                    } else if (p.bwd_mode == 2) x = z[q] > 0.f ? x : 0.1f * x;
+                    else if (p.bwd_mode == 3) x = z[q] > 0.f ? x : 0.f;
+                    else if (want_stats) { s1[q] += x; s2[q] += x * x; }
+                    v[q] = x;
+                }
+            }
+            float *dst = Cout + (long long)m * p.ldc + n;
+            if (vec) {
+                float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                if (p.accumulate && p.split_k == 1) { const float4 c4 = *(const float4 *)dst; o.x += c4.x; o.y += c4.y; o.z += c4.z; o.w += c4.w; }
+                *(float4 *)dst = o;
+            } else {
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < p.N) dst[q] = (p.accumulate && p.split_k == 1) ? dst[q] + v[q] : v[q];
+            }
         }
     }
     if (want_stats) {
