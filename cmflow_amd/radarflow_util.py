@@ -115,8 +115,28 @@ class MultiScaleEncoder(nn.Module):
         if kpad:
             wf_all = F.pad(wf_all, (0, kpad))
         y_all = FB.linear(feats, wf_all)
-        outs = [FB.set_conv(sa, xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
+        if not self.multi_stream:
+            outs = [FB.set_conv(sa, xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
+            return torch.cat(outs, dim=2)
+        # The four scales are independent until the concat and most of their kernels are far too small to
+        # fill 256 CUs (N = 256): run each scale on its own HIP stream so they overlap.  Autograd replays
+        # each block's backward on the stream its forward ran on and orders the streams itself.
+        main = torch.cuda.current_stream()
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+        outs = []
+        for i, (sa, st) in enumerate(zip(self.ms_ls, self._streams)):
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                o = FB.set_conv(sa, xyz_t, y_all[:, :, i * o1:(i + 1) * o1])
+            o.record_stream(main)
+            outs.append(o)
+        for st in self._streams:
+            main.wait_stream(st)
         return torch.cat(outs, dim=2)
+
+    multi_stream = True
+    _streams = None
 
     use_blocks = True
 

@@ -23,6 +23,8 @@ class TrainStep:
         self.bucket = FlatGradBucket(net)
         self.opt = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay)
         self.recurrent = hasattr(net, "gru")
+        # the scales of an encoder run on side streams while the gradient bucket lives on the main stream
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.gfeat = None
 
     def reset_clip(self):
