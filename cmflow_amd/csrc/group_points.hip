@@ -12,13 +12,14 @@
 #include "../../include/cmflow_hip.h"
 
 constexpr int GP_THREADS = 256;
-constexpr int GP_CH = 8;              // channels per workgroup
+// channels per workgroup: 8 when the rows are short (8 rows of n floats in LDS), 2 for long rows so that
+// several workgroups still fit on a CU (occupancy hides the LDS gather latency)
 constexpr int GP_VEC = 4;             // idx entries per thread per step (one float4 store)
 constexpr int GP_STEPS = 4;           // steps per thread -> GP_TILE = 256*4*4 = 4096 entries
 constexpr int GP_TILE = GP_THREADS * GP_VEC * GP_STEPS;
-constexpr int GP_MAX_N_LDS = 4096;    // rows staged in LDS up to this n (GP_CH*n*4 = 128 KiB)
+constexpr int GP_MAX_N_LDS = 8192;    // rows staged in LDS up to this n
 
-template <bool ROWS_IN_LDS>
+template <bool ROWS_IN_LDS, int GP_CH>
 __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(
     int c, int n, int total /* npoints*nsample */, int tiles_per_sample,
     const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out)
@@ -79,20 +80,24 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
     if (b == 0 || c == 0 || total == 0) return 0;
     CMF_CHECK_ARG(points && idx && out && n > 0 && total < (1LL << 31));
     const int tiles = cmf_divup(total, GP_TILE);
-    dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, GP_CH));
     hipStream_t st = (hipStream_t)stream;
-    if (n <= GP_MAX_N_LDS) {
-        const size_t lds = (size_t)GP_CH * n * sizeof(float);
+    if (n <= 1024) {
+        dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 8));
+        hipLaunchKernelGGL((group_points_kernel<true, 8>), grid, dim3(GP_THREADS), (size_t)8 * n * sizeof(float), st,
+                           c, n, (int)total, tiles, points, idx, out);
+    } else if (n <= GP_MAX_N_LDS) {
+        dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 2));
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)group_points_kernel<true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GP_CH * GP_MAX_N_LDS * 4);
+            (void)hipFuncSetAttribute((const void *)group_points_kernel<true, 2>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_MAX_N_LDS * 4);
             attr_set = true;
         }
-        hipLaunchKernelGGL(group_points_kernel<true>, grid, dim3(GP_THREADS), lds, st,
+        hipLaunchKernelGGL((group_points_kernel<true, 2>), grid, dim3(GP_THREADS), (size_t)2 * n * sizeof(float), st,
                            c, n, (int)total, tiles, points, idx, out);
     } else {
-        hipLaunchKernelGGL(group_points_kernel<false>, grid, dim3(GP_THREADS), 0, st,
+        dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 8));
+        hipLaunchKernelGGL((group_points_kernel<false, 8>), grid, dim3(GP_THREADS), 0, st,
                            c, n, (int)total, tiles, points, idx, out);
     }
     return cmf_launch_status();
@@ -101,61 +106,54 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
 // ---------------------------------------------------------------------------------------------
 // Backward: grad_points[b,c,idx[b,p,s]] += grad_out[b,c,p,s].
 // The reference issues one global fp32 atomicAdd per element (538 M atomics for one scale of
-// mse_layer2).  Here a workgroup owns (sample, GG_CH channels): it accumulates into an LDS copy
-// of its rows with LDS atomics (ds_add_f32), reading grad_out with coalesced 16-byte loads, and
-// finally adds the rows to grad_points with plain stores (each row has exactly one owner).
-// Summation order inside a row is unordered, like the reference's atomics.
+// mse_layer2, order undefined).  Here the scatter becomes a GATHER over the inverse index of idx
+// (cmf_build_inverse: for every target point the entries that reference it, ascending): a workgroup
+// owns (sample, GG_CH channels), stages one grad_out row (npoints*nsample floats) in LDS with coalesced
+// 16-byte loads, and thread j sums row[inv[t]] over its segment -- no atomics, fixed summation order
+// (bit-reproducible and bit-equal to the CPU oracle's scan-order sum), each grad_points element written
+// once with a coalesced store.
 // ---------------------------------------------------------------------------------------------
-constexpr int GG_THREADS = 256;
-constexpr int GG_MAX_LDS_FLOATS = 32768;   // 128 KiB
+int cmf_build_inverse_rows(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream, int entries);
 
+constexpr int GG_THREADS = 256;
+constexpr int GG_CH = 8;
+constexpr int GG_MAX_TOTAL_LDS = 12288;    // grad_out row + inverse list staged in LDS up to this many entries
+
+template <bool IN_LDS>
 __global__ __launch_bounds__(GG_THREADS) void group_points_grad_kernel(
-    int c, int n, int total, int ch_per_block,
-    const float *__restrict__ grad_out, const int *__restrict__ idx, float *__restrict__ grad_points)
+    int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ offsets,
+    const int *__restrict__ inv, float *__restrict__ grad_points)
 {
-    extern __shared__ __attribute__((aligned(16))) float acc[];    // [ch_per_block][n]
+    extern __shared__ __attribute__((aligned(16))) int sm[];       // IN_LDS: [total] inv | [total] row
     const int bs = blockIdx.x;
-    const int c0 = blockIdx.y * ch_per_block;
-    const int nch = min(ch_per_block, c - c0);
-    const int *ix = idx + (size_t)bs * total;
+    const int c0 = blockIdx.y * GG_CH;
+    const int nch = min(GG_CH, c - c0);
+    const int *off = offsets + (size_t)bs * (n + 1);
+    const int *lst = inv + (size_t)bs * total;
     const float *g = grad_out + ((size_t)bs * c + c0) * total;
     float *gp = grad_points + ((size_t)bs * c + c0) * n;
-
-    for (int i = threadIdx.x; i < nch * n; i += GG_THREADS) acc[i] = 0.f;
-    __syncthreads();
-    const bool vec_ok = (total % 4) == 0;
-    if (vec_ok) {
-        for (int e = threadIdx.x * 4; e < total; e += GG_THREADS * 4) {
-            const int4 j = *reinterpret_cast<const int4 *>(ix + e);
-            for (int ch = 0; ch < nch; ++ch) {
-                const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)ch * total + e);
-                float *row = acc + (size_t)ch * n;
-                atomicAdd(row + j.x, v.x);
-                atomicAdd(row + j.y, v.y);
-                atomicAdd(row + j.z, v.z);
-                atomicAdd(row + j.w, v.w);
-            }
+    int *linv = sm;
+    float *row = reinterpret_cast<float *>(sm + (IN_LDS ? total : 0));
+    if (IN_LDS) {
+        for (int i = threadIdx.x; i < total; i += GG_THREADS) linv[i] = lst[i];
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const float *src = g + (size_t)ch * total;
+        if (IN_LDS) {
+            __syncthreads();
+            if ((total & 3) == 0)
+                for (int i = threadIdx.x * 4; i < total; i += GG_THREADS * 4) *(float4 *)(row + i) = *(const float4 *)(src + i);
+            else
+                for (int i = threadIdx.x; i < total; i += GG_THREADS) row[i] = src[i];
+            __syncthreads();
         }
-    } else {
-        for (int e = threadIdx.x; e < total; e += GG_THREADS) {
-            const int j = ix[e];
-            for (int ch = 0; ch < nch; ++ch) atomicAdd(acc + (size_t)ch * n + j, g[(size_t)ch * total + e]);
+        for (int j = threadIdx.x; j < n; j += GG_THREADS) {
+            const int beg = off[j], end = off[j + 1];
+            float acc = 0.f;
+            for (int t = beg; t < end; ++t) acc += IN_LDS ? row[linv[t]] : src[lst[t]];
+            gp[(size_t)ch * n + j] += acc;
         }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nch * n; i += GG_THREADS) gp[i] += acc[i];
-}
-
-// n too large for LDS rows: global atomics, one thread per element (the reference's scheme).
-__global__ __launch_bounds__(GG_THREADS) void group_points_grad_global_kernel(
-    int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ idx,
-    float *__restrict__ grad_points)
-{
-    const int bs = blockIdx.z, ch = blockIdx.y;
-    const int e = blockIdx.x * GG_THREADS + threadIdx.x;
-    if (e >= total) return;
-    atomicAdd(grad_points + ((size_t)bs * c + ch) * n + idx[(size_t)bs * total + e],
-              grad_out[((size_t)bs * c + ch) * total + e]);
 }
 
 extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
@@ -166,24 +164,30 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     if (b == 0 || c == 0 || total == 0) return 0;
     CMF_CHECK_ARG(grad_out && idx && grad_points && n > 0 && total < (1LL << 31));
     hipStream_t st = (hipStream_t)stream;
-    if (n <= GG_MAX_LDS_FLOATS) {
-        int chpb = GG_MAX_LDS_FLOATS / n;
-        if (chpb > 8) chpb = 8;
-        // keep >= ~1024 workgroups in flight when the problem allows it
-        while (chpb > 1 && (long long)b * cmf_divup(c, chpb) < 1024) chpb >>= 1;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)group_points_grad_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, GG_MAX_LDS_FLOATS * 4);
-            attr_set = true;
+    // stream-ordered scratch for the inverse index (nothing is retained after the call)
+    int *scratch = nullptr;
+    const size_t n_off = (size_t)b * (n + 1), n_inv = (size_t)b * total;
+    hipError_t e = hipMallocAsync((void **)&scratch, (n_off + n_inv) * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    int *offsets = scratch, *inv = scratch + n_off;
+    int err = cmf_build_inverse_rows(b, n, npoints, nsample, idx, offsets, inv, stream, (int)total);
+    if (!err) {
+        dim3 grid(b, cmf_divup(c, GG_CH));
+        if (total <= GG_MAX_TOTAL_LDS) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void *)group_points_grad_kernel<true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GG_MAX_TOTAL_LDS * 8);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(group_points_grad_kernel<true>, grid, dim3(GG_THREADS), (size_t)total * 8, st,
+                               c, n, (int)total, grad_out, offsets, inv, grad_points);
+        } else {
+            hipLaunchKernelGGL(group_points_grad_kernel<false>, grid, dim3(GG_THREADS), 0, st,
+                               c, n, (int)total, grad_out, offsets, inv, grad_points);
         }
-        dim3 grid(b, cmf_divup(c, chpb));
-        hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(GG_THREADS), (size_t)chpb * n * sizeof(float), st,
-                           c, n, (int)total, chpb, grad_out, idx, grad_points);
-    } else {
-        dim3 grid(cmf_divup(total, GG_THREADS), c, b);
-        hipLaunchKernelGGL(group_points_grad_global_kernel, grid, dim3(GG_THREADS), 0, st,
-                           c, n, (int)total, grad_out, idx, grad_points);
+        err = cmf_launch_status();
     }
-    return cmf_launch_status();
+    (void)hipFreeAsync(scratch, st);
+    return err;
 }

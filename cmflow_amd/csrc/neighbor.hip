@@ -16,15 +16,24 @@
 // The scan order is the semantics (first nsample hits in index order), so there is no
 // reordering to exploit; the kernel is latency bound at N=256.
 // ---------------------------------------------------------------------------------------------
-constexpr int BQ_TILE = 1024;       // points per LDS tile (12 KiB)
+constexpr int BQ_TILE = 1024;       // points per LDS tile (16 KiB as float4)
+constexpr int BQ_MAX_NS_LDS = 64;   // hit lists up to this nsample are buffered in LDS and written coalesced
 
+// One lane per centre.  Points are staged in LDS as float4 so a point is ONE ds_read_b128 that every lane
+// of the wave reads at the same address (broadcast, conflict free); the scan is unrolled by 4 so the LDS
+// latency of the next points hides under the distance arithmetic.  Hits are collected per lane in LDS
+// ([slot][lane] layout: conflict free) and written out at the end with coalesced stores -- the 64
+// centres of a wave own one contiguous 64*nsample block of idx.
+template <bool HITS_IN_LDS>
 __global__ __launch_bounds__(CMF_WAVE) void ball_query_kernel(
     int n, int m, float radius2, int nsample,
     const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx)
 {
-    __shared__ float tile[BQ_TILE * 3];
+    __shared__ float4 tile[BQ_TILE];
+    __shared__ int hits[HITS_IN_LDS ? BQ_MAX_NS_LDS * CMF_WAVE : 1];
     const int bs = blockIdx.y;
-    const int pt = blockIdx.x * CMF_WAVE + threadIdx.x;
+    const int lane = threadIdx.x;
+    const int pt = blockIdx.x * CMF_WAVE + lane;
     const bool live = pt < m;
     const float *pts = xyz + (size_t)bs * n * 3;
     float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -36,31 +45,61 @@ __global__ __launch_bounds__(CMF_WAVE) void ball_query_kernel(
     int cnt = live ? 0 : nsample;       // dead lanes count as finished
     int first = 0;
 
+    auto dist2 = [&](const float4 p) {
+        const float dx = cx - p.x;
+        const float dy = cy - p.y;
+        const float dz = cz - p.z;
+        const float xx = dx * dx;
+        const float yy = dy * dy;
+        const float zz = dz * dz;
+        const float s = xx + yy;
+        return s + zz;
+    };
+    auto take = [&](bool hit, int k) {
+        if (hit && cnt < nsample) {
+            if (cnt == 0) first = k;
+            if (HITS_IN_LDS) hits[cnt * CMF_WAVE + lane] = k; else out[cnt] = k;
+            ++cnt;
+        }
+    };
+
     for (int base = 0; base < n; base += BQ_TILE) {
         const int len = min(BQ_TILE, n - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < len * 3; i += CMF_WAVE) tile[i] = pts[(size_t)base * 3 + i];
+        for (int i = lane; i < len; i += CMF_WAVE) {
+            const float *q = pts + (size_t)(base + i) * 3;
+            tile[i] = make_float4(q[0], q[1], q[2], 0.f);
+        }
         __syncthreads();
         if (__all(cnt >= nsample)) break;           // wave-uniform early exit
-        for (int k = 0; k < len; ++k) {
-            const float dx = cx - tile[k * 3 + 0];
-            const float dy = cy - tile[k * 3 + 1];
-            const float dz = cz - tile[k * 3 + 2];
-            const float xx = dx * dx;
-            const float yy = dy * dy;
-            const float zz = dz * dz;
-            const float s = xx + yy;
-            const float d2 = s + zz;
-            if (d2 < radius2 && cnt < nsample) {
-                if (cnt == 0) first = base + k;
-                out[cnt] = base + k;
-                ++cnt;
+        int k = 0;
+        for (; k + 4 <= len; k += 4) {
+            const float4 p0 = tile[k], p1 = tile[k + 1], p2 = tile[k + 2], p3 = tile[k + 3];
+            const bool h0 = dist2(p0) < radius2, h1 = dist2(p1) < radius2;
+            const bool h2 = dist2(p2) < radius2, h3 = dist2(p3) < radius2;
+            // hits are rare (<= nsample of n): one wave-uniform branch skips the bookkeeping for 4 points
+            if (__any(h0 | h1 | h2 | h3)) {
+                take(h0, base + k); take(h1, base + k + 1); take(h2, base + k + 2); take(h3, base + k + 3);
             }
         }
+        for (; k < len; ++k) take(dist2(tile[k]) < radius2, base + k);
     }
     // pad with the first hit (ball_query_gpu.cu:37-41); an empty ball leaves idx untouched
+    if (!HITS_IN_LDS) {
+        if (live && cnt > 0)
+            for (int l = cnt; l < nsample; ++l) out[l] = first;
+        return;
+    }
     if (live && cnt > 0)
-        for (int l = cnt; l < nsample; ++l) out[l] = first;
+        for (int l = cnt; l < nsample; ++l) hits[l * CMF_WAVE + lane] = first;
+    // coalesced write-out of the wave's 64 x nsample block; lanes with an empty ball keep idx as it was
+    const unsigned long long nonempty = __ballot(live && cnt > 0);
+    const int total = CMF_WAVE * nsample;
+    int *blk = idx + ((size_t)bs * m + (size_t)blockIdx.x * CMF_WAVE) * nsample;
+    for (int e = lane; e < total; e += CMF_WAVE) {
+        const int c = e / nsample, sl = e - c * nsample;
+        if ((nonempty >> c) & 1ull) blk[e] = hits[sl * CMF_WAVE + c];
+    }
 }
 
 extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
@@ -70,8 +109,12 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     if (b == 0 || m == 0 || n == 0) return 0;
     CMF_CHECK_ARG(new_xyz && xyz && idx);
     dim3 grid(cmf_divup(m, CMF_WAVE), b);
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
-                       n, m, radius * radius, nsample, new_xyz, xyz, idx);
+    if (nsample <= BQ_MAX_NS_LDS && n <= 1024)      // small clouds: latency bound, coalesced write-out pays
+        hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
+                           n, m, radius * radius, nsample, new_xyz, xyz, idx);
+    else
+        hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
+                           n, m, radius * radius, nsample, new_xyz, xyz, idx);
     return cmf_launch_status();
 }
 
