@@ -35,8 +35,8 @@ class FlatGradBucket:
                     p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
                 raise RuntimeError("a gradient left the flat bucket (zero_grad(set_to_none=True)?)")
 
-    def all_reduce_mean(self, group=None):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    def all_reduce_mean(self, group=None, force=False):
+        if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.mul_(1.0 / dist.get_world_size(group))
 
