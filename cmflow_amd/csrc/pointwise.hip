@@ -23,8 +23,17 @@ __device__ __forceinline__ double fin_reduce(int tiles, int ncols, int col, cons
 {
     const int cl = threadIdx.x % FIN_COLS, tl = threadIdx.x / FIN_COLS;
     double s = 0.0;
-    if (col < ncols)
-        for (int t = tl; t < tiles; t += FIN_LANES) s += (double)partial[(size_t)t * ncols + col];
+    if (col < ncols) {
+        int t = tl;
+        for (; t + 7 * FIN_LANES < tiles; t += 8 * FIN_LANES) {       // 8 loads in flight; order of the sum is fixed
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(t + u * FIN_LANES) * ncols + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
+        for (; t < tiles; t += FIN_LANES) s += (double)partial[(size_t)t * ncols + col];
+    }
     sh[tl * FIN_COLS + cl] = s;
     __syncthreads();
     double r = 0.0;
