@@ -209,7 +209,19 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_kernel(
     for (int col = lane * VEC; col < c; col += CMF_WAVE * VEC) {
         if (VEC == 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int t = beg; t < end; ++t) {
+            int t = beg;
+            for (; t + 4 <= end; t += 4) {          // 4 index loads, then 4 row loads in flight; sum order unchanged
+                const int e0 = lst[t], e1 = lst[t + 1], e2 = lst[t + 2], e3 = lst[t + 3];
+                const float4 v0 = *reinterpret_cast<const float4 *>(g + (size_t)e0 * c + col);
+                const float4 v1 = *reinterpret_cast<const float4 *>(g + (size_t)e1 * c + col);
+                const float4 v2 = *reinterpret_cast<const float4 *>(g + (size_t)e2 * c + col);
+                const float4 v3 = *reinterpret_cast<const float4 *>(g + (size_t)e3 * c + col);
+                acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+                acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+                acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+                acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+            }
+            for (; t < end; ++t) {
                 const float4 v = *reinterpret_cast<const float4 *>(g + (size_t)lst[t] * c + col);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }

@@ -154,27 +154,44 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
         for (int k = 0; k < 3; ++k) wx[j][k] = Wx[(size_t)(tm.col + j) * ldw + k];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     const long long row0 = (long long)blockIdx.x * PW_ROWS;
-    for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
-        const long long row = row0 + r;                 // (b*P + p)*S + s
-        if (row >= rows) break;
-        const long long bp = row / S;
-        const int b = (int)(bp / P);
-        const int j = idx[row];
-        const float *xs = xyz_src + ((size_t)b * n_src + j) * 3;
-        const float *xc = xyz_ctr + (size_t)bp * 3;
-        const float dx = xs[0] - xc[0], dy = xs[1] - xc[1], dz = xs[2] - xc[2];
-        float4 v = *(const float4 *)(ysrc + ((size_t)b * n_src + j) * ld_src + tm.col);
-        if (yctr) { const float4 c = *(const float4 *)(yctr + (size_t)bp * ld_ctr + tm.col); v.x += c.x; v.y += c.y; v.z += c.z; v.w += c.w; }
-        v.x += fmaf(wx[0][2], dz, fmaf(wx[0][1], dy, wx[0][0] * dx));
-        v.y += fmaf(wx[1][2], dz, fmaf(wx[1][1], dy, wx[1][0] * dx));
-        v.z += fmaf(wx[2][2], dz, fmaf(wx[2][1], dy, wx[2][0] * dx));
-        v.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
-        if (act == 2) { v.x = v.x > 0.f ? v.x : 0.1f * v.x; v.y = v.y > 0.f ? v.y : 0.1f * v.y;
-                        v.z = v.z > 0.f ? v.z : 0.1f * v.z; v.w = v.w > 0.f ? v.w : 0.1f * v.w; }
-        *(float4 *)(z + (size_t)row * C + tm.col) = v;
-        if (dxyz && tm.col == 0) *(float4 *)(dxyz + (size_t)row * 4) = make_float4(dx, dy, dz, 0.f);
-        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+    // 4 rows per step: the idx -> source-row dependent loads of 4 rows are in flight together
+    for (int rb = tm.r0; rb < PW_ROWS; rb += 4 * tm.rl) {
+        long long rows4[4]; int jj[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rows4[u] = row0 + rb + u * tm.rl;
+            ok[u] = (rb + u * tm.rl < PW_ROWS) && rows4[u] < rows;
+            jj[u] = ok[u] ? idx[rows4[u]] : 0;
+        }
+        float4 v[4], cc[4]; float d[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long row = ok[u] ? rows4[u] : 0;
+            const long long bp = row / S;
+            const int b = (int)(bp / P);
+            const float *xs = xyz_src + ((size_t)b * n_src + jj[u]) * 3;
+            const float *xc = xyz_ctr + (size_t)bp * 3;
+            d[u][0] = xs[0] - xc[0]; d[u][1] = xs[1] - xc[1]; d[u][2] = xs[2] - xc[2];
+            v[u] = *(const float4 *)(ysrc + ((size_t)b * n_src + jj[u]) * ld_src + tm.col);
+            cc[u] = yctr ? *(const float4 *)(yctr + (size_t)bp * ld_ctr + tm.col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!ok[u]) continue;
+            const float dx = d[u][0], dy = d[u][1], dz = d[u][2];
+            float4 o = v[u];
+            o.x += cc[u].x; o.y += cc[u].y; o.z += cc[u].z; o.w += cc[u].w;
+            o.x += fmaf(wx[0][2], dz, fmaf(wx[0][1], dy, wx[0][0] * dx));
+            o.y += fmaf(wx[1][2], dz, fmaf(wx[1][1], dy, wx[1][0] * dx));
+            o.z += fmaf(wx[2][2], dz, fmaf(wx[2][1], dy, wx[2][0] * dx));
+            o.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
+            if (act == 2) { o.x = o.x > 0.f ? o.x : 0.1f * o.x; o.y = o.y > 0.f ? o.y : 0.1f * o.y;
+                            o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
+            *(float4 *)(z + (size_t)rows4[u] * C + tm.col) = o;
+            if (dxyz && tm.col == 0) *(float4 *)(dxyz + (size_t)rows4[u] * 4) = make_float4(dx, dy, dz, 0.f);
+            s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
+            s2.x += o.x * o.x; s2.y += o.y * o.y; s2.z += o.z * o.z; s2.w += o.w * o.w;
+        }
     }
     if (partial) tile_reduce_store(s1, s2, tm, C, partial, red);
 }
