@@ -53,6 +53,8 @@ struct GemmArgs {
     int bwd_mode;
     const float *Z; long long ldz;
     const float *ea, *ec, *emean, *einvstd;
+    const float *dxyz;          // bwd_mode 1 only, optional: rows of (dx,dy,dz,0); adds partials q_k = sum dU * d_k (k=0..2)
+                                // -> stats is then [tiles_m][5][N] (s1, s2, q0, q1, q2): the set-conv dW_xyz without a pass
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
 };
@@ -335,6 +337,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                 if (p.bwd_mode == 1) { ea[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
             }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float qs[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    const bool want_q = want_stats && p.bwd_mode == 1 && p.dxyz != nullptr;
+    const int nstat = want_q ? 5 : 2;
 #pragma unroll
     for (int band = 0; band < WARPS_M; ++band) {
         if (band > 0) __syncthreads();                   // previous band fully consumed
@@ -358,6 +363,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             float v[4] = {t4.x, t4.y, t4.z, t4.w};
             if (p.split_k == 1) {
                 float z[4] = {0, 0, 0, 0};
+                float4 dd = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (want_q) dd = *(const float4 *)(p.dxyz + (long long)m * 4);
                 if (p.bwd_mode) {
                     const float *zp = p.Z + (long long)m * p.ldz + n;
                     if (vec) { const float4 z4 = *(const float4 *)zp; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w; }
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                     if (p.bwd_mode == 1) {
                         x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
                         s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
+                        if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
                     } else if (p.bwd_mode == 2) x = z[q] > 0.f ? x : 0.1f * x;
                     else if (p.bwd_mode == 3) x = z[q] > 0.f ? x : 0.f;
                     else if (want_stats) { s1[q] += x; s2[q] += x * x; }
@@ -388,17 +396,20 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     }
     if (want_stats) {
         __syncthreads();                                 // all tile reads done: reuse LDS for the column reduction
-        float *red = smem;                               // [RPP][2][BN]
+        float *red = smem;                               // [RPP][nstat][BN]
         const int rg = tid / TPR;
-        *(float4 *)(red + (rg * 2 + 0) * BN + col) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-        *(float4 *)(red + (rg * 2 + 1) * BN + col) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        *(float4 *)(red + (rg * nstat + 0) * BN + col) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *(float4 *)(red + (rg * nstat + 1) * BN + col) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        if (want_q)
+            for (int k = 0; k < 3; ++k)
+                *(float4 *)(red + (rg * nstat + 2 + k) * BN + col) = make_float4(qs[k][0], qs[k][1], qs[k][2], qs[k][3]);
         __syncthreads();
-        for (int c = tid; c < 2 * BN; c += G_THREADS) {
+        for (int c = tid; c < nstat * BN; c += G_THREADS) {
             const int which = c / BN, cc = c % BN;
             float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < RPP; ++g) sum += red[(g * 2 + which) * BN + cc];
-            if (n0 + cc < p.N) p.stats[((long long)tm * 2 + which) * p.N + n0 + cc] = sum;
+            for (int g = 0; g < RPP; ++g) sum += red[(g * nstat + which) * BN + cc];
+            if (n0 + cc < p.N) p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
         }
     }
 }
@@ -463,7 +474,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
                         const float *bias, int act, float *stats,
                         int bwd_mode, const float *Z, long long ldz,
                         const float *ea, const float *ec, const float *emean, const float *einvstd,
-                        int split_k, float *workspace, int accumulate, void *stream)
+                        const float *dxyz, int split_k, float *workspace, int accumulate, void *stream)
 {
     CMF_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && split_k >= 1);
     if (M == 0 || N == 0) return 0;
@@ -480,7 +491,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.C = split_k > 1 ? workspace : C; g.ldc = split_k > 1 ? N : ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.prob_a = prob_a; g.prob_c = prob_c;
     g.bias = bias; g.act = act; g.stats = stats; g.bwd_mode = bwd_mode; g.Z = Z; g.ldz = ldz;
-    g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.split_k = split_k;
+    g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz; g.split_k = split_k;
     g.accumulate = split_k > 1 ? 0 : accumulate;
     int err;
     const bool wide = N > 64, tall = M > 64;

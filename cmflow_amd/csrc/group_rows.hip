@@ -253,3 +253,72 @@ extern "C" int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, in
                             n, c, ldg, entries, accumulate, (int)waves, grad_out, offsets, inv, grad_feat);
     return cmf_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Set-conv first-layer backward: scatter of dZ with the BatchNorm backward fused in.
+//   dZ[e,:] = a*(dU[e,:] - s1/M - zhat[e,:]*s2/M),  zhat = (z - mean)*invstd     (never written)
+//   grad_feat[b,j,:] = sum_{e in inv(j)} dZ[e,:]      (ascending e: deterministic)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_kernel(
+    int n, int c, int entries, int total_waves, const float *__restrict__ dU, const float *__restrict__ z,
+    const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ sums, float inv_count,
+    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat)
+{
+    const int wave = (blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
+    if (wave >= total_waves) return;
+    const int lane = threadIdx.x % CMF_WAVE;
+    const int bs = wave / n, j = wave - bs * n;
+    const int *off = offsets + (size_t)bs * (n + 1);
+    const int beg = off[j], end = off[j + 1];
+    const int *lst = inv + (size_t)bs * entries;
+    const float *gu = dU + (size_t)bs * entries * c;
+    const float *gz = z + (size_t)bs * entries * c;
+    float *dst = grad_feat + ((size_t)bs * n + j) * c;
+    for (int col = lane * 4; col < c; col += CMF_WAVE * 4) {
+        const float4 sa = *(const float4 *)(a + col);
+        float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, mu = k0;     // dZ = sa*(dU - k0 - (z-mu)*k1)
+        if (sums) {
+            const float4 t1 = *(const float4 *)(sums + col), t2 = *(const float4 *)(sums + c + col);
+            const float4 is = *(const float4 *)(invstd + col);
+            mu = *(const float4 *)(mean + col);
+            k0 = make_float4(t1.x * inv_count, t1.y * inv_count, t1.z * inv_count, t1.w * inv_count);
+            k1 = make_float4(is.x * t2.x * inv_count, is.y * t2.y * inv_count, is.z * t2.z * inv_count, is.w * t2.w * inv_count);
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = beg;
+        for (; t + 2 <= end; t += 2) {
+            const int e0 = lst[t], e1 = lst[t + 1];
+            const float4 u0 = *(const float4 *)(gu + (size_t)e0 * c + col), u1 = *(const float4 *)(gu + (size_t)e1 * c + col);
+            float4 z0 = mu, z1 = mu;
+            if (sums) { z0 = *(const float4 *)(gz + (size_t)e0 * c + col); z1 = *(const float4 *)(gz + (size_t)e1 * c + col); }
+            acc.x += sa.x * (u0.x - k0.x - (z0.x - mu.x) * k1.x); acc.y += sa.y * (u0.y - k0.y - (z0.y - mu.y) * k1.y);
+            acc.z += sa.z * (u0.z - k0.z - (z0.z - mu.z) * k1.z); acc.w += sa.w * (u0.w - k0.w - (z0.w - mu.w) * k1.w);
+            acc.x += sa.x * (u1.x - k0.x - (z1.x - mu.x) * k1.x); acc.y += sa.y * (u1.y - k0.y - (z1.y - mu.y) * k1.y);
+            acc.z += sa.z * (u1.z - k0.z - (z1.z - mu.z) * k1.z); acc.w += sa.w * (u1.w - k0.w - (z1.w - mu.w) * k1.w);
+        }
+        for (; t < end; ++t) {
+            const int e0 = lst[t];
+            const float4 u0 = *(const float4 *)(gu + (size_t)e0 * c + col);
+            float4 z0 = mu;
+            if (sums) z0 = *(const float4 *)(gz + (size_t)e0 * c + col);
+            acc.x += sa.x * (u0.x - k0.x - (z0.x - mu.x) * k1.x); acc.y += sa.y * (u0.y - k0.y - (z0.y - mu.y) * k1.y);
+            acc.z += sa.z * (u0.z - k0.z - (z0.z - mu.z) * k1.z); acc.w += sa.w * (u0.w - k0.w - (z0.w - mu.w) * k1.w);
+        }
+        *(float4 *)(dst + col) = acc;
+    }
+}
+
+extern "C" int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, const float *z,
+                                      const float *a, const float *mean, const float *invstd, const float *sums,
+                                      float inv_count, const int *offsets, const int *inv, float *grad_feat, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && c % 4 == 0 && entries >= 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(dU && a && offsets && inv && grad_feat && (!sums || (z && mean && invstd)));
+    const long long waves = (long long)b * n;
+    const int grid = (int)((waves * CMF_WAVE + GR_THREADS - 1) / GR_THREADS);
+    hipLaunchKernelGGL(group_rows_grad_bn_kernel, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                       n, c, entries, (int)waves, dU, z, a, mean, invstd, sums, inv_count, offsets, inv, grad_feat);
+    return cmf_launch_status();
+}

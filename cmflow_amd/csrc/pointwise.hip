@@ -104,6 +104,42 @@ extern "C" int cmf_colsum_finalize(int tiles, int C, const float *partial, float
     return cmf_launch_status();
 }
 
+extern "C" int cmf_colsum(int tiles, int ncols, const float *partial, float *out, void *stream)
+{
+    CMF_CHECK_ARG(tiles > 0 && ncols > 0 && partial && out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(ncols, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
+                       tiles, ncols, partial, out);
+    return cmf_launch_status();
+}
+
+// dW_xyz of the set-conv first layer from column sums (see cmflow_hip.h)
+__global__ void setconv_dwx_kernel(int C, float inv_count, int train, const float *__restrict__ bwd5,
+                                   const float *__restrict__ fwd, const float *__restrict__ a,
+                                   const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ dwx)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = bwd5[c], s2 = bwd5[C + c];
+    for (int k = 0; k < 3; ++k) {
+        const float q = bwd5[(2 + k) * C + c];
+        float g = q;
+        if (train) {
+            const float u = fwd[3 * C + k], tz = fwd[k * C + c];
+            g = q - (s1 * inv_count) * u - (s2 * inv_count) * invstd[c] * (tz - mean[c] * u);
+        }
+        dwx[c * 3 + k] = a[c] * g;
+    }
+}
+
+extern "C" int cmf_setconv_dwx(int C, float inv_count, int train, const float *bwd5, const float *fwd,
+                               const float *a, const float *mean, const float *invstd, float *dwx, void *stream)
+{
+    CMF_CHECK_ARG(C > 0 && bwd5 && a && dwx && (!train || (fwd && mean && invstd)));
+    hipLaunchKernelGGL(setconv_dwx_kernel, dim3(cmf_divup(C, 64)), dim3(64), 0, (hipStream_t)stream,
+                       C, inv_count, train, bwd5, fwd, a, mean, invstd, dwx);
+    return cmf_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile-shaped streaming helper: a workgroup owns PW_ROWS rows x all C columns; thread t owns the
 // float4 column group (t % CG) and the rows (t / CG) + k*RL.  Column partial sums are reduced over
@@ -143,10 +179,12 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
     const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr, int ld_ctr,
     const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
     const float *__restrict__ Wx, int ldw, const int *__restrict__ idx, int act,
-    float *__restrict__ z, float *__restrict__ dxyz, float *__restrict__ partial)
+    float *__restrict__ z, float *__restrict__ dxyz, float *__restrict__ partial, float *__restrict__ partial_x)
 {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const TileMap tm = tile_map(C);
+    float4 tz0 = make_float4(0.f, 0.f, 0.f, 0.f), tz1 = tz0, tz2 = tz0;     // sum z*dx, z*dy, z*dz per channel
+    float ud0 = 0.f, ud1 = 0.f, ud2 = 0.f;                                   // sum dx, dy, dz (column group 0 only)
     float wx[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -191,23 +229,53 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             if (dxyz && tm.col == 0) *(float4 *)(dxyz + (size_t)rows4[u] * 4) = make_float4(dx, dy, dz, 0.f);
             s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
             s2.x += o.x * o.x; s2.y += o.y * o.y; s2.z += o.z * o.z; s2.w += o.w * o.w;
+            if (partial_x) {
+                tz0.x += o.x * dx; tz0.y += o.y * dx; tz0.z += o.z * dx; tz0.w += o.w * dx;
+                tz1.x += o.x * dy; tz1.y += o.y * dy; tz1.z += o.z * dy; tz1.w += o.w * dy;
+                tz2.x += o.x * dz; tz2.y += o.y * dz; tz2.z += o.z * dz; tz2.w += o.w * dz;
+                ud0 += dx; ud1 += dy; ud2 += dz;
+            }
         }
     }
     if (partial) tile_reduce_store(s1, s2, tm, C, partial, red);
+    if (partial_x) {
+        // same tree as tile_reduce_store, for the 3 z*d_k column sums and the 3 scalar d_k sums: row
+        // layout of partial_x is [tz0[C] | tz1[C] | tz2[C] | u0 u1 u2 0]
+        __syncthreads();
+        float *r = red + (size_t)tm.r0 * 2 * C;          // reuse [rl][2][C]: two passes
+        float *px = partial_x + (size_t)blockIdx.x * (3 * C + 4);
+        *(float4 *)(r + tm.col) = tz0; *(float4 *)(r + C + tm.col) = tz1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += PW_THREADS) {
+            float sum = 0.f;
+            for (int l = 0; l < tm.rl; ++l) sum += red[(size_t)l * 2 * C + i];
+            px[i] = sum;
+        }
+        __syncthreads();
+        *(float4 *)(r + tm.col) = tz2;
+        if (tm.col == 0) *(float4 *)(r + C) = make_float4(ud0, ud1, ud2, 0.f);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C + 4; i += PW_THREADS) {
+            float sum = 0.f;
+            for (int l = 0; l < tm.rl; ++l) sum += red[(size_t)l * 2 * C + i];
+            px[2 * C + i] = sum;
+        }
+    }
 }
 
 extern "C" int cmf_group_affine(int b, int n_src, int P, int S, int C,
                                 const float *ysrc, int ld_src, const float *yctr, int ld_ctr,
                                 const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
-                                const int *idx, int act, float *z, float *dxyz, float *partial, void *stream)
+                                const int *idx, int act, float *z, float *dxyz, float *partial, float *partial_x, void *stream)
 {
     CMF_CHECK_ARG(b >= 0 && n_src > 0 && P > 0 && S > 0 && tile_ok(C));
     if (b == 0) return 0;
     CMF_CHECK_ARG(ysrc && xyz_src && xyz_ctr && Wx && idx && z && ld_src % 4 == 0 && (!yctr || ld_ctr % 4 == 0));
+    CMF_CHECK_ARG(!partial_x || (partial && C >= 4));
     const long long rows = (long long)b * P * S;
     const int tiles = cmf_divup(rows, PW_ROWS);
     hipLaunchKernelGGL(group_affine_kernel, dim3(tiles), dim3(PW_THREADS), partial ? tile_lds(C) : 0, (hipStream_t)stream,
-                       n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial);
+                       n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial, partial_x);
     return cmf_launch_status();
 }
 

@@ -117,8 +117,9 @@ def gemm(A, B, *, a_t=False, b_t=True, out=None, pro=None, prob=None, bias=None,
         out = torch.empty(M, N, dtype=_f32, device=dev)
     assert out.stride(1) == 1 and out.shape == (M, N)
     st = None
+    dxyz = bwd[6] if (bwd is not None and len(bwd) > 6) else None
     if stats or (bwd is not None and bwd[0] == 1):
-        st = torch.empty(_lib.lib().cmf_gemm_tiles_m(M), 2, N, dtype=_f32, device=dev)
+        st = torch.empty(_lib.lib().cmf_gemm_tiles_m(M), 5 if dxyz is not None else 2, N, dtype=_f32, device=dev)
     ws = torch.empty(split_k, M, N, dtype=_f32, device=dev) if split_k > 1 else None
     mode, Z, ea, ec, em, ei = 0, None, None, None, None, None
     if bwd is not None:
@@ -130,6 +131,6 @@ def gemm(A, B, *, a_t=False, b_t=True, out=None, pro=None, prob=None, bias=None,
         M, N, K, int(a_t), int(b_t), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0),
         _p(pro[0]) if pro else None, _p(pro[1]) if pro else None, _p(prob[0]) if prob else None,
         _p(prob[1]) if prob else None, _p(bias), act, _p(st), mode, _p(Z), Z.stride(0) if Z is not None else 0,
-        _p(ea), _p(ec), _p(em), _p(ei), split_k, _p(ws), int(accumulate), _lib.stream_ptr()))
+        _p(ea), _p(ec), _p(em), _p(ei), _p(dxyz), split_k, _p(ws), int(accumulate), _lib.stream_ptr()))
     _lib.check(err, "cmf_gemm")
     return (out, st) if st is not None else out

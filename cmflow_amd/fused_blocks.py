@@ -68,8 +68,8 @@ def colsum(partial):
     return out
 
 
-def group_affine(ysrc, yctr, xyz_src, xyz_ctr, wx, idx, act=0, stats=True, want_dxyz=True):
-    """-> z (B,P,S,C), dxyz (B,P,S,4) or None, partial or None.  ysrc (B,n_src,C) row-strided view."""
+def group_affine(ysrc, yctr, xyz_src, xyz_ctr, wx, idx, act=0, stats=True, want_dxyz=True, extra=False):
+    """-> z (B,P,S,C), dxyz (B,P,S,4) or None, partial or None[, partial_x].  ysrc (B,n_src,C) row-strided view."""
     B, n_src, C = ysrc.shape
     _, P, S = idx.shape
     assert ysrc.stride(2) == 1 and ysrc.stride(0) == n_src * ysrc.stride(1)
@@ -77,12 +77,15 @@ def group_affine(ysrc, yctr, xyz_src, xyz_ctr, wx, idx, act=0, stats=True, want_
     z = torch.empty(B, P, S, C, dtype=_f32, device=dev)
     dxyz = torch.empty(B, P, S, 4, dtype=_f32, device=dev) if want_dxyz else None
     part = torch.empty(_tiles(B * P * S), 2, C, dtype=_f32, device=dev) if stats else None
+    part_x = torch.empty(_tiles(B * P * S), 3 * C + 4, dtype=_f32, device=dev) if (stats and extra) else None
     wx = wx.contiguous()
     err = L().cmf_group_affine(B, n_src, P, S, C, ysrc.data_ptr(), ysrc.stride(1),
                                _p(yctr), yctr.stride(1) if yctr is not None else 0,
                                _p(xyz_src), _p(xyz_ctr), _p(wx), wx.stride(0), _p(idx), act,
-                               _p(z), _p(dxyz), _p(part), _lib.stream_ptr())
+                               _p(z), _p(dxyz), _p(part), _p(part_x), _lib.stream_ptr())
     _lib.check(err, "cmf_group_affine")
+    if extra:
+        return z, dxyz, part, part_x
     return z, dxyz, part
 
 
@@ -124,6 +127,14 @@ def act_bwd_stats(dY, z, st):
                                 _p(st.mean), _p(st.invstd), _p(dU), _p(part), _lib.stream_ptr())
     _lib.check(err, "cmf_act_bwd_stats")
     return dU, part
+
+
+def colsum_n(partial):
+    """[tiles][...] -> [...] column sums in fixed order"""
+    ncols = partial[0].numel()
+    out = torch.empty(partial.shape[1:], dtype=_f32, device=partial.device)
+    _lib.check(L().cmf_colsum(partial.shape[0], ncols, _p(partial), _p(out), _lib.stream_ptr()), "cmf_colsum")
+    return out
 
 
 def bn_backward(dU, part, z, st):
@@ -306,7 +317,12 @@ class SetConvFn(Function):
         wx, g1, b1, w2, g2, b2, w3, g3, b3, w4, g4, b4, w5, g5, b5, w6, g6, b6 = params
         idx = pointutils.ball_query(radius, nsample, xyz_t, xyz_t)
         nbr = Neighbors(idx, N)
-        z1, dxyz, part = group_affine(y, None, xyz_t, xyz_t, wx, idx, act=0, stats=training)
+        if training:
+            z1, dxyz, part, part_x = group_affine(y, None, xyz_t, xyz_t, wx, idx, act=0, stats=True, extra=True)
+            fwd_sums = colsum_n(part_x)                     # [3*O1 + 4]: sum z*d_k per channel, sum d_k
+        else:
+            z1, dxyz, part = group_affine(y, None, xyz_t, xyz_t, wx, idx, act=0, stats=False)
+            fwd_sums = None
         M = B * N * nsample
         z1 = z1.view(M, -1)
         st1 = bn_fold(bns[0], part, M)
@@ -319,12 +335,12 @@ class SetConvFn(Function):
         z6, st6 = _fwd_layer(z5, st5, w6, bns[5], training)
         res = affine_relu(z6, st6)
         ctx.saved = (nbr, dxyz, z1, z2, z3, am, x, z4, z5, z6, (st1, st2, st3, st4, st5, st6), (w2, w3, w4, w5, w6),
-                     (B, N, nsample), y.shape[2])
+                     (B, N, nsample), y.shape[2], fwd_sums)
         return res.view(B, N, -1)
 
     @staticmethod
     def backward(ctx, dout):
-        nbr, dxyz, z1, z2, z3, am, x, z4, z5, z6, sts, ws, (B, N, S), O1 = ctx.saved
+        nbr, dxyz, z1, z2, z3, am, x, z4, z5, z6, sts, ws, (B, N, S), O1, fwd_sums = ctx.saved
         st1, st2, st3, st4, st5, st6 = sts
         w2, w3, w4, w5, w6 = ws
         dout = dout.reshape(B * N, -1)
@@ -340,16 +356,26 @@ class SetConvFn(Function):
         dZ3, g["g3"], g["b3"] = bn_backward(dU, part, z3, st3)
         g["w3"], dU, part = _bwd_layer(dZ3, z2, st2, w3)
         dZ2, g["g2"], g["b2"] = bn_backward(dU, part, z2, st2)
-        g["w2"], dU, part = _bwd_layer(dZ2, z1, st1, w2)
-        dZ1, g["g1"], g["b1"] = bn_backward(dU, part, z1, st1)
-        # z1 = y[idx] + wx . dxyz
-        dwx = gemm_dw(dZ1, dxyz.view(-1, 4))[:, :3]
+        # first layer: z1 = y[idx] + wx . dxyz.  The dX GEMM masks by ReLU'(z1) and emits, next to the two BN sums,
+        # the three column sums of dU*d_k; the BN backward is then folded into the scatter (dZ1 is never written)
+        # and dW_xyz follows from column sums alone (no pass over the M x O1 tensor, no N=4 GEMM).
+        g["w2"] = gemm_dw(dZ2, z1, prob=(st1.a, st1.c))
+        dU, part = gemm(dZ2, w2, b_t=False, bwd=(1, z1, st1.a, st1.c, st1.mean, st1.invstd, dxyz.view(-1, 4)))
+        sums5 = colsum_n(part)                               # [5][O1]: s1, s2, q0, q1, q2
+        g["g1"], g["b1"] = sums5[1], sums5[0]
+        M = dU.shape[0]
+        dwx = torch.empty(O1, 3, dtype=_f32, device=dU.device)
+        err = L().cmf_setconv_dwx(O1, 1.0 / M, int(st1.training), _p(sums5), _p(fwd_sums), _p(st1.a), _p(st1.mean),
+                                  _p(st1.invstd), _p(dwx), _lib.stream_ptr())
+        _lib.check(err, "cmf_setconv_dwx")
         dy = None
         if ctx.needs_input_grad[1]:
             off, inv = nbr.inverse()
-            dy = torch.empty(B, N, O1, dtype=_f32, device=dZ1.device)
-            err = L().cmf_group_rows_grad(B, N, O1, O1, N * S, 0, _p(dZ1), _p(off), _p(inv), _p(dy), _lib.stream_ptr())
-            _lib.check(err, "cmf_group_rows_grad")
+            dy = torch.empty(B, N, O1, dtype=_f32, device=dU.device)
+            err = L().cmf_group_rows_grad_bn(B, N, O1, N * S, _p(dU), _p(z1), _p(st1.a), _p(st1.mean), _p(st1.invstd),
+                                             _p(sums5) if st1.training else None, 1.0 / M, _p(off), _p(inv), _p(dy),
+                                             _lib.stream_ptr())
+            _lib.check(err, "cmf_group_rows_grad_bn")
         return (None, dy, None, None, None, None, dwx, g["g1"], g["b1"], g["w2"], g["g2"], g["b2"], g["w3"], g["g3"],
                 g["b3"], g["w4"], g["g4"], g["b4"], g["w5"], g["g5"], g["b5"], g["w6"], g["g6"], g["b6"])
 

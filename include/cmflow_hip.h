@@ -95,6 +95,8 @@ int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, int accumulat
  *   bias [N], act: 0 none / 1 relu / 2 leaky(0.1) / 3 sigmoid
  *   stats: [ceil(M/128)][2][N] per-row-tile partial (sum, sum of squares) of the stored C
  *   bwd_mode 1: C = acc * [ea[n]*Z + ec[n] > 0], stats <- partial (sum C, sum C*(Z-emean)*einvstd)
+ *   dxyz (bwd_mode 1, optional): rows of (dx,dy,dz,0) per output row; stats becomes [tiles][5][N] with the
+ *                three extra partials sum C*d_k -- the set-conv's dW_xyz comes out of the epilogue
  *   bwd_mode 2: C = acc * (Z > 0 ? 1 : 0.1)        bwd_mode 3: C = acc * [Z > 0]
  *   split_k > 1: contraction split over split_k slabs in `workspace` ([split_k][M][N] floats),
  *                summed in a fixed order by a second kernel (deterministic weight gradients)
@@ -106,7 +108,7 @@ int cmf_gemm(int M, int N, int K, int a_t, int b_t,
              const float *bias, int act, float *stats,
              int bwd_mode, const float *Z, long long ldz,
              const float *ea, const float *ec, const float *emean, const float *einvstd,
-             int split_k, float *workspace, int accumulate, void *stream);
+             const float *dxyz, int split_k, float *workspace, int accumulate, void *stream);
 int cmf_gemm_tiles_m(int M);
 
 /* ---- BatchNorm / activation / pooling kernels around the GEMMs (point-major) ---------------------- *
@@ -120,6 +122,8 @@ int cmf_bn_finalize(int tiles, int C, double count, const float *partial, const 
                     float *mean_out, float *invstd_out, float *a_out, float *c_out, void *stream);
 /* out[2][C] = sum over tiles of partial[t][2][C] */
 int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void *stream);
+/* out[ncols] = sum over tiles of partial[t][ncols] (fixed order) */
+int cmf_colsum(int tiles, int ncols, const float *partial, float *out, void *stream);
 
 /* Set-conv / cost-volume grouping with the first 1x1 conv hoisted per point
  * (QueryAndGroup + first Conv2d, lib/pointnet2_utils.py:277-285 + radarflow_util.py:151;
@@ -127,11 +131,12 @@ int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void
  *   z[b,p,s,:] = act( ysrc[b,idx[b,p,s],:] + (yctr ? yctr[b,p,:] : 0) + Wx (xyz_src[b,idx] - xyz_ctr[b,p]) )
  * ysrc (b,n_src,ld_src), yctr (b,P,ld_ctr) or NULL, Wx (C,3) with row stride ldw, idx (b,P,S);
  * act 0 none / 2 leaky(0.1); z (b,P,S,C); dxyz (b,P,S,4) relative coordinates (optional);
- * partial: BN statistics of z (optional). */
+ * partial: BN statistics of z (optional); partial_x (optional, with partial): [tiles][3*C+4] extra sums
+ * sum z*d_k (k=0..2, per channel) and sum d_k, used by cmf_setconv_dwx in the backward pass. */
 int cmf_group_affine(int b, int n_src, int P, int S, int C,
                      const float *ysrc, int ld_src, const float *yctr, int ld_ctr,
                      const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
-                     const int *idx, int act, float *z, float *dxyz, float *partial, void *stream);
+                     const int *idx, int act, float *z, float *dxyz, float *partial, float *partial_x, void *stream);
 
 /* out[p,:] = max_s relu(a*z[p,s,:] + c): BN + ReLU + max over the ball (radarflow_util.py:151-155);
  * argmax (P,C) uint8 optional. */
@@ -151,6 +156,21 @@ int cmf_act_bwd_stats(long long M, int C, const float *dY, long long ldy, const 
 /* in place: dZ = a*(dU - s1/M - zhat*s2/M) with sums = {s1[C], s2[C]}; sums == NULL: dZ = a*dU (eval BN) */
 int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, long long ldz, const float *a,
                      const float *mean, const float *invstd, const float *sums, void *stream);
+
+/* Backward of the set-conv's grouping with the BatchNorm backward of the first layer fused in
+ * (radarflow_util.py:148-151 backward): dZ = a*(dU - s1/M - zhat*s2/M) is formed on the fly from dU and z,
+ * summed over the inverse index into grad_feat (b,n,c), and never written.  sums = {s1[C], s2[C]} or NULL
+ * (eval-mode BN: dZ = a*dU). */
+int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, const float *z,
+                           const float *a, const float *mean, const float *invstd, const float *sums,
+                           float inv_count, const int *offsets, const int *inv, float *grad_feat, void *stream);
+
+/* dW_xyz of the set-conv's first conv from column sums only (no pass over the grouped tensor):
+ *   dWx[c,k] = a_c*( q_k[c] - (s1_c/M)*u_k - (s2_c/M)*invstd_c*(tz_k[c] - mean_c*u_k) )
+ * bwd5 = {s1,s2,q0,q1,q2}[C] (cmf_gemm dxyz partials, reduced), fwd = {tz0,tz1,tz2}[C] then {u0,u1,u2,.}
+ * (cmf_group_affine extra partials, reduced); train == 0: dWx = a*q. */
+int cmf_setconv_dwx(int C, float inv_count, int train, const float *bwd5, const float *fwd,
+                    const float *a, const float *mean, const float *invstd, float *dwx, void *stream);
 
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);

@@ -23,4 +23,4 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): step(batch)
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(25)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
