@@ -29,7 +29,7 @@ SIGNATURES = {
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
-    "cmf_bn_finalize": [_ci, _ci, ctypes.c_double, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_bn_finalize": [_ci, _ci, ctypes.c_double, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp],
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _vp],
@@ -71,9 +71,15 @@ def lib():
     return _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
     """hipStream_t of torch's current stream (what at::cuda::getCurrentCUDAStream() is to the
-    reference wrappers, lib/src/ball_query.cpp:22)."""
+    reference wrappers, lib/src/ball_query.cpp:22).  Uses torch's raw-stream accessor when present:
+    torch.cuda.current_stream() builds a Python Stream object (~8 us), and this runs once per launch."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -48,9 +48,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float *__restrict__ gamma, const float *__restrict__ beta,
     float eps, float momentum, float *__restrict__ running_mean,
     float *__restrict__ running_var, float *__restrict__ mean_out,
-    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out)
+    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out,
+    long long *__restrict__ num_batches_tracked)
 {
     __shared__ double sh[FIN_COLS * FIN_LANES];
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     const int ch = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
     double mean = 0.0, var = 1.0;
     if (tiles > 0) {
@@ -79,11 +81,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
 extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *partial, const float *gamma,
                                const float *beta, float eps, float momentum, float *running_mean,
                                float *running_var, float *mean_out, float *invstd_out, float *a_out,
-                               float *c_out, void *stream)
+                               float *c_out, long long *num_batches_tracked, void *stream)
 {
     CMF_CHECK_ARG(C > 0 && a_out && c_out && (tiles == 0 ? (running_mean && running_var) : partial != nullptr));
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cmf_divup(C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream, tiles, C, count,
-                       partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out);
+                       partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
+                       num_batches_tracked);
     return cmf_launch_status();
 }
 

@@ -47,16 +47,19 @@ def bn_fold(bn, partial, count):
     st.training = partial is not None
     st.count = count
     if st.training:
-        if bn.track_running_stats:
+        track = bn.track_running_stats
+        if bn.momentum is None:                              # cumulative moving average needs the count on the host
             bn.num_batches_tracked.add_(1)
-        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            mom, nbt = 1.0 / float(bn.num_batches_tracked), None
+        else:
+            mom, nbt = bn.momentum, (_p(bn.num_batches_tracked) if track else None)   # counter bumped by the kernel
         err = L().cmf_bn_finalize(partial.shape[0], C, float(count), _p(partial), _p(bn.weight), _p(bn.bias),
-                                  bn.eps, mom, _p(bn.running_mean) if bn.track_running_stats else None,
-                                  _p(bn.running_var) if bn.track_running_stats else None,
-                                  _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), _lib.stream_ptr())
+                                  bn.eps, mom, _p(bn.running_mean) if track else None,
+                                  _p(bn.running_var) if track else None,
+                                  _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), nbt, _lib.stream_ptr())
     else:
         err = L().cmf_bn_finalize(0, C, 1.0, None, _p(bn.weight), _p(bn.bias), bn.eps, 0.0, _p(bn.running_mean),
-                                  _p(bn.running_var), _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), _lib.stream_ptr())
+                                  _p(bn.running_var), _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), None, _lib.stream_ptr())
     _lib.check(err, "cmf_bn_finalize")
     return st
 

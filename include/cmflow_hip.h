@@ -116,10 +116,12 @@ int cmf_gemm_tiles_m(int M);
 
 /* partial (sum, sumsq) over `count` rows -> mean, invstd (biased variance), running-stat update
  * (momentum, unbiased variance: torch BatchNorm2d train semantics, radarflow_util.py:133-139), and the
- * folded affine a = gamma*invstd, c = beta - mean*a.  tiles == 0: eval mode, fold the running stats. */
+ * folded affine a = gamma*invstd, c = beta - mean*a.  tiles == 0: eval mode, fold the running stats.
+ * num_batches_tracked (int64, optional) is incremented by one (nn.BatchNorm2d's counter). */
 int cmf_bn_finalize(int tiles, int C, double count, const float *partial, const float *gamma,
                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
-                    float *mean_out, float *invstd_out, float *a_out, float *c_out, void *stream);
+                    float *mean_out, float *invstd_out, float *a_out, float *c_out,
+                    long long *num_batches_tracked, void *stream);
 /* out[2][C] = sum over tiles of partial[t][2][C] */
 int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void *stream);
 /* out[ncols] = sum over tiles of partial[t][ncols] (fixed order) */

@@ -9,7 +9,7 @@ from cmflow_amd.train import TrainStep
 dev = torch.device("cuda:0")
 net = CMFlow(bench.Args()); net.load_state_dict(bench.load_weights("cmflow")); net = net.to(dev).train()
 step = TrainStep(net)
-batch = {k: v.to(dev) for k, v in synth.make_batch(64, seed=1234, train_extras=True).items()}
+batch = {k: v.to(dev) for k, v in synth.make_batch(int(os.environ.get("PROBE_B", "64")), seed=1234, train_extras=True).items()}
 for _ in range(3): step(batch)
 torch.cuda.synchronize()
 K = 10
