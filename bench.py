@@ -178,22 +178,44 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    def roofline_of(prof):
+        if not (prof and prof["launches"]):
+            return None
+        avg_ms = prof["ms"] / prof["launches"]
+        per_launch = prof["units"] / prof["launches"]
+        if prof["bound"] == "hbm":
+            achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        return {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
+                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
+                "algorithmic_per_launch": per_launch,
+                "launch_filter": "launches >= %.0e units (cmflow_amd/_lib.py TRACK_MIN_UNITS)" %
+                                 _lib.TRACK_MIN_UNITS.get(prof["kernel"], 0.0)}
+
+    # In the timed region the four scales of an encoder run on four HIP streams, so a bracketed launch shares
+    # the chip with kernels of the other streams and its duration is a contended one.  A short extra pass with
+    # the scales serialised (outside the timed region, not part of `value`) gives the kernel's own rate.
+    iso = None
+    if rank == 0 and a.path == "pm":
+        from cmflow_amd.radarflow_util import MultiScaleEncoder
+        for m in net.modules():
+            if isinstance(m, MultiScaleEncoder):
+                m.multi_stream = False
+        one(); torch.cuda.synchronize()
+        _lib.profile_begin(track, "hbm" if track == "cmf_group_points" else "mfma")
+        for _ in range(3):
+            one()
+        iso = roofline_of(_lib.profile_end())
+        if iso:
+            iso["note"] = "3 extra steps with the encoder scales serialised on one stream (outside the timed region)"
+
     if rank == 0:
         pairs = a.batch * world * a.steps
-        roof = None
-        if prof and prof["launches"]:
-            avg_ms = prof["ms"] / prof["launches"]
-            per_launch = prof["units"] / prof["launches"]
-            if prof["bound"] == "hbm":
-                achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-            else:
-                achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-            roof = {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
-                    "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
-                    "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
-                    "algorithmic_per_launch": per_launch,
-                    "launch_filter": "launches >= %.0e units (cmflow_amd/_lib.py TRACK_MIN_UNITS)" %
-                                     _lib.TRACK_MIN_UNITS.get(prof["kernel"], 0.0)}
+        roof = roofline_of(prof)
+        if roof:
+            roof["note"] = "durations include contention from kernels of the 3 other encoder-scale streams"
         cpu = None
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(a.mode, a.model)
@@ -208,7 +230,7 @@ def main():
                                      if a.mode == "train" else "fwd-only inference (eval-mode BN)", a.batch,
                                      a.batch * world, "; dp%d RCCL grad all-reduce" % world if world > 1 else "")),
                        "parallelism": "dp%d" % world},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_isolated": iso, "cpu_baseline": cpu,
             # model-level rate against the reference's ALGORITHMIC work (25.52 GFLOP per frame pair forward,
             # x3 for fwd+bwd) -- the build's hoisted first convs execute fewer FLOPs than that
             "algorithmic_model_tflops": round(pairs / dt * 25.52e9 * (3.0 if a.mode == "train" else 1.0) / 1e12, 2),
