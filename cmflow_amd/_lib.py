@@ -29,6 +29,13 @@ SIGNATURES = {
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
+    "cmf_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_gather_points_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_furthest_point_sampling": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_knn_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_three_nn": [_ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_three_interpolate": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_three_interpolate_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_bn_finalize": [_ci, _ci, ctypes.c_double, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp],
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],

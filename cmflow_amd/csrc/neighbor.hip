@@ -134,7 +134,11 @@ __device__ __forceinline__ float sqnorm3(float x, float y, float z)
     return s + zz;
 }
 
-template <int K>
+// PLAIN = false: the torch-level kNN of the model (matmul-form distance, radarflow_util.py:8-30).
+// PLAIN = true : the extension's knn / three_nn kernels (lib/src/interpolate_gpu.cu:9-57,81-124), which use the
+//                direct form d = (ux-x)^2 + (uy-y)^2 + (uz-z)^2 (non-contracted here) and keep the first-seen
+//                point on ties -- identical bookkeeping, only the distance differs.
+template <int K, bool PLAIN>
 __global__ __launch_bounds__(CMF_WAVE) void knn_kernel(
     int n, int s, int nsample, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     int *__restrict__ idx, float *__restrict__ dist)
@@ -167,13 +171,25 @@ __global__ __launch_bounds__(CMF_WAVE) void knn_kernel(
         __syncthreads();
         for (int k = 0; k < len; ++k) {
             const float4 p = tile[k];
-            const float p0 = qx * p.x;
-            const float p01 = __builtin_fmaf(qy, p.y, p0);
-            const float dot = __builtin_fmaf(qz, p.z, p01);
-            const float t = -2.0f * dot;
-            const float u = t + ss;
-            float v = u + p.w;
-            v = (v > 0.0f) ? v : 0.0f;
+            float v;
+            if (PLAIN) {
+                const float dx = qx - p.x;
+                const float dy = qy - p.y;
+                const float dz = qz - p.z;
+                const float xx = dx * dx;
+                const float yy = dy * dy;
+                const float zz = dz * dz;
+                const float sxy = xx + yy;
+                v = sxy + zz;
+            } else {
+                const float p0 = qx * p.x;
+                const float p01 = __builtin_fmaf(qy, p.y, p0);
+                const float dot = __builtin_fmaf(qz, p.z, p01);
+                const float t = -2.0f * dot;
+                const float u = t + ss;
+                v = u + p.w;
+                v = (v > 0.0f) ? v : 0.0f;
+            }
             if (v < bd[K - 1]) {
                 bd[K - 1] = v;
                 bi[K - 1] = base + k;
@@ -211,10 +227,101 @@ extern "C" int cmf_knn(int b, int n, int s, int nsample, const float *xyz, const
     hipStream_t st = (hipStream_t)stream;
     // the list length is a compile-time constant so it stays in registers; the list is sorted,
     // so running a longer list and emitting its first nsample entries is exact.
-    if (nsample <= 1)       hipLaunchKernelGGL(knn_kernel<1>,  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
-    else if (nsample <= 4)  hipLaunchKernelGGL(knn_kernel<4>,  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
-    else if (nsample <= 8)  hipLaunchKernelGGL(knn_kernel<8>,  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
-    else if (nsample <= 16) hipLaunchKernelGGL(knn_kernel<16>, grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
-    else                    hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    if (nsample <= 1)       hipLaunchKernelGGL((knn_kernel<1, false>),  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else if (nsample <= 4)  hipLaunchKernelGGL((knn_kernel<4, false>),  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else if (nsample <= 8)  hipLaunchKernelGGL((knn_kernel<8, false>),  grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else if (nsample <= 16) hipLaunchKernelGGL((knn_kernel<16, false>), grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    else                    hipLaunchKernelGGL((knn_kernel<32, false>), grid, block, 0, st, n, s, nsample, xyz, new_xyz, idx, dist);
+    return cmf_launch_status();
+}
+
+// ---- rest of the pointnet2_cuda neighbour surface (not called by CMFlow) -------------------
+
+// knn_wrapper (lib/src/interpolate_gpu.cu:9-57): unknown (b,n,3) queries, known (b,m,3) -> dist2, idx (b,n,k).
+extern "C" int cmf_knn_points(int b, int n, int m, int k, const float *unknown, const float *known,
+                              float *dist2, int *idx, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && k > 0 && k <= 64);      // the reference allows k <= 200
+    if (b == 0 || n == 0) return 0;
+    CMF_CHECK_ARG(unknown && known && dist2 && idx);
+    dim3 grid(cmf_divup(n, CMF_WAVE), b), block(CMF_WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 4)       hipLaunchKernelGGL((knn_kernel<4, true>),  grid, block, 0, st, m, n, k, known, unknown, idx, dist2);
+    else if (k <= 8)  hipLaunchKernelGGL((knn_kernel<8, true>),  grid, block, 0, st, m, n, k, known, unknown, idx, dist2);
+    else if (k <= 16) hipLaunchKernelGGL((knn_kernel<16, true>), grid, block, 0, st, m, n, k, known, unknown, idx, dist2);
+    else if (k <= 32) hipLaunchKernelGGL((knn_kernel<32, true>), grid, block, 0, st, m, n, k, known, unknown, idx, dist2);
+    else              hipLaunchKernelGGL((knn_kernel<64, true>), grid, block, 0, st, m, n, k, known, unknown, idx, dist2);
+    return cmf_launch_status();
+}
+
+// three_nn_wrapper (lib/src/interpolate_gpu.cu:81-124): the 3 nearest known points, dist^2 returned.
+extern "C" int cmf_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                            float *dist2, int *idx, void *stream)
+{
+    return cmf_knn_points(b, n, m, 3, unknown, known, dist2, idx, stream);
+}
+
+// furthest_point_sampling_wrapper (lib/src/sampling_gpu.cu:93-209): one workgroup per sample, m sequential
+// rounds; temp (b,n) holds the running min distance (caller fills it with 1e10, lib/pointnet2_utils.py:26).
+// Ties in the arg-max go to the LOWEST index (the reference's tree reduction prefers the lower thread).
+constexpr int FPS_THREADS = 256;
+__global__ __launch_bounds__(FPS_THREADS) void fps_kernel(int n, int m, const float *__restrict__ dataset,
+                                                          float *__restrict__ temp, int *__restrict__ idxs)
+{
+    __shared__ float sv[FPS_THREADS / CMF_WAVE];
+    __shared__ int si[FPS_THREADS / CMF_WAVE];
+    __shared__ int s_old;
+    const int bs = blockIdx.x, tid = threadIdx.x;
+    const float *d = dataset + (size_t)bs * n * 3;
+    float *t = temp + (size_t)bs * n;
+    int *o = idxs + (size_t)bs * m;
+    if (m <= 0) return;
+    int old = 0;
+    if (tid == 0) o[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = d[old * 3 + 0], y1 = d[old * 3 + 1], z1 = d[old * 3 + 2];
+        float best = -1.f;
+        int besti = 0;
+        for (int k = tid; k < n; k += FPS_THREADS) {
+            const float dx = d[k * 3 + 0] - x1;
+            const float dy = d[k * 3 + 1] - y1;
+            const float dz = d[k * 3 + 2] - z1;
+            const float xx = dx * dx;
+            const float yy = dy * dy;
+            const float zz = dz * dz;
+            const float sxy = xx + yy;
+            const float dd = sxy + zz;
+            const float d2 = fminf(dd, t[k]);
+            t[k] = d2;
+            if (d2 > best) { best = d2; besti = k; }
+        }
+        // arg-max with lowest-index tie-break: wave shuffle tree, then across the 4 waves
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = besti; }
+        __syncthreads();
+        if (tid == 0) {
+            float bv = sv[0]; int bi = si[0];
+            for (int w = 1; w < FPS_THREADS / CMF_WAVE; ++w)
+                if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+            s_old = bi;
+            o[j] = bi;
+        }
+        __syncthreads();
+        old = s_old;
+        __syncthreads();
+    }
+}
+
+extern "C" int cmf_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && m >= 0);
+    if (b == 0 || m == 0) return 0;
+    CMF_CHECK_ARG(dataset && temp && idxs);
+    hipLaunchKernelGGL(fps_kernel, dim3(b), dim3(FPS_THREADS), 0, (hipStream_t)stream, n, m, dataset, temp, idxs);
     return cmf_launch_status();
 }

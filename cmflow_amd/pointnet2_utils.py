@@ -46,10 +46,58 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     return 1
 
 
+def _call(name, *args):
+    _lib.check(getattr(_lib.lib(), name)(*args, _lib.stream_ptr()), name)
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    """lib/src/sampling.cpp (gather_points_wrapper_fast)"""
+    return _call("cmf_gather_points", b, c, n, npoints, _lib.dev_ptr(points, _f32), _lib.dev_ptr(idx, _i32), _lib.dev_ptr(out, _f32))
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    return _call("cmf_gather_points_grad", b, c, n, npoints, _lib.dev_ptr(grad_out, _f32), _lib.dev_ptr(idx, _i32),
+                 _lib.dev_ptr(grad_points, _f32))
+
+
+def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    return _call("cmf_furthest_point_sampling", b, n, m, _lib.dev_ptr(points, _f32), _lib.dev_ptr(temp, _f32), _lib.dev_ptr(idx, _i32))
+
+
+def knn_wrapper(b, n, m, k, unknown, known, dist2, idx):
+    """lib/src/interpolate.cpp (knn_wrapper_fast)"""
+    return _call("cmf_knn_points", b, n, m, k, _lib.dev_ptr(unknown, _f32), _lib.dev_ptr(known, _f32),
+                 _lib.dev_ptr(dist2, _f32), _lib.dev_ptr(idx, _i32))
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    return _call("cmf_three_nn", b, n, m, _lib.dev_ptr(unknown, _f32), _lib.dev_ptr(known, _f32),
+                 _lib.dev_ptr(dist2, _f32), _lib.dev_ptr(idx, _i32))
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    return _call("cmf_three_interpolate", b, c, m, n, _lib.dev_ptr(points, _f32), _lib.dev_ptr(idx, _i32),
+                 _lib.dev_ptr(weight, _f32), _lib.dev_ptr(out, _f32))
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    return _call("cmf_three_interpolate_grad", b, c, n, m, _lib.dev_ptr(grad_out, _f32), _lib.dev_ptr(idx, _i32),
+                 _lib.dev_ptr(weight, _f32), _lib.dev_ptr(grad_points, _f32))
+
+
+# all ten entry points of lib/src/pointnet2_api.cpp:10-25
 pointnet2_cuda = types.SimpleNamespace(
     ball_query_wrapper=ball_query_wrapper,
     group_points_wrapper=group_points_wrapper,
     group_points_grad_wrapper=group_points_grad_wrapper,
+    gather_points_wrapper=gather_points_wrapper,
+    gather_points_grad_wrapper=gather_points_grad_wrapper,
+    furthest_point_sampling_wrapper=furthest_point_sampling_wrapper,
+    knn_wrapper=knn_wrapper,
+    three_nn_wrapper=three_nn_wrapper,
+    three_interpolate_wrapper=three_interpolate_wrapper,
+    three_interpolate_grad_wrapper=three_interpolate_grad_wrapper,
 )
 
 
@@ -121,4 +169,140 @@ class QueryAndGroup(nn.Module):
                 return torch.cat([grouped_xyz, grouped_features], dim=1)
             return grouped_features
         assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        return grouped_xyz
+
+
+# ---- the reference's remaining Functions (lib/pointnet2_utils.py:10-181; unused by CMFlow) ----------------
+class FurthestPointSampling(Function):
+    """lib/pointnet2_utils.py:10-36"""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        output = torch.empty(B, npoint, dtype=_i32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=_f32, device=xyz.device)
+        furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    """lib/pointnet2_utils.py:39-72"""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        output = torch.empty(B, C, npoint, dtype=_f32, device=features.device)
+        gather_points_wrapper(B, C, N, npoint, features, idx, output)
+        ctx.for_backwards = (idx, C, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad_features = torch.zeros(B, C, N, dtype=_f32, device=grad_out.device)
+        gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class KNN(Function):
+    """lib/pointnet2_utils.py:75-102 (returns sqrt of the squared distances, like the reference)"""
+
+    @staticmethod
+    def forward(ctx, k: int, unknown: torch.Tensor, known: torch.Tensor):
+        assert unknown.is_contiguous()
+        assert known.is_contiguous()
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = torch.empty(B, N, k, dtype=_f32, device=unknown.device)
+        idx = torch.empty(B, N, k, dtype=_i32, device=unknown.device)
+        knn_wrapper(B, N, m, k, unknown, known, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None
+
+
+knn = KNN.apply
+
+
+class ThreeNN(Function):
+    """lib/pointnet2_utils.py:104-133"""
+
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor):
+        assert unknown.is_contiguous()
+        assert known.is_contiguous()
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = torch.empty(B, N, 3, dtype=_f32, device=unknown.device)
+        idx = torch.empty(B, N, 3, dtype=_i32, device=unknown.device)
+        three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """lib/pointnet2_utils.py:136-181"""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        assert weight.is_contiguous()
+        B, c, m = features.size()
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        output = torch.empty(B, c, n, dtype=_f32, device=features.device)
+        three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros(B, c, m, dtype=_f32, device=grad_out.device)
+        three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupAll(nn.Module):
+    """lib/pointnet2_utils.py:295-318"""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is not None:
+            grouped_features = features.unsqueeze(2)
+            return torch.cat([grouped_xyz, grouped_features], dim=1) if self.use_xyz else grouped_features
         return grouped_xyz

@@ -174,6 +174,28 @@ int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, co
 int cmf_setconv_dwx(int C, float inv_count, int train, const float *bwd5, const float *fwd,
                     const float *a, const float *mean, const float *invstd, float *dwx, void *stream);
 
+/* ---- the rest of the reference's pointnet2_cuda extension (lib/src/pointnet2_api.cpp:10-25) ------------ *
+ * Not called by CMFlow (only by the unused lib/pointnet2_modules.py); provided so the drop-in module is
+ * complete.  Argument order = the reference launchers. */
+/* gather_points_kernel_launcher_fast (sampling_gpu.cu:27-44): out[b,c,j] = points[b,c,idx[b,j]] */
+int cmf_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx, float *out, void *stream);
+/* gather_points_grad_kernel_launcher_fast (sampling_gpu.cu:66-83): accumulates into grad_points */
+int cmf_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                           float *grad_points, void *stream);
+/* furthest_point_sampling_kernel_launcher (sampling_gpu.cu:212-250): temp (b,n) pre-filled with 1e10 */
+int cmf_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs, void *stream);
+/* knn_kernel_launcher_fast (interpolate_gpu.cu:60-78): k nearest `known` points per `unknown`, ascending,
+ * first-seen wins ties, squared distances; k <= 64 here (reference: k <= 200) */
+int cmf_knn_points(int b, int n, int m, int k, const float *unknown, const float *known,
+                   float *dist2, int *idx, void *stream);
+/* three_nn_kernel_launcher_fast (interpolate_gpu.cu:127-146) */
+int cmf_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx, void *stream);
+/* three_interpolate_kernel_launcher_fast (interpolate_gpu.cu:172-189) and its grad (:217-233) */
+int cmf_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                          const float *weight, float *out, void *stream);
+int cmf_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                               const float *weight, float *grad_points, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 

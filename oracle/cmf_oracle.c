@@ -208,6 +208,48 @@ void orc_three_nn(int b, int n, int m, const float *unknown, const float *known,
         }
 }
 
+/* lib/src/interpolate_gpu.cu:9-57 (knn_kernel_fast) -- k nearest known points per unknown point, direct
+ * (ux-x)^2 form, ascending, strict '<' so the first-seen point wins ties; returns dist^2 (k <= 200). */
+void orc_knn_points(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2, int *idx)
+{
+    double best[200];
+    int besti[200];
+    for (int bs = 0; bs < b; ++bs)
+        for (int i = 0; i < n; ++i) {
+            const float *u = unknown + ((size_t)bs * n + i) * 3;
+            for (int t = 0; t < k; ++t) { best[t] = 1e40; besti[t] = 0; }
+            for (int j = 0; j < m; ++j) {
+                const float *p = known + ((size_t)bs * m + j) * 3;
+                const float dx = u[0] - p[0], dy = u[1] - p[1], dz = u[2] - p[2];
+                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const float s = xx + yy;
+                const float d = s + zz;
+                for (int t = 0; t < k; ++t)
+                    if (d < best[t]) {
+                        for (int l = k - 1; l > t; --l) { best[l] = best[l - 1]; besti[l] = besti[l - 1]; }
+                        best[t] = d; besti[t] = j;
+                        break;
+                    }
+            }
+            for (int t = 0; t < k; ++t) {
+                idx[((size_t)bs * n + i) * k + t] = besti[t];
+                dist2[((size_t)bs * n + i) * k + t] = (float)best[t];
+            }
+        }
+}
+
+/* lib/src/interpolate_gpu.cu:192-214 -- grad_points[b,c,idx[b,i,j]] += grad_out[b,c,i] * w[b,i,j] */
+void orc_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                const float *weight, float *grad_points)
+{
+    for (int bs = 0; bs < b; ++bs)
+        for (int ch = 0; ch < c; ++ch)
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < 3; ++j)
+                    grad_points[((size_t)bs * c + ch) * m + idx[((size_t)bs * n + i) * 3 + j]] +=
+                        grad_out[((size_t)bs * c + ch) * n + i] * weight[((size_t)bs * n + i) * 3 + j];
+}
+
 /* lib/src/interpolate_gpu.cu:149-169 -- out[b,c,i] = sum_j w[b,i,j] * points[b,c,idx[b,i,j]] */
 void orc_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
                            const float *weight, float *out)

@@ -83,6 +83,17 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     return 1
 
 
+def knn_wrapper(b, n, m, k, unknown, known, dist2, idx):
+    lib().orc_knn_points(_ci(b), _ci(n), _ci(m), _ci(k), _p(unknown, _f), _p(known, _f), _p(dist2, _f), _p(idx, _i))
+    return 1
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    lib().orc_three_interpolate_grad(_ci(b), _ci(c), _ci(n), _ci(m), _p(grad_out, _f), _p(idx, _i), _p(weight, _f),
+                                     _p(grad_points, _f))
+    return 1
+
+
 def furthest_point_sampling_wrapper(b, n, m, dataset, temp, idxs):
     lib().orc_furthest_point_sampling(_ci(b), _ci(n), _ci(m), _p(dataset, _f), _p(temp, _f), _p(idxs, _i))
     return 1

@@ -62,9 +62,12 @@ def test_ball_query_isa_has_no_fma_contraction():
     start = asm.index("_Z17ball_query_kernel")
     body = asm[start:asm.index("s_endpgm", start)]
     assert not re.search(r"v_(fma|fmac|mad|pk_fma)_f32", body)
-    knn = asm[asm.index("_Z10knn_kernelILi8EE"):]
+    knn = asm[asm.index("_Z10knn_kernelILi8ELb0EE"):]
     knn = knn[:knn.index("s_endpgm")]
     assert re.search(r"v_(fma|fmac)_f32", knn)        # the k-ordered FMA chain of the dot product IS required there
+    plain = asm[asm.index("_Z10knn_kernelILi8ELb1EE"):]
+    plain = plain[:plain.index("s_endpgm")]
+    assert not re.search(r"v_(fma|fmac|mad|pk_fma)_f32", plain)      # extension knn / three_nn: direct form, no FMA
 
 
 def test_product_fails_loudly_without_gpu():

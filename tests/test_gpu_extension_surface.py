@@ -1,0 +1,89 @@
+"""GPU: the rest of the reference's `pointnet2_cuda` export table (lib/src/pointnet2_api.cpp:10-25) -- the seven
+kernels CMFlow itself never calls -- against the C oracle.  Indices bit-exact, copies bit-exact, scatter-adds
+to 1e-5 (the reference uses unordered atomics there)."""
+import numpy as np
+import pytest
+import torch
+
+from cmflow_amd import synth
+from oracle import ops as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _clouds(B, N, M, seed):
+    b = synth.make_batch(B, N=max(N, M), seed=seed)
+    return b["pc1"].permute(0, 2, 1)[:, :N].contiguous(), b["pc2"].permute(0, 2, 1)[:, :M].contiguous()
+
+
+def test_export_table_is_complete():
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    for name in ("ball_query_wrapper", "group_points_wrapper", "group_points_grad_wrapper", "gather_points_wrapper",
+                 "gather_points_grad_wrapper", "furthest_point_sampling_wrapper", "knn_wrapper", "three_nn_wrapper",
+                 "three_interpolate_wrapper", "three_interpolate_grad_wrapper"):
+        assert callable(getattr(ext, name))
+
+
+@pytest.mark.parametrize("B,N,m", [(3, 256, 64), (2, 1000, 128), (1, 37, 37)])
+def test_furthest_point_sampling(dev, B, N, m):
+    from cmflow_amd.pointnet2_utils import furthest_point_sample
+    xyz, _ = _clouds(B, N, N, seed=N + m)
+    ref = torch.empty(B, m, dtype=torch.int32)
+    orc.furthest_point_sampling_wrapper(B, N, m, xyz, torch.full((B, N), 1e10), ref)
+    assert torch.equal(furthest_point_sample(xyz.to(dev), m).cpu(), ref)
+
+
+@pytest.mark.parametrize("B,N,M,k", [(2, 256, 256, 8), (2, 100, 300, 16), (1, 64, 50, 3), (1, 128, 500, 40)])
+def test_knn_and_three_nn(dev, B, N, M, k):
+    from cmflow_amd.pointnet2_utils import knn, three_nn
+    unknown, known = _clouds(B, N, M, seed=N + M + k)
+    d_ref, i_ref = torch.empty(B, N, k), torch.empty(B, N, k, dtype=torch.int32)
+    orc.knn_wrapper(B, N, M, k, unknown, known, d_ref, i_ref)
+    d, i = knn(k, unknown.to(dev), known.to(dev))
+    assert torch.equal(i.cpu(), i_ref)
+    np.testing.assert_allclose(d.cpu().numpy(), np.sqrt(d_ref.numpy()), rtol=1e-6, atol=0)
+    d3_ref, i3_ref = torch.empty(B, N, 3), torch.empty(B, N, 3, dtype=torch.int32)
+    orc.three_nn_wrapper(B, N, M, unknown, known, d3_ref, i3_ref)
+    d3, i3 = three_nn(unknown.to(dev), known.to(dev))
+    assert torch.equal(i3.cpu(), i3_ref)
+    np.testing.assert_allclose((d3 * d3).cpu().numpy(), d3_ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_gather_and_interpolate(dev):
+    from cmflow_amd.pointnet2_utils import gather_operation, three_interpolate
+    g = torch.Generator().manual_seed(2)
+    B, C, N, P = 2, 19, 300, 77
+    feats = torch.randn(B, C, N, generator=g)
+    idx = torch.randint(0, N, (B, P), generator=g, dtype=torch.int32)
+    a = feats.clone().to(dev).requires_grad_(True)
+    out = gather_operation(a, idx.to(dev))
+    ref = torch.empty(B, C, P)
+    orc.gather_points_wrapper(B, C, N, P, feats, idx, ref)
+    assert torch.equal(out.cpu(), ref)
+    go = torch.randn(B, C, P, generator=g)
+    out.backward(go.to(dev))
+    gref = torch.zeros(B, C, N)
+    orc.gather_points_grad_wrapper(B, C, N, P, go, idx, gref)
+    np.testing.assert_allclose(a.grad.cpu().numpy(), gref.numpy(), rtol=1e-5, atol=1e-5)
+    # three_interpolate: (B,C,M) known features -> (B,C,n)
+    M, n = 40, 123
+    known = torch.randn(B, C, M, generator=g)
+    idx3 = torch.randint(0, M, (B, n, 3), generator=g, dtype=torch.int32)
+    w = torch.rand(B, n, 3, generator=g)
+    w = w / w.sum(-1, keepdim=True)
+    k = known.clone().to(dev).requires_grad_(True)
+    o = three_interpolate(k, idx3.to(dev), w.to(dev))
+    oref = torch.empty(B, C, n)
+    orc.three_interpolate_wrapper(B, C, M, n, known, idx3, w, oref)
+    assert torch.equal(o.cpu(), oref)                       # same non-contracted (w0*p0 + w1*p1) + w2*p2
+    go = torch.randn(B, C, n, generator=g)
+    o.backward(go.to(dev))
+    gk = torch.zeros(B, C, M)
+    orc.three_interpolate_grad_wrapper(B, C, n, M, go, idx3, w, gk)
+    np.testing.assert_allclose(k.grad.cpu().numpy(), gk.numpy(), rtol=1e-5, atol=1e-5)
