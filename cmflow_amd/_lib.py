@@ -37,10 +37,10 @@ SIGNATURES = {
     "cmf_three_interpolate": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_three_interpolate_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_bn_finalize": [_ci, _ci, ctypes.c_double, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp],
+    "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
-    "cmf_colsum": [_ci, _ci, _vp, _vp, _vp],
-    "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
+    "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],
     "cmf_group_rows_grad_bn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
     "cmf_bn_relu_maxpool": [_ll, _ci, _ci, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "cmf_maxpool_bwd": [_ll, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

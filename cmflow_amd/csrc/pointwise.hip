@@ -91,34 +91,42 @@ extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *part
 }
 
 // column sums of the partial buffer: out[2][C] = sum_t partial[t][2][C]  (dbeta, dgamma in backward)
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out)
+// acc0 / acc1 (optional): accumulate columns [0,C) into acc0 and [C,2C) into acc1 -- the BN-backward sums go
+// straight into beta.grad / gamma.grad (one launch instead of a reduction plus two tiny torch adds).
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
+                                                              int C, float *__restrict__ acc0, float *__restrict__ acc1)
 {
     __shared__ double sh[FIN_COLS * FIN_LANES];
     const int col = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
     const double s = fin_reduce(tiles, C2, col, partial, sh);
-    if (threadIdx.x < FIN_COLS && col < C2) out[col] = (float)s;
+    if (threadIdx.x < FIN_COLS && col < C2) {
+        out[col] = (float)s;
+        if (acc0 && col < C) acc0[col] += (float)s;
+        if (acc1 && col >= C && col < 2 * C) acc1[col - C] += (float)s;
+    }
 }
 
-extern "C" int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void *stream)
+extern "C" int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, float *acc0, float *acc1, void *stream)
 {
     CMF_CHECK_ARG(tiles > 0 && C > 0 && partial && out);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(2 * C, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
-                       tiles, 2 * C, partial, out);
+                       tiles, 2 * C, partial, out, C, acc0, acc1);
     return cmf_launch_status();
 }
 
-extern "C" int cmf_colsum(int tiles, int ncols, const float *partial, float *out, void *stream)
+extern "C" int cmf_colsum(int tiles, int ncols, const float *partial, float *out, int C, float *acc0, float *acc1, void *stream)
 {
     CMF_CHECK_ARG(tiles > 0 && ncols > 0 && partial && out);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(ncols, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
-                       tiles, ncols, partial, out);
+                       tiles, ncols, partial, out, C, acc0, acc1);
     return cmf_launch_status();
 }
 
 // dW_xyz of the set-conv first layer from column sums (see cmflow_hip.h)
 __global__ void setconv_dwx_kernel(int C, float inv_count, int train, const float *__restrict__ bwd5,
                                    const float *__restrict__ fwd, const float *__restrict__ a,
-                                   const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ dwx)
+                                   const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ dwx,
+                                   int ld, int accumulate)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -130,16 +138,18 @@ __global__ void setconv_dwx_kernel(int C, float inv_count, int train, const floa
             const float u = fwd[3 * C + k], tz = fwd[k * C + c];
             g = q - (s1 * inv_count) * u - (s2 * inv_count) * invstd[c] * (tz - mean[c] * u);
         }
-        dwx[c * 3 + k] = a[c] * g;
+        float *dst = dwx + (size_t)c * ld + k;
+        *dst = accumulate ? *dst + a[c] * g : a[c] * g;
     }
 }
 
 extern "C" int cmf_setconv_dwx(int C, float inv_count, int train, const float *bwd5, const float *fwd,
-                               const float *a, const float *mean, const float *invstd, float *dwx, void *stream)
+                               const float *a, const float *mean, const float *invstd, float *dwx, int ld, int accumulate,
+                               void *stream)
 {
-    CMF_CHECK_ARG(C > 0 && bwd5 && a && dwx && (!train || (fwd && mean && invstd)));
+    CMF_CHECK_ARG(C > 0 && bwd5 && a && dwx && ld >= 3 && (!train || (fwd && mean && invstd)));
     hipLaunchKernelGGL(setconv_dwx_kernel, dim3(cmf_divup(C, 64)), dim3(64), 0, (hipStream_t)stream,
-                       C, inv_count, train, bwd5, fwd, a, mean, invstd, dwx);
+                       C, inv_count, train, bwd5, fwd, a, mean, invstd, dwx, ld, accumulate);
     return cmf_launch_status();
 }
 

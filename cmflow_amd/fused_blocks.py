@@ -64,10 +64,29 @@ def bn_fold(bn, partial, count):
     return st
 
 
-def colsum(partial):
+def grad_sink(t):
+    """The gradient buffer a parameter-gradient can be accumulated into directly, or None.
+
+    `t` is a Function input that is a leaf Parameter or the (out,in) view of a 1x1 conv weight.  When the
+    parameter already owns a dense .grad (TrainStep keeps all of them as views into one flat bucket, zeroed
+    once per step), the backward kernels write / accumulate straight into it and the Function returns None
+    for that input -- otherwise autograd launches one tiny `grad += g` kernel per parameter (~300 per step,
+    each ~25 us of host time on the autograd thread)."""
+    base = t._base if t._base is not None else t
+    if not base.is_leaf or base.grad is None or not base.grad.is_contiguous():
+        return None
+    if t is base:
+        return base.grad
+    if t.dim() == 2 and base.dim() == 4 and t.is_contiguous() and t.numel() == base.numel():
+        return base.grad.view(t.shape)
+    return None
+
+
+def colsum(partial, acc_beta=None, acc_gamma=None):
     C = partial.shape[2]
     out = torch.empty(2, C, dtype=_f32, device=partial.device)
-    _lib.check(L().cmf_colsum_finalize(partial.shape[0], C, _p(partial), _p(out), _lib.stream_ptr()), "cmf_colsum_finalize")
+    _lib.check(L().cmf_colsum_finalize(partial.shape[0], C, _p(partial), _p(out), _p(acc_beta), _p(acc_gamma),
+                                       _lib.stream_ptr()), "cmf_colsum_finalize")
     return out
 
 
@@ -132,33 +151,43 @@ def act_bwd_stats(dY, z, st):
     return dU, part
 
 
-def colsum_n(partial):
+def colsum_n(partial, C=0, acc_beta=None, acc_gamma=None):
     """[tiles][...] -> [...] column sums in fixed order"""
     ncols = partial[0].numel()
     out = torch.empty(partial.shape[1:], dtype=_f32, device=partial.device)
-    _lib.check(L().cmf_colsum(partial.shape[0], ncols, _p(partial), _p(out), _lib.stream_ptr()), "cmf_colsum")
+    _lib.check(L().cmf_colsum(partial.shape[0], ncols, _p(partial), _p(out), C, _p(acc_beta), _p(acc_gamma),
+                              _lib.stream_ptr()), "cmf_colsum")
     return out
 
 
-def bn_backward(dU, part, z, st):
-    """dU (M,C) masked upstream gradient + its partial sums -> dZ (in place), dgamma, dbeta."""
-    sums = colsum(part)                                   # [0] = sum dU = dbeta, [1] = sum dU*zhat = dgamma
+def bn_backward(dU, part, z, st, gamma=None, beta=None):
+    """dU (M,C) masked upstream gradient + its partial sums -> dZ (in place), dgamma, dbeta.
+    gamma / beta: the BN parameters; if they own a gradient buffer the sums are accumulated into it by the
+    reduction kernel and None is returned in their place."""
+    sg = grad_sink(gamma) if gamma is not None else None
+    sb = grad_sink(beta) if beta is not None else None
+    sums = colsum(part, sb, sg)                           # [0] = sum dU = dbeta, [1] = sum dU*zhat = dgamma
     M, C = dU.shape
     err = L().cmf_bn_bwd_apply(M, C, _p(dU), z.data_ptr(), z.stride(0), _p(st.a), _p(st.mean), _p(st.invstd),
                                _p(sums) if st.training else None, _lib.stream_ptr())
     _lib.check(err, "cmf_bn_bwd_apply")
-    return dU, sums[1], sums[0]
+    return dU, (None if sg is not None else sums[1]), (None if sb is not None else sums[0])
 
 
-def gemm_dw(dZ, X, prob=None):
+def gemm_dw(dZ, X, prob=None, w=None):
     """Weight gradient dW[N,K] = dZ[M,N]^T @ act(X)[M,K]; contraction over the positions, split-K so that
-    the launch fills the chip, slabs summed in fixed order (deterministic)."""
+    the launch fills the chip, slabs summed in fixed order (deterministic).  w: the weight input of the
+    Function; when it owns a gradient buffer (grad_sink) dW is accumulated there and None is returned."""
+    sink = grad_sink(w) if w is not None else None
     M, N = dZ.shape
     K = X.shape[1]
     tiles = ((N + 127) // 128 if N > 64 else 1) * ((K + 127) // 128 if K > 64 else 1)
     chunks = (M + 31) // 32
     # ~2 workgroups per CU; every slab costs an extra N*K*4-byte round trip in the reduction
     split = max(1, min(chunks // 16, (512 + tiles - 1) // tiles))
+    if sink is not None:
+        gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split, out=sink, accumulate=True)
+        return None
     return gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split)
 
 
@@ -183,10 +212,10 @@ def _fwd_layer(x, x_st, w, bn, training):
     return gemm(x, w, pro=pro), bn_fold(bn, None, x.shape[0])
 
 
-def _bwd_layer(dZ, x, x_st, w, need_dx=True):
+def _bwd_layer(dZ, x, x_st, w, need_dx=True, w_in=None):
     """Given dZ of Z = act(x) @ w^T: -> dW, and (dU_x, partial) = gradient wrt x's PRE-activation, masked by
     x's ReLU with the BN-backward sums of layer x (x_st given), or the plain dX (x_st None)."""
-    dW = gemm_dw(dZ, x, prob=(x_st.a, x_st.c) if x_st is not None else None)
+    dW = gemm_dw(dZ, x, prob=(x_st.a, x_st.c) if x_st is not None else None, w=w_in)
     if not need_dx:
         return dW, None, None
     if x_st is None:
@@ -279,22 +308,23 @@ class MLPChainFn(Function):
             cur, cur_st = z, st
         y = affine_relu(cur, cur_st)
         ctx.x, ctx.zs, ctx.sts, ctx.ws = x, zs, sts, [params[3 * i].contiguous() for i in range(len(bns))]
+        ctx.params = params
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, zs, sts, ws = ctx.x, ctx.zs, ctx.sts, ctx.ws
+        x, zs, sts, ws, P = ctx.x, ctx.zs, ctx.sts, ctx.ws, ctx.params
         Lr = len(zs)
         grads = [None] * (3 * Lr)
         dU, part = act_bwd_stats(dy, zs[-1], sts[-1])
         dx = None
         for i in range(Lr - 1, -1, -1):
-            dZ, dg, db = bn_backward(dU, part, zs[i], sts[i])
+            dZ, dg, db = bn_backward(dU, part, zs[i], sts[i], P[3 * i + 1], P[3 * i + 2])
             grads[3 * i + 1], grads[3 * i + 2] = dg, db
             if i > 0:
-                grads[3 * i], dU, part = _bwd_layer(dZ, zs[i - 1], sts[i - 1], ws[i])
+                grads[3 * i], dU, part = _bwd_layer(dZ, zs[i - 1], sts[i - 1], ws[i], w_in=P[3 * i])
             else:
-                grads[0], dx, _ = _bwd_layer(dZ, x, None, ws[0], need_dx=ctx.needs_input_grad[0])
+                grads[0], dx, _ = _bwd_layer(dZ, x, None, ws[0], need_dx=ctx.needs_input_grad[0], w_in=P[0])
         return (dx, None, None, *grads)
 
 
@@ -339,6 +369,7 @@ class SetConvFn(Function):
         res = affine_relu(z6, st6)
         ctx.saved = (nbr, dxyz, z1, z2, z3, am, x, z4, z5, z6, (st1, st2, st3, st4, st5, st6), (w2, w3, w4, w5, w6),
                      (B, N, nsample), y.shape[2], fwd_sums)
+        ctx.params = params
         return res.view(B, N, -1)
 
     @staticmethod
@@ -347,29 +378,39 @@ class SetConvFn(Function):
         st1, st2, st3, st4, st5, st6 = sts
         w2, w3, w4, w5, w6 = ws
         dout = dout.reshape(B * N, -1)
+        (pwx, pg1, pb1, pw2, pg2, pb2, pw3, pg3, pb3, pw4, pg4, pb4, pw5, pg5, pb5, pw6, pg6, pb6) = ctx.params
         g = {}
         dU, part = act_bwd_stats(dout, z6, st6)
-        dZ6, g["g6"], g["b6"] = bn_backward(dU, part, z6, st6)
-        g["w6"], dU, part = _bwd_layer(dZ6, z5, st5, w6)
-        dZ5, g["g5"], g["b5"] = bn_backward(dU, part, z5, st5)
-        g["w5"], dU, part = _bwd_layer(dZ5, z4, st4, w5)
-        dZ4, g["g4"], g["b4"] = bn_backward(dU, part, z4, st4)
-        g["w4"], dx, _ = _bwd_layer(dZ4, x, None, w4)
+        dZ6, g["g6"], g["b6"] = bn_backward(dU, part, z6, st6, pg6, pb6)
+        g["w6"], dU, part = _bwd_layer(dZ6, z5, st5, w6, w_in=pw6)
+        dZ5, g["g5"], g["b5"] = bn_backward(dU, part, z5, st5, pg5, pb5)
+        g["w5"], dU, part = _bwd_layer(dZ5, z4, st4, w5, w_in=pw5)
+        dZ4, g["g4"], g["b4"] = bn_backward(dU, part, z4, st4, pg4, pb4)
+        g["w4"], dx, _ = _bwd_layer(dZ4, x, None, w4, w_in=pw4)
         dU, part = maxpool_bwd(dx, z3.view(B * N, S, -1), st3, am)
-        dZ3, g["g3"], g["b3"] = bn_backward(dU, part, z3, st3)
-        g["w3"], dU, part = _bwd_layer(dZ3, z2, st2, w3)
-        dZ2, g["g2"], g["b2"] = bn_backward(dU, part, z2, st2)
+        dZ3, g["g3"], g["b3"] = bn_backward(dU, part, z3, st3, pg3, pb3)
+        g["w3"], dU, part = _bwd_layer(dZ3, z2, st2, w3, w_in=pw3)
+        dZ2, g["g2"], g["b2"] = bn_backward(dU, part, z2, st2, pg2, pb2)
         # first layer: z1 = y[idx] + wx . dxyz.  The dX GEMM masks by ReLU'(z1) and emits, next to the two BN sums,
         # the three column sums of dU*d_k; the BN backward is then folded into the scatter (dZ1 is never written)
         # and dW_xyz follows from column sums alone (no pass over the M x O1 tensor, no N=4 GEMM).
-        g["w2"] = gemm_dw(dZ2, z1, prob=(st1.a, st1.c))
+        g["w2"] = gemm_dw(dZ2, z1, prob=(st1.a, st1.c), w=pw2)
         dU, part = gemm(dZ2, w2, b_t=False, bwd=(1, z1, st1.a, st1.c, st1.mean, st1.invstd, dxyz.view(-1, 4)))
-        sums5 = colsum_n(part)                               # [5][O1]: s1, s2, q0, q1, q2
-        g["g1"], g["b1"] = sums5[1], sums5[0]
+        sg1, sb1 = grad_sink(pg1), grad_sink(pb1)
+        sums5 = colsum_n(part, O1, sb1, sg1)                 # [5][O1]: s1, s2, q0, q1, q2
+        g["g1"], g["b1"] = (None if sg1 is not None else sums5[1]), (None if sb1 is not None else sums5[0])
         M = dU.shape[0]
-        dwx = torch.empty(O1, 3, dtype=_f32, device=dU.device)
+        # wx is the [:, :3] slice of the first conv's (out, 3+C) weight: accumulate into the same slice of its grad
+        wbase = pwx._base if pwx._base is not None else pwx
+        direct = wbase.is_leaf and wbase.grad is not None and wbase.grad.is_contiguous() and wbase.dim() == 4 and \
+            pwx.shape == (O1, 3) and pwx.storage_offset() == wbase.storage_offset()
+        if direct:
+            dwx, dst, ld, acc = None, wbase.grad, wbase.shape[1], 1
+        else:
+            dwx = torch.empty(O1, 3, dtype=_f32, device=dU.device)
+            dst, ld, acc = dwx, 3, 0
         err = L().cmf_setconv_dwx(O1, 1.0 / M, int(st1.training), _p(sums5), _p(fwd_sums), _p(st1.a), _p(st1.mean),
-                                  _p(st1.invstd), _p(dwx), _lib.stream_ptr())
+                                  _p(st1.invstd), _p(dst), ld, acc, _lib.stream_ptr())
         _lib.check(err, "cmf_setconv_dwx")
         dy = None
         if ctx.needs_input_grad[1]:
@@ -413,6 +454,7 @@ class CostVolumeMLPFn(Function):
         x2 = gemm(x1, w2, bias=b2, act=2)
         x3 = gemm(x2, w3, bias=b3, act=2)
         ctx.saved = (nbr, dxyz, x1, x2, x3, w2, w3, (B, N1, K, C), p2.shape[1])
+        ctx.params = (w2, w3)
         ctx.mark_non_differentiable(dxyz)
         return x3.view(B, N1, K, -1), dxyz
 
@@ -423,10 +465,10 @@ class CostVolumeMLPFn(Function):
         dx3 = dx3.reshape(M, -1)
         dz3 = torch.where(x3 > 0, dx3, 0.1 * dx3)                 # leaky'(z) has the sign of the stored activation
         db3 = dz3.sum(0)
-        dw3 = gemm_dw(dz3, x2)
+        dw3 = gemm_dw(dz3, x2, w=ctx.params[1])
         dz2 = gemm(dz3, w3, b_t=False, bwd=(2, x2))
         db2 = dz2.sum(0)
-        dw2 = gemm_dw(dz2, x1)
+        dw2 = gemm_dw(dz2, x1, w=ctx.params[0])
         dz1 = gemm(dz2, w2, b_t=False, bwd=(2, x1))
         dwd = gemm_dw(dz1, dxyz.view(-1, 4))[:, :3]
         dp1 = dz1.view(B, N1, K, C).sum(dim=2)

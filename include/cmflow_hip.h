@@ -122,10 +122,11 @@ int cmf_bn_finalize(int tiles, int C, double count, const float *partial, const 
                     const float *beta, float eps, float momentum, float *running_mean, float *running_var,
                     float *mean_out, float *invstd_out, float *a_out, float *c_out,
                     long long *num_batches_tracked, void *stream);
-/* out[2][C] = sum over tiles of partial[t][2][C] */
-int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, void *stream);
-/* out[ncols] = sum over tiles of partial[t][ncols] (fixed order) */
-int cmf_colsum(int tiles, int ncols, const float *partial, float *out, void *stream);
+/* out[2][C] = sum over tiles of partial[t][2][C]; optionally acc0[C] += row 0 (dbeta), acc1[C] += row 1
+ * (dgamma): the BN-backward sums land directly in the parameters' gradient buffers */
+int cmf_colsum_finalize(int tiles, int C, const float *partial, float *out, float *acc0, float *acc1, void *stream);
+/* out[ncols] = sum over tiles of partial[t][ncols] (fixed order); same optional accumulation of the first 2*C columns */
+int cmf_colsum(int tiles, int ncols, const float *partial, float *out, int C, float *acc0, float *acc1, void *stream);
 
 /* Set-conv / cost-volume grouping with the first 1x1 conv hoisted per point
  * (QueryAndGroup + first Conv2d, lib/pointnet2_utils.py:277-285 + radarflow_util.py:151;
@@ -170,9 +171,11 @@ int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, co
 /* dW_xyz of the set-conv's first conv from column sums only (no pass over the grouped tensor):
  *   dWx[c,k] = a_c*( q_k[c] - (s1_c/M)*u_k - (s2_c/M)*invstd_c*(tz_k[c] - mean_c*u_k) )
  * bwd5 = {s1,s2,q0,q1,q2}[C] (cmf_gemm dxyz partials, reduced), fwd = {tz0,tz1,tz2}[C] then {u0,u1,u2,.}
- * (cmf_group_affine extra partials, reduced); train == 0: dWx = a*q. */
+ * (cmf_group_affine extra partials, reduced); train == 0: dWx = a*q.  dwx rows have stride ld floats
+ * (the xyz columns of the (out, 3+C) conv weight gradient); accumulate: += instead of =. */
 int cmf_setconv_dwx(int C, float inv_count, int train, const float *bwd5, const float *fwd,
-                    const float *a, const float *mean, const float *invstd, float *dwx, void *stream);
+                    const float *a, const float *mean, const float *invstd, float *dwx, int ld, int accumulate,
+                    void *stream);
 
 /* ---- the rest of the reference's pointnet2_cuda extension (lib/src/pointnet2_api.cpp:10-25) ------------ *
  * Not called by CMFlow (only by the unused lib/pointnet2_modules.py); provided so the drop-in module is
