@@ -29,6 +29,9 @@ SIGNATURES = {
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
+    "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
+    "cmf_setconv_forward": [_vp, _vp],
+    "cmf_setconv_backward": [_vp, _vp],
     "cmf_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_gather_points_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_furthest_point_sampling": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
@@ -48,6 +51,17 @@ SIGNATURES = {
     "cmf_act_bwd_stats": [_ll, _ci, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_bn_bwd_apply": [_ll, _ci, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp],
 }
+
+
+class SetConvDesc(ctypes.Structure):
+    """cmf_setconv_desc of include/cmflow_hip.h"""
+    _fields_ = [("B", _ci), ("N", _ci), ("S", _ci), ("O1", _ci), ("C", _ci * 5), ("radius", _cf), ("training", _ci),
+                ("eps", _cf * 6), ("momentum", _cf * 6),
+                ("xyz", _vp), ("y", _vp), ("ldy", _ll), ("wx", _vp), ("ldwx", _ll), ("w", _vp * 5),
+                ("gamma", _vp * 6), ("beta", _vp * 6), ("rmean", _vp * 6), ("rvar", _vp * 6), ("nbt", _vp * 6),
+                ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
+                ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
+                ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6)]
 
 
 def build(force: bool = False) -> str:

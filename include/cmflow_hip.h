@@ -199,6 +199,38 @@ int cmf_three_interpolate(int b, int c, int m, int n, const float *points, const
 int cmf_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                const float *weight, float *grad_points, void *stream);
 
+/* ---- one set-conv block (PointLocalFeature, radarflow_util.py:121-162) per call ------------------------- *
+ * Host-side sequencing of the kernels above for one (radius, nsample) scale: ball query -> gather with the
+ * hoisted first conv -> (BN, ReLU, 1x1 conv) x 2 -> BN + ReLU + max over the ball -> (1x1 conv, BN, ReLU) x 3.
+ * All device memory is caller provided: `saved` keeps what backward needs, `scratch` is transient; sizes come
+ * from cmf_setconv_sizes.  The forward and backward calls must see the same descriptor geometry and `saved`. */
+typedef struct cmf_setconv_desc {
+    int B, N, S;                 /* samples, points per sample, nsample (<= 64) */
+    int O1;                      /* channels of the hoisted first conv */
+    int C[5];                    /* output channels of layers 2..6 */
+    float radius;
+    int training;                /* 1: batch statistics + running-stat update; 0: fold the running statistics */
+    float eps[6], momentum[6];
+    const float *xyz;            /* (B,N,3) */
+    const float *y; long long ldy;      /* (B,N,O1) rows, stride ldy: feats @ W_f^T */
+    const float *wx; long long ldwx;    /* (O1,3) xyz columns of the first conv weight, row stride ldwx */
+    const float *w[5];           /* layers 2..6 weights (C[i], C_in) dense */
+    const float *gamma[6], *beta[6];
+    float *rmean[6], *rvar[6];
+    long long *nbt[6];           /* num_batches_tracked counters (may be NULL) */
+    float *saved, *scratch;
+    float *out; long long ldo;   /* (B*N, C[4]) */
+    /* backward */
+    const float *dout; long long lddout;
+    float *dy;                   /* (B,N,O1) dense, or NULL */
+    float *dwx; long long lddwx; int acc_wx;
+    float *dw[5]; int acc_w[5];  /* weight gradients: written (0) or accumulated into (1) */
+    float *dgamma[6], *dbeta[6]; int acc_bn[6];
+} cmf_setconv_desc;
+int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
+int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
+int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 
