@@ -32,32 +32,7 @@ constexpr int G_KT = G_BK / 4;            // threads covering one k-contiguous r
 constexpr int G_RP = 256 / G_KT;          // rows staged per pass by the 256 threads
 constexpr int G_LDS_LD = G_BK + 4;      // 20 floats (BK=16) / 36 (BK=32): row strides whose 16-B slots tile all 64 banks -> conflict-free b128 reads
 
-struct GemmArgs {
-    int M, N, K;                // C is MxN, contraction length K (this split's range is [k_begin,k_end))
-    const float *A; long long lda;
-    const float *B; long long ldb;
-    float *C; long long ldc;
-    // prologue on A (A_MK only): per-contraction-index affine + relu
-    const float *pro_a, *pro_c;
-    // prologue on B by output column (used by the weight-gradient GEMM: B = activated layer input)
-    const float *prob_a, *prob_c;
-    // epilogue
-    const float *bias;          // [N] or null
-    int act;                    // 0 none, 1 relu, 2 leaky(0.1), 3 sigmoid
-    float *stats;               // [tiles_m][2][N] partial (sum, sumsq) of the STORED values, or null
-    // backward epilogue: multiply by the activation derivative of the producer layer
-    //   mode 1 (BN+ReLU):  dU = acc * [ea[n]*Z[m,n] + ec[n] > 0];  partials s1 = sum dU,
-    //                      s2 = sum dU * (Z - mean[n]) * invstd[n]  -> stats[tiles_m][2][N]
-    //   mode 2 (leaky):    dZ = acc * (Z[m,n] > 0 ? 1 : 0.1)
-    //   mode 3 (relu on stored activation Z>0)
-    int bwd_mode;
-    const float *Z; long long ldz;
-    const float *ea, *ec, *emean, *einvstd;
-    const float *dxyz;          // bwd_mode 1 only, optional: rows of (dx,dy,dz,0); adds partials q_k = sum dU * d_k (k=0..2)
-                                // -> stats is then [tiles_m][5][N] (s1, s2, q0, q1, q2): the set-conv dW_xyz without a pass
-    int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
-    int accumulate;             // C += result (beta = 1)
-};
+#include "gemm_args.h"
 
 __device__ __forceinline__ float act_fn(float v, int act)
 {
@@ -493,12 +468,15 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.bias = bias; g.act = act; g.stats = stats; g.bwd_mode = bwd_mode; g.Z = Z; g.ldz = ldz;
     g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz; g.split_k = split_k;
     g.accumulate = split_k > 1 ? 0 : accumulate;
-    int err;
+    int err = cmf_thin_gemm(g, a_t, b_t, st);            // narrow layers (<= 64 channels): barrier-free per-wave kernels
+    if (err > 0) return err;
+    const bool thin_done = (err == 0);
     const bool wide = N > 64, tall = M > 64;
 #define CMF_PICK(AT, BT)                                                                                   \
     (tall ? (wide ? launch<128, 128, AT, BT>(g, st) : launch<128, 64, AT, BT>(g, st))                      \
           : (wide ? launch<64, 128, AT, BT>(g, st) : launch<64, 64, AT, BT>(g, st)))
-    if (!a_t && b_t)       err = CMF_PICK(false, true);
+    if (thin_done)         err = 0;
+    else if (!a_t && b_t)  err = CMF_PICK(false, true);
     else if (!a_t && !b_t) err = CMF_PICK(false, false);
     else if (a_t && !b_t)  err = CMF_PICK(true, false);
     else                   err = CMF_PICK(true, true);

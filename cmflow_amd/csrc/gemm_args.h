@@ -1,0 +1,34 @@
+// Argument block shared by the tiled GEMM (gemm.hip) and the thin GEMMs (thin_gemm.hip); see cmf_gemm in
+// include/cmflow_hip.h for the meaning of every field.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct GemmArgs {
+    int M, N, K;                // C is MxN, contraction length K (this split's range is [k_begin,k_end))
+    const float *A; long long lda;
+    const float *B; long long ldb;
+    float *C; long long ldc;
+    // prologue on A (A_MK only): per-contraction-index affine + relu
+    const float *pro_a, *pro_c;
+    // prologue on B by output column (used by the weight-gradient GEMM: B = activated layer input)
+    const float *prob_a, *prob_c;
+    // epilogue
+    const float *bias;          // [N] or null
+    int act;                    // 0 none, 1 relu, 2 leaky(0.1), 3 sigmoid
+    float *stats;               // [tiles_m][2][N] partial (sum, sumsq) of the STORED values, or null
+    // backward epilogue: multiply by the activation derivative of the producer layer
+    //   mode 1 (BN+ReLU):  dU = acc * [ea[n]*Z[m,n] + ec[n] > 0];  partials s1 = sum dU,
+    //                      s2 = sum dU * (Z - mean[n]) * invstd[n]  -> stats[tiles_m][2][N]
+    //   mode 2 (leaky):    dZ = acc * (Z[m,n] > 0 ? 1 : 0.1)
+    //   mode 3 (relu on stored activation Z>0)
+    int bwd_mode;
+    const float *Z; long long ldz;
+    const float *ea, *ec, *emean, *einvstd;
+    const float *dxyz;          // bwd_mode 1 only, optional: rows of (dx,dy,dz,0); adds partials q_k = sum dU * d_k (k=0..2)
+                                // -> stats is then [tiles_m][5][N] (s1, s2, q0, q1, q2): the set-conv dW_xyz without a pass
+    int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
+    int accumulate;             // C += result (beta = 1)
+};
+
+// thin_gemm.hip: returns -1 when the shape is not handled there
+int cmf_thin_gemm(const GemmArgs &g, int a_t, int b_t, hipStream_t st);

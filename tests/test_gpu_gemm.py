@@ -140,3 +140,45 @@ def test_gemm_backward_throughput_report(dev):
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 5
             print("%s M=%d N=%d K=%d: %.3f ms = %.1f TFLOP/s" % (name, M, N, K, ms, 2e-9 * M * N * K / ms))
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 32, 32), (1000, 64, 64), (16384, 64, 32), (130, 32, 64), (524288, 64, 32), (77, 32, 8)])
+def test_thin_gemm_forward_and_dx(dev, M, N, K):
+    """Narrow layers (<= 64 channels) take the barrier-free per-wave kernels of thin_gemm.hip."""
+    from cmflow_amd.fused import gemm
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(dev); W = torch.randn(N, K, generator=g).to(dev)
+    pa, pc = (torch.rand(K, generator=g) + 0.5).to(dev), torch.randn(K, generator=g).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    C, st = gemm(A, W, pro=(pa, pc), bias=bias, act=1, stats=True)
+    ref = torch.relu(torch.relu(A * pa + pc).double() @ W.double().t() + bias.double())
+    np.testing.assert_allclose(C.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    s = st.double().sum(0)
+    np.testing.assert_allclose(s[0].cpu().numpy(), ref.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(s[1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+    # data gradient with the BN+ReLU mask, the two BN sums and the three dxyz sums
+    dZ = torch.randn(M, N, generator=g).to(dev)
+    Zp = torch.randn(M, K, generator=g).to(dev)
+    ea, ec = (torch.rand(K, generator=g) + 0.5).to(dev), (0.3 * torch.randn(K, generator=g)).to(dev)
+    mean, invstd = torch.randn(K, generator=g).to(dev), (torch.rand(K, generator=g) + 0.5).to(dev)
+    dxyz = torch.randn(M, 4, generator=g).to(dev)
+    dU, st = gemm(dZ, W, b_t=False, bwd=(1, Zp, ea, ec, mean, invstd, dxyz))
+    refu = (dZ.double() @ W.double()) * ((ea * Zp + ec) > 0)
+    np.testing.assert_allclose(dU.cpu().numpy(), refu.float().cpu().numpy(), rtol=2e-5, atol=2e-4)
+    s = st.double().sum(0)
+    np.testing.assert_allclose(s[0].cpu().numpy(), refu.sum(0).cpu().numpy(), rtol=1e-4, atol=2e-2)
+    np.testing.assert_allclose(s[1].cpu().numpy(), (refu * ((Zp - mean) * invstd).double()).sum(0).cpu().numpy(), rtol=1e-4, atol=5e-2)
+    for k in range(3):
+        np.testing.assert_allclose(s[2 + k].cpu().numpy(), (refu * dxyz[:, k:k + 1].double()).sum(0).cpu().numpy(), rtol=1e-4, atol=5e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 32, 32), (16384, 64, 64), (1000, 64, 32), (524288, 32, 64)])
+def test_thin_gemm_weight_gradient(dev, M, N, K):
+    from cmflow_amd.fused_blocks import gemm_dw
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    dZ = torch.randn(M, N, generator=g).to(dev); Zp = torch.randn(M, K, generator=g).to(dev)
+    ea, ec = (torch.rand(K, generator=g) + 0.5).to(dev), (0.3 * torch.randn(K, generator=g)).to(dev)
+    X = torch.relu(ea * Zp + ec)
+    dW = gemm_dw(dZ, Zp, prob=(ea, ec))
+    _check(dW, dZ.double().t() @ X.double(), dZ.double().abs().t() @ X.double().abs(), tol=4e-6)
+    assert torch.equal(dW, gemm_dw(dZ, Zp, prob=(ea, ec)))            # deterministic
