@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", choices=["pm", "pm_torch", "ref"], default="pm",
                     help="pm: fused point-major HIP path (product); ref: unfused reference-layout ops")
+    ap.add_argument("--serial", action="store_true",
+                    help="diagnostic: encoder scales on ONE stream (per-kernel durations free of contention)")
     ap.add_argument("--track", choices=["cmf_gemm", "cmf_group_points"], default=None)
     a = ap.parse_args()
 
@@ -162,6 +164,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.serial:
+        from cmflow_amd.radarflow_util import MultiScaleEncoder as _MSE
+        _MSE.multi_stream = False
     for _ in range(a.warmup):
         one()
     track = a.track or ("cmf_group_points" if a.path == "ref" else "cmf_gemm")

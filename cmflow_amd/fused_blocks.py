@@ -426,94 +426,205 @@ class SetConvFn(Function):
                 g["b3"], g["w4"], g["g4"], g["b4"], g["w5"], g["g5"], g["b5"], g["w6"], g["g6"], g["b6"])
 
 
+def _block_forward(xyz_t, y, radius, nsample, bns, training, params, out=None):
+    """Fill a cmf_setconv_desc, allocate saved/scratch/out on the CURRENT stream and issue
+    cmf_setconv_forward there.  out: optional (B*N, 64) strided view to write into."""
+    import ctypes
+    B, N, _ = xyz_t.shape
+    dev = xyz_t.device
+    wx = params[0]
+    ws = [params[i].contiguous() for i in (3, 6, 9, 12, 15)]
+    assert y.stride(2) == 1 and y.stride(0) == N * y.stride(1)
+    xyz_t = xyz_t.contiguous()
+    d = _lib.SetConvDesc()
+    d.B, d.N, d.S, d.O1, d.radius, d.training = B, N, nsample, y.shape[2], radius, int(training)
+    for i, w in enumerate(ws):
+        d.C[i] = w.shape[0]
+        d.w[i] = w.data_ptr()
+    for l, bn in enumerate(bns):
+        d.eps[l] = bn.eps
+        d.momentum[l] = bn.momentum if bn.momentum is not None else 0.1
+        assert bn.momentum is not None, "cumulative moving average BN is not supported by the block call"
+        d.gamma[l], d.beta[l] = bn.weight.data_ptr(), bn.bias.data_ptr()
+        d.rmean[l], d.rvar[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+        d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats) else None
+    d.xyz, d.y, d.ldy = xyz_t.data_ptr(), y.data_ptr(), y.stride(1)
+    if wx.stride(1) != 1:
+        wx = wx.contiguous()
+    d.wx, d.ldwx = wx.data_ptr(), wx.stride(0)
+    n_saved, n_f, n_b = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+    _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), ctypes.addressof(n_saved), ctypes.addressof(n_f),
+                                     ctypes.addressof(n_b)), "cmf_setconv_sizes")
+    saved = torch.empty(n_saved.value, dtype=_f32, device=dev)
+    scratch = torch.empty(n_f.value, dtype=_f32, device=dev)
+    if out is None:
+        out = torch.empty(B * N, ws[4].shape[0], dtype=_f32, device=dev)
+    d.saved, d.scratch, d.out, d.ldo = saved.data_ptr(), scratch.data_ptr(), out.data_ptr(), out.stride(0)
+    _lib.check(L().cmf_setconv_forward(ctypes.addressof(d), _lib.stream_ptr()), "cmf_setconv_forward")
+    return out, dict(desc=d, keep=(xyz_t, y, wx, ws, saved), n_bwd=n_b.value, params=params)
+
+
+def _block_backward(state, dout, need_dy):
+    """cmf_setconv_backward on the CURRENT stream.  dout: (B*N, 64) view (unit channel stride).
+    -> (dy or None, 18 parameter gradients; None where the kernel accumulated into a grad sink)."""
+    import ctypes
+    d, (xyz_t, y, wx, ws, saved), params = state["desc"], state["keep"], state["params"]
+    dev = dout.device
+    B, N, O1 = d.B, d.N, d.O1
+    if dout.stride(1) != 1 or dout.stride(0) % 4:
+        dout = dout.contiguous()
+    scratch = torch.empty(state["n_bwd"], dtype=_f32, device=dev)
+    d.scratch, d.dout, d.lddout = scratch.data_ptr(), dout.data_ptr(), dout.stride(0)
+    grads = [None] * 18
+    # wx: the [:, :3] slice of the first conv's weight
+    pwx = params[0]
+    wbase = pwx._base if pwx._base is not None else pwx
+    if wbase.is_leaf and wbase.grad is not None and wbase.grad.is_contiguous() and wbase.dim() == 4 and \
+            pwx.shape == (O1, 3) and pwx.storage_offset() == wbase.storage_offset():
+        d.dwx, d.lddwx, d.acc_wx = wbase.grad.data_ptr(), wbase.shape[1], 1
+    else:
+        g = torch.empty(O1, 3, dtype=_f32, device=dev)
+        grads[0] = g
+        d.dwx, d.lddwx, d.acc_wx = g.data_ptr(), 3, 0
+    for i in range(5):                                   # layer weights 2..6 at params[3,6,9,12,15]
+        sink = grad_sink(params[3 + 3 * i])
+        if sink is not None:
+            d.dw[i], d.acc_w[i] = sink.data_ptr(), 1
+        else:
+            g = torch.empty_like(ws[i])
+            grads[3 + 3 * i] = g
+            d.dw[i], d.acc_w[i] = g.data_ptr(), 0
+    for l in range(6):                                   # (gamma, beta) of BN layer l at params[1+3l], params[2+3l]
+        sg, sb = grad_sink(params[1 + 3 * l]), grad_sink(params[2 + 3 * l])
+        if sg is not None and sb is not None:
+            d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sg.data_ptr(), sb.data_ptr(), 1
+        else:
+            gg, gb = torch.empty_like(params[1 + 3 * l]), torch.empty_like(params[2 + 3 * l])
+            grads[1 + 3 * l], grads[2 + 3 * l] = gg, gb
+            d.dgamma[l], d.dbeta[l], d.acc_bn[l] = gg.data_ptr(), gb.data_ptr(), 0
+    dy = None
+    if need_dy:
+        dy = torch.empty(B, N, O1, dtype=_f32, device=dev)
+        d.dy = dy.data_ptr()
+    else:
+        d.dy = None
+    _lib.check(L().cmf_setconv_backward(ctypes.addressof(d), _lib.stream_ptr()), "cmf_setconv_backward")
+    return dy, grads
+
+
 class SetConvBlockFn(Function):
     """SetConvFn with the kernel sequence issued by ONE C-ABI call per direction (csrc/setconv_block.hip):
     same kernels, same order, same numerics -- only the ~70 Python-level launches per block are gone."""
 
     @staticmethod
     def forward(ctx, xyz_t, y, radius, nsample, bns, training, *params):
-        import ctypes
         B, N, _ = xyz_t.shape
-        dev = xyz_t.device
-        wx = params[0]
-        ws = [params[i].contiguous() for i in (3, 6, 9, 12, 15)]
-        assert y.stride(2) == 1 and y.stride(0) == N * y.stride(1)
-        xyz_t = xyz_t.contiguous()
-        d = _lib.SetConvDesc()
-        d.B, d.N, d.S, d.O1, d.radius, d.training = B, N, nsample, y.shape[2], radius, int(training)
-        for i, w in enumerate(ws):
-            d.C[i] = w.shape[0]
-            d.w[i] = w.data_ptr()
-        for l, bn in enumerate(bns):
-            d.eps[l] = bn.eps
-            d.momentum[l] = bn.momentum if bn.momentum is not None else 0.1
-            assert bn.momentum is not None, "cumulative moving average BN is not supported by the block call"
-            d.gamma[l], d.beta[l] = bn.weight.data_ptr(), bn.bias.data_ptr()
-            d.rmean[l], d.rvar[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-            d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats) else None
-        d.xyz, d.y, d.ldy = xyz_t.data_ptr(), y.data_ptr(), y.stride(1)
-        if wx.stride(1) != 1:
-            wx = wx.contiguous()
-        d.wx, d.ldwx = wx.data_ptr(), wx.stride(0)
-        n_saved, n_f, n_b = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
-        _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), ctypes.addressof(n_saved), ctypes.addressof(n_f),
-                                         ctypes.addressof(n_b)), "cmf_setconv_sizes")
-        saved = torch.empty(n_saved.value, dtype=_f32, device=dev)
-        scratch = torch.empty(n_f.value, dtype=_f32, device=dev)
-        out = torch.empty(B * N, ws[4].shape[0], dtype=_f32, device=dev)
-        d.saved, d.scratch, d.out, d.ldo = saved.data_ptr(), scratch.data_ptr(), out.data_ptr(), out.stride(0)
-        _lib.check(L().cmf_setconv_forward(ctypes.addressof(d), _lib.stream_ptr()), "cmf_setconv_forward")
-        ctx.desc, ctx.keep, ctx.n_bwd = d, (xyz_t, y, wx, ws, saved), n_b.value
-        ctx.params = params
+        out, ctx.state = _block_forward(xyz_t, y, radius, nsample, bns, training, params)
         return out.view(B, N, -1)
 
     @staticmethod
     def backward(ctx, dout):
-        import ctypes
-        d, (xyz_t, y, wx, ws, saved), params = ctx.desc, ctx.keep, ctx.params
-        dev = dout.device
-        B, N, O1 = d.B, d.N, d.O1
-        dout = dout.reshape(B * N, -1)
-        if dout.stride(1) != 1 or dout.stride(0) % 4:
-            dout = dout.contiguous()
-        scratch = torch.empty(ctx.n_bwd, dtype=_f32, device=dev)
-        d.scratch, d.dout, d.lddout = scratch.data_ptr(), dout.data_ptr(), dout.stride(0)
-        grads = [None] * 18
-        hold = []
-        # wx: the [:, :3] slice of the first conv's weight
-        pwx = params[0]
-        wbase = pwx._base if pwx._base is not None else pwx
-        if wbase.is_leaf and wbase.grad is not None and wbase.grad.is_contiguous() and wbase.dim() == 4 and \
-                pwx.shape == (O1, 3) and pwx.storage_offset() == wbase.storage_offset():
-            d.dwx, d.lddwx, d.acc_wx = wbase.grad.data_ptr(), wbase.shape[1], 1
-        else:
-            g = torch.empty(O1, 3, dtype=_f32, device=dev)
-            grads[0] = g
-            d.dwx, d.lddwx, d.acc_wx = g.data_ptr(), 3, 0
-        for i in range(5):                                   # layer weights 2..6 at params[3,6,9,12,15]
-            sink = grad_sink(params[3 + 3 * i])
-            if sink is not None:
-                d.dw[i], d.acc_w[i] = sink.data_ptr(), 1
-            else:
-                g = torch.empty_like(ws[i])
-                grads[3 + 3 * i] = g
-                d.dw[i], d.acc_w[i] = g.data_ptr(), 0
-        for l in range(6):                                   # (gamma, beta) of BN layer l at params[1+3l], params[2+3l]
-            sg, sb = grad_sink(params[1 + 3 * l]), grad_sink(params[2 + 3 * l])
-            if sg is not None and sb is not None:
-                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sg.data_ptr(), sb.data_ptr(), 1
-            else:
-                gg, gb = torch.empty_like(params[1 + 3 * l]), torch.empty_like(params[2 + 3 * l])
-                grads[1 + 3 * l], grads[2 + 3 * l] = gg, gb
-                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = gg.data_ptr(), gb.data_ptr(), 0
-        dy = None
-        if ctx.needs_input_grad[1]:
-            dy = torch.empty(B, N, O1, dtype=_f32, device=dev)
-            d.dy = dy.data_ptr()
-        else:
-            d.dy = None
-        _lib.check(L().cmf_setconv_backward(ctypes.addressof(d), _lib.stream_ptr()), "cmf_setconv_backward")
+        st = ctx.state
+        dy, grads = _block_backward(st, dout.reshape(st["desc"].B * st["desc"].N, -1), ctx.needs_input_grad[1])
         return (None, dy, None, None, None, None, *grads)
+
+
+_POOL = None
+
+
+def _pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="cmf_enqueue")
+    return _POOL
+
+
+class MultiScaleBlockFn(Function):
+    """The four set-conv scales of a MultiScaleEncoder (radarflow_util.py:101-118) as one autograd node.
+    Each scale's block call is issued from its own host thread on its own HIP stream: with N = 256 the
+    ~20 (forward) / ~45 (backward) kernels of a scale run for 5-40 us each, about as long as a launch takes
+    to enqueue, so one host thread cannot keep four streams fed -- four can (ctypes releases the GIL for
+    the duration of the C call).  The scales write disjoint channel slices of one (B,N,4*64) output and the
+    input gradient comes back as one (B,N,4*O1) tensor, so the concat / slice-grad kernels are gone too.
+    Numerics are those of SetConvBlockFn: same kernels per scale, no cross-scale arithmetic."""
+
+    @staticmethod
+    def forward(ctx, xyz_t, y_all, scales, streams, training, *params):
+        # scales: [(radius, nsample, bns)], params: 18 per scale
+        B, N, _ = xyz_t.shape
+        ns = len(scales)
+        o1 = y_all.shape[2] // ns
+        dev = xyz_t.device
+        main = torch.cuda.current_stream()
+        co = params[15].shape[0]
+        out_all = torch.empty(B * N, ns * co, dtype=_f32, device=dev)
+        for st in streams:
+            st.wait_stream(main)
+
+        def work(i):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                r, s, bns = scales[i]
+                return _block_forward(xyz_t, y_all[:, :, i * o1:(i + 1) * o1], r, s, bns, training,
+                                      params[18 * i:18 * (i + 1)], out=out_all[:, i * co:(i + 1) * co])[1]
+
+        ctx.states = list(_pool().map(work, range(ns)))
+        for st in streams:
+            main.wait_stream(st)
+        ctx.streams, ctx.o1, ctx.co = streams, o1, co
+        return out_all.view(B, N, ns * co)
+
+    @staticmethod
+    def backward(ctx, dout):
+        streams, co = ctx.streams, ctx.co
+        ns = len(streams)
+        d0 = ctx.states[0]["desc"]
+        B, N = d0.B, d0.N
+        dout = dout.reshape(B * N, ns * co)
+        if dout.stride(1) != 1:
+            dout = dout.contiguous()
+        dev = dout.device
+        main = torch.cuda.current_stream()
+        need_dy = ctx.needs_input_grad[1]
+        for st in streams:
+            st.wait_stream(main)
+
+        def work(i):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                return _block_backward(ctx.states[i], dout[:, i * co:(i + 1) * co], need_dy)
+
+        res = list(_pool().map(work, range(ns)))
+        for st in streams:
+            main.wait_stream(st)
+        grads = []
+        for dy, g in res:
+            grads += g
+            for t in [dy] + g:
+                if t is not None:
+                    t.record_stream(main)
+        dy_all = torch.cat([r[0] for r in res], dim=2) if need_dy else None
+        return (None, dy_all, None, None, None, *grads)
+
+
+def set_conv_params(module):
+    w2d = lambda conv: conv.weight.view(conv.weight.shape[0], conv.weight.shape[1])
+    c, b = module.mlp_convs, module.mlp_bns
+    c2, b2 = module.mlp2_convs, module.mlp2_bns
+    params = [w2d(c[0])[:, :3], b[0].weight, b[0].bias, w2d(c[1]), b[1].weight, b[1].bias, w2d(c[2]), b[2].weight, b[2].bias,
+              w2d(c2[0]), b2[0].weight, b2[0].bias, w2d(c2[1]), b2[1].weight, b2[1].bias, w2d(c2[2]), b2[2].weight, b2[2].bias]
+    return params, [b[0], b[1], b[2], b2[0], b2[1], b2[2]]
+
+
+def multi_scale_set_conv(modules, streams, xyz_t, y_all):
+    """modules: the PointLocalFeature scales; y_all (B,N,len*O1) the stacked hoisted first-conv features."""
+    scales, params = [], []
+    for m in modules:
+        p, bns = set_conv_params(m)
+        scales.append((m.radius, m.nsample, bns))
+        params += p
+    return MultiScaleBlockFn.apply(xyz_t, y_all, scales, streams, modules[0].mlp_bns[0].training, *params)
 
 
 def set_conv(module, xyz_t, y):

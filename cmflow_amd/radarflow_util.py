@@ -121,9 +121,12 @@ class MultiScaleEncoder(nn.Module):
         # The four scales are independent until the concat and most of their kernels are far too small to
         # fill 256 CUs (N = 256): run each scale on its own HIP stream so they overlap.  Autograd replays
         # each block's backward on the stream its forward ran on and orders the streams itself.
-        main = torch.cuda.current_stream()
         if self._streams is None:
             self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+        if FB.USE_BLOCK_CALLS and self.threaded_enqueue:
+            # one host thread per scale as well: see fused_blocks.MultiScaleBlockFn
+            return FB.multi_scale_set_conv(list(self.ms_ls), self._streams, xyz_t, y_all)
+        main = torch.cuda.current_stream()
         outs = []
         for i, (sa, st) in enumerate(zip(self.ms_ls, self._streams)):
             st.wait_stream(main)
@@ -135,6 +138,7 @@ class MultiScaleEncoder(nn.Module):
             main.wait_stream(st)
         return torch.cat(outs, dim=2)
 
+    threaded_enqueue = True
     multi_stream = True
     _streams = None
 
