@@ -106,25 +106,68 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
 // ---------------------------------------------------------------------------------------------
 // Backward: grad_points[b,c,idx[b,p,s]] += grad_out[b,c,p,s].
 // The reference issues one global fp32 atomicAdd per element (538 M atomics for one scale of
-// mse_layer2, order undefined).  Here the scatter becomes a GATHER over the inverse index of idx
-// (cmf_build_inverse: for every target point the entries that reference it, ascending): a workgroup
-// owns (sample, GG_CH channels), stages one grad_out row (npoints*nsample floats) in LDS with coalesced
-// 16-byte loads, and thread j sums row[inv[t]] over its segment -- no atomics, fixed summation order
-// (bit-reproducible and bit-equal to the CPU oracle's scan-order sum), each grad_points element written
-// once with a coalesced store.
+// mse_layer2, order undefined).  grad_out is read exactly once, in full coalesced rows; the scatter
+// happens in LDS.  Two kernels:
+//
+//  * rows of up to 8192 entries (every shape of the model, N = 256): "balanced" kernel.  The scatter
+//    becomes a GATHER over the inverse index of idx (cmf_build_inverse: entries sorted by target).  A
+//    workgroup owns (sample, a run of channels); thread t owns the E consecutive SORTED entries
+//    t*E..t*E+E-1 -- their positions in the row and the segment boundaries among them live in
+//    registers for the whole channel loop, so per channel a thread does E independent LDS reads of
+//    the staged row and a short segmented sum; nothing depends on how skewed the index is (with
+//    first-hit padding the lists of low-numbered points are 10x the mean).  Segments that span
+//    chunks are stitched from per-chunk tails in fixed order: no atomics, bit-reproducible (the
+//    association differs from a sequential scan, so equal to the oracle to rounding, not bitwise).
+//    The next channel's row is fetched into registers while the current one is reduced.
+//  * longer rows (N = 4096 x K = 64: 1 MB per row): workgroup per (sample, 4 channels), the row
+//    streamed with 16-byte loads, idx read once per 4 channels, sums kept in LDS per target with
+//    ds_add_f32 (order undefined, like the reference; LDS atomics instead of HBM atomics).
 // ---------------------------------------------------------------------------------------------
 int cmf_build_inverse_rows(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream, int entries);
 
 constexpr int GG_THREADS = 256;
-constexpr int GG_CH = 8;
-constexpr int GG_MAX_TOTAL_LDS = 12288;    // grad_out row + inverse list staged in LDS up to this many entries
+constexpr int GG_CH = 16;                  // channels per workgroup (balanced kernel): amortises the index set-up
+constexpr int GG_MAX_E = 32;               // sorted entries per thread  => rows of up to 8192 entries
+constexpr int GG_MAX_N_BAL = 4096;         // targets per sample the balanced kernel keeps tables for
 
-template <bool IN_LDS>
-__global__ __launch_bounds__(GG_THREADS) void group_points_grad_kernel(
+// inclusive prefix sum over the 256 threads of a workgroup (4 waves); wsum: 4 ints of LDS
+__device__ __forceinline__ int gg_block_scan(int v, int *wsum, int &block_total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    __syncthreads();                                                // previous users of wsum are done
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < GG_THREADS / 64; ++w) {
+        const int x = wsum[w];
+        if (w < wave) add += x;
+        tot += x;
+    }
+    block_total = tot;
+    return v + add;
+}
+
+template <int E>
+__global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_bal_kernel(
     int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ offsets,
     const int *__restrict__ inv, float *__restrict__ grad_points)
 {
-    extern __shared__ __attribute__((aligned(16))) int sm[];       // IN_LDS: [total] inv | [total] row
+    constexpr int RS = GG_THREADS * E + 4;                          // row buffer: entries + one zero slot (padding reads)
+    constexpr int JT = 2;                                           // targets per thread whose tables live in registers
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *row = sm;
+    float *ranked = row + RS;                                       // [n]   sum up to each segment end inside its chunk
+    float *tails = ranked + n;                                      // [256] chunk sum after its last boundary
+    int *offs = reinterpret_cast<int *>(tails + GG_THREADS);        // [n+1]
+    int *rank_of = offs + n + 1;                                    // [n]   rank among non-empty targets, -1 if empty
+    int *scan = rank_of + n;                                        // [4]   scratch for the block scans
+    const int tid = threadIdx.x;
     const int bs = blockIdx.x;
     const int c0 = blockIdx.y * GG_CH;
     const int nch = min(GG_CH, c - c0);
@@ -132,28 +175,215 @@ __global__ __launch_bounds__(GG_THREADS) void group_points_grad_kernel(
     const int *lst = inv + (size_t)bs * total;
     const float *g = grad_out + ((size_t)bs * c + c0) * total;
     float *gp = grad_points + ((size_t)bs * c + c0) * n;
-    int *linv = sm;
-    float *row = reinterpret_cast<float *>(sm + (IN_LDS ? total : 0));
-    if (IN_LDS) {
-        for (int i = threadIdx.x; i < total; i += GG_THREADS) linv[i] = lst[i];
+
+    // ---- per-sample set-up (once per workgroup) ----
+    for (int j = tid; j <= n; j += GG_THREADS) offs[j] = off[j];
+    unsigned char *flags = reinterpret_cast<unsigned char *>(row);  // aliases the row buffer until the first row arrives
+    for (int i = tid; i < GG_THREADS * E / 4; i += GG_THREADS) reinterpret_cast<int *>(flags)[i] = 0;
+    __syncthreads();
+    for (int j = tid; j < n; j += GG_THREADS)
+        if (offs[j + 1] > offs[j]) flags[offs[j + 1] - 1] = 1;
+    __syncthreads();
+    unsigned pos2[E / 2];                                           // two 16-bit row positions per register
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < E; k += 2) {
+        const int t = tid * E + k;
+        const unsigned p0 = t < total ? (unsigned)lst[t] : GG_THREADS * E;        // padding reads the zero slot
+        const unsigned p1 = t + 1 < total ? (unsigned)lst[t + 1] : GG_THREADS * E;
+        pos2[k / 2] = p0 | (p1 << 16);
+        mask |= ((unsigned)flags[t] << k) | ((unsigned)flags[t + 1] << (k + 1));
     }
+    // rank of this chunk's first boundary = boundaries in earlier chunks (exclusive block scan)
+    int tot;
+    const int rank0 = gg_block_scan(__popc(mask), scan, tot) - __popc(mask);
+    // rank_of[j] = non-empty targets before j (targets in blocks of 256, running base)
+    int base = 0;
+    for (int j0 = 0; j0 < n; j0 += GG_THREADS) {
+        const int j = j0 + tid;
+        const int ne = (j < n && offs[j + 1] > offs[j]) ? 1 : 0;
+        const int inc = gg_block_scan(ne, scan, tot);
+        if (j < n) rank_of[j] = ne ? base + inc - 1 : -1;
+        base += tot;
+    }
+    __syncthreads();
+    int rj[JT], sc[JT], ec[JT];                                     // this thread's first JT targets: tid, tid+256
+#pragma unroll
+    for (int q = 0; q < JT; ++q) {
+        const int j = tid + q * GG_THREADS;
+        rj[q] = j < n ? rank_of[j] : -1;
+        sc[q] = rj[q] >= 0 ? offs[j] / E : 0;
+        ec[q] = rj[q] >= 0 ? (offs[j + 1] - 1) / E : 0;
+    }
+    // ---- rows ----
+    constexpr int V = E / 4;                                        // float4 per thread per row
+    const bool vec = (total & 3) == 0 && ((uintptr_t)grad_out & 15) == 0;
+    auto fetch = [&](const float *src, float4 (&r)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int i = (v * GG_THREADS + tid) * 4;
+            if (vec) r[v] = i < total ? *(const float4 *)(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                r[v].x = i < total ? src[i] : 0.f;         r[v].y = i + 1 < total ? src[i + 1] : 0.f;
+                r[v].z = i + 2 < total ? src[i + 2] : 0.f; r[v].w = i + 3 < total ? src[i + 3] : 0.f;
+            }
+        }
+    };
+    auto stash = [&](const float4 (&r)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) *(float4 *)(row + (v * GG_THREADS + tid) * 4) = r[v];
+        if (tid == 0) row[GG_THREADS * E] = 0.f;
+    };
+    float4 nxt[V];
+    fetch(g, nxt);
+    stash(nxt);
+    __syncthreads();
     for (int ch = 0; ch < nch; ++ch) {
-        const float *src = g + (size_t)ch * total;
-        if (IN_LDS) {
-            __syncthreads();
-            if ((total & 3) == 0)
-                for (int i = threadIdx.x * 4; i < total; i += GG_THREADS * 4) *(float4 *)(row + i) = *(const float4 *)(src + i);
-            else
-                for (int i = threadIdx.x; i < total; i += GG_THREADS) row[i] = src[i];
-            __syncthreads();
+        if (ch + 1 < nch) fetch(g + (size_t)(ch + 1) * total, nxt);  // in flight during the reduction below
+        float old[JT];                                              // grad_points accumulates: fetch the old value early
+#pragma unroll
+        for (int q = 0; q < JT; ++q) old[q] = rj[q] >= 0 ? gp[(size_t)ch * n + tid + q * GG_THREADS] : 0.f;
+        // phase 1: segmented sums over this thread's E sorted entries (LDS reads issued 8 at a time)
+        float run = 0.f;
+        int rk = rank0;
+#pragma unroll
+        for (int k0 = 0; k0 < E; k0 += 8) {
+            float val[8];
+#pragma unroll
+            for (int k = 0; k < 8 && k0 + k < E; ++k) {
+                const unsigned pp = pos2[(k0 + k) / 2];
+                val[k] = row[((k0 + k) & 1) ? (pp >> 16) : (pp & 0xffffu)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8 && k0 + k < E; ++k) {
+                run += val[k];
+                if ((mask >> (k0 + k)) & 1u) { ranked[rk++] = run; run = 0.f; }
+            }
         }
-        for (int j = threadIdx.x; j < n; j += GG_THREADS) {
-            const int beg = off[j], end = off[j + 1];
-            float acc = 0.f;
-            for (int t = beg; t < end; ++t) acc += IN_LDS ? row[linv[t]] : src[lst[t]];
-            gp[(size_t)ch * n + j] += acc;
+        tails[tid] = run;
+        __syncthreads();
+        if (ch + 1 < nch) stash(nxt);                               // every read of the current row is done
+        // phase 2: one target per thread; a segment that began in earlier chunks adds their tails in order
+#pragma unroll
+        for (int q = 0; q < JT; ++q)
+            if (rj[q] >= 0) {
+                float s = 0.f;
+                for (int k = sc[q]; k < ec[q]; ++k) s += tails[k];
+                s += ranked[rj[q]];
+                gp[(size_t)ch * n + tid + q * GG_THREADS] = old[q] + s;
+            }
+        for (int j = tid + JT * GG_THREADS; j < n; j += GG_THREADS) {
+            const int r = rank_of[j];
+            if (r < 0) continue;
+            const int s0 = offs[j] / E, e0 = (offs[j + 1] - 1) / E;
+            float s = 0.f;
+            for (int k = s0; k < e0; ++k) s += tails[k];
+            s += ranked[r];
+            gp[(size_t)ch * n + j] += s;
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int GA_CH = 4;                    // channels per workgroup (streamed kernel)
+constexpr int GA_THREADS = 512;
+constexpr int GA_RUN = 8;                   // consecutive entries per thread
+
+__global__ __launch_bounds__(GA_THREADS) void group_points_grad_stream_kernel(
+    int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points)
+{
+    extern __shared__ __attribute__((aligned(16))) float acc[];     // [GA_CH][n]
+    const int tid = threadIdx.x;
+    const int bs = blockIdx.x;
+    const int c0 = blockIdx.y * GA_CH;
+    const int nch = min(GA_CH, c - c0);
+    const int *id = idx + (size_t)bs * total;
+    const float *g = grad_out + ((size_t)bs * c + c0) * total;
+    float *gp = grad_points + ((size_t)bs * c + c0) * n;
+    for (int i = tid; i < GA_CH * n; i += GA_THREADS) acc[i] = 0.f;
+    __syncthreads();
+    if ((total & 3) == 0 && (((uintptr_t)grad_out | (uintptr_t)idx) & 15) == 0) {
+        // a thread owns GA_RUN consecutive entries (neighbours of one centre: with first-hit padding mostly
+        // the SAME target) and adds each run of equal targets once -- the same-address LDS conflicts that
+        // serialise a naive per-entry ds_add_f32 disappear
+        for (int i0 = tid * GA_RUN; i0 < total; i0 += GA_THREADS * GA_RUN) {
+            int t[GA_RUN];
+            float v[GA_CH][GA_RUN];
+#pragma unroll
+            for (int q = 0; q < GA_RUN / 4; ++q) {
+                const int i = i0 + 4 * q;
+                const bool ok = i < total;
+                const int4 tt = ok ? *(const int4 *)(id + i) : make_int4(0, 0, 0, 0);
+                t[4 * q] = tt.x; t[4 * q + 1] = tt.y; t[4 * q + 2] = tt.z; t[4 * q + 3] = tt.w;
+#pragma unroll
+                for (int ch = 0; ch < GA_CH; ++ch) {
+                    const float4 x = (ok && ch < nch) ? *(const float4 *)(g + (size_t)ch * total + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[ch][4 * q] = x.x; v[ch][4 * q + 1] = x.y; v[ch][4 * q + 2] = x.z; v[ch][4 * q + 3] = x.w;
+                }
+            }
+            int cur = t[0];
+            float run[GA_CH];
+#pragma unroll
+            for (int ch = 0; ch < GA_CH; ++ch) run[ch] = v[ch][0];
+#pragma unroll
+            for (int k = 1; k <= GA_RUN; ++k) {
+                const bool flush = k == GA_RUN || t[k < GA_RUN ? k : 0] != cur;
+                if (flush) {
+#pragma unroll
+                    for (int ch = 0; ch < GA_CH; ++ch)
+                        if (ch < nch) __hip_atomic_fetch_add(acc + ch * n + cur, run[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (k < GA_RUN) {
+                        cur = t[k];
+#pragma unroll
+                        for (int ch = 0; ch < GA_CH; ++ch) run[ch] = v[ch][k];
+                    }
+                } else {
+#pragma unroll
+                    for (int ch = 0; ch < GA_CH; ++ch) run[ch] += v[ch][k < GA_RUN ? k : 0];
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < total; i += GA_THREADS) {
+            const int t = id[i];
+            for (int ch = 0; ch < nch; ++ch)
+                __hip_atomic_fetch_add(acc + ch * n + t, g[(size_t)ch * total + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    __syncthreads();
+    for (int i = tid; i < nch * n; i += GA_THREADS) gp[i] += acc[i];
+}
+
+// generic fall-back (any n): thread per target over the inverse index, row read through the caches
+__global__ __launch_bounds__(GG_THREADS) void group_points_grad_generic_kernel(
+    int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ offsets,
+    const int *__restrict__ inv, float *__restrict__ grad_points)
+{
+    const int bs = blockIdx.x, ch = blockIdx.y;
+    const int *off = offsets + (size_t)bs * (n + 1);
+    const int *lst = inv + (size_t)bs * total;
+    const float *src = grad_out + ((size_t)bs * c + ch) * total;
+    float *gp = grad_points + ((size_t)bs * c + ch) * n;
+    for (int j = threadIdx.x; j < n; j += GG_THREADS) {
+        float a = 0.f;
+        for (int t = off[j]; t < off[j + 1]; ++t) a += src[lst[t]];
+        gp[j] += a;
+    }
+}
+
+template <int E>
+static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int total, const float *grad_out,
+                       const int *offsets, const int *inv, float *grad_points)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)group_points_grad_bal_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  ((GG_THREADS * E + 4) + 3 * GG_MAX_N_BAL + GG_THREADS + 16) * 4);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(group_points_grad_bal_kernel<E>, grid, dim3(GG_THREADS), lds, st, c, n, total, grad_out, offsets, inv,
+                       grad_points);
 }
 
 extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
@@ -164,6 +394,18 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     if (b == 0 || c == 0 || total == 0) return 0;
     CMF_CHECK_ARG(grad_out && idx && grad_points && n > 0 && total < (1LL << 31));
     hipStream_t st = (hipStream_t)stream;
+    const bool balanced = total <= GG_THREADS * GG_MAX_E && n <= GG_MAX_N_BAL;
+    if (!balanced && (size_t)GA_CH * n * sizeof(float) <= 128 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)group_points_grad_stream_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(group_points_grad_stream_kernel, dim3(b, cmf_divup(c, GA_CH)), dim3(GA_THREADS),
+                           (size_t)GA_CH * n * sizeof(float), st, c, n, (int)total, grad_out, idx, grad_points);
+        return cmf_launch_status();
+    }
     // stream-ordered scratch for the inverse index (nothing is retained after the call)
     int *scratch = nullptr;
     const size_t n_off = (size_t)b * (n + 1), n_inv = (size_t)b * total;
@@ -172,18 +414,17 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     int *offsets = scratch, *inv = scratch + n_off;
     int err = cmf_build_inverse_rows(b, n, npoints, nsample, idx, offsets, inv, stream, (int)total);
     if (!err) {
-        dim3 grid(b, cmf_divup(c, GG_CH));
-        if (total <= GG_MAX_TOTAL_LDS) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void *)group_points_grad_kernel<true>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, GG_MAX_TOTAL_LDS * 8);
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(group_points_grad_kernel<true>, grid, dim3(GG_THREADS), (size_t)total * 8, st,
-                               c, n, (int)total, grad_out, offsets, inv, grad_points);
+        if (balanced) {
+            const dim3 grid(b, cmf_divup(c, GG_CH));
+            const int e_need = (int)cmf_divup(total, GG_THREADS);
+            const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
+            const size_t lds = (size_t)((GG_THREADS * E + 4) + 3 * n + GG_THREADS + 16) * 4;
+            if (E == 4) launch_bal<4>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
+            else if (E == 8) launch_bal<8>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
+            else if (E == 16) launch_bal<16>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
+            else launch_bal<32>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
         } else {
-            hipLaunchKernelGGL(group_points_grad_kernel<false>, grid, dim3(GG_THREADS), 0, st,
+            hipLaunchKernelGGL(group_points_grad_generic_kernel, dim3(b, c), dim3(GG_THREADS), 0, st,
                                c, n, (int)total, grad_out, offsets, inv, grad_points);
         }
         err = cmf_launch_status();

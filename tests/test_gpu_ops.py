@@ -54,7 +54,9 @@ def test_ball_query_edge_cases(dev):
 
 
 @pytest.mark.parametrize("B,C,N,P,S", [(4, 3, 256, 256, 4), (2, 64, 256, 256, 32), (2, 1027, 256, 256, 8),
-                                       (1, 5, 100, 37, 3), (1, 2, 5000, 64, 16), (2, 9, 4096, 512, 64)])
+                                       (1, 5, 100, 37, 3), (1, 2, 5000, 64, 16), (2, 9, 4096, 512, 64),
+                                       (2, 33, 256, 256, 16), (1, 20, 300, 250, 32), (1, 2, 35000, 16, 8),
+                                       (1, 17, 700, 1, 1)])
 def test_group_points_and_grad(dev, B, C, N, P, S):
     from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
     g = torch.Generator().manual_seed(B + C + N)
@@ -67,12 +69,31 @@ def test_group_points_and_grad(dev, B, C, N, P, S):
     gp = torch.zeros(B, C, N, device=dev)
     ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp)
     ref = orc.group_points_grad(go, idx, N)
-    # deterministic segmented sum in ascending entry order == the oracle's scan-order scatter: bit-exact
-    # (the reference's atomicAdd order is undefined)
-    assert torch.equal(gp.cpu(), ref)
+    # the reference's atomicAdd order is undefined; ours is a fixed chunked order (rows <= 8192 entries) or LDS
+    # atomics (longer rows): equal to the oracle's scan-order sum to fp32 rounding of the partial sums
+    np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(S * P / N + 1) ** 0.5 * 4)
+    if P * S <= 8192 and N <= 4096:                                   # balanced kernel: bit-reproducible run to run
+        gp2 = torch.zeros(B, C, N, device=dev)
+        ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp2)
+        assert torch.equal(gp2.cpu(), gp.cpu())
     # accumulates INTO grad_points (lib/pointnet2_utils.py:218 zero-fills first)
     ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp)
     np.testing.assert_allclose(gp.cpu().numpy(), 2 * ref.numpy(), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("r,S", [(2.0, 32), (16.0, 32), (4.0, 8), (0.01, 4)])
+def test_group_points_grad_skewed_index(dev, r, S):
+    """Real ball-query indices: first-hit padding makes the inverse lists of low-numbered points ~10x the
+    mean (and r=0.01 leaves every list at exactly S entries of the point itself)."""
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    xyz, _ = clouds(3, 256, seed=11)
+    idx = orc.ball_query(r, S, xyz, xyz)
+    go = torch.randn(3, 40, 256, S, generator=torch.Generator().manual_seed(3))
+    gp = torch.zeros(3, 40, 256, device=dev)
+    ext.group_points_grad_wrapper(3, 40, 256, 256, S, go.to(dev), idx.to(dev), gp)
+    ref = orc.group_points_grad(go, idx, 256)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6 * scale)
 
 
 def test_grouping_operation_autograd(dev):
