@@ -50,7 +50,10 @@ SIGNATURES = {
     "cmf_affine_relu": [_ll, _ci, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "cmf_act_bwd_stats": [_ll, _ci, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_bn_bwd_apply": [_ll, _ci, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp],
+    "cmf_radar_loss_workspace": [_ci, _ci],
+    "cmf_radar_loss": [_vp, _vp],
 }
+RESTYPES = {"cmf_radar_loss_workspace": _ll}
 
 
 class SetConvDesc(ctypes.Structure):
@@ -62,6 +65,17 @@ class SetConvDesc(ctypes.Structure):
                 ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
                 ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
                 ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6)]
+
+
+class RadarLossDesc(ctypes.Structure):
+    """cmf_radar_loss_desc of include/cmflow_hip.h"""
+    _fields_ = [("B", _ci), ("N", _ci),
+                ("pc1", _vp), ("pc2", _vp), ("pred_f", _vp), ("gt_f", _vp),
+                ("vel1", _vp), ("mseg_pre", _vp), ("mseg_gt", _vp), ("dyn_mask", _vp), ("radar_u", _vp), ("radar_v", _vp),
+                ("opt", _vp), ("pre_trans", _vp), ("gt_trans", _vp), ("camera_inverse", _vp), ("t_camera_radar", _vp),
+                ("w_self", _cf), ("w_em", _cf), ("w_ms", _cf), ("w_opt", _cf), ("w_dyn", _cf),
+                ("zeta", _cf), ("alpha", _cf), ("num_nb", _ci), ("lower_bound", _cf),
+                ("items", _vp), ("d_pred_f", _vp), ("d_pre_trans", _vp), ("d_mseg_pre", _vp), ("workspace", _vp)]
 
 
 def build(force: bool = False) -> str:
@@ -87,7 +101,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
-            fn.restype = _ci
+            fn.restype = RESTYPES.get(name, _ci)
         _lib.cmf_version.restype = ctypes.c_char_p
     return _lib
 

@@ -1,0 +1,415 @@
+// RadarFlowLoss (losses/radar_loss.py:260-292, model 'cmflow' / 'cmflow_t') -- the seven cross-modal loss terms
+// and their gradients with respect to the network outputs, in three launches:
+//
+//   loss_count_kernel     : the four batch-wide normalisers (class counts of the pseudo motion-seg label,
+//                           sum(1 - mseg_gt), sum(1 - dyn_mask))
+//   loss_sample_kernel    : one workgroup per sample.  Everything of a sample lives in LDS (N <= 704 points):
+//                           the N x N distance work of SoftChamfer (radar_loss.py:17-58) and SpatialSmoothness
+//                           (:60-97) is evaluated on the fly per thread (no (B,N,N) tensors, no top-k pass, no
+//                           grouping call), the per-point terms (RadialDisplacement :99-122, EgoMotion :162-183,
+//                           MotionSeg :185-205, OpticalFlow :207-243 with utils/util.py:31-58, DynamicFlow :245-258)
+//                           ride along; the gradient w.r.t. pred_f / pre_trans / mseg_pre is written directly
+//                           (scatter terms as LDS gathers: no atomics, fixed summation order).
+//   loss_finalize_kernel  : fixed-order sum of the per-sample partials -> the 8 reported items + the total.
+//
+// Arithmetic follows the reference's expressions: squared distances in the matmul form of
+// radarflow_util.py:8-30, d = max(((-2*dot) + |a|^2) + |b|^2, 0) with dot = fma(az,bz, fma(ay,by, ax*bx)) -- the
+// same canonical evaluation as cmf_knn (neighbor.hip); the file is compiled with -ffp-contract=off.
+#include "cmf_common.h"
+#include "../../include/cmflow_hip.h"
+
+constexpr int LS_THREADS = 256;
+constexpr int LS_NB = 8;                    // smoothness neighbours (radar_loss.py:66 num_nb)
+constexpr int LS_MAX_N = 704;               // 48 words of LDS per point
+constexpr int LS_WORDS_PER_POINT = 48;
+constexpr int LS_PARTIALS = 8;              // sc, ss, rd, em, ms0, ms1, of, dyn  (per-sample un-normalised sums)
+
+__device__ __forceinline__ float ls_sqnorm3(float x, float y, float z)
+{
+    const float xx = x * x;
+    const float yy = y * y;
+    const float zz = z * z;
+    const float s = xx + yy;
+    return s + zz;
+}
+
+// square_distance element (radarflow_util.py:24-29): a = source row, b = destination row
+__device__ __forceinline__ float ls_sqdist(float ax, float ay, float az, float aa, float bx, float by, float bz, float bb)
+{
+    const float p0 = ax * bx;
+    const float p01 = __builtin_fmaf(ay, by, p0);
+    const float dot = __builtin_fmaf(az, bz, p01);
+    const float t = -2.0f * dot;
+    const float u = t + aa;
+    const float v = u + bb;
+    return v > 0.0f ? v : 0.0f;
+}
+
+// fixed-order workgroup reductions; red: LS_THREADS/64 floats of LDS.  All threads get the result.
+__device__ __forceinline__ float ls_block_sum(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < LS_THREADS / 64; ++w) s += red[w];
+    return s;
+}
+
+__device__ __forceinline__ float ls_block_max(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int w = 1; w < LS_THREADS / 64; ++w) s = fmaxf(s, red[w]);
+    return s;
+}
+
+__global__ __launch_bounds__(1024) void loss_count_kernel(long long total, const float *__restrict__ mseg_gt,
+                                                          const float *__restrict__ dyn_mask, float *__restrict__ counts)
+{
+    __shared__ float red[4][16];
+    float c0 = 0.f, c1 = 0.f, om = 0.f, od = 0.f;
+    for (long long i = threadIdx.x; i < total; i += 1024) {
+        const float m = mseg_gt[i], d = dyn_mask[i];
+        c0 += (m == 0.f) ? 1.f : 0.f;
+        c1 += (m == 1.f) ? 1.f : 0.f;
+        om += 1.f - m;
+        od += 1.f - d;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_xor(c0, off, 64); c1 += __shfl_xor(c1, off, 64);
+        om += __shfl_xor(om, off, 64); od += __shfl_xor(od, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[0][w] = c0; red[1][w] = c1; red[2][w] = om; red[3][w] = od;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w) s += red[threadIdx.x][w];
+        counts[threadIdx.x] = s;
+    }
+}
+
+struct LossArgs {
+    int B, N;
+    const float *pc1, *pc2, *pred_f, *gt_f, *vel1, *mseg_pre, *mseg_gt, *dyn_mask, *radar_u, *radar_v, *opt;
+    const float *pre_trans, *gt_trans, *cam_inv, *t_cr;
+    float w_self, w_em, w_ms, w_opt, w_dyn, zeta, alpha, lower_bound;
+    const float *counts;
+    float *partials, *d_pred_f, *d_pre_trans, *d_mseg_pre;
+};
+
+__global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(const LossArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int N = a.N, tid = threadIdx.x, bs = blockIdx.x;
+    float *p1 = sm;                 // [3][N] pc1
+    float *p2 = p1 + 3 * N;         // [3][N] pc2
+    float *pw = p2 + 3 * N;         // [3][N] pc1 + pred_f
+    float *fl = pw + 3 * N;         // [3][N] pred_f
+    float *n1 = fl + 3 * N;         // |pc1|^2, |pc2|^2, |pc1w|^2
+    float *n2 = n1 + N;
+    float *nw = n2 + N;
+    int *arg2 = reinterpret_cast<int *>(nw + N);        // [N] argmin over i of d(pc1w_i, pc2_j), -1 if that term is inactive
+    int *nbr = arg2 + N;                                // [N][8] smoothness neighbours
+    float *gv = reinterpret_cast<float *>(nbr + LS_NB * N);   // [N][8][3] pair gradients (pushed to the neighbour)
+    __shared__ float red[LS_THREADS / 64];
+    __shared__ float sT[32];                            // pre_trans, gt_trans
+    __shared__ float sC[9 + 16];                        // camera_inverse, t_camera_radar
+
+    const size_t o3 = (size_t)bs * 3 * N, o1 = (size_t)bs * N;
+    for (int i = tid; i < 3 * N; i += LS_THREADS) {
+        const float x = a.pc1[o3 + i], f = a.pred_f[o3 + i];
+        p1[i] = x; p2[i] = a.pc2[o3 + i]; fl[i] = f; pw[i] = x + f;
+    }
+    if (tid < 16) { sT[tid] = a.pre_trans[(size_t)bs * 16 + tid]; sT[16 + tid] = a.gt_trans[(size_t)bs * 16 + tid]; }
+    if (tid < 9) sC[tid] = a.cam_inv[tid];
+    if (tid >= 32 && tid < 48) sC[9 + tid - 32] = a.t_cr[tid - 32];
+    __syncthreads();
+    for (int i = tid; i < N; i += LS_THREADS) {
+        n1[i] = ls_sqnorm3(p1[i], p1[N + i], p1[2 * N + i]);
+        n2[i] = ls_sqnorm3(p2[i], p2[N + i], p2[2 * N + i]);
+        nw[i] = ls_sqnorm3(pw[i], pw[N + i], pw[2 * N + i]);
+    }
+    __syncthreads();
+
+    const float inv_bn = 1.0f / ((float)a.B * (float)N);
+    const float cnt0 = a.counts[0], cnt1 = a.counts[1];
+    const float den_of = fmaxf(a.counts[2], 1.0f), den_dyn = fmaxf(a.counts[3], 1.0f);
+    float part[LS_PARTIALS];
+#pragma unroll
+    for (int t = 0; t < LS_PARTIALS; ++t) part[t] = 0.f;
+    float emax_local = 0.f;                             // exp(-d/alpha) > 0
+    float et[12];                                       // d total / d pre_trans[:3,:4] partial sums
+#pragma unroll
+    for (int t = 0; t < 12; ++t) et[t] = 0.f;
+
+    // ---------------- pass 1: the N x N work of this thread's points ----------------
+    for (int i = tid; i < N; i += LS_THREADS) {
+        const float ax = p1[i], ay = p1[N + i], az = p1[2 * N + i], aa = n1[i];
+        const float wx = pw[i], wy = pw[N + i], wz = pw[2 * N + i], ww = nw[i];
+        const float bx = p2[i], by = p2[N + i], bz = p2[2 * N + i], bb = n2[i];
+        float bd[LS_NB + 1];
+        int bi[LS_NB + 1];
+#pragma unroll
+        for (int t = 0; t <= LS_NB; ++t) { bd[t] = __builtin_inff(); bi[t] = 0; }
+        float dens1 = 0.f, dens2 = 0.f, min1 = __builtin_inff(), min2 = __builtin_inff();
+        int am1 = 0, am2 = 0;
+        for (int j = 0; j < N; ++j) {
+            const float qx = p1[j], qy = p1[N + j], qz = p1[2 * N + j], qq = n1[j];
+            const float rx = p2[j], ry = p2[N + j], rz = p2[2 * N + j], rr = n2[j];
+            // smoothness: top-(8+1) of square_distance(pc1, pc1)[i, :], ascending, ties -> lowest index
+            const float d11 = ls_sqdist(ax, ay, az, aa, qx, qy, qz, qq);
+            if (d11 < bd[LS_NB]) {
+                bd[LS_NB] = d11; bi[LS_NB] = j;
+#pragma unroll
+                for (int t = LS_NB; t > 0; --t)
+                    if (bd[t] < bd[t - 1]) {
+                        const float td = bd[t]; bd[t] = bd[t - 1]; bd[t - 1] = td;
+                        const int ti = bi[t]; bi[t] = bi[t - 1]; bi[t - 1] = ti;
+                    }
+            }
+            // chamfer, this thread as pc1 point i: density of pc1_i in pc2, nearest pc2 point of the warped pc1_i
+            const float d12 = ls_sqdist(ax, ay, az, aa, rx, ry, rz, rr);
+            dens1 += expf(-d12 / 2.0f) / 2.5f;
+            const float dw = ls_sqdist(wx, wy, wz, ww, rx, ry, rz, rr);
+            if (dw < min1) { min1 = dw; am1 = j; }
+            // chamfer, this thread as pc2 point i: density of pc2_i in pc1, nearest warped pc1 point
+            const float d21 = ls_sqdist(bx, by, bz, bb, qx, qy, qz, qq);
+            dens2 += expf(-d21 / 2.0f) / 2.5f;
+            const float dwt = ls_sqdist(pw[j], pw[N + j], pw[2 * N + j], nw[j], bx, by, bz, bb);
+            if (dwt < min2) { min2 = dwt; am2 = j; }
+        }
+        const bool mask1 = dens1 / (float)N > a.zeta, mask2 = dens2 / (float)N > a.zeta;
+        const float r1 = min1 - 0.01f, r2 = min2 - 0.01f;
+        if (mask1 && r1 > 0.f) part[0] += r1;
+        if (mask2 && r2 > 0.f) part[0] += r2;
+        // reuse: bd[0]/bi[0] (the nearest = the point itself or a duplicate) is dropped (radar_loss.py:86-87)
+        arg2[i] = (mask2 && r2 > 0.f) ? am2 : -1;
+        // keep what pass 2 needs in LDS/regs: neighbour list, e = exp(-d/alpha)
+#pragma unroll
+        for (int t = 0; t < LS_NB; ++t) {
+            nbr[i * LS_NB + t] = bi[t + 1];
+            const float e = expf(-bd[t + 1] / a.alpha);
+            gv[(i * LS_NB + t) * 3] = e;                // parked until the soft-max normaliser is known
+            emax_local = fmaxf(emax_local, e);
+        }
+        // chamfer gradient of term 1 (own nearest neighbour) goes to this point: parked in gv? no: written below
+        gv[(i * LS_NB) * 3 + 1] = (mask1 && r1 > 0.f) ? (float)am1 : -1.0f;
+    }
+    const float emax = ls_block_max(emax_local, red);
+    float zsum_local = 0.f;
+    for (int i = tid; i < N; i += LS_THREADS)
+#pragma unroll
+        for (int t = 0; t < LS_NB; ++t) zsum_local += expf(gv[(i * LS_NB + t) * 3] - emax);
+    const float zsum = ls_block_sum(zsum_local, red);
+
+    // ---------------- pass 2: per-point terms, own-point gradients, pair gradients ----------------
+    // gradient accumulators of up to LS_MAX_N/LS_THREADS = 3 points per thread stay in registers
+    constexpr int PT = (LS_MAX_N + LS_THREADS - 1) / LS_THREADS;
+    float gx[PT], gy[PT], gz[PT];
+#pragma unroll
+    for (int q = 0; q < PT; ++q) { gx[q] = gy[q] = gz[q] = 0.f; }
+    const float k_self = a.w_self * inv_bn;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = tid + q * LS_THREADS;
+        if (i >= N) continue;
+        const float ax = p1[i], ay = p1[N + i], az = p1[2 * N + i];
+        const float fx = fl[i], fy = fl[N + i], fz = fl[2 * N + i];
+        const float wx = pw[i], wy = pw[N + i], wz = pw[2 * N + i];
+        // chamfer term 1
+        const int am1 = (int)gv[(i * LS_NB) * 3 + 1];
+        if (am1 >= 0) {
+            gx[q] += k_self * 2.0f * (wx - p2[am1]);
+            gy[q] += k_self * 2.0f * (wy - p2[N + am1]);
+            gz[q] += k_self * 2.0f * (wz - p2[2 * N + am1]);
+        }
+        // smoothness (radar_loss.py:88-96): weights = softmax over the sample's N*8 values exp(-d/alpha)
+        float ss_i = 0.f;
+#pragma unroll
+        for (int t = 0; t < LS_NB; ++t) {
+            const int j = nbr[i * LS_NB + t];
+            const float w = expf(gv[(i * LS_NB + t) * 3] - emax) / zsum;
+            const float dx = fl[j] - fx, dy = fl[N + j] - fy, dz = fl[2 * N + j] - fz;
+            const float nrm = sqrtf(ls_sqnorm3(dx, dy, dz));
+            const float nw_ = (float)N * w;
+            ss_i += nw_ * nrm;
+            const float s = nrm > 0.f ? k_self * nw_ / nrm : 0.f;       // torch.norm backward: 0 at the origin
+            const float vx = s * dx, vy = s * dy, vz = s * dz;           // d/d f_j ; d/d f_i is the negative
+            gx[q] -= vx; gy[q] -= vy; gz[q] -= vz;
+            gv[(i * LS_NB + t) * 3] = vx; gv[(i * LS_NB + t) * 3 + 1] = vy; gv[(i * LS_NB + t) * 3 + 2] = vz;
+        }
+        part[1] += ss_i;
+        // radial displacement (radar_loss.py:99-122): |v_r * 0.1 - <f, p>/|p||
+        const float pn = sqrtf(ls_sqnorm3(ax, ay, az));
+        const float fr = ((fx * ax + fy * ay) + fz * az) / pn;
+        const float rdv = a.vel1[o1 + i] * 0.1f - fr;
+        part[2] += fabsf(rdv);
+        const float sg = rdv > 0.f ? -1.f : (rdv < 0.f ? 1.f : 0.f);
+        gx[q] += k_self * sg * ax / pn; gy[q] += k_self * sg * ay / pn; gz[q] += k_self * sg * az / pn;
+        // ego-motion (radar_loss.py:162-183): |(R p + t) - (R_gt p + t_gt)|
+        float e3[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float pre = ((sT[4 * r] * ax + sT[4 * r + 1] * ay) + sT[4 * r + 2] * az) + sT[4 * r + 3];
+            const float gt = ((sT[16 + 4 * r] * ax + sT[16 + 4 * r + 1] * ay) + sT[16 + 4 * r + 2] * az) + sT[16 + 4 * r + 3];
+            e3[r] = pre - gt;
+        }
+        const float en = sqrtf(ls_sqnorm3(e3[0], e3[1], e3[2]));
+        part[3] += en;
+        if (en > 0.f) {
+            const float ke = a.w_em * inv_bn / en;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                et[4 * r] += ke * e3[r] * ax; et[4 * r + 1] += ke * e3[r] * ay;
+                et[4 * r + 2] += ke * e3[r] * az; et[4 * r + 3] += ke * e3[r];
+            }
+        }
+        // motion segmentation (radar_loss.py:185-205): BCE averaged separately over the two classes
+        const float p = a.mseg_pre[o1 + i], y = a.mseg_gt[o1 + i];
+        const float bce = -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+        float dms = 0.f;
+        if (y == 0.f) { part[4] += bce; dms = 0.5f / cnt0; }
+        else if (y == 1.f) { part[5] += bce; dms = 0.5f / cnt1; }
+        if (a.d_mseg_pre) a.d_mseg_pre[o1 + i] = a.w_ms * dms * (p - y) / fmaxf((1.f - p) * p, 1e-12f);
+        // optical flow (radar_loss.py:207-243, utils/util.py:31-58): distance of the warped point to the pixel ray
+        const float u = a.radar_u[o1 + i] + a.opt[(o1 + i) * 2], v = a.radar_v[o1 + i] + a.opt[(o1 + i) * 2 + 1];
+        float ray[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) ray[r] = (sC[3 * r] * u + sC[3 * r + 1] * v) + sC[3 * r + 2];
+        const float rn = sqrtf(ls_sqnorm3(ray[0], ray[1], ray[2]));
+        const float ux = ray[0] / rn, uy = ray[1] / rn, uz = ray[2] / rn;
+        const float *T = sC + 9;
+        float wc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) wc[r] = ((T[4 * r] * wx + T[4 * r + 1] * wy) + T[4 * r + 2] * wz) + T[4 * r + 3];
+        const float cx = uy * wc[2] - uz * wc[1], cy = uz * wc[0] - ux * wc[2], cz = ux * wc[1] - uy * wc[0];
+        const float cn = sqrtf(ls_sqnorm3(cx, cy, cz));
+        const float om = 1.f - y;
+        const float div = cn - a.lower_bound;
+        if (div > 0.f) {
+            part[6] += om * div;
+            if (cn > 0.f) {
+                const float ko = a.w_opt * om / den_of / cn;
+                // d|u x w| / dw = c_hat x u ; back to the radar frame through R_cr^T
+                const float hx = cy * uz - cz * uy, hy = cz * ux - cx * uz, hz = cx * uy - cy * ux;
+                gx[q] += ko * ((T[0] * hx + T[4] * hy) + T[8] * hz);
+                gy[q] += ko * ((T[1] * hx + T[5] * hy) + T[9] * hz);
+                gz[q] += ko * ((T[2] * hx + T[6] * hy) + T[10] * hz);
+            }
+        }
+        // dynamic flow (radar_loss.py:245-258)
+        const float od = 1.f - a.dyn_mask[o1 + i];
+        const float ex = a.gt_f[o3 + i] - fx, ey = a.gt_f[o3 + N + i] - fy, ez = a.gt_f[o3 + 2 * N + i] - fz;
+        const float dn = sqrtf(ls_sqnorm3(ex, ey, ez));
+        part[7] += od * dn;
+        if (dn > 0.f) {
+            const float kd = a.w_dyn * od / den_dyn / dn;
+            gx[q] -= kd * ex; gy[q] -= kd * ey; gz[q] -= kd * ez;
+        }
+    }
+    __syncthreads();
+    // ---------------- pass 3: gather the gradients other points push onto this one ----------------
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int i = tid + q * LS_THREADS;
+        if (i >= N) continue;
+        const float wx = pw[i], wy = pw[N + i], wz = pw[2 * N + i];
+        for (int j = 0; j < N; ++j)                       // chamfer term 2: pc2_j whose nearest warped point is i
+            if (arg2[j] == i) {
+                gx[q] += k_self * 2.0f * (wx - p2[j]);
+                gy[q] += k_self * 2.0f * (wy - p2[N + j]);
+                gz[q] += k_self * 2.0f * (wz - p2[2 * N + j]);
+            }
+        for (int e = 0; e < N * LS_NB; ++e)               // smoothness pairs (i', k) whose neighbour is i
+            if (nbr[e] == i) { gx[q] += gv[e * 3]; gy[q] += gv[e * 3 + 1]; gz[q] += gv[e * 3 + 2]; }
+        if (a.d_pred_f) { a.d_pred_f[o3 + i] = gx[q]; a.d_pred_f[o3 + N + i] = gy[q]; a.d_pred_f[o3 + 2 * N + i] = gz[q]; }
+    }
+    // ---------------- per-sample partial sums ----------------
+#pragma unroll
+    for (int t = 0; t < LS_PARTIALS; ++t) {
+        const float s = ls_block_sum(part[t], red);
+        if (tid == 0) a.partials[(size_t)bs * LS_PARTIALS + t] = s;
+    }
+    if (a.d_pre_trans) {
+#pragma unroll
+        for (int t = 0; t < 12; ++t) {
+            const float s = ls_block_sum(et[t], red);
+            if (tid == 0) a.d_pre_trans[(size_t)bs * 16 + t] = s;
+        }
+        if (tid < 4) a.d_pre_trans[(size_t)bs * 16 + 12 + tid] = 0.f;
+    }
+}
+
+// items: [0] total, [1] Loss (self-supervised sum), [2] smoothnessLoss, [3] chamferLoss, [4] veloLoss, [5] egoLoss,
+//        [6] maskLoss, [7] opticalLoss, [8] superviseLoss     (radar_loss.py:285-288)
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const LossArgs a, float *__restrict__ items)
+{
+    const int t = threadIdx.x;
+    __shared__ float s[LS_PARTIALS];
+    if (t < LS_PARTIALS) {
+        float acc = 0.f;
+        for (int b = 0; b < a.B; ++b) acc += a.partials[(size_t)b * LS_PARTIALS + t];
+        s[t] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const float inv_bn = 1.0f / ((float)a.B * (float)a.N);
+        const float sc = s[0] * inv_bn, ss = s[1] * inv_bn, rd = s[2] * inv_bn, em = s[3] * inv_bn;
+        const float ms = (s[4] / a.counts[0] + s[5] / a.counts[1]) / 2.f;
+        const float of = s[6] / fmaxf(a.counts[2], 1.0f), dyn = s[7] / fmaxf(a.counts[3], 1.0f);
+        const float self_sup = (sc + ss) + rd;
+        items[0] = (((a.w_self * self_sup + a.w_em * em) + a.w_ms * ms) + a.w_opt * of) + a.w_dyn * dyn;
+        items[1] = self_sup; items[2] = ss; items[3] = sc; items[4] = rd; items[5] = em; items[6] = ms;
+        items[7] = of; items[8] = dyn;
+    }
+}
+
+extern "C" long long cmf_radar_loss_workspace(int b, int n)
+{
+    (void)n;
+    return 4 + (long long)b * LS_PARTIALS;
+}
+
+extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
+{
+    CMF_CHECK_ARG(d && d->B >= 0 && d->N > LS_NB && d->N <= LS_MAX_N && d->num_nb == LS_NB);
+    if (d->B == 0) return 0;
+    CMF_CHECK_ARG(d->pc1 && d->pc2 && d->pred_f && d->gt_f && d->vel1 && d->mseg_pre && d->mseg_gt && d->dyn_mask &&
+                  d->radar_u && d->radar_v && d->opt && d->pre_trans && d->gt_trans && d->camera_inverse &&
+                  d->t_camera_radar && d->items && d->workspace && d->alpha > 0.f);
+    hipStream_t st = (hipStream_t)stream;
+    LossArgs a;
+    a.B = d->B; a.N = d->N;
+    a.pc1 = d->pc1; a.pc2 = d->pc2; a.pred_f = d->pred_f; a.gt_f = d->gt_f; a.vel1 = d->vel1; a.mseg_pre = d->mseg_pre;
+    a.mseg_gt = d->mseg_gt; a.dyn_mask = d->dyn_mask; a.radar_u = d->radar_u; a.radar_v = d->radar_v; a.opt = d->opt;
+    a.pre_trans = d->pre_trans; a.gt_trans = d->gt_trans; a.cam_inv = d->camera_inverse; a.t_cr = d->t_camera_radar;
+    a.w_self = d->w_self; a.w_em = d->w_em; a.w_ms = d->w_ms; a.w_opt = d->w_opt; a.w_dyn = d->w_dyn;
+    a.zeta = d->zeta; a.alpha = d->alpha; a.lower_bound = d->lower_bound;
+    a.counts = d->workspace; a.partials = d->workspace + 4;
+    a.d_pred_f = d->d_pred_f; a.d_pre_trans = d->d_pre_trans; a.d_mseg_pre = d->d_mseg_pre;
+    hipLaunchKernelGGL(loss_count_kernel, dim3(1), dim3(1024), 0, st, (long long)d->B * d->N, d->mseg_gt, d->dyn_mask,
+                       d->workspace);
+    const size_t lds = (size_t)LS_WORDS_PER_POINT * d->N * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)loss_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LS_WORDS_PER_POINT * LS_MAX_N * (int)sizeof(float));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(loss_sample_kernel, dim3(d->B), dim3(LS_THREADS), lds, st, a);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, d->items);
+    return cmf_launch_status();
+}

@@ -1,16 +1,23 @@
 """The seven cross-modal loss terms and the label prep of the reference's training step.
 
 Mirrors ``losses/radar_loss.py`` (RadarFlowLoss :260-292 and its components) and the label
-prep of ``main_util.py`` (:209-225 extract_dynamic_from_fg, :253-265 mseg_label_RRV).  Torch
-ops on device tensors; the neighbour gather of the smoothness term goes through the HIP group
-kernel like the reference (radar_loss.py:94 -> index_points_group).  Unlike the reference the
-loss items stay on the device (no 8 ``.item()`` host syncs per step, radar_loss.py:156-159,285-288)
-until the caller asks for them.
+prep of ``main_util.py`` (:209-225 extract_dynamic_from_fg, :253-265 mseg_label_RRV).
+
+``RadarFlowLoss`` runs the fused HIP kernel ``cmf_radar_loss`` (csrc/loss.hip: all seven terms and
+their gradients w.r.t. the network outputs in one call, 3 launches) whenever 9 <= N <= 704; the
+component modules below are the same terms as torch ops on device tensors (the reference's own
+structure; used for larger clouds and as the second implementation the tests compare against).
+Unlike the reference the loss items stay on the device (no 8 ``.item()`` host syncs per step,
+radar_loss.py:156-159,285-288) until the caller asks for them.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
+from torch.autograd import Function
 from torch.nn import Module
 
+from . import _lib
 from .radarflow_util import index_points_group, square_distance
 from .cmflow import CMFlow
 
@@ -145,12 +152,63 @@ class DynamicFlowLoss(Module):
         return torch.sum((1 - dyn_mask) * torch.norm(gt_f - pred_f, dim=1)) / torch.clamp_min(torch.sum(1 - dyn_mask), 1.0)
 
 
+NATIVE_MIN_N, NATIVE_MAX_N = 9, 704          # csrc/loss.hip: a sample's working set lives in LDS
+ITEM_KEYS = ('Loss', 'smoothnessLoss', 'chamferLoss', 'veloLoss', 'egoLoss', 'maskLoss', 'opticalLoss', 'superviseLoss')
+
+
+class RadarFlowLossFn(Function):
+    """total, items = cmf_radar_loss(...); the kernel writes d total / d (pred_f, pre_trans, mseg_pre) in the same
+    pass, backward only scales them by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, pred_f, pre_trans, mseg_pre, data, hyper):
+        pc1 = data["pc1"]
+        B, _, N = pc1.shape
+        dev = pc1.device
+        f32 = torch.float32
+        t = {k: v.contiguous() for k, v in data.items()}
+        pred_f, pre_trans, mseg_pre = pred_f.contiguous(), pre_trans.contiguous(), mseg_pre.contiguous()
+        for v in list(t.values()) + [pred_f, pre_trans, mseg_pre]:
+            _lib.dev_ptr(v, f32)                                  # device / dtype / density checks (no CPU fallback)
+        need = any(ctx.needs_input_grad[:3])
+        d = _lib.RadarLossDesc()
+        d.B, d.N = B, N
+        d.pc1, d.pc2, d.pred_f, d.gt_f = t["pc1"].data_ptr(), t["pc2"].data_ptr(), pred_f.data_ptr(), t["gt_f"].data_ptr()
+        d.vel1, d.mseg_pre, d.mseg_gt = t["vel1"].data_ptr(), mseg_pre.data_ptr(), t["mseg_gt"].data_ptr()
+        d.dyn_mask, d.radar_u, d.radar_v = t["dyn_mask"].data_ptr(), t["radar_u"].data_ptr(), t["radar_v"].data_ptr()
+        d.opt, d.pre_trans, d.gt_trans = t["opt"].data_ptr(), pre_trans.data_ptr(), t["gt_trans"].data_ptr()
+        d.camera_inverse, d.t_camera_radar = t["camera_inverse"].data_ptr(), t["t_camera_radar"].data_ptr()
+        d.w_self, d.w_em, d.w_ms, d.w_opt, d.w_dyn = hyper["w"]
+        d.zeta, d.alpha, d.num_nb, d.lower_bound = hyper["zeta"], hyper["alpha"], hyper["num_nb"], hyper["lower_bound"]
+        items = torch.empty(9, dtype=f32, device=dev)
+        ws = torch.empty(_lib.lib().cmf_radar_loss_workspace(B, N), dtype=f32, device=dev)
+        d.items, d.workspace = items.data_ptr(), ws.data_ptr()
+        if need:
+            g_f = torch.empty(B, 3, N, dtype=f32, device=dev)
+            g_t = torch.empty(B, 4, 4, dtype=f32, device=dev)
+            g_m = torch.empty(mseg_pre.shape, dtype=f32, device=dev)
+            d.d_pred_f, d.d_pre_trans, d.d_mseg_pre = g_f.data_ptr(), g_t.data_ptr(), g_m.data_ptr()
+            ctx.grads = (g_f, g_t, g_m)
+        _lib.check(_lib.lib().cmf_radar_loss(ctypes.addressof(d), _lib.stream_ptr()), "cmf_radar_loss")
+        ctx.mark_non_differentiable(items)
+        return items[0], items
+
+    @staticmethod
+    def backward(ctx, g_total, _g_items):
+        g_f, g_t, g_m = ctx.grads
+        need = ctx.needs_input_grad
+        return (g_f * g_total if need[0] else None, g_t * g_total if need[1] else None,
+                g_m * g_total if need[2] else None, None, None)
+
+
 class RadarFlowLoss(Module):
     """radar_loss.py:260-292 for model in {'cmflow','cmflow_t'}; weights (1,1,1,0.1,1) (:262).
-    Returns (total_loss, items) with items as 0-d device tensors (call .item() when needed)."""
+    Returns (total_loss, items) with items as 0-d device tensors (call .item() when needed).
+    native=True (default): the fused HIP kernel when the cloud size allows; native=False: the torch-op terms."""
 
-    def __init__(self, camera_projection, t_camera_radar, w_self=1, w_em=1, w_ms=1, w_opt=0.1, w_dyn=1):
+    def __init__(self, camera_projection, t_camera_radar, w_self=1, w_em=1, w_ms=1, w_opt=0.1, w_dyn=1, native=True):
         super().__init__()
+        self.native = native
         self.w_self, self.w_em, self.w_ms, self.w_opt, self.w_dyn = w_self, w_em, w_ms, w_opt, w_dyn
         self.register_buffer("camera_projection", torch.as_tensor(camera_projection, dtype=torch.float32))
         self.register_buffer("camera_inverse", torch.inverse(self.camera_projection[:3, :3].cpu()))
@@ -161,6 +219,16 @@ class RadarFlowLoss(Module):
 
     def forward(self, pc1, pc2, pred_f, vel1, gt_f, pre_trans, mseg_pre, gt_trans, mseg_gt, dyn_mask,
                 radar_u, radar_v, opt):
+        N = pc1.shape[2]
+        if self.native and pc1.is_cuda and NATIVE_MIN_N <= N <= NATIVE_MAX_N:
+            data = dict(pc1=pc1, pc2=pc2, gt_f=gt_f, vel1=vel1, gt_trans=gt_trans, mseg_gt=mseg_gt.to(pc1.dtype),
+                        dyn_mask=dyn_mask.to(pc1.dtype), radar_u=radar_u, radar_v=radar_v, opt=opt,
+                        camera_inverse=self.camera_inverse, t_camera_radar=self.t_camera_radar)
+            hyper = dict(w=(self.w_self, self.w_em, self.w_ms, self.w_opt, self.w_dyn), zeta=self.sc_loss.zeta,
+                         alpha=self.ss_loss.alpha, num_nb=self.ss_loss.num_nb, lower_bound=self.opt_flow_loss.lower_bound)
+            if self.ss_loss.num_nb == 8:
+                total, items = RadarFlowLossFn.apply(pred_f, pre_trans, mseg_pre, data, hyper)
+                return total, {k: items[i + 1] for i, k in enumerate(ITEM_KEYS)}
         pc1_warp = pc1 + pred_f
         sc = self.sc_loss(pc1, pc2, pc1_warp)
         ss = self.ss_loss(pc1, pred_f)

@@ -231,6 +231,32 @@ int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long l
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
 int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
 
+/* ---- the training step's loss -------------------------------------------------------------
+ * RadarFlowLoss of losses/radar_loss.py:260-292 for model 'cmflow' / 'cmflow_t': SoftChamfer (:17-58),
+ * SpatialSmoothness (:60-97), RadialDisplacement (:99-122), EgoMotion (:162-183), MotionSeg (:185-205),
+ * OpticalFlow (:207-243 with utils/util.py:31-58) and DynamicFlow (:245-258), forward AND the gradient of the
+ * weighted total with respect to the three network outputs, in one call (3 launches, no host sync; the
+ * reference reads 8 loss items back with .item(), :156-159,285-288).  Layouts are the reference's:
+ * clouds/flows (B,3,N), per-point scalars (B,N), opt (B,N,2), transforms (B,4,4) row-major.
+ * items[9] = total, Loss (self-supervised sum), smoothnessLoss, chamferLoss, veloLoss, egoLoss, maskLoss,
+ * opticalLoss, superviseLoss.  Gradient outputs may be NULL (evaluation).  9 <= N <= 704, num_nb == 8. */
+typedef struct cmf_radar_loss_desc {
+    int B, N;
+    const float *pc1, *pc2, *pred_f, *gt_f;                                    /* (B,3,N) */
+    const float *vel1, *mseg_pre, *mseg_gt, *dyn_mask, *radar_u, *radar_v;     /* (B,N) */
+    const float *opt;                                                          /* (B,N,2) */
+    const float *pre_trans, *gt_trans;                                         /* (B,4,4) */
+    const float *camera_inverse;                                               /* (3,3) inverse intrinsics */
+    const float *t_camera_radar;                                               /* (4,4) */
+    float w_self, w_em, w_ms, w_opt, w_dyn;                                    /* radar_loss.py:262: 1,1,1,0.1,1 */
+    float zeta, alpha; int num_nb; float lower_bound;                          /* 0.005, 0.5, 8, 0.25 */
+    float *items;                                                              /* [9] */
+    float *d_pred_f, *d_pre_trans, *d_mseg_pre;                                /* (B,3,N), (B,4,4), (B,N) or NULL */
+    float *workspace;                                                          /* cmf_radar_loss_workspace floats */
+} cmf_radar_loss_desc;
+long long cmf_radar_loss_workspace(int b, int n);
+int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 
