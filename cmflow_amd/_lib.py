@@ -52,6 +52,8 @@ SIGNATURES = {
     "cmf_bn_bwd_apply": [_ll, _ci, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp],
     "cmf_radar_loss_workspace": [_ci, _ci],
     "cmf_radar_loss": [_vp, _vp],
+    "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
+    "cmf_eval_metrics": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _cf, _cf, _vp, _vp, _vp],
 }
 RESTYPES = {"cmf_radar_loss_workspace": _ll}
 

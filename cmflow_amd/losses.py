@@ -42,7 +42,25 @@ def mseg_label_RRV(pc1, trans, vel1, interval, vr_thres):
 
 
 def make_labels(batch, vr_thres):
-    """main_util.py:63-67: dyn_mask and the merged pseudo motion-segmentation label."""
+    """main_util.py:63-67: dyn_mask and the merged pseudo motion-segmentation label -- one launch of
+    cmf_pseudo_labels (csrc/eval.hip) on device tensors."""
+    pc1 = batch["pc1"]
+    if not pc1.is_cuda:
+        raise RuntimeError("cmflow_amd.losses.make_labels runs on the GPU only (got %s tensors)" % pc1.device)
+    B, _, N = pc1.shape
+    f32 = torch.float32
+    c = lambda t: t.to(f32).contiguous()
+    pc, T, vel, dt = c(pc1), c(batch["gt_trans"]), c(batch["ft1"][:, 0]), c(batch["interval"])
+    fg, fl = c(batch["fg_mask"]), c(batch["flow_label"])
+    dyn_mask, mseg_gt = torch.empty(B, N, dtype=f32, device=pc1.device), torch.empty(B, N, dtype=f32, device=pc1.device)
+    p = lambda t: _lib.dev_ptr(t, f32)
+    _lib.check(_lib.lib().cmf_pseudo_labels(B, N, p(pc), p(T), p(vel), p(dt), p(fg), p(fl), vr_thres, p(dyn_mask),
+                                            p(mseg_gt), None, _lib.stream_ptr()), "cmf_pseudo_labels")
+    return dyn_mask.to(batch["fg_mask"].dtype), mseg_gt
+
+
+def make_labels_torch(batch, vr_thres):
+    """The same label prep as torch ops (the reference's own structure)."""
     pc1 = batch["pc1"]
     dyn_mask = extract_dynamic_from_fg(batch["fg_mask"], pc1, batch["gt_trans"], batch["flow_label"].transpose(2, 1))
     mseg_gt, _ = mseg_label_RRV(pc1, batch["gt_trans"], batch["ft1"][:, 0], batch["interval"], vr_thres)

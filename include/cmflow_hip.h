@@ -257,6 +257,24 @@ typedef struct cmf_radar_loss_desc {
 long long cmf_radar_loss_workspace(int b, int n);
 int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream);
 
+/* ---- evaluation metrics of one batch ------------------------------------------------------
+ * utils/eval_util.py: eval_scene_flow :42-86, eval_motion_seg :104-118, eval_trans_RPE :89-102 (with
+ * utils/odometry_util.py:61-160), which copy every tensor to the host and run numpy.  pc (B,3,N) as
+ * main_util.py:175 passes it; pred, labels (B,N,3); mask, pred_m (B,N) with 1 = static; transforms (B,4,4);
+ * (r_res, theta_res, phi_res) the radar resolution of dataset/vod.py:21-23.
+ * metrics[14] (fp64) = rne, 50-50 rne, mov_rne, stat_rne, sas, ras, epe, accs, accr, acc, miou, sen, RTE, RAE.
+ * workspace: 16 * B doubles. */
+int cmf_eval_metrics(int b, int n, const float *pc, const float *pred, const float *labels, const float *mask,
+                     const float *pred_m, const float *gt_trans, const float *pred_trans,
+                     float r_res, float theta_res, float phi_res, double *metrics, double *workspace, void *stream);
+
+/* Pseudo labels of the training step (main_util.py:63-67): dyn_mask = extract_dynamic_from_fg (:209-225), mseg_gt =
+ * where(dyn_mask == 1, mseg_label_RRV (:253-265), dyn_mask).  pc1 (B,3,N); gt_trans (B,4,4); vel1, fg_mask (B,N)
+ * (fg_mask 1 = background); interval (B); flow_label (B,N,3).  Outputs (B,N) floats, 1 = static; residual may be NULL. */
+int cmf_pseudo_labels(int b, int n, const float *pc1, const float *gt_trans, const float *vel1, const float *interval,
+                      const float *fg_mask, const float *flow_label, float vr_thres,
+                      float *dyn_mask, float *mseg_gt, float *residual, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 

@@ -177,3 +177,23 @@ def test_group_points_and_grad():
     gp = ops.group_points_grad(go, idx, 16)
     ref = torch.zeros(2, 5, 16).scatter_add_(2, idx.long().view(2, 1, -1).expand(-1, 5, -1), go.view(2, 5, -1))
     np.testing.assert_allclose(gp.numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_eval_metric_oracle_matches_reference_goldens(golden_dir):
+    """the numpy restatement of utils/eval_util.py against outputs of the reference's own
+    functions (tests/golden/make_golden_eval.py)."""
+    import warnings
+    from oracle import eval_oracle as EO
+    g = np.load(os.path.join(golden_dir, "eval_metrics_kat.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) >= 6
+    res = {'r_res': 0.2, 'theta_res': 1.5 * np.pi / 180, 'phi_res': 1.5 * np.pi / 180}
+    for n in names:
+        i = lambda k: g["%s/in/%s" % (n, k)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = {**EO.scene_flow_metrics(i("pc"), i("pred"), i("labels"), i("mask"), res),
+                   **EO.motion_seg_metrics(i("pred_m"), i("mask")), **EO.pose_metrics(i("trans"), i("pred_t"))}
+        for k, v in got.items():
+            ref = float(g["%s/out/%s" % (n, k)])
+            assert (np.isnan(v) and np.isnan(ref)) or abs(v - ref) <= 1e-6 * max(1.0, abs(ref)), (n, k, v, ref)
