@@ -76,7 +76,7 @@ class RadarLossDesc(ctypes.Structure):
                 ("vel1", _vp), ("mseg_pre", _vp), ("mseg_gt", _vp), ("dyn_mask", _vp), ("radar_u", _vp), ("radar_v", _vp),
                 ("opt", _vp), ("pre_trans", _vp), ("gt_trans", _vp), ("camera_inverse", _vp), ("t_camera_radar", _vp),
                 ("w_self", _cf), ("w_em", _cf), ("w_ms", _cf), ("w_opt", _cf), ("w_dyn", _cf),
-                ("zeta", _cf), ("alpha", _cf), ("num_nb", _ci), ("lower_bound", _cf),
+                ("zeta", _cf), ("alpha", _cf), ("num_nb", _ci), ("lower_bound", _cf), ("self_only", _ci),
                 ("items", _vp), ("d_pred_f", _vp), ("d_pre_trans", _vp), ("d_mseg_pre", _vp), ("workspace", _vp)]
 
 

@@ -56,6 +56,10 @@ class CMFlow(nn.Module):
     def _declare_recurrent(self, width):
         pass
 
+    def _second_encoder(self):
+        """The encoder over the flow embeddings (mse_layer2 here, fd_layer.mse in RaFlow)."""
+        return self.mse_layer2
+
     @staticmethod
     def rigid_to_flow(pc, trans):
         """cmflow.py:51-55"""
@@ -76,7 +80,7 @@ class CMFlow(nn.Module):
         pc2_features = torch.cat((pc2_features, gfeat_2), dim=1)
         cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
         embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
-        prop_features = self.mse_layer2(pc1, embeddings)
+        prop_features = self._second_encoder()(pc1, embeddings)
         self.last = {"pc1_features": pc1_features[:, :256], "pc2_features": pc2_features[:, :256],
                      "cor_features": cor_features, "prop_features": prop_features}
         return prop_features
@@ -93,7 +97,7 @@ class CMFlow(nn.Module):
         # embeddings (B,N,1027) with one zero column so rows are 16-byte aligned for the GEMM (K = 1028)
         emb = torch.cat((a1, f1, cor, torch.zeros_like(a1[:, :, :1])), dim=2) if self.path == "pm" else \
             torch.cat((a1, f1, cor), dim=2)
-        prop = self.mse_layer2.forward_pm(x1, emb)                                         # (B,N,256)
+        prop = self._second_encoder().forward_pm(x1, emb)                                         # (B,N,256)
         self.last = {"pc1_features": f1[:, :, :256].transpose(1, 2), "pc2_features": f2[:, :, :256].transpose(1, 2),
                      "cor_features": cor.transpose(1, 2), "prop_features": prop.transpose(1, 2)}
         return prop.transpose(1, 2)
@@ -172,6 +176,9 @@ def init_model(args, device="cuda"):
     RCCL gradient all-reduce (cmflow_amd/dp.py)."""
     if args.model == 'cmflow':
         net = CMFlow(args)
+    elif args.model == 'raflow':
+        from .raflow import RaFlow
+        net = RaFlow(args)
     elif args.model == 'cmflow_t':
         net = CMFlow_T(args)
     else:

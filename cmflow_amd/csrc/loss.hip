@@ -106,6 +106,7 @@ struct LossArgs {
     const float *pc1, *pc2, *pred_f, *gt_f, *vel1, *mseg_pre, *mseg_gt, *dyn_mask, *radar_u, *radar_v, *opt;
     const float *pre_trans, *gt_trans, *cam_inv, *t_cr;
     float w_self, w_em, w_ms, w_opt, w_dyn, zeta, alpha, lower_bound;
+    int self_only;
     const float *counts;
     float *partials, *d_pred_f, *d_pre_trans, *d_mseg_pre;
 };
@@ -133,9 +134,11 @@ __global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(const LossArgs 
         const float x = a.pc1[o3 + i], f = a.pred_f[o3 + i];
         p1[i] = x; p2[i] = a.pc2[o3 + i]; fl[i] = f; pw[i] = x + f;
     }
-    if (tid < 16) { sT[tid] = a.pre_trans[(size_t)bs * 16 + tid]; sT[16 + tid] = a.gt_trans[(size_t)bs * 16 + tid]; }
-    if (tid < 9) sC[tid] = a.cam_inv[tid];
-    if (tid >= 32 && tid < 48) sC[9 + tid - 32] = a.t_cr[tid - 32];
+    if (!a.self_only) {
+        if (tid < 16) { sT[tid] = a.pre_trans[(size_t)bs * 16 + tid]; sT[16 + tid] = a.gt_trans[(size_t)bs * 16 + tid]; }
+        if (tid < 9) sC[tid] = a.cam_inv[tid];
+        if (tid >= 32 && tid < 48) sC[9 + tid - 32] = a.t_cr[tid - 32];
+    }
     __syncthreads();
     for (int i = tid; i < N; i += LS_THREADS) {
         n1[i] = ls_sqnorm3(p1[i], p1[N + i], p1[2 * N + i]);
@@ -145,8 +148,8 @@ __global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(const LossArgs 
     __syncthreads();
 
     const float inv_bn = 1.0f / ((float)a.B * (float)N);
-    const float cnt0 = a.counts[0], cnt1 = a.counts[1];
-    const float den_of = fmaxf(a.counts[2], 1.0f), den_dyn = fmaxf(a.counts[3], 1.0f);
+    const float cnt0 = a.self_only ? 1.f : a.counts[0], cnt1 = a.self_only ? 1.f : a.counts[1];
+    const float den_of = a.self_only ? 1.f : fmaxf(a.counts[2], 1.0f), den_dyn = a.self_only ? 1.f : fmaxf(a.counts[3], 1.0f);
     float part[LS_PARTIALS];
 #pragma unroll
     for (int t = 0; t < LS_PARTIALS; ++t) part[t] = 0.f;
@@ -259,6 +262,10 @@ __global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(const LossArgs 
         part[2] += fabsf(rdv);
         const float sg = rdv > 0.f ? -1.f : (rdv < 0.f ? 1.f : 0.f);
         gx[q] += k_self * sg * ax / pn; gy[q] += k_self * sg * ay / pn; gz[q] += k_self * sg * az / pn;
+        if (a.self_only) {                                   // RaFlow: the self-supervised terms are the whole loss
+            if (a.d_mseg_pre) a.d_mseg_pre[o1 + i] = 0.f;
+            continue;
+        }
         // ego-motion (radar_loss.py:162-183): |(R p + t) - (R_gt p + t_gt)|
         float e3[3];
 #pragma unroll
@@ -368,9 +375,15 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const LossArgs a, flo
     if (t == 0) {
         const float inv_bn = 1.0f / ((float)a.B * (float)a.N);
         const float sc = s[0] * inv_bn, ss = s[1] * inv_bn, rd = s[2] * inv_bn, em = s[3] * inv_bn;
+        const float self_sup = (sc + ss) + rd;
+        if (a.self_only) {
+            items[0] = a.w_self * self_sup;
+            items[1] = self_sup; items[2] = ss; items[3] = sc; items[4] = rd;
+            items[5] = items[6] = items[7] = items[8] = 0.f;
+            return;
+        }
         const float ms = (s[4] / a.counts[0] + s[5] / a.counts[1]) / 2.f;
         const float of = s[6] / fmaxf(a.counts[2], 1.0f), dyn = s[7] / fmaxf(a.counts[3], 1.0f);
-        const float self_sup = (sc + ss) + rd;
         items[0] = (((a.w_self * self_sup + a.w_em * em) + a.w_ms * ms) + a.w_opt * of) + a.w_dyn * dyn;
         items[1] = self_sup; items[2] = ss; items[3] = sc; items[4] = rd; items[5] = em; items[6] = ms;
         items[7] = of; items[8] = dyn;
@@ -387,9 +400,9 @@ extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
 {
     CMF_CHECK_ARG(d && d->B >= 0 && d->N > LS_NB && d->N <= LS_MAX_N && d->num_nb == LS_NB);
     if (d->B == 0) return 0;
-    CMF_CHECK_ARG(d->pc1 && d->pc2 && d->pred_f && d->gt_f && d->vel1 && d->mseg_pre && d->mseg_gt && d->dyn_mask &&
-                  d->radar_u && d->radar_v && d->opt && d->pre_trans && d->gt_trans && d->camera_inverse &&
-                  d->t_camera_radar && d->items && d->workspace && d->alpha > 0.f);
+    CMF_CHECK_ARG(d->pc1 && d->pc2 && d->pred_f && d->vel1 && d->items && d->workspace && d->alpha > 0.f);
+    CMF_CHECK_ARG(d->self_only || (d->gt_f && d->mseg_pre && d->mseg_gt && d->dyn_mask && d->radar_u && d->radar_v &&
+                                   d->opt && d->pre_trans && d->gt_trans && d->camera_inverse && d->t_camera_radar));
     hipStream_t st = (hipStream_t)stream;
     LossArgs a;
     a.B = d->B; a.N = d->N;
@@ -397,11 +410,12 @@ extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
     a.mseg_gt = d->mseg_gt; a.dyn_mask = d->dyn_mask; a.radar_u = d->radar_u; a.radar_v = d->radar_v; a.opt = d->opt;
     a.pre_trans = d->pre_trans; a.gt_trans = d->gt_trans; a.cam_inv = d->camera_inverse; a.t_cr = d->t_camera_radar;
     a.w_self = d->w_self; a.w_em = d->w_em; a.w_ms = d->w_ms; a.w_opt = d->w_opt; a.w_dyn = d->w_dyn;
-    a.zeta = d->zeta; a.alpha = d->alpha; a.lower_bound = d->lower_bound;
+    a.zeta = d->zeta; a.alpha = d->alpha; a.lower_bound = d->lower_bound; a.self_only = d->self_only;
     a.counts = d->workspace; a.partials = d->workspace + 4;
     a.d_pred_f = d->d_pred_f; a.d_pre_trans = d->d_pre_trans; a.d_mseg_pre = d->d_mseg_pre;
-    hipLaunchKernelGGL(loss_count_kernel, dim3(1), dim3(1024), 0, st, (long long)d->B * d->N, d->mseg_gt, d->dyn_mask,
-                       d->workspace);
+    if (!d->self_only)
+        hipLaunchKernelGGL(loss_count_kernel, dim3(1), dim3(1024), 0, st, (long long)d->B * d->N, d->mseg_gt, d->dyn_mask,
+                           d->workspace);
     const size_t lds = (size_t)LS_WORDS_PER_POINT * d->N * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -185,17 +185,21 @@ class RadarFlowLossFn(Function):
         dev = pc1.device
         f32 = torch.float32
         t = {k: v.contiguous() for k, v in data.items()}
-        pred_f, pre_trans, mseg_pre = pred_f.contiguous(), pre_trans.contiguous(), mseg_pre.contiguous()
+        pred_f = pred_f.contiguous()
+        pre_trans = pre_trans.contiguous() if pre_trans is not None else None
+        mseg_pre = mseg_pre.contiguous() if mseg_pre is not None else None
         for v in list(t.values()) + [pred_f, pre_trans, mseg_pre]:
             _lib.dev_ptr(v, f32)                                  # device / dtype / density checks (no CPU fallback)
         need = any(ctx.needs_input_grad[:3])
         d = _lib.RadarLossDesc()
         d.B, d.N = B, N
-        d.pc1, d.pc2, d.pred_f, d.gt_f = t["pc1"].data_ptr(), t["pc2"].data_ptr(), pred_f.data_ptr(), t["gt_f"].data_ptr()
-        d.vel1, d.mseg_pre, d.mseg_gt = t["vel1"].data_ptr(), mseg_pre.data_ptr(), t["mseg_gt"].data_ptr()
-        d.dyn_mask, d.radar_u, d.radar_v = t["dyn_mask"].data_ptr(), t["radar_u"].data_ptr(), t["radar_v"].data_ptr()
-        d.opt, d.pre_trans, d.gt_trans = t["opt"].data_ptr(), pre_trans.data_ptr(), t["gt_trans"].data_ptr()
-        d.camera_inverse, d.t_camera_radar = t["camera_inverse"].data_ptr(), t["t_camera_radar"].data_ptr()
+        d.self_only = int(hyper.get("self_only", False))
+        d.pc1, d.pc2, d.pred_f, d.vel1 = t["pc1"].data_ptr(), t["pc2"].data_ptr(), pred_f.data_ptr(), t["vel1"].data_ptr()
+        if not d.self_only:
+            d.gt_f, d.mseg_pre, d.mseg_gt = t["gt_f"].data_ptr(), mseg_pre.data_ptr(), t["mseg_gt"].data_ptr()
+            d.dyn_mask, d.radar_u, d.radar_v = t["dyn_mask"].data_ptr(), t["radar_u"].data_ptr(), t["radar_v"].data_ptr()
+            d.opt, d.pre_trans, d.gt_trans = t["opt"].data_ptr(), pre_trans.data_ptr(), t["gt_trans"].data_ptr()
+            d.camera_inverse, d.t_camera_radar = t["camera_inverse"].data_ptr(), t["t_camera_radar"].data_ptr()
         d.w_self, d.w_em, d.w_ms, d.w_opt, d.w_dyn = hyper["w"]
         d.zeta, d.alpha, d.num_nb, d.lower_bound = hyper["zeta"], hyper["alpha"], hyper["num_nb"], hyper["lower_bound"]
         items = torch.empty(9, dtype=f32, device=dev)
@@ -203,9 +207,11 @@ class RadarFlowLossFn(Function):
         d.items, d.workspace = items.data_ptr(), ws.data_ptr()
         if need:
             g_f = torch.empty(B, 3, N, dtype=f32, device=dev)
-            g_t = torch.empty(B, 4, 4, dtype=f32, device=dev)
-            g_m = torch.empty(mseg_pre.shape, dtype=f32, device=dev)
-            d.d_pred_f, d.d_pre_trans, d.d_mseg_pre = g_f.data_ptr(), g_t.data_ptr(), g_m.data_ptr()
+            g_t = torch.empty(B, 4, 4, dtype=f32, device=dev) if pre_trans is not None else None
+            g_m = torch.empty(mseg_pre.shape, dtype=f32, device=dev) if mseg_pre is not None else None
+            d.d_pred_f = g_f.data_ptr()
+            d.d_pre_trans = g_t.data_ptr() if g_t is not None else None
+            d.d_mseg_pre = g_m.data_ptr() if g_m is not None else None
             ctx.grads = (g_f, g_t, g_m)
         _lib.check(_lib.lib().cmf_radar_loss(ctypes.addressof(d), _lib.stream_ptr()), "cmf_radar_loss")
         ctx.mark_non_differentiable(items)
@@ -215,8 +221,11 @@ class RadarFlowLossFn(Function):
     def backward(ctx, g_total, _g_items):
         g_f, g_t, g_m = ctx.grads
         need = ctx.needs_input_grad
-        return (g_f * g_total if need[0] else None, g_t * g_total if need[1] else None,
-                g_m * g_total if need[2] else None, None, None)
+        return (g_f * g_total if need[0] else None, g_t * g_total if (need[1] and g_t is not None) else None,
+                g_m * g_total if (need[2] and g_m is not None) else None, None, None)
+
+
+SELF_ITEM_KEYS = ITEM_KEYS[:4]
 
 
 class RadarFlowLoss(Module):
@@ -235,9 +244,30 @@ class RadarFlowLoss(Module):
         self.ego_motion_loss, self.motion_seg_loss = EgoMotionLoss(), MotionSegLoss()
         self.opt_flow_loss, self.dyn_flow_loss = OpticalFlowLoss(), DynamicFlowLoss()
 
-    def forward(self, pc1, pc2, pred_f, vel1, gt_f, pre_trans, mseg_pre, gt_trans, mseg_gt, dyn_mask,
-                radar_u, radar_v, opt):
+    def _self_terms(self, pc1, pc2, pred_f, vel1):
+        sc = self.sc_loss(pc1, pc2, pc1 + pred_f)
+        ss = self.ss_loss(pc1, pred_f)
+        rd = self.rd_loss(pc1, pred_f, vel1)
+        return sc + ss + rd, sc, ss, rd
+
+    def _self_supervised(self, pc1, pc2, pred_f, vel1):
         N = pc1.shape[2]
+        if self.native and pc1.is_cuda and NATIVE_MIN_N <= N <= NATIVE_MAX_N and self.ss_loss.num_nb == 8:
+            hyper = dict(w=(self.w_self, 0.0, 0.0, 0.0, 0.0), zeta=self.sc_loss.zeta, alpha=self.ss_loss.alpha,
+                         num_nb=self.ss_loss.num_nb, lower_bound=0.0, self_only=True)
+            total, items = RadarFlowLossFn.apply(pred_f, None, None, dict(pc1=pc1, pc2=pc2, vel1=vel1), hyper)
+            return total, {k: items[i + 1] for i, k in enumerate(SELF_ITEM_KEYS)}
+        self_sup, sc, ss, rd = self._self_terms(pc1, pc2, pred_f, vel1)
+        return self.w_self * self_sup, {'Loss': self_sup.detach(), 'smoothnessLoss': ss.detach(),
+                                        'chamferLoss': sc.detach(), 'veloLoss': rd.detach()}
+
+    def forward(self, pc1, pc2, pred_f, vel1, gt_f=None, pre_trans=None, mseg_pre=None, gt_trans=None, mseg_gt=None,
+                dyn_mask=None, radar_u=None, radar_v=None, opt=None):
+        """With only (pc1, pc2, pred_f, vel1) this is the loss of model 'raflow' (radar_loss.py:274-276): the three
+        self-supervised terms; items then has the four keys of SelfSupervisedLoss (:153-158)."""
+        N = pc1.shape[2]
+        if gt_f is None:
+            return self._self_supervised(pc1, pc2, pred_f, vel1)
         if self.native and pc1.is_cuda and NATIVE_MIN_N <= N <= NATIVE_MAX_N:
             data = dict(pc1=pc1, pc2=pc2, gt_f=gt_f, vel1=vel1, gt_trans=gt_trans, mseg_gt=mseg_gt.to(pc1.dtype),
                         dyn_mask=dyn_mask.to(pc1.dtype), radar_u=radar_u, radar_v=radar_v, opt=opt,
@@ -247,11 +277,8 @@ class RadarFlowLoss(Module):
             if self.ss_loss.num_nb == 8:
                 total, items = RadarFlowLossFn.apply(pred_f, pre_trans, mseg_pre, data, hyper)
                 return total, {k: items[i + 1] for i, k in enumerate(ITEM_KEYS)}
+        self_sup, sc, ss, rd = self._self_terms(pc1, pc2, pred_f, vel1)
         pc1_warp = pc1 + pred_f
-        sc = self.sc_loss(pc1, pc2, pc1_warp)
-        ss = self.ss_loss(pc1, pred_f)
-        rd = self.rd_loss(pc1, pred_f, vel1)
-        self_sup = sc + ss + rd
         em = self.ego_motion_loss(pc1, pre_trans, gt_trans)
         ms = self.motion_seg_loss(mseg_pre, mseg_gt)
         dyn = self.dyn_flow_loss(pred_f, gt_f, dyn_mask)

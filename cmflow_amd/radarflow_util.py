@@ -386,3 +386,26 @@ class MotionHead(nn.Module):
         return torch.sigmoid(F.linear(feat, w2d(self.conv2)))
 
     use_blocks = True
+
+
+FlowPredictor = FlowHead        # radarflow_util.py:388-409: same layers and parameter names as FlowHead (:240-261)
+
+
+class FlowDecoder(nn.Module):
+    """radarflow_util.py:321-350 (RaFlow): multi-scale propagation of the flow embeddings + flow predictor."""
+
+    def __init__(self, fc_inch):
+        super().__init__()
+        ep_radius = [2.0, 4.0, 8.0, 16.0]
+        ep_nsamples = [4, 8, 16, 32]
+        ep_mlps = [fc_inch, int(fc_inch / 2), int(fc_inch / 8)]
+        ep_mlp2s = [int(fc_inch / 8), int(fc_inch / 8), int(fc_inch / 8)]
+        self.mse = MultiScaleEncoder(ep_radius, ep_nsamples, in_channel=fc_inch * 2 + 3, mlp=ep_mlps, mlp2=ep_mlp2s)
+        sf_inch = len(ep_radius) * ep_mlp2s[-1] * 2
+        self.fp = FlowPredictor(in_channel=sf_inch, mlp=[int(sf_inch / 2), int(sf_inch / 4), int(sf_inch / 8)])
+
+    def forward(self, pc1, feature1, pc1_features, cor_features):
+        embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
+        prop_features = self.mse(pc1, embeddings)
+        gfeat = torch.max(prop_features, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
+        return self.fp(torch.cat((prop_features, gfeat), dim=1))

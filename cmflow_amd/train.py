@@ -23,6 +23,7 @@ class TrainStep:
         self.bucket = FlatGradBucket(net)
         self.opt = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay)
         self.recurrent = hasattr(net, "gru")
+        self.self_supervised = hasattr(net, "fd_layer")
         # the scales of an encoder run on side streams while the gradient bucket lives on the main stream
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.gfeat = None
@@ -32,8 +33,12 @@ class TrainStep:
         self.gfeat = None
 
     def forward_loss(self, batch):
-        dyn_mask, mseg_gt = make_labels(batch, self.vr_thres)
         pc1, pc2, ft1, ft2 = batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"]
+        if self.self_supervised:                                   # model 'raflow': main_util.py:57-60
+            output, pred_f, pre_trans, mask_s = self.net(pc1, pc2, ft1, ft2, batch["interval"])
+            loss, items = self.loss_obj(pc1, pc2, pred_f, ft1[:, 0])
+            return loss, items, (pred_f, output, pre_trans, mask_s), (None, None)
+        dyn_mask, mseg_gt = make_labels(batch, self.vr_thres)
         if self.recurrent:
             g = self.gfeat.detach() if self.gfeat is not None else None          # clip_util.py:54
             pred_f, mseg_pre, pre_trans, mask, self.gfeat = self.net(pc1, pc2, ft1, ft2, mseg_gt, 'train', g)

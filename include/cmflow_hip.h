@@ -250,6 +250,8 @@ typedef struct cmf_radar_loss_desc {
     const float *t_camera_radar;                                               /* (4,4) */
     float w_self, w_em, w_ms, w_opt, w_dyn;                                    /* radar_loss.py:262: 1,1,1,0.1,1 */
     float zeta, alpha; int num_nb; float lower_bound;                          /* 0.005, 0.5, 8, 0.25 */
+    int self_only;             /* 1: model 'raflow' (radar_loss.py:274-276) -- only the three self-supervised terms;
+                                  the inputs of the other four may be NULL, their items are reported as 0 */
     float *items;                                                              /* [9] */
     float *d_pred_f, *d_pre_trans, *d_mseg_pre;                                /* (B,3,N), (B,4,4), (B,N) or NULL */
     float *workspace;                                                          /* cmf_radar_loss_workspace floats */

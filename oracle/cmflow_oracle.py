@@ -307,6 +307,73 @@ class CMFlow_T(CMFlow):
         return (*self._heads(final, pc1, label_m, mode), gfeat)
 
 
+class FlowDecoder(nn.Module):
+    """utils/model_utils/radarflow_util.py:321-350 (FlowPredictor :388-409 has the layout of FlowHead)"""
+
+    def __init__(self, fc_inch):
+        super().__init__()
+        radius, nsamples = [2.0, 4.0, 8.0, 16.0], [4, 8, 16, 32]
+        self.mse = MultiScaleEncoder(radius, nsamples, fc_inch * 2 + 3, [fc_inch, fc_inch // 2, fc_inch // 8],
+                                     [fc_inch // 8, fc_inch // 8, fc_inch // 8])
+        sf = 4 * (fc_inch // 8) * 2
+        self.fp = FlowHead(sf, [sf // 2, sf // 4, sf // 8])
+
+    def forward(self, pc1, feature1, pc1_features, cor_features):
+        prop = self.mse(pc1, torch.cat((feature1, pc1_features, cor_features), dim=1))
+        g = torch.max(prop, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
+        return self.fp(torch.cat((prop, g), dim=1))
+
+
+def rigid_transform_masked(A, B, M):
+    """models/raflow.py:121-157: Kabsch over the points selected by M.  The centroids are torch.mean over ALL N
+    points of the masked coordinates (:132-133), i.e. sum over the mask / N -- weights M/N in weighted_kabsch."""
+    return weighted_kabsch(A, B, M.to(A.dtype) / A.size(2))
+
+
+class RaFlow(nn.Module):
+    """models/raflow.py:10-165"""
+
+    def __init__(self, args):
+        super().__init__()
+        self.rigid_thres = args.rigid_thres
+        self.rigid_pcs = 0.25
+        self.npoints = args.num_points
+        radius, nsamples = [2.0, 4.0, 8.0, 16.0], [4, 8, 16, 32]
+        self.mse_layer = MultiScaleEncoder(radius, nsamples, 3, [32, 32, 64], [64, 64, 64])
+        fc = 4 * 64 * 2
+        self.fc_layer = FeatureCorrelator(8, fc * 2 + 3, [fc, fc, fc])
+        self.fd_layer = FlowDecoder(fc)
+
+    def ROFE_module(self, pc1, pc2, feature1, feature2):
+        f1 = self.mse_layer(pc1, feature1)
+        f2 = self.mse_layer(pc2, feature2)
+        f1 = torch.cat((f1, torch.max(f1, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))), dim=1)
+        f2 = torch.cat((f2, torch.max(f2, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))), dim=1)
+        cor = self.fc_layer(pc1, pc2, f1, f2)
+        return self.fd_layer(pc1, feature1, f1, cor)
+
+    def SFR_module(self, output, pc1, feature1, interval):
+        N = pc1.size(2)
+        warp = pc1 + output
+        trans = rigid_transform_masked(pc1, warp, torch.ones(pc1.size(0), N, dtype=pc1.dtype))
+        sf_rg = rigid_to_flow(pc1, trans)
+        vel = feature1[:, 0]
+        proj = torch.sum(sf_rg * pc1, dim=1) / torch.norm(pc1, dim=1)
+        residual = vel * interval.unsqueeze(1) - proj
+        mask_s = torch.abs(residual / vel) < self.rigid_thres
+        # raflow.py:106-116: per sample, when more than rigid_pcs of the points are inliers, re-fit on the inliers
+        # and replace their flow vectors by the rigid flow
+        refit = rigid_transform_masked(pc1, warp, mask_s)
+        use = (mask_s.sum(dim=1).to(pc1.dtype) / N) > self.rigid_pcs
+        pre_trans = torch.where(use.view(-1, 1, 1), refit, trans)
+        sf_agg = torch.where(use.view(-1, 1, 1) & mask_s.unsqueeze(1), rigid_to_flow(pc1, pre_trans), output)
+        return sf_agg, pre_trans, mask_s
+
+    def forward(self, pc1, pc2, feature1, feature2, interval):
+        output = self.ROFE_module(pc1, pc2, feature1, feature2)
+        return (output, *self.SFR_module(output, pc1, feature1, interval))
+
+
 def set_trace(net, on=True):
     """Collect ball-query / kNN index tensors in call order (for index-level parity tests)."""
     bq, knn = ([] if on else None), ([] if on else None)

@@ -145,6 +145,16 @@ def radar_flow_loss(batch, pred_f, pre_trans, mseg_pre, mseg_gt, dyn_mask, P, Tc
     return total, items
 
 
+def self_supervised_loss(batch, pred_f):
+    """losses/radar_loss.py:124-160 -- all RaFlow trains on (:274-276)."""
+    pc1, pc2 = batch["pc1"], batch["pc2"]
+    sc = soft_chamfer(pc1, pc2, pc1 + pred_f)
+    ss = smoothness(pc1, pred_f)
+    rd = radial_displacement(pc1, pred_f, batch["ft1"][:, 0])
+    total = sc + ss + rd
+    return total, {"Loss": total.item(), "smoothnessLoss": ss.item(), "chamferLoss": sc.item(), "veloLoss": rd.item()}
+
+
 def train_step(net, opt, batch, P, Tcr):
     """main_util.py:63-76: labels -> forward('train') -> loss -> zero_grad/backward/step."""
     dyn, mseg = make_labels(batch)

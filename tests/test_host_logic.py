@@ -77,3 +77,65 @@ def test_label_prep_matches_reference_golden(golden_dir):
     batch = {k: torch.from_numpy(g[k]) for k in ("pc1", "ft1", "gt_trans", "flow_label", "fg_mask", "interval")}
     dyn, mseg = make_labels(batch, 0.3)
     assert np.array_equal(dyn.numpy(), g["dyn_mask"]) and np.array_equal(mseg.numpy(), g["mseg_gt"])
+
+
+def test_vod_dataset_matches_reference_loader(golden_dir, tmp_path):
+    """cmflow_amd.dataset.vodDataset against the tuples the reference's dataset/vod.py produced
+    from the same sample files (tests/golden/make_golden_raflow.py), incl. the seeded resampling to 256 points."""
+    import json
+    import numpy as np
+    from cmflow_amd import dataset as D
+    g = np.load(os.path.join(golden_dir, "vod_dataset_kat.npz"))
+    files = [k[6:] for k in g.files if k.startswith("file::")]
+    assert len(files) == 6
+    for rel in files:
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(str(g["file::" + rel]))
+
+    class A:
+        num_points = 256
+        eval = False
+
+    for part, ev in (("train", False), ("test", True)):
+        a = A()
+        a.eval = ev
+        ds = D.vodDataset(a, root=str(tmp_path) + "/", partition=part)
+        assert len(ds) == int(g["%s/len" % part])
+        np.testing.assert_array_equal(np.array([ds.res['r_res'], ds.res['theta_res'], ds.res['phi_res']]), g["%s/res" % part])
+        np.testing.assert_allclose(ds.camera_projection_matrix, g["%s/camera_projection_matrix" % part], rtol=1e-6)
+        np.testing.assert_allclose(ds.t_camera_radar, g["%s/t_camera_radar" % part], rtol=1e-6)
+        if ev:
+            assert ds.clips_info == json.loads(str(g["%s/clips_info" % part]))
+        np.random.seed(11)
+        for i in range(len(ds)):
+            item = ds[i]
+            assert len(item) == 11
+            for j, v in enumerate(item):
+                ref = g["%s/%d/%d" % (part, i, j)]
+                v = np.asarray(v)
+                assert v.shape == ref.shape and v.dtype == ref.dtype, (part, i, j, v.dtype, ref.dtype)
+                np.testing.assert_array_equal(v, ref)
+    # collate + extract_data_info (main_util.py:21-36): model layout, on CPU here
+    a = A()
+    ds = D.vodDataset(a, root=str(tmp_path) + "/", partition="train")
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)))
+    info = D.extract_data_info(batch, device="cpu")
+    assert info[0].shape == (2, 3, 256) and info[2].shape == (2, 3, 256) and info[4].shape == (2, 4, 4)
+    assert info[5].shape == (2, 256, 3) and info[10].shape == (2, 256, 2) and all(t.dtype == torch.float32 for t in info)
+    assert set(D.as_batch_dict(info)) >= {"pc1", "ft1", "gt_trans", "flow_label", "fg_mask", "interval", "opt_flow"}
+
+
+def test_raflow_checkpoint_layout(golden_dir):
+    """RaFlow mirror: the reference's 355 state tensors in the reference's order."""
+    import json
+    from cmflow_amd.raflow import RaFlow
+
+    class A:
+        num_points = 256
+        rigid_thres = 0.15
+
+    man = json.load(open(os.path.join(golden_dir, "state_manifest_raflow.json")))
+    sd = RaFlow(A).state_dict()
+    assert [k for k, _, _ in man] == list(sd.keys())
+    assert all(list(sd[k].shape) == list(s) for k, s, _ in man)

@@ -197,3 +197,58 @@ def test_eval_metric_oracle_matches_reference_goldens(golden_dir):
         for k, v in got.items():
             ref = float(g["%s/out/%s" % (n, k)])
             assert (np.isnan(v) and np.isnan(ref)) or abs(v - ref) <= 1e-6 * max(1.0, abs(ref)), (n, k, v, ref)
+
+
+# ---- RaFlow and the sample format -----------------------------------------------------------
+class RaArgs:
+    num_points = 256
+    rigid_thres = 0.15
+    eval = False
+
+
+def _raflow(golden_dir, thres=0.15):
+    import json
+    man = json.load(open(os.path.join(golden_dir, "state_manifest_raflow.json")))
+    a = RaArgs()
+    a.rigid_thres = thres
+    net = O.RaFlow(a)
+    assert [k for k, _, _ in man] == list(net.state_dict().keys())          # 355 tensors, the reference's order
+    net.load_state_dict(synth.synth_state_dict(man, seed=1234, calib=os.path.join(golden_dir, "bn_calib_raflow.npz")))
+    return net
+
+
+@pytest.mark.parametrize("tag,thres", [("raflow_eval_synth_b2", 0.15), ("raflow_eval_synth_b4_loose", 2.0)])
+def test_raflow_oracle_eval_matches_reference(golden_dir, tag, thres):
+    g = _load(golden_dir, tag)
+    net = _raflow(golden_dir, thres).eval()
+    with torch.no_grad():
+        out, sf, trans, mask_s = net(*(torch.from_numpy(g[k]) for k in ("pc1", "pc2", "ft1", "ft2", "interval")))
+    assert np.array_equal(mask_s.numpy(), g["mask_s"])
+    np.testing.assert_allclose(out.numpy(), g["output"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(sf.numpy(), g["sf_agg"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(trans.numpy(), g["pre_trans"], rtol=2e-5, atol=1e-4)
+    if thres > 1:
+        assert np.abs(g["sf_agg"] - g["output"]).max() > 0.1                 # the re-fit branch is exercised
+
+
+def test_raflow_oracle_train_step_matches_reference(golden_dir):
+    g = _load(golden_dir, "raflow_train_synth_b4")
+    net = _raflow(golden_dir).train()
+    batch = {k: torch.from_numpy(g[k]) for k in ("pc1", "pc2", "ft1", "ft2", "interval")}
+    opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=1e-4)
+    _, pred_f, _, _ = net(batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"], batch["interval"])
+    loss, items = TO.self_supervised_loss(batch, pred_f)
+    opt.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    for k, v in items.items():
+        assert abs(v - float(g["item_" + k])) < 1e-4, k
+    np.testing.assert_allclose(pred_f.detach().numpy(), g["sf_agg"], rtol=0, atol=1e-4)
+    params = dict(net.named_parameters())
+    for name, ref in zip(g["grad_names"], g["grad_norms"]):
+        got = float(params[str(name)].grad.norm())
+        assert abs(got - ref) <= 5e-3 * max(ref, 1e-3), (name, got, ref)
+    opt.step()
+    for k in g:
+        if k.startswith("after::"):
+            np.testing.assert_allclose(params[k[7:]].detach().reshape(-1)[:64].numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
