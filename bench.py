@@ -33,6 +33,7 @@ class Args:
     num_points = 256
     stat_thres = 0.5
     vr_thres = 0.3
+    rigid_thres = 0.15
 
 
 def load_weights(model_name):
@@ -56,15 +57,19 @@ def cpu_baseline(mode, model_name, budget_s=20.0):
         avail = os.cpu_count() or 1
     cores = max(1, min(16, avail))
     torch.set_num_threads(cores)
-    net = (O.CMFlow_T if model_name == "cmflow_t" else O.CMFlow)(Args())
+    net = {"cmflow": O.CMFlow, "cmflow_t": O.CMFlow_T, "raflow": O.RaFlow}[model_name](Args())
     net.load_state_dict(load_weights(model_name))
     B = 4
     b = synth.make_batch(B, seed=1, train_extras=True)
     P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
     if mode == "train":
         net.train()
-        opt = torch.optim.Adam(net.parameters(), lr=0.001, weight_decay=1e-4)
-        if model_name == "cmflow_t":
+        opt = torch.optim.Adam(net.parameters(), lr=1e-6 if model_name == "raflow" else 0.001, weight_decay=1e-4)
+        if model_name == "raflow":
+            def one():
+                loss, _ = TO.self_supervised_loss(b, net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], b["interval"])[1])
+                opt.zero_grad(); loss.backward(); opt.step()
+        elif model_name == "cmflow_t":
             def one():
                 dyn, mseg = TO.make_labels(b)
                 out = net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], mseg, "train", None)
@@ -73,7 +78,7 @@ def cpu_baseline(mode, model_name, budget_s=20.0):
         else:
             def one():
                 TO.train_step(net, opt, b, P, Tcr)
-        what = "fwd+bwd+7 losses+Adam, train-mode BN"
+        what = "fwd+bwd+%s losses+Adam, train-mode BN" % ("3 self-supervised" if model_name == "raflow" else "7")
     else:
         net.eval()
 
@@ -81,6 +86,8 @@ def cpu_baseline(mode, model_name, budget_s=20.0):
             with torch.no_grad():
                 if model_name == "cmflow_t":
                     net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test", None)
+                elif model_name == "raflow":
+                    net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], b["interval"])
                 else:
                     net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
         what = "fwd, eval-mode BN"
@@ -103,7 +110,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["train", "fwd"], default="train")
-    ap.add_argument("--model", choices=["cmflow", "cmflow_t"], default="cmflow")
+    ap.add_argument("--model", choices=["cmflow", "cmflow_t", "raflow"], default="cmflow")
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", choices=["pm", "pm_torch", "ref"], default="pm",
@@ -133,7 +140,8 @@ def main():
     from cmflow_amd.train import TrainStep
     _lib.lib()                                       # fail loudly if the HIP extension is missing
 
-    net = (CMFlow_T if a.model == "cmflow_t" else CMFlow)(Args())
+    from cmflow_amd.raflow import RaFlow
+    net = {"cmflow": CMFlow, "cmflow_t": CMFlow_T, "raflow": RaFlow}[a.model](Args())
     net.load_state_dict(load_weights(a.model))
     net = net.to(dev)
     net.path = a.path
@@ -142,7 +150,9 @@ def main():
 
     if a.mode == "train":
         net.train()
-        step = TrainStep(net, vr_thres=Args.vr_thres)
+        # RaFlow's purely self-supervised loss diverges within a few Adam steps on seeded random weights (NaN -> the
+        # CPU SVD of the baseline leg throws): same work per step with a small learning rate
+        step = TrainStep(net, vr_thres=Args.vr_thres, lr=1e-6 if a.model == "raflow" else 0.001)
 
         def one():
             if a.model == "cmflow_t":
@@ -155,6 +165,8 @@ def main():
             with torch.no_grad():
                 if a.model == "cmflow_t":
                     net(batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"], None, "test", None)
+                elif a.model == "raflow":
+                    net(batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"], batch["interval"])
                 else:
                     net(batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"], None, "test")
 
@@ -225,13 +237,15 @@ def main():
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(a.mode, a.model)
         line = {
-            "metric": "frame-pairs/sec CMFlow fwd+bwd" if a.mode == "train" else "frame-pairs/sec CMFlow fwd",
+            "metric": "frame-pairs/sec %s %s" % ({"cmflow": "CMFlow", "cmflow_t": "CMFlow-T", "raflow": "RaFlow"}[a.model],
+                                                   "fwd+bwd" if a.mode == "train" else "fwd"),
             "value": round(pairs / dt, 2), "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("%s %s step, N=256, B=%d per GPU (global %d), ball-query r=2/4/8/16 K=4/8/16/32, "
                                     "kNN K=8%s; synthetic clouds, seeded random-init weights" %
-                                    (a.model, "fwd+bwd training (7 cross-modal losses + Adam, train-mode BN)"
+                                    (a.model, ("fwd+bwd training (3 self-supervised losses + Adam, train-mode BN)" if a.model == "raflow"
+                                               else "fwd+bwd training (7 cross-modal losses + Adam, train-mode BN)")
                                      if a.mode == "train" else "fwd-only inference (eval-mode BN)", a.batch,
                                      a.batch * world, "; dp%d RCCL grad all-reduce" % world if world > 1 else "")),
                        "parallelism": "dp%d" % world},
