@@ -650,7 +650,10 @@ class CostVolumeMLPFn(Function):
     p1 (B,N1,C), p2 (B,N2,C) per-point GEMM outputs; wd (C,3) the direction columns of the first conv."""
 
     @staticmethod
-    def forward(ctx, xyz1_t, xyz2_t, p1, p2, nbr, wd, w2, b2, w3, b3):
+    def forward(ctx, xyz1_t, xyz2_t, p1, p2, nbr, wd, w2, b2, w3, b3, preact_grad=False):
+        # preact_grad: the consumer of x3 (WeightedKSumFn with leaky=True) already applies leaky'(x3), i.e. the
+        # incoming gradient is w.r.t. the pre-activation z3
+        ctx.preact_grad = preact_grad
         B, N1, C = p1.shape
         K = nbr.S
         p1c, p2c = p1.contiguous(), p2.contiguous()
@@ -670,7 +673,8 @@ class CostVolumeMLPFn(Function):
         nbr, dxyz, x1, x2, x3, w2, w3, (B, N1, K, C), N2 = ctx.saved
         M = B * N1 * K
         dx3 = dx3.reshape(M, -1)
-        dz3 = torch.where(x3 > 0, dx3, 0.1 * dx3)                 # leaky'(z) has the sign of the stored activation
+        # leaky'(z) has the sign of the stored activation
+        dz3 = dx3.contiguous() if ctx.preact_grad else torch.where(x3 > 0, dx3, 0.1 * dx3)
         db3 = dz3.sum(0)
         dw3 = gemm_dw(dz3, x2, w=ctx.params[1])
         dz2 = gemm(dz3, w3, b_t=False, bwd=(2, x2))
@@ -683,4 +687,43 @@ class CostVolumeMLPFn(Function):
         dp2 = torch.empty(B, N2, C, dtype=_f32, device=dz1.device)
         err = L().cmf_group_rows_grad(B, N2, C, C, N1 * K, 0, _p(dz1), _p(off), _p(inv), _p(dp2), _lib.stream_ptr())
         _lib.check(err, "cmf_group_rows_grad")
-        return None, None, dp1, dp2, None, dwd, dw2, db2, dw3, db3
+        return None, None, dp1, dp2, None, dwd, dw2, db2, dw3, db3, None
+
+
+class WeightedKSumFn(Function):
+    """cost[b,n,:] = sum_k weights[b,n,k,:] * x[b,n,k,:] (radarflow_util.py:219-221) or, with nbr given,
+    sum_k weights[b,n,k,:] * x[b, nbr[b,n,k], :] (:234-236, x = per-point rows, the grouped tensor is never
+    written) -- cmf_weighted_ksum / cmf_weighted_ksum_grad (csrc/wsum.hip).  leaky=True: x is a stored
+    LeakyReLU(0.1) activation and the gradient returned for it is the one w.r.t. its pre-activation."""
+
+    @staticmethod
+    def forward(ctx, weights, x, nbr, leaky):
+        B, N1, K, C = weights.shape
+        weights, x = weights.contiguous(), x.contiguous()
+        out = torch.empty(B, N1, C, dtype=_f32, device=weights.device)
+        idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
+        n_src = nbr.n if nbr is not None else 0
+        _lib.check(L().cmf_weighted_ksum(B * N1, K, C, N1, n_src, _lib.dev_ptr(weights, _f32), _lib.dev_ptr(x, _f32), idx,
+                                         _p(out), _lib.stream_ptr()), "cmf_weighted_ksum")
+        ctx.saved = (weights, x, nbr, bool(leaky))
+        return out
+
+    @staticmethod
+    def backward(ctx, dcost):
+        weights, x, nbr, leaky = ctx.saved
+        B, N1, K, C = weights.shape
+        dcost = dcost.contiguous()
+        need_w, need_x = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dw = torch.empty_like(weights) if need_w else None
+        dx = torch.empty(B, N1, K, C, dtype=_f32, device=weights.device) if need_x else None
+        idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
+        n_src = nbr.n if nbr is not None else 0
+        _lib.check(L().cmf_weighted_ksum_grad(B * N1, K, C, N1, n_src, int(leaky), _p(dcost), _p(weights), _p(x), idx,
+                                              _p(dw), _p(dx), _lib.stream_ptr()), "cmf_weighted_ksum_grad")
+        if nbr is not None and need_x:                       # scatter the per-slot gradients back to the points
+            off, inv = nbr.inverse()
+            dp = torch.empty(B, nbr.n, C, dtype=_f32, device=weights.device)
+            _lib.check(L().cmf_group_rows_grad(B, nbr.n, C, C, N1 * K, 0, _p(dx), _p(off), _p(inv), _p(dp), _lib.stream_ptr()),
+                       "cmf_group_rows_grad")
+            dx = dp
+        return dw, dx, None, None

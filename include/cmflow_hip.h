@@ -231,6 +231,17 @@ int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long l
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
 int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
 
+/* Cost-volume weighting (radarflow_util.py:219-221,235-236): out[m,c] = sum_k w[m,k,c] * x[m,k,c] over rows
+ * m = sample*n1 + point.  idx == NULL: x is (M,K,C) dense.  idx (M,K) int32: x is (samples*n_src, C) per-point rows
+ * and the k-th operand of row m is x[sample*n_src + idx[m,k]] (the grouped tensor is never materialised).
+ * The gradient call writes dw = dcost*x and dx = dcost*w, each (M,K,C) (either may be NULL); leaky != 0: x is a
+ * stored LeakyReLU(0.1) activation and dx is multiplied by its derivative (gradient w.r.t. the pre-activation).
+ * C % 4 == 0, 16-byte aligned pointers. */
+int cmf_weighted_ksum(long long M, int K, int C, int n1, int n_src, const float *w, const float *x, const int *idx,
+                      float *out, void *stream);
+int cmf_weighted_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *w,
+                           const float *x, const int *idx, float *dw, float *dx, void *stream);
+
 /* ---- the training step's loss -------------------------------------------------------------
  * RadarFlowLoss of losses/radar_loss.py:260-292 for model 'cmflow' / 'cmflow_t': SoftChamfer (:17-58),
  * SpatialSmoothness (:60-97), RadialDisplacement (:99-122), EgoMotion (:162-183), MotionSeg (:185-205),

@@ -185,3 +185,38 @@ def test_product_refuses_cpu_tensors():
     x = torch.zeros(1, 4, 3)
     with pytest.raises(RuntimeError):
         ball_query(1.0, 2, x, x)
+
+
+@pytest.mark.parametrize("B,N1,N2,K,C", [(2, 64, 64, 8, 512), (3, 50, 70, 5, 12), (1, 33, 33, 16, 64)])
+def test_weighted_ksum_matches_torch(dev, B, N1, N2, K, C):
+    """cmf_weighted_ksum(_grad) (radarflow_util.py:219-221,234-236) against the torch expressions, dense and gathered."""
+    from cmflow_amd.fused import Neighbors, group_rows
+    from cmflow_amd.fused_blocks import WeightedKSumFn
+    g = torch.Generator().manual_seed(B + N1 + K)
+    w = torch.randn(B, N1, K, C, generator=g).to(dev).requires_grad_(True)
+    x = torch.randn(B, N1, K, C, generator=g).to(dev).requires_grad_(True)
+    go = torch.randn(B, N1, C, generator=g).to(dev)
+    for leaky in (False, True):
+        w.grad = x.grad = None
+        WeightedKSumFn.apply(w, x, None, leaky).backward(go)
+        gw, gx = w.grad.clone(), x.grad.clone()
+        w.grad = x.grad = None
+        ref = torch.sum(w * x, dim=2)
+        np.testing.assert_allclose(WeightedKSumFn.apply(w, x, None, leaky).detach().cpu().numpy(), ref.detach().cpu().numpy(),
+                                   rtol=1e-5, atol=1e-5)
+        ref.backward(go)
+        rx = torch.where(x > 0, x.grad, 0.1 * x.grad) if leaky else x.grad
+        np.testing.assert_allclose(gw.cpu().numpy(), w.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(gx.cpu().numpy(), rx.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    p = torch.randn(B, N2, C, generator=g).to(dev).requires_grad_(True)
+    nbr = Neighbors(torch.randint(0, N2, (B, N1, K), generator=g, dtype=torch.int32).to(dev), N2)
+    w.grad = None
+    out = WeightedKSumFn.apply(w, p, nbr, False)
+    out.backward(go)
+    gw, gp = w.grad.clone(), p.grad.clone()
+    w.grad = p.grad = None
+    ref = torch.sum(w * group_rows(p, nbr), dim=2)
+    ref.backward(go)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gw.cpu().numpy(), w.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(gp.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
