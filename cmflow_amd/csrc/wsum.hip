@@ -61,9 +61,16 @@ __global__ __launch_bounds__(WS_THREADS) void wsum_bwd_kernel(
         const float4 wv = *(const float4 *)(w + mk * C + c);
         const long long row = idx ? (m / n1) * n_src + idx[mk] : mk;
         const float4 xv = *(const float4 *)(x + row * C + c);
-        if (dw) *(float4 *)(dw + mk * C + c) = make_float4(g.x * xv.x, g.y * xv.y, g.z * xv.z, g.w * xv.w);
+        if (dw) {
+            float4 e = make_float4(g.x * xv.x, g.y * xv.y, g.z * xv.z, g.w * xv.w);
+            if (leaky & 2) {                                  // w is a stored ReLU activation: gradient w.r.t. its pre-activation
+                e.x = wv.x > 0.f ? e.x : 0.f; e.y = wv.y > 0.f ? e.y : 0.f;
+                e.z = wv.z > 0.f ? e.z : 0.f; e.w = wv.w > 0.f ? e.w : 0.f;
+            }
+            *(float4 *)(dw + mk * C + c) = e;
+        }
         float4 d = make_float4(g.x * wv.x, g.y * wv.y, g.z * wv.z, g.w * wv.w);
-        if (leaky) {
+        if (leaky & 1) {
             d.x = xv.x > 0.f ? d.x : 0.1f * d.x; d.y = xv.y > 0.f ? d.y : 0.1f * d.y;
             d.z = xv.z > 0.f ? d.z : 0.1f * d.z; d.w = xv.w > 0.f ? d.w : 0.1f * d.w;
         }

@@ -232,7 +232,9 @@ class LinearFn(Function):
     Operands whose row stride is not a multiple of 4 floats are copied into padded buffers."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, act):
+    def forward(ctx, x, w, bias, act, preact_grad=False):
+        # preact_grad: the consumer hands back the gradient w.r.t. the pre-activation (WeightedKSumFn relu_w=True)
+        ctx.preact_grad = preact_grad
         ok = x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[1] % 4 == 0
         x2 = x if ok else _pad_cols(x)
         w2 = _pad_cols(w)
@@ -246,7 +248,9 @@ class LinearFn(Function):
         x2, w2, y = ctx.saved_tensors
         N, K = ctx.shape
         dy = dy.contiguous()
-        if ctx.act == 1:
+        if ctx.preact_grad:
+            pass
+        elif ctx.act == 1:
             dy = dy * (y > 0)
         elif ctx.act == 2:
             dy = torch.where(y > 0, dy, 0.1 * dy)
@@ -261,7 +265,7 @@ class LinearFn(Function):
             dw = gemm_dw(dyp, x2)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 def _pad_k(t):
@@ -285,10 +289,10 @@ def _pad_cols(t):
     return buf
 
 
-def linear(x, w, bias=None, act=0):
+def linear(x, w, bias=None, act=0, preact_grad=False):
     """(..., K) -> (..., N) through cmf_gemm"""
     shp = x.shape
-    y = LinearFn.apply(x.reshape(-1, shp[-1]), w, bias, act)
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), w, bias, act, preact_grad)
     return y.view(*shp[:-1], w.shape[0])
 
 
@@ -697,7 +701,9 @@ class WeightedKSumFn(Function):
     LeakyReLU(0.1) activation and the gradient returned for it is the one w.r.t. its pre-activation."""
 
     @staticmethod
-    def forward(ctx, weights, x, nbr, leaky):
+    def forward(ctx, weights, x, nbr, leaky, relu_w=False):
+        # relu_w: weights is a stored ReLU activation whose producer (LinearFn preact_grad=True) expects the gradient
+        # w.r.t. its pre-activation
         B, N1, K, C = weights.shape
         weights, x = weights.contiguous(), x.contiguous()
         out = torch.empty(B, N1, C, dtype=_f32, device=weights.device)
@@ -705,7 +711,7 @@ class WeightedKSumFn(Function):
         n_src = nbr.n if nbr is not None else 0
         _lib.check(L().cmf_weighted_ksum(B * N1, K, C, N1, n_src, _lib.dev_ptr(weights, _f32), _lib.dev_ptr(x, _f32), idx,
                                          _p(out), _lib.stream_ptr()), "cmf_weighted_ksum")
-        ctx.saved = (weights, x, nbr, bool(leaky))
+        ctx.saved = (weights, x, nbr, int(bool(leaky)) | (2 if relu_w else 0))
         return out
 
     @staticmethod
@@ -726,4 +732,4 @@ class WeightedKSumFn(Function):
             _lib.check(L().cmf_group_rows_grad(B, nbr.n, C, C, N1 * K, 0, _p(dx), _p(off), _p(inv), _p(dp), _lib.stream_ptr()),
                        "cmf_group_rows_grad")
             dx = dp
-        return dw, dx, None, None
+        return dw, dx, None, None, None

@@ -219,12 +219,15 @@ class WeightNet(nn.Module):
             weights = F.relu(self.mlp_bns[i](conv(weights))) if self.bn else F.relu(conv(weights))
         return weights
 
-    def forward_pm(self, dxyz, use_blocks=False):
-        """dxyz (B,N,K,3) -> (B,N,K,out)"""
+    def forward_pm(self, dxyz, use_blocks=False, preact_grad=False):
+        """dxyz (B,N,K,3) -> (B,N,K,out).  preact_grad: the consumer (WeightedKSumFn relu_w=True) returns the gradient
+        of the last layer's pre-activation."""
         assert not self.bn
         w = dxyz
-        for conv in self.mlp_convs:
-            w = FB.linear(w, w2d(conv), conv.bias, act=1) if use_blocks else F.relu(F.linear(w, w2d(conv), conv.bias))
+        last = len(self.mlp_convs) - 1
+        for i, conv in enumerate(self.mlp_convs):
+            w = FB.linear(w, w2d(conv), conv.bias, act=1, preact_grad=preact_grad and i == last) if use_blocks else \
+                F.relu(F.linear(w, w2d(conv), conv.bias))
         return w
 
 
@@ -313,12 +316,12 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     p1 = FB.linear(f1, w0[:, :D1], c0.bias)
     p2 = FB.linear(f2, w0[:, D1:D1 + D2])
     x, dxyz = FB.CostVolumeMLPFn.apply(xyz1_t, xyz2_t, p1, p2, nbr, w0[:, D1 + D2:], w2d(c1), c1.bias, w2d(c2), c2.bias, True)
-    weights = self.weightnet1.forward_pm(dxyz, use_blocks=True)
-    p2p = FB.WeightedKSumFn.apply(weights, x, None, True)                                  # sum_k weights * x
+    weights = self.weightnet1.forward_pm(dxyz, use_blocks=True, preact_grad=True)
+    p2p = FB.WeightedKSumFn.apply(weights, x, None, True, True)                            # sum_k weights * x
     nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
     dxyz2 = F.pad(group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2), (0, 1))
-    weights = self.weightnet2.forward_pm(dxyz2, use_blocks=True)
-    return FB.WeightedKSumFn.apply(weights, p2p, nbr, False)                               # sum_k weights * p2p[idx]
+    weights = self.weightnet2.forward_pm(dxyz2, use_blocks=True, preact_grad=True)
+    return FB.WeightedKSumFn.apply(weights, p2p, nbr, False, True)                         # sum_k weights * p2p[idx]
 
 
 FeatureCorrelator._forward_blocks = _fc_blocks

@@ -21,7 +21,8 @@ class TrainStep:
         self.loss_obj = RadarFlowLoss(camera_projection or synth.CAMERA_PROJECTION,
                                       t_camera_radar or synth.T_CAMERA_RADAR).to(dev)
         self.bucket = FlatGradBucket(net)
-        self.opt = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay)
+        # fused=True: one multi-tensor kernel per step instead of ~10 foreach launches (same update rule)
+        self.opt = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay, fused=dev.type == "cuda")
         self.recurrent = hasattr(net, "gru")
         self.self_supervised = hasattr(net, "fd_layer")
         # the scales of an encoder run on side streams while the gradient bucket lives on the main stream

@@ -234,8 +234,9 @@ int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
 /* Cost-volume weighting (radarflow_util.py:219-221,235-236): out[m,c] = sum_k w[m,k,c] * x[m,k,c] over rows
  * m = sample*n1 + point.  idx == NULL: x is (M,K,C) dense.  idx (M,K) int32: x is (samples*n_src, C) per-point rows
  * and the k-th operand of row m is x[sample*n_src + idx[m,k]] (the grouped tensor is never materialised).
- * The gradient call writes dw = dcost*x and dx = dcost*w, each (M,K,C) (either may be NULL); leaky != 0: x is a
- * stored LeakyReLU(0.1) activation and dx is multiplied by its derivative (gradient w.r.t. the pre-activation).
+ * The gradient call writes dw = dcost*x and dx = dcost*w, each (M,K,C) (either may be NULL).  leaky bit 0: x is a
+ * stored LeakyReLU(0.1) activation and dx is multiplied by its derivative; bit 1: w is a stored ReLU activation
+ * (WeightNet, radarflow_util.py:307-318) and dw is masked by w > 0 -- gradients w.r.t. the pre-activations.
  * C % 4 == 0, 16-byte aligned pointers. */
 int cmf_weighted_ksum(long long M, int K, int C, int n1, int n_src, const float *w, const float *x, const int *idx,
                       float *out, void *stream);

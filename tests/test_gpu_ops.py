@@ -198,8 +198,12 @@ def test_weighted_ksum_matches_torch(dev, B, N1, N2, K, C):
     go = torch.randn(B, N1, C, generator=g).to(dev)
     for leaky in (False, True):
         w.grad = x.grad = None
+        WeightedKSumFn.apply(w, x, None, leaky, True).backward(go)           # relu_w: dw masked by w > 0
+        gw_relu = w.grad.clone()
+        w.grad = x.grad = None
         WeightedKSumFn.apply(w, x, None, leaky).backward(go)
         gw, gx = w.grad.clone(), x.grad.clone()
+        assert torch.equal(gw_relu, torch.where(w > 0, gw, torch.zeros_like(gw)))
         w.grad = x.grad = None
         ref = torch.sum(w * x, dim=2)
         np.testing.assert_allclose(WeightedKSumFn.apply(w, x, None, leaky).detach().cpu().numpy(), ref.detach().cpu().numpy(),
