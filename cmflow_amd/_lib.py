@@ -32,6 +32,8 @@ SIGNATURES = {
     "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
     "cmf_setconv_forward": [_vp, _vp],
     "cmf_setconv_backward": [_vp, _vp],
+    "cmf_setconv_forward_multi": [_ci, _vp, _vp],
+    "cmf_setconv_backward_multi": [_ci, _vp, _vp],
     "cmf_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_gather_points_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_furthest_point_sampling": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
@@ -44,7 +46,7 @@ SIGNATURES = {
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],
-    "cmf_group_rows_grad_bn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
+    "cmf_group_rows_grad_bn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _ci, _vp],
     "cmf_bn_relu_maxpool": [_ll, _ci, _ci, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "cmf_maxpool_bwd": [_ll, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_affine_relu": [_ll, _ci, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
@@ -67,7 +69,7 @@ class SetConvDesc(ctypes.Structure):
                 ("xyz", _vp), ("y", _vp), ("ldy", _ll), ("wx", _vp), ("ldwx", _ll), ("w", _vp * 5),
                 ("gamma", _vp * 6), ("beta", _vp * 6), ("rmean", _vp * 6), ("rvar", _vp * 6), ("nbt", _vp * 6),
                 ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
-                ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
+                ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("lddy", _ll), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
                 ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6)]
 
 

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_kernel(
     int n, int c, int entries, int total_waves, const float *__restrict__ dU, const float *__restrict__ z,
     const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ sums, float inv_count,
-    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat)
+    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg)
 {
     const int wave = (blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
     if (wave >= total_waves) return;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_kernel(
     const int *lst = inv + (size_t)bs * entries;
     const float *gu = dU + (size_t)bs * entries * c;
     const float *gz = z + (size_t)bs * entries * c;
-    float *dst = grad_feat + ((size_t)bs * n + j) * c;
+    float *dst = grad_feat + ((size_t)bs * n + j) * ldg;
     for (int col = lane * 4; col < c; col += CMF_WAVE * 4) {
         const float4 sa = *(const float4 *)(a + col);
         float4 k0 = make_float4(0.f, 0.f, 0.f, 0.f), k1 = k0, mu = k0;     // dZ = sa*(dU - k0 - (z-mu)*k1)
@@ -311,14 +311,14 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_kernel(
 
 extern "C" int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, const float *z,
                                       const float *a, const float *mean, const float *invstd, const float *sums,
-                                      float inv_count, const int *offsets, const int *inv, float *grad_feat, void *stream)
+                                      float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream)
 {
-    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && c % 4 == 0 && entries >= 0);
+    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && c % 4 == 0 && entries >= 0 && ldg >= c && ldg % 4 == 0);
     if (b == 0) return 0;
     CMF_CHECK_ARG(dU && a && offsets && inv && grad_feat && (!sums || (z && mean && invstd)));
     const long long waves = (long long)b * n;
     const int grid = (int)((waves * CMF_WAVE + GR_THREADS - 1) / GR_THREADS);
     hipLaunchKernelGGL(group_rows_grad_bn_kernel, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
-                       n, c, entries, (int)waves, dU, z, a, mean, invstd, sums, inv_count, offsets, inv, grad_feat);
+                       n, c, entries, (int)waves, dU, z, a, mean, invstd, sums, inv_count, offsets, inv, grad_feat, ldg);
     return cmf_launch_status();
 }

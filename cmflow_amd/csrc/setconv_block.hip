@@ -245,7 +245,44 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     if (d->dy) {
         CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
         CMF_TRY(cmf_group_rows_grad_bn(d->B, d->N, O1, d->N * d->S, L.dU1, L.z1, b0 + 2 * O1, b0, b0 + O1,
-                                       d->training ? L.sums : nullptr, (float)(1.0 / (double)M), L.offsets, L.inv, d->dy, st));
+                                       d->training ? L.sums : nullptr, (float)(1.0 / (double)M), L.offsets, L.inv, d->dy,
+                                       d->lddy ? (int)d->lddy : O1, st));
     }
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The independent scales of a MultiScaleEncoder (radarflow_util.py:101-118) in ONE call: descs[i] is issued on
+// streams[i] from its own host thread.  At N = 256 a scale's ~20 (forward) / ~45 (backward) kernels run about as long
+// as they take to enqueue, so one host thread cannot keep four streams fed.  Stream ordering against the
+// caller's stream is the caller's business (events before / after the call); nothing is synchronised here.
+// ---------------------------------------------------------------------------------------------------------------
+#include <thread>
+
+static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *streams, bool backward)
+{
+    CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    int err[16] = {0};
+    std::thread th[16];
+    auto run = [&](int i) {
+        if (i > 0 && hipSetDevice(dev) != hipSuccess) { err[i] = (int)hipGetLastError(); return; }
+        err[i] = backward ? cmf_setconv_backward(&descs[i], streams[i]) : cmf_setconv_forward(&descs[i], streams[i]);
+    };
+    for (int i = 1; i < n; ++i) th[i] = std::thread(run, i);
+    if (n > 0) run(0);                                  // the calling thread takes the first scale
+    for (int i = 1; i < n; ++i) th[i].join();
+    for (int i = 0; i < n; ++i) if (err[i]) return err[i];
+    return 0;
+}
+
+extern "C" int cmf_setconv_forward_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
+{
+    return setconv_multi(n, descs, streams, false);
+}
+
+extern "C" int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
+{
+    return setconv_multi(n, descs, streams, true);
 }

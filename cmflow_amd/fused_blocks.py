@@ -423,7 +423,7 @@ class SetConvFn(Function):
             off, inv = nbr.inverse()
             dy = torch.empty(B, N, O1, dtype=_f32, device=dU.device)
             err = L().cmf_group_rows_grad_bn(B, N, O1, N * S, _p(dU), _p(z1), _p(st1.a), _p(st1.mean), _p(st1.invstd),
-                                             _p(sums5) if st1.training else None, 1.0 / M, _p(off), _p(inv), _p(dy),
+                                             _p(sums5) if st1.training else None, 1.0 / M, _p(off), _p(inv), _p(dy), O1,
                                              _lib.stream_ptr())
             _lib.check(err, "cmf_group_rows_grad_bn")
         return (None, dy, None, None, None, None, dwx, g["g1"], g["b1"], g["w2"], g["g2"], g["b2"], g["w3"], g["g3"],
@@ -533,83 +533,162 @@ class SetConvBlockFn(Function):
         return (None, dy, None, None, None, None, *grads)
 
 
-_POOL = None
+class EncoderPlan:
+    """Everything about a MultiScaleEncoder call that does not change from step to step, built once per
+    (batch, points, training, device): the four cmf_setconv_desc structs with geometry, hyper-parameters and the
+    parameter / BN-buffer pointers filled in (optimizers update parameters in place), and the arena sizes.  A call
+    then only sets the per-call pointers (xyz, y, saved, scratch, out) -- the Python work per encoder call drops
+    from ~0.5 ms to a few tens of microseconds, which at N = 256 is what the GPU was waiting for."""
 
+    def __init__(self, modules, B, N, O1, training, device):
+        import ctypes
+        self.n = n = len(modules)
+        self.key = (B, N, O1, bool(training), str(device))
+        self.descs = (_lib.SetConvDesc * n)()
+        self.keep, self.params, self.bns = [], [], []
+        self.n_saved, self.n_fwd, self.n_bwd = [], [], []
+        for i, m in enumerate(modules):
+            params, bns = set_conv_params(m)
+            d = self.descs[i]
+            wx = params[0]
+            ws = [params[j] for j in (3, 6, 9, 12, 15)]
+            assert all(w.is_contiguous() for w in ws) and wx.stride(1) == 1
+            d.B, d.N, d.S, d.O1, d.radius, d.training = B, N, m.nsample, O1, m.radius, int(training)
+            for j, w in enumerate(ws):
+                d.C[j] = w.shape[0]
+                d.w[j] = w.data_ptr()
+            for l, bn in enumerate(bns):
+                assert bn.momentum is not None, "cumulative moving average BN is not supported by the block call"
+                d.eps[l], d.momentum[l] = bn.eps, bn.momentum
+                d.gamma[l], d.beta[l] = bn.weight.data_ptr(), bn.bias.data_ptr()
+                d.rmean[l], d.rvar[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats) else None
+            d.wx, d.ldwx = wx.data_ptr(), wx.stride(0)
+            d.ldy = n * O1                                          # y is a column slice of the stacked (B,N,n*O1) GEMM output
+            ns, nf, nb = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+            _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), ctypes.addressof(ns), ctypes.addressof(nf),
+                                             ctypes.addressof(nb)), "cmf_setconv_sizes")
+            self.n_saved.append(ns.value); self.n_fwd.append(nf.value); self.n_bwd.append(nb.value)
+            self.params.append(params); self.bns.append(bns)
+        self.co = self.params[0][15].shape[0]
+        self.check_ptrs = [p[15].data_ptr() for p in self.params] + [p[0].data_ptr() for p in self.params]
+        al = lambda v: (v + 63) // 64 * 64                          # keep every arena 256-byte aligned
+        self.off_saved = [0]
+        for v in self.n_saved:
+            self.off_saved.append(self.off_saved[-1] + al(v))
+        self.off_fwd, self.off_bwd = [0], [0]
+        for v in self.n_fwd:
+            self.off_fwd.append(self.off_fwd[-1] + al(v))
+        for v in self.n_bwd:
+            self.off_bwd.append(self.off_bwd[-1] + al(v))
 
-def _pool():
-    global _POOL
-    if _POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL = ThreadPoolExecutor(max_workers=4, thread_name_prefix="cmf_enqueue")
-    return _POOL
+    def valid(self):
+        """Parameters are updated in place by optimizers and load_state_dict; .to()/.float() re-allocate them."""
+        return self.check_ptrs == [p[15].data_ptr() for p in self.params] + [p[0].data_ptr() for p in self.params]
+
+    def sinks_ready(self):
+        """All parameter gradients can be accumulated in place (TrainStep's flat bucket)."""
+        return all(grad_sink(t) is not None for params in self.params for t in params[1:]) and \
+            all(self._wx_sink(params[0]) is not None for params in self.params)
+
+    @staticmethod
+    def _wx_sink(pwx):
+        base = pwx._base if pwx._base is not None else pwx
+        if base.is_leaf and base.grad is not None and base.grad.is_contiguous() and base.dim() == 4 and \
+                pwx.shape[1] == 3 and pwx.storage_offset() == base.storage_offset():
+            return base.grad
+        return None
 
 
 class MultiScaleBlockFn(Function):
-    """The four set-conv scales of a MultiScaleEncoder (radarflow_util.py:101-118) as one autograd node.
-    Each scale's block call is issued from its own host thread on its own HIP stream: with N = 256 the
-    ~20 (forward) / ~45 (backward) kernels of a scale run for 5-40 us each, about as long as a launch takes
-    to enqueue, so one host thread cannot keep four streams fed -- four can (ctypes releases the GIL for
-    the duration of the C call).  The scales write disjoint channel slices of one (B,N,4*64) output and the
-    input gradient comes back as one (B,N,4*O1) tensor, so the concat / slice-grad kernels are gone too.
-    Numerics are those of SetConvBlockFn: same kernels per scale, no cross-scale arithmetic."""
+    """The four set-conv scales of a MultiScaleEncoder (radarflow_util.py:101-118) as one autograd node and ONE
+    C-ABI call per direction (cmf_setconv_forward_multi / _backward_multi: each scale is issued on its own HIP
+    stream from its own host thread inside the library -- with N = 256 the ~20 / ~45 kernels of a scale run about
+    as long as they take to enqueue, so one host thread cannot keep four streams fed).  The scales write disjoint
+    channel slices of one (B,N,4*64) output and the input gradient comes back as one (B,N,4*O1) tensor, so the
+    concat / slice-gradient kernels are gone too.  With every parameter gradient accumulated in place (grad sinks)
+    the parameters are not even autograd inputs of the node.  Numerics: same kernels per scale as SetConvBlockFn."""
 
     @staticmethod
-    def forward(ctx, xyz_t, y_all, scales, streams, training, *params):
-        # scales: [(radius, nsample, bns)], params: 18 per scale
+    def forward(ctx, xyz_t, y_all, plan, streams, sink_mode, *params):
+        import ctypes
         B, N, _ = xyz_t.shape
-        ns = len(scales)
-        o1 = y_all.shape[2] // ns
-        dev = xyz_t.device
+        n, co, dev = plan.n, plan.co, xyz_t.device
+        xyz_t = xyz_t.contiguous()
+        assert y_all.is_contiguous() and y_all.shape[2] == n * plan.descs[0].O1
         main = torch.cuda.current_stream()
-        co = params[15].shape[0]
-        out_all = torch.empty(B * N, ns * co, dtype=_f32, device=dev)
+        out_all = torch.empty(B * N, n * co, dtype=_f32, device=dev)
+        saved = torch.empty(plan.off_saved[-1], dtype=_f32, device=dev)
+        scratch = torch.empty(plan.off_fwd[-1], dtype=_f32, device=dev)
+        o1 = plan.descs[0].O1
+        for i in range(n):
+            d = plan.descs[i]
+            d.xyz, d.y = xyz_t.data_ptr(), y_all.data_ptr() + 4 * i * o1
+            d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_fwd[i]
+            d.out, d.ldo = out_all.data_ptr() + 4 * i * co, n * co
+        sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
         for st in streams:
             st.wait_stream(main)
-
-        def work(i):
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[i]):
-                r, s, bns = scales[i]
-                return _block_forward(xyz_t, y_all[:, :, i * o1:(i + 1) * o1], r, s, bns, training,
-                                      params[18 * i:18 * (i + 1)], out=out_all[:, i * co:(i + 1) * co])[1]
-
-        ctx.states = list(_pool().map(work, range(ns)))
+        _lib.check(L().cmf_setconv_forward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_forward_multi")
         for st in streams:
             main.wait_stream(st)
-        ctx.streams, ctx.o1, ctx.co = streams, o1, co
-        return out_all.view(B, N, ns * co)
+        ctx.plan, ctx.keep, ctx.streams, ctx.sink_mode = plan, (xyz_t, y_all, saved), streams, sink_mode
+        return out_all.view(B, N, n * co)
 
     @staticmethod
     def backward(ctx, dout):
-        streams, co = ctx.streams, ctx.co
-        ns = len(streams)
-        d0 = ctx.states[0]["desc"]
-        B, N = d0.B, d0.N
-        dout = dout.reshape(B * N, ns * co)
-        if dout.stride(1) != 1:
-            dout = dout.contiguous()
+        import ctypes
+        plan, (xyz_t, y_all, saved), streams = ctx.plan, ctx.keep, ctx.streams
+        n, co = plan.n, plan.co
+        B, N, o1 = plan.descs[0].B, plan.descs[0].N, plan.descs[0].O1
         dev = dout.device
+        dout = dout.reshape(B * N, n * co)
+        if dout.stride(1) != 1 or dout.stride(0) % 4:
+            dout = dout.contiguous()
         main = torch.cuda.current_stream()
         need_dy = ctx.needs_input_grad[1]
+        scratch = torch.empty(plan.off_bwd[-1], dtype=_f32, device=dev)
+        dy_all = torch.empty(B, N, n * o1, dtype=_f32, device=dev) if need_dy else None
+        grads = []
+        for i in range(n):
+            d, params = plan.descs[i], plan.params[i]
+            d.xyz, d.y = xyz_t.data_ptr(), y_all.data_ptr() + 4 * i * o1
+            d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_bwd[i]
+            d.dout, d.lddout = dout.data_ptr() + 4 * i * co, dout.stride(0)
+            d.dy, d.lddy = (dy_all.data_ptr() + 4 * i * o1, n * o1) if need_dy else (None, 0)
+            g = [None] * 18
+            wsink = plan._wx_sink(params[0])
+            if wsink is not None:
+                d.dwx, d.lddwx, d.acc_wx = wsink.data_ptr(), params[0].stride(0), 1
+            else:
+                if ctx.sink_mode:
+                    raise RuntimeError("parameter .grad buffers disappeared between forward and backward")
+                g[0] = torch.empty(o1, 3, dtype=_f32, device=dev)
+                d.dwx, d.lddwx, d.acc_wx = g[0].data_ptr(), 3, 0
+            for j in range(5):
+                sink = grad_sink(params[3 + 3 * j])
+                if sink is not None:
+                    d.dw[j], d.acc_w[j] = sink.data_ptr(), 1
+                else:
+                    g[3 + 3 * j] = torch.empty_like(params[3 + 3 * j])
+                    d.dw[j], d.acc_w[j] = g[3 + 3 * j].data_ptr(), 0
+            for l in range(6):
+                sg, sb = grad_sink(params[1 + 3 * l]), grad_sink(params[2 + 3 * l])
+                if sg is not None and sb is not None:
+                    d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sg.data_ptr(), sb.data_ptr(), 1
+                else:
+                    g[1 + 3 * l], g[2 + 3 * l] = torch.empty_like(params[1 + 3 * l]), torch.empty_like(params[2 + 3 * l])
+                    d.dgamma[l], d.dbeta[l], d.acc_bn[l] = g[1 + 3 * l].data_ptr(), g[2 + 3 * l].data_ptr(), 0
+            grads += g
+        if ctx.sink_mode and any(t is not None for t in grads):
+            raise RuntimeError("parameter .grad buffers disappeared between forward and backward")
+        sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
         for st in streams:
             st.wait_stream(main)
-
-        def work(i):
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[i]):
-                return _block_backward(ctx.states[i], dout[:, i * co:(i + 1) * co], need_dy)
-
-        res = list(_pool().map(work, range(ns)))
+        _lib.check(L().cmf_setconv_backward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_backward_multi")
         for st in streams:
             main.wait_stream(st)
-        grads = []
-        for dy, g in res:
-            grads += g
-            for t in [dy] + g:
-                if t is not None:
-                    t.record_stream(main)
-        dy_all = torch.cat([r[0] for r in res], dim=2) if need_dy else None
-        return (None, dy_all, None, None, None, *grads)
+        return (None, dy_all, None, None, None, *(() if ctx.sink_mode else grads))
 
 
 def set_conv_params(module):
@@ -621,14 +700,23 @@ def set_conv_params(module):
     return params, [b[0], b[1], b[2], b2[0], b2[1], b2[2]]
 
 
-def multi_scale_set_conv(modules, streams, xyz_t, y_all):
+def multi_scale_set_conv(encoder, modules, streams, xyz_t, y_all):
     """modules: the PointLocalFeature scales; y_all (B,N,len*O1) the stacked hoisted first-conv features."""
-    scales, params = [], []
-    for m in modules:
-        p, bns = set_conv_params(m)
-        scales.append((m.radius, m.nsample, bns))
-        params += p
-    return MultiScaleBlockFn.apply(xyz_t, y_all, scales, streams, modules[0].mlp_bns[0].training, *params)
+    B, N, _ = xyz_t.shape
+    o1 = y_all.shape[2] // len(modules)
+    training = modules[0].mlp_bns[0].training
+    key = (B, N, o1, bool(training), str(xyz_t.device))
+    plans = encoder.__dict__.setdefault("_plans", {})
+    plan = plans.get(key)
+    if plan is None or not plan.valid():
+        plan = plans[key] = EncoderPlan(modules, B, N, o1, training, xyz_t.device)
+    y_all = y_all.contiguous()
+    sink_mode = torch.is_grad_enabled() and plan.sinks_ready()
+    params = () if (sink_mode or not torch.is_grad_enabled()) else tuple(t for p in plan.params for t in p)
+    if sink_mode and not y_all.requires_grad:
+        # the node must exist for the parameter gradients even when the input features carry none (first encoder)
+        y_all = y_all.detach().requires_grad_(True)
+    return MultiScaleBlockFn.apply(xyz_t, y_all, plan, streams, sink_mode, *params)
 
 
 def set_conv(module, xyz_t, y):

@@ -125,7 +125,7 @@ class MultiScaleEncoder(nn.Module):
             self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
         if FB.USE_BLOCK_CALLS and self.threaded_enqueue:
             # one host thread per scale as well: see fused_blocks.MultiScaleBlockFn
-            return FB.multi_scale_set_conv(list(self.ms_ls), self._streams, xyz_t, y_all)
+            return FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz_t, y_all)
         main = torch.cuda.current_stream()
         outs = []
         for i, (sa, st) in enumerate(zip(self.ms_ls, self._streams)):

@@ -162,11 +162,11 @@ int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, long long ld
 
 /* Backward of the set-conv's grouping with the BatchNorm backward of the first layer fused in
  * (radarflow_util.py:148-151 backward): dZ = a*(dU - s1/M - zhat*s2/M) is formed on the fly from dU and z,
- * summed over the inverse index into grad_feat (b,n,c), and never written.  sums = {s1[C], s2[C]} or NULL
+ * summed over the inverse index into grad_feat (b,n,c) with row stride ldg, and never written.  sums = {s1[C], s2[C]} or NULL
  * (eval-mode BN: dZ = a*dU). */
 int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, const float *z,
                            const float *a, const float *mean, const float *invstd, const float *sums,
-                           float inv_count, const int *offsets, const int *inv, float *grad_feat, void *stream);
+                           float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream);
 
 /* dW_xyz of the set-conv's first conv from column sums only (no pass over the grouped tensor):
  *   dWx[c,k] = a_c*( q_k[c] - (s1_c/M)*u_k - (s2_c/M)*invstd_c*(tz_k[c] - mean_c*u_k) )
@@ -222,7 +222,7 @@ typedef struct cmf_setconv_desc {
     float *out; long long ldo;   /* (B*N, C[4]) */
     /* backward */
     const float *dout; long long lddout;
-    float *dy;                   /* (B,N,O1) dense, or NULL */
+    float *dy; long long lddy;   /* (B,N,O1) rows with stride lddy (0 = dense O1), or NULL */
     float *dwx; long long lddwx; int acc_wx;
     float *dw[5]; int acc_w[5];  /* weight gradients: written (0) or accumulated into (1) */
     float *dgamma[6], *dbeta[6]; int acc_bn[6];
@@ -230,6 +230,11 @@ typedef struct cmf_setconv_desc {
 int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
 int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
+/* The independent scales of a MultiScaleEncoder (radarflow_util.py:101-118) in one call: descs[i] is issued on
+ * streams[i] from its own host thread inside the library (n <= 16).  The caller orders the streams against its own
+ * (events before and after); nothing is synchronised. */
+int cmf_setconv_forward_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
+int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
 
 /* Cost-volume weighting (radarflow_util.py:219-221,235-236): out[m,c] = sum_k w[m,k,c] * x[m,k,c] over rows
  * m = sample*n1 + point.  idx == NULL: x is (M,K,C) dense.  idx (M,K) int32: x is (samples*n_src, C) per-point rows

@@ -32,3 +32,22 @@ print("window %.1f ms: busy %.1f%%, idle %.1f%%, mean concurrency while busy %.2
 print("time with exactly one kernel running: %.1f%% of the window; by kernel:" % (100 * sum(solo.values()) / tot))
 for k, v in solo.most_common(25):
     print("  %-50s %6.2f%%" % (k, 100 * v / tot))
+
+# the largest idle gaps inside the window, with the kernels that end before / start after them
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:40]) for r in rows
+            if int(r["End_Timestamp"]) > a and int(r["Start_Timestamp"]) < b)
+gaps = []
+cur_end, cur_name = iv[0][1], iv[0][2]
+for s_, e_, nm in iv[1:]:
+    if s_ > cur_end:
+        gaps.append((s_ - cur_end, cur_name, nm, (cur_end - a) / 1e6))
+    if e_ > cur_end:
+        cur_end, cur_name = e_, nm
+gaps.sort(reverse=True)
+print("idle gaps: %d, total %.2f ms; > 20 us: %d (%.2f ms)" % (len(gaps), sum(g[0] for g in gaps) / 1e6,
+      sum(1 for g in gaps if g[0] > 20000), sum(g[0] for g in gaps if g[0] > 20000) / 1e6))
+by = collections.Counter()
+for g in gaps:
+    by[(g[1], g[2])] += g[0]
+for (p_, n_), v in by.most_common(25):
+    print("  %8.1f us total  after %-40s before %-40s" % (v / 1e3, p_, n_))
