@@ -587,9 +587,32 @@ class EncoderPlan:
         return self.check_ptrs == [p[15].data_ptr() for p in self.params] + [p[0].data_ptr() for p in self.params]
 
     def sinks_ready(self):
-        """All parameter gradients can be accumulated in place (TrainStep's flat bucket)."""
-        return all(grad_sink(t) is not None for params in self.params for t in params[1:]) and \
-            all(self._wx_sink(params[0]) is not None for params in self.params)
+        """All parameter gradients can be accumulated in place (TrainStep's flat bucket).  The sink pointers are
+        written into the descriptors once; afterwards two representative .grad pointers per scale are re-checked
+        (a flat bucket either keeps all of them or none)."""
+        probe = []
+        for params in self.params:
+            for t in (params[1], params[17]):
+                g = t.grad
+                if g is None:
+                    self._sink_probe = None
+                    return False
+                probe.append(g.data_ptr())
+        if getattr(self, "_sink_probe", None) == probe:
+            return True
+        for d, params in zip(self.descs, self.params):
+            wsink = self._wx_sink(params[0])
+            sinks = [grad_sink(t) for t in params[1:]]
+            if wsink is None or any(x is None for x in sinks):
+                self._sink_probe = None
+                return False
+            d.dwx, d.lddwx, d.acc_wx = wsink.data_ptr(), params[0].stride(0), 1
+            for j in range(5):
+                d.dw[j], d.acc_w[j] = sinks[2 + 3 * j].data_ptr(), 1
+            for l in range(6):
+                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sinks[3 * l].data_ptr(), sinks[3 * l + 1].data_ptr(), 1
+        self._sink_probe = probe
+        return True
 
     @staticmethod
     def _wx_sink(pwx):
@@ -650,12 +673,17 @@ class MultiScaleBlockFn(Function):
         scratch = torch.empty(plan.off_bwd[-1], dtype=_f32, device=dev)
         dy_all = torch.empty(B, N, n * o1, dtype=_f32, device=dev) if need_dy else None
         grads = []
+        if ctx.sink_mode and not plan.sinks_ready():
+            raise RuntimeError("parameter .grad buffers disappeared between forward and backward")
         for i in range(n):
             d, params = plan.descs[i], plan.params[i]
             d.xyz, d.y = xyz_t.data_ptr(), y_all.data_ptr() + 4 * i * o1
             d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_bwd[i]
             d.dout, d.lddout = dout.data_ptr() + 4 * i * co, dout.stride(0)
             d.dy, d.lddy = (dy_all.data_ptr() + 4 * i * o1, n * o1) if need_dy else (None, 0)
+            if ctx.sink_mode:                                       # sink pointers already sit in the descriptors
+                continue
+            plan._sink_probe = None                                 # the descriptors get per-call gradient buffers below
             g = [None] * 18
             wsink = plan._wx_sink(params[0])
             if wsink is not None:
