@@ -10,7 +10,8 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libcmflow_hip.so")
+# CMF_LIB: kernel-diagnostic builds of the same library (tools/gemm_variants.py); the product uses the in-tree path
+SO_PATH = os.environ.get("CMF_LIB") or os.path.join(_HERE, "libcmflow_hip.so")
 
 _vp, _ci, _cf, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 

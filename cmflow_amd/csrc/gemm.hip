@@ -5,9 +5,10 @@
 //
 // * v_mfma_f32_32x32x2_f32: exact fp32 (bit-equal to an fmaf chain), 64 FLOP/clk/SIMD = the chip's
 //   157 TF fp32 peak (no TF32/xf32 on gfx950; bf16 would break the 1e-4 parity bound).
-// * 256 threads = 4 wavefronts; block tile BM x BN x 32; operands staged global -> registers ->
-//   LDS (double buffered, one barrier per K-chunk); LDS rows padded to 36 floats so the
-//   ds_read_b128 fragment loads are bank-conflict free.
+// * 256 threads = 4 wavefronts; block tile BM x BN x 16, 3 workgroups per CU.  Interior tiles stage operands with
+//   LDS-direct loads (global_load_lds_dwordx4: no VGPR round trip; 3 stages, prefetch distance 2, swizzled
+//   unpadded LDS image); edge tiles / ragged K go global -> registers -> LDS (double buffered, rows padded to
+//   BK+4 floats).  One s_barrier per K-chunk either way.
 // * K-permutation trick: a lane reads 4 consecutive k of its row with ONE ds_read_b128 (lanes
 //   0-31 take k0..k0+3, lanes 32-63 take k0+4..k0+7) and feeds them to 4 MFMAs; step t of the 4
 //   contracts k in {k0+t, k0+4+t}.  A and B use the same map, so the sum is just reordered.
@@ -23,6 +24,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CMF_GEMM_DIAG
+#define CMF_GEMM_DIAG 0
+#endif
 constexpr int G_THREADS = 256;
 #ifndef CMF_GEMM_BK
 #define CMF_GEMM_BK 16
@@ -41,6 +45,41 @@ __device__ __forceinline__ float act_fn(float v, int act)
     if (act == 3) return 1.0f / (1.0f + __expf(-v));
     return v;
 }
+
+// ---- LDS-direct staging (interior tiles, K a multiple of the chunk) ------------------------------------------
+// global_load_lds_dwordx4 (gfx950) moves 16 bytes per lane straight from global memory into LDS at
+// M0-base + lane*16: no VGPR round trip, no ds_write, and -- the point -- no s_waitcnt vmcnt in the middle of the
+// MFMA stream (measured: the register-staged loop loses ~20 % of the MFMA rate to exactly that; the same loop with
+// the staging removed runs 120-135 TF).  Three stages, prefetch distance two.  The LDS image is dictated by the
+// instruction (consecutive lanes -> consecutive 16-byte slots), so rows are unpadded and bank conflicts are
+// avoided by choosing WHICH global 16 bytes a lane fetches: slot(row, kq) = row*4 + (kq ^ swz(row)).  swz makes
+// the 8 (32-bank model) and the 16 (64-bank model) lanes that ds_read_b128 serves together hit distinct slots.
+constexpr int G_STAGES = 3;
+__device__ __forceinline__ int g_swz(int row) { return (((row >> 2) & 1) << 1) | (((row >> 1) & 1) ^ ((row >> 3) & 1)); }
+#define CMF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0F70)
+typedef const __attribute__((address_space(1))) void *g_gptr;
+typedef __attribute__((address_space(3))) void *g_lptr;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Fragment reads of the direct loop are issued as inline asm: the compiler's waitcnt insertion treats every LDS
+// read as possibly aliasing the in-flight LDS-direct loads and would put s_waitcnt vmcnt(0) in front of it
+// (prefetch distance zero).  Which stage is complete is known here (wait_prev + barrier), so the reads are
+// invisible to that pass and their own completion is awaited explicitly (g_lds_wait + g_pin).
+__device__ __forceinline__ unsigned g_lds_addr(const float *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const float *)p; }
+__device__ __forceinline__ f32x4 g_lds_read128(unsigned addr)
+{
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ float g_lds_read32(unsigned addr)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void g_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void g_pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
 
 // A_T: A stored [K][M] (contraction-major) instead of [M][K].  B_T: B stored [N][K] (i.e. W[out][in],
 // the forward layout) instead of [K][N].
@@ -246,6 +285,132 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- main loop, LDS-direct variant ----
+    constexpr int D_ASLOTS = BM * (G_BK / 4), D_BSLOTS = BN * (G_BK / 4);     // 16-byte slots per operand chunk
+    constexpr int D_ANI = D_ASLOTS / G_THREADS, D_BNI = D_BSLOTS / G_THREADS; // load instructions per thread
+    constexpr int D_STAGE = (D_ASLOTS + D_BSLOTS) * 4 + 32;                   // floats: A | B | pro_a[16] pro_c[16]
+    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && CMF_GEMM_DIAG == 0 && !p.no_direct;
+    if (direct && kc_begin < kc_end) {
+        const long long pro_delta = proA ? (long long)(p.pro_c - p.pro_a) : 0ll;
+        // A plain s_barrier: __syncthreads() carries a workgroup fence, which makes the compiler drain EVERY outstanding
+        // LDS-direct load (vmcnt(0)) -- the prefetch distance would collapse to zero.  Visibility of the stage that is
+        // consumed next is established explicitly: each wave waits for its own loads of that stage (wait_prev), then
+        // the barrier; nothing else writes LDS in this loop.
+        auto issue = [&](int kc, int st) {
+            const int k0 = kc * G_BK;
+            float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
+#pragma unroll
+            for (int q = 0; q < D_ANI; ++q) {
+                const int grp = q * 4 + wid, sl = grp * 64 + lane;
+                const float *g;
+                if (!A_T) { const int row = sl >> 2; g = p.A + (long long)(m0 + row) * p.lda + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
+                else { const int k = sl / (BM / 4); g = p.A + (long long)(k0 + k) * p.lda + m0 + 4 * ((sl % (BM / 4)) ^ (((k >> 2) & 1) * 8)); }
+                __builtin_amdgcn_global_load_lds((g_gptr)g, (g_lptr)(sa + grp * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < D_BNI; ++q) {
+                const int grp = q * 4 + wid, sl = grp * 64 + lane;
+                const float *g;
+                if (B_T) { const int row = sl >> 2; g = p.B + (long long)(n0 + row) * p.ldb + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
+                else { const int k = sl / (BN / 4); g = p.B + (long long)(k0 + k) * p.ldb + n0 + 4 * ((sl % (BN / 4)) ^ (((k >> 2) & 1) * 8)); }
+                __builtin_amdgcn_global_load_lds((g_gptr)g, (g_lptr)(sb + grp * 256), 16, 0, 0);
+            }
+            if (proA && wid == 0 && lane < 8)                       // this chunk's 16 prologue scales and shifts
+                __builtin_amdgcn_global_load_lds((g_gptr)(p.pro_a + (lane < 4 ? 0ll : pro_delta) + k0 + 4 * (lane & 3)), (g_lptr)sp, 16, 0, 0);
+        };
+        // all but the newest issue() of this wave complete (vector-memory loads retire in order)
+        auto wait_prev = [&](bool newest_outstanding) {
+            if (!newest_outstanding) { CMF_WAIT_VMCNT(0); return; }
+            if (proA && wid == 0) { CMF_WAIT_VMCNT(D_ANI + D_BNI + 1); } else { CMF_WAIT_VMCNT(D_ANI + D_BNI); }
+        };
+        const int nch = kc_end - kc_begin;
+        issue(kc_begin, 0);
+        if (nch > 1) issue(kc_begin + 1, 1);
+        wait_prev(nch > 1);
+        __builtin_amdgcn_s_barrier();
+        const int frow = lane & 31, h = lane >> 5;
+        int arow[TM], aswz[TM], brow[TN], bswz[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { arow[i] = wm * WM + i * 32 + frow; aswz[i] = g_swz(arow[i]); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { brow[j] = wn * WN + j * 32 + frow; bswz[j] = g_swz(brow[j]); }
+        float qa[TN], qc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + brow[j];
+            qa[j] = (proB && n < p.N) ? p.prob_a[n] : 1.f; qc[j] = (proB && n < p.N) ? p.prob_c[n] : 0.f;
+        }
+        // fragment loader for one k8 step of stage (sa, sb, sp): issues the reads, does not wait
+        f32x4 af[2][TM], bf[2][TN], pa4[2], pc4[2];
+        auto read_frags = [&](const float *sa, const float *sb, const float *sp, int k8, int w) {
+            const int kq = k8 / 4 + h;                                          // this lane's 4 consecutive k: 4*kq .. 4*kq+3
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (!A_T) af[w][i] = g_lds_read128(g_lds_addr(sa + (arow[i] * 4 + (kq ^ aswz[i])) * 4));
+                else {
+                    const unsigned q = g_lds_addr(sa + (4 * kq) * BM + ((((arow[i] >> 2) ^ (h * 8)) << 2) | (arow[i] & 3)));
+                    af[w][i].x = g_lds_read32<0>(q); af[w][i].y = g_lds_read32<BM * 4>(q);
+                    af[w][i].z = g_lds_read32<BM * 8>(q); af[w][i].w = g_lds_read32<BM * 12>(q);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_T) bf[w][j] = g_lds_read128(g_lds_addr(sb + (brow[j] * 4 + (kq ^ bswz[j])) * 4));
+                else {
+                    const unsigned q = g_lds_addr(sb + (4 * kq) * BN + ((((brow[j] >> 2) ^ (h * 8)) << 2) | (brow[j] & 3)));
+                    bf[w][j].x = g_lds_read32<0>(q); bf[w][j].y = g_lds_read32<BN * 4>(q);
+                    bf[w][j].z = g_lds_read32<BN * 8>(q); bf[w][j].w = g_lds_read32<BN * 12>(q);
+                }
+            }
+            if (proA) { pa4[w] = g_lds_read128(g_lds_addr(sp + 4 * kq)); pc4[w] = g_lds_read128(g_lds_addr(sp + 16 + 4 * kq)); }
+        };
+        auto pin_frags = [&](int w) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) g_pin(af[w][i]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) g_pin(bf[w][j]);
+            if (proA) { g_pin(pa4[w]); g_pin(pc4[w]); }
+        };
+        auto mfma_step = [&](int w) {
+            if (proA) {                                                         // fused BN + ReLU of the producer layer
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    af[w][i].x = fmaxf(fmaf(pa4[w].x, af[w][i].x, pc4[w].x), 0.f); af[w][i].y = fmaxf(fmaf(pa4[w].y, af[w][i].y, pc4[w].y), 0.f);
+                    af[w][i].z = fmaxf(fmaf(pa4[w].z, af[w][i].z, pc4[w].z), 0.f); af[w][i].w = fmaxf(fmaf(pa4[w].w, af[w][i].w, pc4[w].w), 0.f);
+                }
+            }
+            if (proB) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bf[w][j].x = fmaxf(fmaf(qa[j], bf[w][j].x, qc[j]), 0.f); bf[w][j].y = fmaxf(fmaf(qa[j], bf[w][j].y, qc[j]), 0.f);
+                    bf[w][j].z = fmaxf(fmaf(qa[j], bf[w][j].z, qc[j]), 0.f); bf[w][j].w = fmaxf(fmaf(qa[j], bf[w][j].w, qc[j]), 0.f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].x, bf[w][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].y, bf[w][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].z, bf[w][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].w, bf[w][j].w, acc[i][j], 0, 0, 0);
+                }
+        };
+        int st = 0;
+        for (int c = 0; c < nch; ++c) {
+            if (c + 2 < nch) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);       // (st + 2) % 3
+            const float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
+            read_frags(sa, sb, sp, 0, 0);
+            g_lds_wait(); pin_frags(0);
+            read_frags(sa, sb, sp, 8, 1);                                       // in flight under the first 16 MFMAs
+            mfma_step(0);
+            g_lds_wait(); pin_frags(1);
+            mfma_step(1);
+            if (c + 1 < nch) wait_prev(c + 2 < nch);                            // chunk c+1 has landed (this wave's part)
+            __builtin_amdgcn_s_barrier();                                       // ... and everybody else's; stage st is free again
+            st = st == 2 ? 0 : st + 1;
+        }
+    } else
     if (kc_begin < kc_end) {
         load_tiles(kc_begin);
         store_A(0); store_B(0);
@@ -254,7 +419,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         const int frow = lane & 31, fk = (lane >> 5) * 4;
         for (int kc = kc_begin; kc < kc_end; ++kc) {
             const bool more = kc + 1 < kc_end;
+#if CMF_GEMM_DIAG == 1                                              /* diagnostic: no global loads after the first chunk */
+            (void)0;
+#else
             if (more) load_tiles(kc + 1);                           // global loads in flight under the MFMAs
+#endif
             const float *a_s = As + buf * A_SZ + (A_T ? fk * A_LD + wm * WM + frow : (wm * WM + frow) * A_LD + fk);
             const float *b_s = Bs + buf * B_SZ + (B_T ? (wn * WN + frow) * B_LD + fk : fk * B_LD + wn * WN + frow);
 #pragma unroll
@@ -284,9 +453,20 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                 // stage the NEXT chunk into the other LDS buffer three quarters of the way through this
                 // chunk's MFMAs: its global loads have had ~3/4 of a chunk to land, and the LDS writes
                 // retire under the remaining MFMAs instead of in front of the barrier.
+#if CMF_GEMM_DIAG == 2 || CMF_GEMM_DIAG == 5                        /* diagnostic: loads issued but never staged (2: and no barrier) */
+                (void)0;
+#elif CMF_GEMM_DIAG == 3                                            /* diagnostic: stage at the END of the chunk */
+                if (k8 == G_BK - 8 + 0 && false) {}
+#else
                 if (k8 == (G_BK >= 32 ? G_BK - 16 : G_BK - 8) && more) { store_A(buf ^ 1); store_B(buf ^ 1); }
+#endif
             }
+#if CMF_GEMM_DIAG == 3
+            if (more) { store_A(buf ^ 1); store_B(buf ^ 1); }
+#endif
+#if CMF_GEMM_DIAG != 2 && CMF_GEMM_DIAG != 4                        /* 4: staged but no barrier */
             __syncthreads();
+#endif
             buf ^= 1;
         }
     }
@@ -435,7 +615,9 @@ static int launch(const GemmArgs &a, hipStream_t st)
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per = (tiles_m + 7) / 8;
     dim3 grid(a.split_k > 1 ? 8 * ((a.split_k + 7) / 8) * tiles_m * tiles_n : 8 * per * tiles_n);
-    const size_t lds = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
+    const size_t lds_reg = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
+    const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + 32) * sizeof(float);
+    const size_t lds = lds_reg > lds_dir ? lds_reg : lds_dir;
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
@@ -468,6 +650,8 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.bias = bias; g.act = act; g.stats = stats; g.bwd_mode = bwd_mode; g.Z = Z; g.ldz = ldz;
     g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz; g.split_k = split_k;
     g.accumulate = split_k > 1 ? 0 : accumulate;
+    static const int no_direct = (getenv("CMF_GEMM_NO_DIRECT") && getenv("CMF_GEMM_NO_DIRECT")[0] == '1') ? 1 : 0;
+    g.no_direct = no_direct;
     int err = cmf_thin_gemm(g, a_t, b_t, st);            // narrow layers (<= 64 channels): barrier-free per-wave kernels
     if (err > 0) return err;
     const bool thin_done = (err == 0);

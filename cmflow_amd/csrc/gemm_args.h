@@ -28,6 +28,7 @@ struct GemmArgs {
                                 // -> stats is then [tiles_m][5][N] (s1, s2, q0, q1, q2): the set-conv dW_xyz without a pass
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
+    int no_direct;              // diagnostics (env CMF_GEMM_NO_DIRECT=1): register-staged main loop everywhere
 };
 
 // thin_gemm.hip: returns -1 when the shape is not handled there
