@@ -19,30 +19,36 @@ constexpr int GP_STEPS = 4;           // steps per thread -> GP_TILE = 256*4*4 =
 constexpr int GP_TILE = GP_THREADS * GP_VEC * GP_STEPS;
 constexpr int GP_MAX_N_LDS = 8192;    // rows staged in LDS up to this n
 
-template <bool ROWS_IN_LDS, int GP_CH>
-__global__ __launch_bounds__(GP_THREADS) void group_points_kernel(
-    int c, int n, int total /* npoints*nsample */, int tiles_per_sample,
+template <bool ROWS_IN_LDS, int GP_CH, int TPB>
+__global__ __launch_bounds__(TPB) void group_points_kernel(
+    int c, int n, int total /* npoints*nsample */, int tiles_per_sample, int tiles_per_wg,
     const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];   // [GP_CH][n] when ROWS_IN_LDS
-    const int tile = blockIdx.x % tiles_per_sample;
-    const int bs = blockIdx.x / tiles_per_sample;
+    // a workgroup stages its feature rows once and walks tiles_per_wg consecutive idx tiles with them: with long rows
+    // (n = 4096: 64 tiles per sample) one tile per workgroup re-staged the rows 64 times -- 2.7 GB of fetches
+    // against 0.1 GB of algorithmic reads (rocprofv3 FETCH_SIZE), enough to pin the kernel at the HBM limit
+    const int groups_per_sample = (tiles_per_sample + tiles_per_wg - 1) / tiles_per_wg;
+    const int tile0 = (blockIdx.x % groups_per_sample) * tiles_per_wg;
+    const int tile1 = min(tile0 + tiles_per_wg, tiles_per_sample);
+    const int bs = blockIdx.x / groups_per_sample;
     const int c0 = blockIdx.y * GP_CH;
     const int nch = min(GP_CH, c - c0);
-    const int e0 = tile * GP_TILE;
     const int *ix = idx + (size_t)bs * total;
     const float *src = points + ((size_t)bs * c + c0) * n;
     float *dst = out + ((size_t)bs * c + c0) * total;
 
     if (ROWS_IN_LDS) {
-        for (int i = threadIdx.x; i < nch * n; i += GP_THREADS) rows[i] = src[i];
+        for (int i = threadIdx.x; i < nch * n; i += TPB) rows[i] = src[i];
     }
+    const bool vec_ok = (total % GP_VEC) == 0;
+    for (int tile = tile0; tile < tile1; ++tile) {
+    const int e0 = tile * (TPB * GP_VEC * GP_STEPS);
     // this thread's idx entries, loaded once and reused for every channel
     int my[GP_STEPS][GP_VEC];
-    const bool vec_ok = (total % GP_VEC) == 0;
 #pragma unroll
     for (int s = 0; s < GP_STEPS; ++s) {
-        const int e = e0 + (s * GP_THREADS + threadIdx.x) * GP_VEC;
+        const int e = e0 + (s * TPB + threadIdx.x) * GP_VEC;
         if (vec_ok && e + GP_VEC <= total) {
             const int4 v = *reinterpret_cast<const int4 *>(ix + e);
             my[s][0] = v.x; my[s][1] = v.y; my[s][2] = v.z; my[s][3] = v.w;
@@ -51,14 +57,14 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(
             for (int j = 0; j < GP_VEC; ++j) my[s][j] = (e + j < total) ? ix[e + j] : 0;
         }
     }
-    if (ROWS_IN_LDS) __syncthreads();
+    if (ROWS_IN_LDS && tile == tile0) __syncthreads();
 
     for (int ch = 0; ch < nch; ++ch) {
         const float *row = ROWS_IN_LDS ? rows + (size_t)ch * n : src + (size_t)ch * n;
         float *o = dst + (size_t)ch * total;
 #pragma unroll
         for (int s = 0; s < GP_STEPS; ++s) {
-            const int e = e0 + (s * GP_THREADS + threadIdx.x) * GP_VEC;
+            const int e = e0 + (s * TPB + threadIdx.x) * GP_VEC;
             if (vec_ok && e + GP_VEC <= total) {
                 float4 v;
                 v.x = row[my[s][0]]; v.y = row[my[s][1]]; v.z = row[my[s][2]]; v.w = row[my[s][3]];
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(GP_THREADS) void group_points_kernel(
             }
         }
     }
+    }
 }
 
 extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
@@ -79,26 +86,46 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
     const long long total = (long long)npoints * nsample;
     if (b == 0 || c == 0 || total == 0) return 0;
     CMF_CHECK_ARG(points && idx && out && n > 0 && total < (1LL << 31));
-    const int tiles = cmf_divup(total, GP_TILE);
+    int tiles = cmf_divup(total, GP_TILE);
     hipStream_t st = (hipStream_t)stream;
+    // tiles per workgroup: as many as possible while the launch still has >= ~1024 workgroups
+    auto tiles_per_wg = [&](int chan_groups) {
+        const long long base = (long long)b * chan_groups;
+        int t = (int)((base * tiles) / 1024);
+        return t < 1 ? 1 : (t > tiles ? tiles : t);
+    };
     if (n <= 1024) {
-        dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 8));
-        hipLaunchKernelGGL((group_points_kernel<true, 8>), grid, dim3(GP_THREADS), (size_t)8 * n * sizeof(float), st,
-                           c, n, (int)total, tiles, points, idx, out);
+        const int t = tiles_per_wg(cmf_divup(c, 8));
+        dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 8));
+        hipLaunchKernelGGL((group_points_kernel<true, 8, GP_THREADS>), grid, dim3(GP_THREADS), (size_t)8 * n * sizeof(float), st,
+                           c, n, (int)total, tiles, t, points, idx, out);
     } else if (n <= GP_MAX_N_LDS) {
-        dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 2));
+        // 4 rows when they fit in 64 KB (two workgroups per CU), else 2
+        const bool four = (size_t)4 * n * sizeof(float) <= 64 * 1024;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)group_points_kernel<true, 2>,
+            (void)hipFuncSetAttribute((const void *)group_points_kernel<true, 2, 512>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_MAX_N_LDS * 4);
+            (void)hipFuncSetAttribute((const void *)group_points_kernel<true, 4, 512>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL((group_points_kernel<true, 2>), grid, dim3(GP_THREADS), (size_t)2 * n * sizeof(float), st,
-                           c, n, (int)total, tiles, points, idx, out);
+        tiles = cmf_divup(total, 512 * GP_VEC * GP_STEPS);                 // 512 threads: twice the waves per CU for the LDS gather
+        if (four) {
+            const int t = tiles_per_wg(cmf_divup(c, 4));
+            dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 4));
+            hipLaunchKernelGGL((group_points_kernel<true, 4, 512>), grid, dim3(512), (size_t)4 * n * sizeof(float), st,
+                               c, n, (int)total, tiles, t, points, idx, out);
+        } else {
+            const int t = tiles_per_wg(cmf_divup(c, 2));
+            dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 2));
+            hipLaunchKernelGGL((group_points_kernel<true, 2, 512>), grid, dim3(512), (size_t)2 * n * sizeof(float), st,
+                               c, n, (int)total, tiles, t, points, idx, out);
+        }
     } else {
         dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 8));
-        hipLaunchKernelGGL((group_points_kernel<false, 8>), grid, dim3(GP_THREADS), 0, st,
-                           c, n, (int)total, tiles, points, idx, out);
+        hipLaunchKernelGGL((group_points_kernel<false, 8, GP_THREADS>), grid, dim3(GP_THREADS), 0, st,
+                           c, n, (int)total, tiles, 1, points, idx, out);
     }
     return cmf_launch_status();
 }

@@ -102,6 +102,112 @@ __global__ __launch_bounds__(CMF_WAVE) void ball_query_kernel(
     }
 }
 
+// Multi-wave variant: the NW waves of a workgroup share the same 64 centres and scan consecutive index ranges of the
+// cloud (wave w: points [w*seg, (w+1)*seg)), each collecting up to nsample hits of its range in LDS; the write-out
+// concatenates the lists in wave order, which IS index order, truncated at nsample and padded with the first hit.
+// One wave per 64 centres leaves the chip at 1-2 waves per SIMD (N = 256: 256 waves in total; N = 4096: 2048) and
+// the scan is a dependent instruction stream: splitting the range gives NW times the waves and 1/NW the loop length.
+constexpr int BQM_NW = 4;
+constexpr int BQM_TILE = 256;       // points per wave per LDS tile
+
+typedef float bq_f2 __attribute__((ext_vector_type(2)));
+
+// HITS_GLOBAL: the per-wave hit lists live in a global scratch buffer instead of LDS.  At nsample = 64 the lists
+// are 8 KB per wave and cap the kernel at 3 waves per SIMD; hits are rare events (<= nsample stores per lane over
+// the whole scan), so spilling them costs nothing and lets the scan run at full occupancy.
+template <bool HITS_GLOBAL>
+__global__ __launch_bounds__(BQM_NW *CMF_WAVE) void ball_query_multi_kernel(
+    int n, int m, float radius2, int nsample, int seg,
+    const float *__restrict__ new_xyz, const float *__restrict__ xyz, int *__restrict__ idx,
+    unsigned short *__restrict__ scratch)
+{
+    // points are staged as PAIRS, (x0,x1,y0,y1) + (z0,z1), and the distance of both is evaluated with packed fp32
+    // instructions (v_pk_add_f32 / v_pk_mul_f32: two individually rounded operations per instruction -- the same
+    // canonical arithmetic at half the VALU issue)
+    __shared__ float4 txy[BQM_NW][BQM_TILE / 2];
+    __shared__ bq_f2 tz[BQM_NW][BQM_TILE / 2];
+    __shared__ unsigned short hits_lds[HITS_GLOBAL ? 1 : BQM_NW * BQ_MAX_NS_LDS * CMF_WAVE];
+    __shared__ int cntw[BQM_NW][CMF_WAVE];
+    const int bs = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int pt = blockIdx.x * CMF_WAVE + lane;
+    const bool live = pt < m;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    // hit lists of the 4 waves, [wave][slot][lane]
+    unsigned short *hits = HITS_GLOBAL ? scratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BQM_NW * BQ_MAX_NS_LDS * CMF_WAVE)
+                                       : hits_lds;
+    unsigned short *mine = hits + w * (BQ_MAX_NS_LDS * CMF_WAVE);
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (live) {
+        const float *c = new_xyz + ((size_t)bs * m + pt) * 3;
+        cx = c[0]; cy = c[1]; cz = c[2];
+    }
+    const bq_f2 cxx = {cx, cx}, cyy = {cy, cy}, czz = {cz, cz};
+    int cnt = live ? 0 : nsample;
+    auto dist2 = [&](const float4 a, const bq_f2 z) {
+        const bq_f2 px = {a.x, a.y}, py = {a.z, a.w};
+        const bq_f2 dx = cxx - px;
+        const bq_f2 dy = cyy - py;
+        const bq_f2 dz = czz - z;
+        const bq_f2 xx = dx * dx;
+        const bq_f2 yy = dy * dy;
+        const bq_f2 zz = dz * dz;
+        const bq_f2 s = xx + yy;
+        return s + zz;
+    };
+    auto take = [&](bool hit, int k) {
+        if (hit && cnt < nsample) { mine[cnt * CMF_WAVE + lane] = (unsigned short)k; ++cnt; }
+    };
+    const int r0 = min(n, w * seg), r1 = min(n, r0 + seg);
+    const float far = __builtin_inff();                         // filler of an odd tail: never inside a ball
+    for (int base = r0; base < r1; base += BQM_TILE) {
+        const int len = min(BQM_TILE, r1 - base);
+        const int pairs = (len + 1) / 2;
+        for (int i = lane; i < pairs; i += CMF_WAVE) {            // this wave's own tile: no workgroup barrier needed
+            const float *q = pts + (size_t)(base + 2 * i) * 3;
+            const bool two = 2 * i + 1 < len;
+            txy[w][i] = make_float4(q[0], two ? q[3] : far, q[1], two ? q[4] : far);
+            tz[w][i] = bq_f2{q[2], two ? q[5] : far};
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (__all(cnt >= nsample)) break;
+        int k = 0;
+        for (; k + 2 <= pairs; k += 2) {
+            const bq_f2 d0 = dist2(txy[w][k], tz[w][k]), d1 = dist2(txy[w][k + 1], tz[w][k + 1]);
+            const bool h0 = d0.x < radius2, h1 = d0.y < radius2, h2 = d1.x < radius2, h3 = d1.y < radius2;
+            if (__any(h0 | h1 | h2 | h3)) {
+                take(h0, base + 2 * k); take(h1, base + 2 * k + 1); take(h2, base + 2 * k + 2); take(h3, base + 2 * k + 3);
+            }
+        }
+        for (; k < pairs; ++k) {
+            const bq_f2 d0 = dist2(txy[w][k], tz[w][k]);
+            take(d0.x < radius2, base + 2 * k); take(d0.y < radius2, base + 2 * k + 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    cntw[w][lane] = live ? cnt : 0;
+    if (HITS_GLOBAL) __threadfence_block();
+    __syncthreads();
+    // write-out: the workgroup's 64 x nsample block of idx, coalesced; centres with an empty ball keep idx as it was
+    const int total = CMF_WAVE * nsample;
+    const int valid = min(CMF_WAVE, m - blockIdx.x * CMF_WAVE);
+    int *blk = idx + ((size_t)bs * m + (size_t)blockIdx.x * CMF_WAVE) * nsample;
+    for (int e = tid; e < total; e += BQM_NW * CMF_WAVE) {
+        const int c = e / nsample, sl = e - c * nsample;
+        if (c >= valid) break;
+        int start = 0, val = -1, first = -1;
+#pragma unroll
+        for (int q = 0; q < BQM_NW; ++q) {
+            const int cq = cntw[q][c];
+            const unsigned short *lst = hits + q * (BQ_MAX_NS_LDS * CMF_WAVE);
+            if (first < 0 && cq > 0) first = lst[c];
+            if (val < 0 && sl < start + cq) val = lst[(sl - start) * CMF_WAVE + c];
+            start += cq;
+        }
+        if (first >= 0) blk[e] = val >= 0 ? val : first;
+    }
+}
+
 extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
                               const float *new_xyz, const float *xyz, int *idx, void *stream)
 {
@@ -109,6 +215,24 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     if (b == 0 || m == 0 || n == 0) return 0;
     CMF_CHECK_ARG(new_xyz && xyz && idx);
     dim3 grid(cmf_divup(m, CMF_WAVE), b);
+    if (nsample <= BQ_MAX_NS_LDS && n <= 65535 && n >= 64) {
+        const int seg = (cmf_divup(n, BQM_NW) + 3) / 4 * 4;
+        const long long wgs = (long long)grid.x * grid.y;
+        if (wgs > 3 * 256) {                                     // enough workgroups for LDS capacity to limit occupancy
+            unsigned short *scratch = nullptr;
+            const size_t bytes = (size_t)wgs * BQM_NW * BQ_MAX_NS_LDS * CMF_WAVE * sizeof(unsigned short);
+            hipError_t e = hipMallocAsync((void **)&scratch, bytes, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(ball_query_multi_kernel<true>, grid, dim3(BQM_NW * CMF_WAVE), 0, (hipStream_t)stream,
+                               n, m, radius * radius, nsample, seg, new_xyz, xyz, idx, scratch);
+            const int err = cmf_launch_status();
+            (void)hipFreeAsync(scratch, (hipStream_t)stream);
+            return err;
+        }
+        hipLaunchKernelGGL(ball_query_multi_kernel<false>, grid, dim3(BQM_NW * CMF_WAVE), 0, (hipStream_t)stream,
+                           n, m, radius * radius, nsample, seg, new_xyz, xyz, idx, (unsigned short *)nullptr);
+        return cmf_launch_status();
+    }
     if (nsample <= BQ_MAX_NS_LDS && n <= 1024)      // small clouds: latency bound, coalesced write-out pays
         hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
                            n, m, radius * radius, nsample, new_xyz, xyz, idx);

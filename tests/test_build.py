@@ -59,9 +59,10 @@ def test_ball_query_isa_has_no_fma_contraction():
                           "--cuda-device-only", "-o", "-", src], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     asm = out.stdout
-    start = asm.index("_Z17ball_query_kernel")
-    body = asm[start:asm.index("s_endpgm", start)]
-    assert not re.search(r"v_(fma|fmac|mad|pk_fma)_f32", body)
+    for sym in ("_Z17ball_query_kernel", "_Z23ball_query_multi_kernelILb0", "_Z23ball_query_multi_kernelILb1"):
+        start = asm.index(sym)
+        body = asm[start:asm.index("s_endpgm", start)]
+        assert not re.search(r"v_(fma|fmac|mad|pk_fma)_f32", body), sym
     knn = asm[asm.index("_Z10knn_kernelILi8ELb0EE"):]
     knn = knn[:knn.index("s_endpgm")]
     assert re.search(r"v_(fma|fmac)_f32", knn)        # the k-ordered FMA chain of the dot product IS required there
