@@ -33,7 +33,7 @@ inline int dw_split(long long M, int N, int K)
     const long long tiles = (long long)(N > 64 ? (N + 127) / 128 : 1) * (K > 64 ? (K + 127) / 128 : 1);
     const long long chunks = (M + 31) / 32;
     long long s = std::min<long long>(chunks / 16, (512 + tiles - 1) / tiles);
-    if (N <= 64 && K <= 64) return (int)std::max<long long>(2, std::min<long long>(M / 256, 1024));   // thin kernel: slab per wave
+    if (N <= 64 && K <= 64) return (int)std::max<long long>(2, std::min<long long>(M / 128, 1024));   // thin kernel: slab per workgroup, >= 128 rows each
     return (int)std::max<long long>(1, s);
 }
 

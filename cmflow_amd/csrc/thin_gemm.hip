@@ -174,14 +174,20 @@ __global__ __launch_bounds__(TG_THREADS) void thin_dx_kernel(const GemmArgs p)
 // channels), B = layer input (rows of KT*32 channels, optionally B' = relu(prob_a[k]*B + prob_c[k])).
 // One MFMA step consumes a row PAIR: lanes 0-31 read row 2s, lanes 32-63 row 2s+1, one dword each, coalesced.
 template <int MT, int KT>
-__global__ __launch_bounds__(TG_THREADS) void thin_dw_kernel(const GemmArgs p, const int rows_per_wave)
+__global__ __launch_bounds__(TG_THREADS) void thin_dw_kernel(const GemmArgs p, const int rows_per_wg)
 {
-    const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * (TG_THREADS / 64) + (threadIdx.x >> 6);            // global wave id = slab id
-    if (gw >= p.split_k) return;
+    // One slab per WORKGROUP: its four waves take a quarter of the workgroup's rows each (16 rows = 8 row pairs in
+    // flight per wave per step) and their accumulators are summed through LDS in fixed order (3 + 2, then 1 + 0).
+    // [The first version gave every wave its own slab and 256 rows with 8 rows in flight: a 64x64 gradient over
+    //  16384 rows took 45 us, pure load latency.]
+    __shared__ float red[2][MT * KT * 16 * CMF_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, cl = lane & 31;
-    const long long r_begin = (long long)gw * rows_per_wave;
-    const long long r_end = r_begin + rows_per_wave < p.K ? r_begin + rows_per_wave : p.K;   // p.K = number of rows (contraction)
+    const long long wg_begin = (long long)blockIdx.x * rows_per_wg;
+    const long long wg_end = wg_begin + rows_per_wg < p.K ? wg_begin + rows_per_wg : p.K;     // p.K = number of rows (contraction)
+    const int rpw = ((rows_per_wg + 3) / 4 + 1) / 2 * 2;
+    const long long r_begin = wg_begin + (long long)wave * rpw;
+    const long long r_end = r_begin + rpw < wg_end ? r_begin + rpw : wg_end;
     float pa[KT], pc[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(TG_THREADS) void thin_dw_kernel(const GemmArgs p, c
         for (int j = 0; j < KT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int U = 4;                                                           // row pairs in flight
+    constexpr int U = 8;                                                           // row pairs in flight
     for (long long r0 = r_begin; r0 < r_end; r0 += 2 * U) {
         float av[U][MT], bv[U][KT];
 #pragma unroll
@@ -224,7 +230,32 @@ __global__ __launch_bounds__(TG_THREADS) void thin_dw_kernel(const GemmArgs p, c
                 for (int j = 0; j < KT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][i], bv[u][j], acc[i][j], 0, 0, 0);
     }
-    float *slab = p.C + (long long)gw * p.M * p.ldc;                               // [M=out ch][ldc = N=in ch]
+    // fixed-order reduction of the four waves: (w2, w3) -> LDS, added by (w0, w1); w1 -> LDS, added by w0
+    auto put = [&](float *dst) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((i * KT + j) * 16 + r) * CMF_WAVE + lane] = acc[i][j][r];
+    };
+    auto add = [&](const float *src) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < KT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * KT + j) * 16 + r) * CMF_WAVE + lane];
+    };
+    if (wave >= 2) put(red[wave - 2]);
+    __syncthreads();
+    if (wave < 2) add(red[wave]);
+    __syncthreads();
+    if (wave == 1) put(red[0]);
+    __syncthreads();
+    if (wave != 0) return;
+    add(red[0]);
+    float *slab = p.C + (long long)blockIdx.x * p.M * p.ldc;                       // [M=out ch][ldc = N=in ch]
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -267,8 +298,8 @@ int cmf_thin_gemm(const GemmArgs &g, int a_t, int b_t, hipStream_t st)
     }
     if (g.split_k > 1 && a_t && !b_t && g.M <= 64 && g.N <= 64 && !g.pro_a) {
         // weight gradient: g.M = out channels, g.N = in channels, g.K = rows; g.C = slab workspace [split][M][N]
-        const int rpw = (int)((((long long)g.K + g.split_k - 1) / g.split_k + 1) / 2 * 2);
-        const dim3 grid((g.split_k + 3) / 4), block(TG_THREADS);
+        const int rpw = (int)((((long long)g.K + g.split_k - 1) / g.split_k + 7) / 8 * 8);      // rows per workgroup = per slab
+        const dim3 grid(g.split_k), block(TG_THREADS);
         const int mt = g.M <= 32 ? 1 : 2, kt = g.N <= 32 ? 1 : 2;
         if (mt == 1 && kt == 1) hipLaunchKernelGGL((thin_dw_kernel<1, 1>), grid, block, 0, st, g, rpw);
         else if (mt == 1) hipLaunchKernelGGL((thin_dw_kernel<1, 2>), grid, block, 0, st, g, rpw);

@@ -186,7 +186,7 @@ def gemm_dw(dZ, X, prob=None, w=None):
     # ~2 workgroups per CU; every slab costs an extra N*K*4-byte round trip in the reduction
     split = max(1, min(chunks // 16, (512 + tiles - 1) // tiles))
     if N <= 64 and K <= 64:
-        split = max(2, min(M // 256, 1024))               # thin kernel: one slab per wavefront, ~256 rows each
+        split = max(2, min(M // 128, 1024))               # thin kernel: one slab per workgroup, >= 128 rows each
     if sink is not None:
         gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split, out=sink, accumulate=True)
         return None
