@@ -54,7 +54,8 @@ SIGNATURES = {
     "cmf_act_bwd_stats": [_ll, _ci, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_bn_bwd_apply": [_ll, _ci, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_ksum": [_ll, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
-    "cmf_weighted_ksum_grad": [_ll, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_weighted_ksum_grad_tiles": [_ci],
+    "cmf_weighted_ksum_grad": [_ll, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_radar_loss_workspace": [_ci, _ci],
     "cmf_radar_loss": [_vp, _vp],
     "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],

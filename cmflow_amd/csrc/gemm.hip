@@ -532,8 +532,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                         x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
                         s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
                         if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
-                    } else if (p.bwd_mode == 2) x = z[q] > 0.f ? x : 0.1f * x;
-                    else if (p.bwd_mode == 3) x = z[q] > 0.f ? x : 0.f;
+                    } else if (p.bwd_mode == 2) { x = z[q] > 0.f ? x : 0.1f * x; if (want_stats) s1[q] += x; }   // column sums: bias gradient
+                    else if (p.bwd_mode == 3) { x = z[q] > 0.f ? x : 0.f; if (want_stats) s1[q] += x; }
                     else if (want_stats) { s1[q] += x; s2[q] += x * x; }
                     v[q] = x;
                 }

@@ -58,8 +58,8 @@ __device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[N
                         x = (fmaf(ea, z, ec) > 0.f) ? x : 0.f;
                         s1 += x; s2 += x * ((z - em) * ei);
                         if (want_q) { const float4 d = *(const float4 *)(p.dxyz + (long long)m * 4); q0 += x * d.x; q1 += x * d.y; q2 += x * d.z; }
-                    } else if (p.bwd_mode == 2) x = z > 0.f ? x : 0.1f * x;
-                    else x = z > 0.f ? x : 0.f;
+                    } else if (p.bwd_mode == 2) { x = z > 0.f ? x : 0.1f * x; if (want_stats) s1 += x; }
+                    else { x = z > 0.f ? x : 0.f; if (want_stats) s1 += x; }
                 } else if (want_stats) { s1 += x; s2 += x * x; }
                 float *dst = p.C + (long long)m * p.ldc + n;
                 *dst = p.accumulate ? *dst + x : x;

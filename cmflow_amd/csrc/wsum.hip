@@ -49,8 +49,14 @@ __global__ __launch_bounds__(WS_THREADS) void wsum_fwd_kernel(
 
 __global__ __launch_bounds__(WS_THREADS) void wsum_bwd_kernel(
     long long M, int K, int C, int n1, int n_src, int leaky, const float *__restrict__ dcost, const float *__restrict__ w,
-    const float *__restrict__ x, const int *__restrict__ idx, float *__restrict__ dw, float *__restrict__ dx)
+    const float *__restrict__ x, const int *__restrict__ idx, float *__restrict__ dw, float *__restrict__ dx,
+    float *__restrict__ dx_colsum)
 {
+    // dx_colsum != NULL: per-workgroup column sums of dx ([gridDim.x][C], summed by cmf_colsum) -- the bias gradient of
+    // the layer that produced x.  The launcher then picks a grid whose thread stride is a multiple of C/4, so a thread
+    // keeps the same 4 channels for all its rows.
+    __shared__ float4 red[WS_THREADS];
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     const int cv = C / 4;
     const long long total = M * K * cv;                   // one thread per (m, k, 4 channels): fully coalesced rows
     for (long long t = (long long)blockIdx.x * WS_THREADS + threadIdx.x; t < total; t += (long long)gridDim.x * WS_THREADS) {
@@ -75,6 +81,17 @@ __global__ __launch_bounds__(WS_THREADS) void wsum_bwd_kernel(
             d.z = xv.z > 0.f ? d.z : 0.1f * d.z; d.w = xv.w > 0.f ? d.w : 0.1f * d.w;
         }
         if (dx) *(float4 *)(dx + mk * C + c) = d;
+        cs.x += d.x; cs.y += d.y; cs.z += d.z; cs.w += d.w;
+    }
+    if (dx_colsum) {
+        // threads t and t + cv (+ 2cv ...) of the workgroup own the same channels: fold them in fixed order
+        red[threadIdx.x] = cs;
+        __syncthreads();
+        if ((int)threadIdx.x < cv) {
+            float4 s = red[threadIdx.x];
+            for (int t = threadIdx.x + cv; t < WS_THREADS; t += cv) { const float4 v = red[t]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+            *(float4 *)(dx_colsum + (long long)blockIdx.x * C + 4 * threadIdx.x) = s;
+        }
     }
 }
 
@@ -94,16 +111,25 @@ extern "C" int cmf_weighted_ksum(long long M, int K, int C, int n1, int n_src, c
     return cmf_launch_status();
 }
 
+extern "C" int cmf_weighted_ksum_grad_tiles(int C)
+{
+    return (C % 4 == 0 && C / 4 <= WS_THREADS && WS_THREADS % (C / 4) == 0) ? 1024 : 0;      // 0: column sums not supported for this C
+}
+
 extern "C" int cmf_weighted_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *w,
-                                      const float *x, const int *idx, float *dw, float *dx, void *stream)
+                                      const float *x, const int *idx, float *dw, float *dx, float *dx_colsum, void *stream)
 {
     CMF_CHECK_ARG(M >= 0 && K > 0 && C > 0 && C % 4 == 0);
     if (M == 0) return 0;
     CMF_CHECK_ARG(dcost && w && x && (dw || dx) && (!idx || (n1 > 0 && n_src > 0)));
     CMF_CHECK_ARG((((uintptr_t)w | (uintptr_t)x | (uintptr_t)dcost | (uintptr_t)dw | (uintptr_t)dx) & 15) == 0);
     const long long total = M * K * (C / 4);
-    const int grid = (int)((total + WS_THREADS - 1) / WS_THREADS < 256 * 64 ? (total + WS_THREADS - 1) / WS_THREADS : 256 * 64);
+    int grid = (int)((total + WS_THREADS - 1) / WS_THREADS < 256 * 64 ? (total + WS_THREADS - 1) / WS_THREADS : 256 * 64);
+    if (dx_colsum) {
+        CMF_CHECK_ARG(dx && cmf_weighted_ksum_grad_tiles(C) > 0);
+        grid = cmf_weighted_ksum_grad_tiles(C);               // every workgroup writes its [C] partial, also when it has no rows
+    }
     hipLaunchKernelGGL(wsum_bwd_kernel, dim3(grid), dim3(WS_THREADS), 0, (hipStream_t)stream, M, K, C, n1, n_src, leaky, dcost, w, x,
-                       idx, dw, dx);
+                       idx, dw, dx, dx_colsum);
     return cmf_launch_status();
 }

@@ -784,7 +784,7 @@ class CostVolumeMLPFn(Function):
         x2 = gemm(x1, w2, bias=b2, act=2)
         x3 = gemm(x2, w3, bias=b3, act=2)
         ctx.saved = (nbr, dxyz, x1, x2, x3, w2, w3, (B, N1, K, C), p2.shape[1])
-        ctx.params = (w2, w3)
+        ctx.params = (w2, w3, b2)
         ctx.mark_non_differentiable(dxyz)
         return x3.view(B, N1, K, -1), dxyz
 
@@ -795,10 +795,13 @@ class CostVolumeMLPFn(Function):
         dx3 = dx3.reshape(M, -1)
         # leaky'(z) has the sign of the stored activation
         dz3 = dx3.contiguous() if ctx.preact_grad else torch.where(x3 > 0, dx3, 0.1 * dx3)
-        db3 = dz3.sum(0)
+        db3 = None if ctx.preact_grad else dz3.sum(0)             # preact_grad: the consumer returns it (WeightedKSumFn x_bias)
         dw3 = gemm_dw(dz3, x2, w=ctx.params[1])
-        dz2 = gemm(dz3, w3, b_t=False, bwd=(2, x2))
-        db2 = dz2.sum(0)
+        dz2, part2 = gemm(dz3, w3, b_t=False, bwd=(2, x2), stats=True)    # column sums of dz2 = db2 from the epilogue
+        sink2 = grad_sink(ctx.params[2])
+        db2 = colsum(part2, sink2, None)[0]
+        if sink2 is not None:
+            db2 = None
         dw2 = gemm_dw(dz2, x1, w=ctx.params[0])
         dz1 = gemm(dz2, w2, b_t=False, bwd=(2, x1))
         dwd = gemm_dw(dz1, dxyz.view(-1, 4))[:, :3]
@@ -817,9 +820,11 @@ class WeightedKSumFn(Function):
     LeakyReLU(0.1) activation and the gradient returned for it is the one w.r.t. its pre-activation."""
 
     @staticmethod
-    def forward(ctx, weights, x, nbr, leaky, relu_w=False):
+    def forward(ctx, weights, x, nbr, leaky, relu_w=False, x_bias=None):
         # relu_w: weights is a stored ReLU activation whose producer (LinearFn preact_grad=True) expects the gradient
-        # w.r.t. its pre-activation
+        # w.r.t. its pre-activation.  x_bias: the bias of the layer that produced x; its gradient (column sums of the
+        # pre-activation gradient) comes out of the same kernel instead of a separate reduction over (M*K, C)
+        ctx.x_bias = x_bias
         B, N1, K, C = weights.shape
         weights, x = weights.contiguous(), x.contiguous()
         out = torch.empty(B, N1, C, dtype=_f32, device=weights.device)
@@ -840,12 +845,24 @@ class WeightedKSumFn(Function):
         dx = torch.empty(B, N1, K, C, dtype=_f32, device=weights.device) if need_x else None
         idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
         n_src = nbr.n if nbr is not None else 0
+        part, db = None, None
+        want_db = ctx.x_bias is not None and len(ctx.needs_input_grad) > 5 and ctx.needs_input_grad[5] and need_x
+        tiles = L().cmf_weighted_ksum_grad_tiles(C) if want_db else 0
+        if tiles > 0:
+            part = torch.empty(tiles, 1, C, dtype=_f32, device=weights.device)
         _lib.check(L().cmf_weighted_ksum_grad(B * N1, K, C, N1, n_src, int(leaky), _p(dcost), _p(weights), _p(x), idx,
-                                              _p(dw), _p(dx), _lib.stream_ptr()), "cmf_weighted_ksum_grad")
+                                              _p(dw), _p(dx), _p(part), _lib.stream_ptr()), "cmf_weighted_ksum_grad")
+        if want_db:
+            if part is not None:
+                sink = grad_sink(ctx.x_bias)
+                sums = colsum_n(part, C, sink, None)                 # fixed-order sum of the per-workgroup partials
+                db = None if sink is not None else sums.view(-1)
+            else:
+                db = dx.view(-1, C).sum(0)
         if nbr is not None and need_x:                       # scatter the per-slot gradients back to the points
             off, inv = nbr.inverse()
             dp = torch.empty(B, nbr.n, C, dtype=_f32, device=weights.device)
             _lib.check(L().cmf_group_rows_grad(B, nbr.n, C, C, N1 * K, 0, _p(dx), _p(off), _p(inv), _p(dp), _lib.stream_ptr()),
                        "cmf_group_rows_grad")
             dx = dp
-        return dw, dx, None, None, None
+        return dw, dx, None, None, None, db

@@ -317,7 +317,7 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     p2 = FB.linear(f2, w0[:, D1:D1 + D2])
     x, dxyz = FB.CostVolumeMLPFn.apply(xyz1_t, xyz2_t, p1, p2, nbr, w0[:, D1 + D2:], w2d(c1), c1.bias, w2d(c2), c2.bias, True)
     weights = self.weightnet1.forward_pm(dxyz, use_blocks=True, preact_grad=True)
-    p2p = FB.WeightedKSumFn.apply(weights, x, None, True, True)                            # sum_k weights * x
+    p2p = FB.WeightedKSumFn.apply(weights, x, None, True, True, c2.bias)                   # sum_k weights * x
     nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
     dxyz2 = F.pad(group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2), (0, 1))
     weights = self.weightnet2.forward_pm(dxyz2, use_blocks=True, preact_grad=True)

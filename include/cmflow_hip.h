@@ -245,8 +245,12 @@ int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, void *const
  * C % 4 == 0, 16-byte aligned pointers. */
 int cmf_weighted_ksum(long long M, int K, int C, int n1, int n_src, const float *w, const float *x, const int *idx,
                       float *out, void *stream);
+/* dx_colsum (optional): [cmf_weighted_ksum_grad_tiles(C)][C] per-workgroup column sums of dx, to be reduced with
+ * cmf_colsum -- the bias gradient of the layer that produced x; cmf_weighted_ksum_grad_tiles returns 0 when C does not
+ * allow it. */
+int cmf_weighted_ksum_grad_tiles(int C);
 int cmf_weighted_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *w,
-                           const float *x, const int *idx, float *dw, float *dx, void *stream);
+                           const float *x, const int *idx, float *dw, float *dx, float *dx_colsum, void *stream);
 
 /* ---- the training step's loss -------------------------------------------------------------
  * RadarFlowLoss of losses/radar_loss.py:260-292 for model 'cmflow' / 'cmflow_t': SoftChamfer (:17-58),
