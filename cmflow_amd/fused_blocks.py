@@ -174,6 +174,24 @@ def bn_backward(dU, part, z, st, gamma=None, beta=None):
     return dU, (None if sg is not None else sums[1]), (None if sb is not None else sums[0])
 
 
+def dw_split(M, N, K):
+    """Split-K factor of a weight gradient (same rule as csrc/setconv_block.hip dw_split)."""
+    if N <= 64 and K <= 64:
+        return max(2, min(M // 128, 1024))                 # thin kernel: one slab per workgroup, >= 128 rows each
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    chunks = (M + 15) // 16
+    if chunks < 64:
+        return 1
+    best, best_cost = 8, 1e30
+    for s in (8, 16, 24, 32, 48, 64, 96, 128):             # multiples of 8: slabs are dealt to the 8 XCDs
+        if chunks // s < 8:
+            break
+        cost = ((tiles * s + 767) // 768) * (chunks / s + 12.0)
+        if cost < best_cost:
+            best, best_cost = s, cost
+    return best
+
+
 def gemm_dw(dZ, X, prob=None, w=None):
     """Weight gradient dW[N,K] = dZ[M,N]^T @ act(X)[M,K]; contraction over the positions, split-K so that
     the launch fills the chip, slabs summed in fixed order (deterministic).  w: the weight input of the
@@ -181,12 +199,7 @@ def gemm_dw(dZ, X, prob=None, w=None):
     sink = grad_sink(w) if w is not None else None
     M, N = dZ.shape
     K = X.shape[1]
-    tiles = ((N + 127) // 128 if N > 64 else 1) * ((K + 127) // 128 if K > 64 else 1)
-    chunks = (M + 31) // 32
-    # ~2 workgroups per CU; every slab costs an extra N*K*4-byte round trip in the reduction
-    split = max(1, min(chunks // 16, (512 + tiles - 1) // tiles))
-    if N <= 64 and K <= 64:
-        split = max(2, min(M // 128, 1024))               # thin kernel: one slab per workgroup, >= 128 rows each
+    split = dw_split(M, N, K)
     if sink is not None:
         gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split, out=sink, accumulate=True)
         return None

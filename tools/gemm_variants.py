@@ -23,7 +23,8 @@ def report(name, M, N, K, fn):
 
 
 only = sys.argv[1] if len(sys.argv) > 1 else ""
-for (M, N, K) in ((524288, 256, 512), (131072, 512, 512), (16384, 2048, 1028), (262144, 256, 512)):
+shapes = ((524288, 256, 512), (131072, 512, 512), (16384, 2048, 1028), (262144, 256, 512)) if 'stacked' not in only else ((16384, 2048, 1028), (16384, 2048, 8), (16384, 512, 512), (131072, 256, 512), (65536, 256, 512))
+for (M, N, K) in shapes:
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
     pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
     bias = torch.randn(N, device=dev)
@@ -40,7 +41,8 @@ for (M, N, K) in ((524288, 256, 512), (131072, 512, 512), (16384, 2048, 1028), (
         report("dX +relu mask +BN sums (mode 1)", M, K, N, lambda: gemm(dZ, W, b_t=False, bwd=(1, Zs, ea, ec, em, ei)))
         report("dX +leaky mask (mode 2)", M, K, N, lambda: gemm(dZ, W, b_t=False, bwd=(2, Zs)))
     if "dw" in only or not only:
-        for sk in (32, 64, 128):
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        for sk in sorted({8, 16, 24, 32, 48, 64, 96, 128}):
             report("dW split_k=%d" % sk, N, K, M, lambda: gemm(dZ, A, a_t=True, b_t=False, split_k=sk))
         report("dW split_k=64 +BN/ReLU on B", N, K, M, lambda: gemm(dZ, A, a_t=True, b_t=False, split_k=64, prob=(pa, pc)))
     del A, W, dZ, Zs
