@@ -89,8 +89,12 @@ class CMFlow(nn.Module):
         """Same computation in point-major layout; returns prop_features as (B,256,N)."""
         x1, x2 = pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous()       # (B,N,3)
         a1, a2 = feature1.transpose(1, 2).contiguous(), feature2.transpose(1, 2).contiguous()
-        f1 = self.mse_layer.forward_pm(x1, a1)                                             # (B,N,256)
-        f2 = self.mse_layer.forward_pm(x2, a2)
+        if self.path == "pm":                                   # one zero column: rows of 4 floats for the stacked first-conv GEMM
+            f1 = self.mse_layer.forward_pm(x1, torch.nn.functional.pad(a1, (0, 1)))        # (B,N,256)
+            f2 = self.mse_layer.forward_pm(x2, torch.nn.functional.pad(a2, (0, 1)))
+        else:
+            f1 = self.mse_layer.forward_pm(x1, a1)
+            f2 = self.mse_layer.forward_pm(x2, a2)
         f1 = torch.cat((f1, f1.max(dim=1, keepdim=True)[0].expand(-1, f1.shape[1], -1)), dim=2)
         f2 = torch.cat((f2, f2.max(dim=1, keepdim=True)[0].expand(-1, f2.shape[1], -1)), dim=2)
         cor = self.fc_layer.forward_pm(x1, x2, f1, f2)                                     # (B,N,512)

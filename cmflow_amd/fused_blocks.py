@@ -281,6 +281,65 @@ class LinearFn(Function):
         return dx, dw, db, None, None
 
 
+class StackedFirstConvFn(Function):
+    """y_all = feats @ [W_f of every scale stacked]^T -- the feature half of the hoisted first convs of a
+    MultiScaleEncoder (radarflow_util.py:132-139 by linearity) as one GEMM, with the weight bookkeeping done here
+    instead of by autograd over cat / slice / pad:
+      * feats (M, Kp) may carry the original feature channels in the order [tail | head] -> [head, tail, zero pad]
+        (n_tail leading channels moved behind the rest and Kp a multiple of 16): the input gradient is then only
+        computed for the first Kp_grad columns (the moved channels are raw inputs, e.g. v_r / RCS, and need none),
+        which makes the data-gradient GEMM N = 1024 wide instead of 1028 (9 -> 8 column tiles);
+      * the weight gradient (n*O1, Kp) is added straight into the conv weights' .grad when they exist."""
+
+    @staticmethod
+    def forward(ctx, feats, n_tail, n_grad, *weights):
+        M, Kp = feats.shape
+        with torch.no_grad():
+            parts = []
+            for w in weights:
+                w2 = w.view(w.shape[0], w.shape[1])[:, 3:]                       # feature columns (xyz columns first)
+                parts.append(torch.cat((w2[:, n_tail:], w2[:, :n_tail]), dim=1) if n_tail else w2)
+            wf = torch.cat(parts, dim=0)
+            if wf.shape[1] < Kp:
+                wf = torch.nn.functional.pad(wf, (0, Kp - wf.shape[1]))
+        y = gemm(feats, wf)
+        ctx.save_for_backward(feats, wf)
+        ctx.n_tail, ctx.n_grad, ctx.weights = n_tail, n_grad, weights
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        feats, wf = ctx.saved_tensors
+        M, Kp = feats.shape
+        dy = dy.contiguous()
+        dfeats = None
+        if ctx.needs_input_grad[0]:
+            ng = ctx.n_grad if ctx.n_grad else Kp
+            dfeats = torch.empty(M, Kp, dtype=_f32, device=dy.device)          # columns >= ng: raw input channels, never read
+            gemm(dy, wf[:, :ng], b_t=False, out=dfeats[:, :ng])
+        dwf = gemm_dw(dy, feats)                                                 # (n*O1, Kp)
+        grads, r0 = [], 0
+        for w in ctx.weights:
+            o, cin = w.shape[0], w.shape[1] - 3
+            blk = dwf[r0:r0 + o]
+            r0 += o
+            head, tail = blk[:, :cin - ctx.n_tail], blk[:, cin - ctx.n_tail:cin]
+            g = w.grad if (w.is_leaf and w.grad is not None) else None
+            if g is not None:
+                g2 = g.view(o, cin + 3)
+                g2[:, 3 + ctx.n_tail:] += head
+                if ctx.n_tail:
+                    g2[:, 3:3 + ctx.n_tail] += tail
+                grads.append(None)
+            else:
+                full = torch.zeros(o, cin + 3, dtype=_f32, device=dy.device)
+                full[:, 3 + ctx.n_tail:] = head
+                if ctx.n_tail:
+                    full[:, 3:3 + ctx.n_tail] = tail
+                grads.append(full.view_as(w))
+        return (dfeats, None, None, *grads)
+
+
 def _pad_k(t):
     """Copy a 2-D tensor into a buffer whose row stride is a multiple of 4 floats (zero padded); returns the
     (rows, K) view of it."""

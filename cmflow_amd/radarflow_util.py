@@ -102,10 +102,20 @@ class MultiScaleEncoder(nn.Module):
     def forward(self, xyz, features):
         return torch.cat([sa(xyz, features) for sa in self.ms_ls], dim=1)
 
-    def forward_pm(self, xyz_t, feats):
+    def forward_pm(self, xyz_t, feats, n_tail=0, n_grad=0):
         """Point-major: xyz_t (B,N,3), feats (B,N,C) -> (B,N,4*64).  The feature half of the four
-        scales' first convs is ONE GEMM over the shared input (W_f of all scales stacked)."""
+        scales' first convs is ONE GEMM over the shared input (W_f of all scales stacked).
+        n_tail / n_grad (fused path only): feats holds the module's input channels as [head, first n_tail channels,
+        zero pad] and only its first n_grad columns need a gradient (fused_blocks.StackedFirstConvFn)."""
         o1 = self.ms_ls[0].mlp_convs[0].weight.shape[0]
+        if self.use_blocks and self.multi_stream and FB.USE_BLOCK_CALLS and self.threaded_enqueue and feats.shape[2] % 4 == 0:
+            B, N, Kp = feats.shape
+            y_all = FB.StackedFirstConvFn.apply(feats.reshape(B * N, Kp), n_tail, n_grad,
+                                                *[sa.mlp_convs[0].weight for sa in self.ms_ls]).view(B, N, -1)
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+            return FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz_t, y_all)
+        assert n_tail == 0
         wf_all = torch.cat([w2d(sa.mlp_convs[0])[:, 3:] for sa in self.ms_ls], dim=0)
         if not self.use_blocks:
             y_all = F.linear(feats, wf_all)                               # (B,N,4*o1)
