@@ -89,7 +89,12 @@ class CMFlow(nn.Module):
         """Same computation in point-major layout; returns prop_features as (B,256,N)."""
         x1, x2 = pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous()       # (B,N,3)
         a1, a2 = feature1.transpose(1, 2).contiguous(), feature2.transpose(1, 2).contiguous()
-        if self.path == "pm":                                   # one zero column: rows of 4 floats for the stacked first-conv GEMM
+        if self.path == "pm" and not self.mse_layer.training and x1.shape == x2.shape:
+            # eval-mode BN has no batch statistics: the two clouds share one call of the (weight-shared) encoder
+            B = x1.shape[0]
+            f12 = self.mse_layer.forward_pm(torch.cat((x1, x2), dim=0), torch.nn.functional.pad(torch.cat((a1, a2), dim=0), (0, 1)))
+            f1, f2 = f12[:B], f12[B:]
+        elif self.path == "pm":                                 # one zero column: rows of 4 floats for the stacked first-conv GEMM
             f1 = self.mse_layer.forward_pm(x1, torch.nn.functional.pad(a1, (0, 1)))        # (B,N,256)
             f2 = self.mse_layer.forward_pm(x2, torch.nn.functional.pad(a2, (0, 1)))
         else:
