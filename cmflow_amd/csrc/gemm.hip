@@ -19,6 +19,7 @@
 //   (blockIdx -> XCD is round-robin), so the panel is fetched from HBM once and re-read from L2.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -83,7 +84,26 @@ __device__ __forceinline__ void g_pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
 
 // A_T: A stored [K][M] (contraction-major) instead of [M][K].  B_T: B stored [N][K] (i.e. W[out][in],
 // the forward layout) instead of [K][N].
-template <int BM, int BN, bool A_T, bool B_T>
+// EMUL (experimental, opt-in via CMF_GEMM_MODE=bf16x3; never the default): the interior-tile main loop evaluates the
+// fp32 product on the bf16 matrix cores.  Every fp32 operand is split exactly into three bf16 pieces
+// (x = hi + mid + lo, 8 + 8 + 8 significand bits) and a chunk of 16 k becomes six v_mfma_f32_32x32x16_bf16
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the three dropped terms are below 2^-26 |a||b|), accumulated in
+// fp32 -- fp32-grade results at 16x the per-instruction rate of v_mfma_f32_32x32x2_f32.
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void g_split3(const f32x4 a, const f32x4 b, g_bf16x8 &hi, g_bf16x8 &mid, g_bf16x8 &lo)
+{
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        const float r1 = x[i] - (float)h;                 // exact
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;                   // exact, <= 8 significant bits left
+        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
+    }
+}
+
+template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0>
 __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             for (int j = 0; j < TN; ++j) g_pin(bf[w][j]);
             if (proA) { g_pin(pa4[w]); g_pin(pc4[w]); }
         };
-        auto mfma_step = [&](int w) {
+        auto prologue_step = [&](int w) {
             if (proA) {                                                         // fused BN + ReLU of the producer layer
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -386,6 +406,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                     bf[w][j].z = fmaxf(fmaf(qa[j], bf[w][j].z, qc[j]), 0.f); bf[w][j].w = fmaxf(fmaf(qa[j], bf[w][j].w, qc[j]), 0.f);
                 }
             }
+        };
+        auto mfma_step = [&](int w) {
+            prologue_step(w);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -400,12 +423,37 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         for (int c = 0; c < nch; ++c) {
             if (c + 2 < nch) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);       // (st + 2) % 3
             const float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
+            if (EMUL) {
+                read_frags(sa, sb, sp, 0, 0);
+                read_frags(sa, sb, sp, 8, 1);
+                g_lds_wait(); pin_frags(0); pin_frags(1);
+                prologue_step(0); prologue_step(1);
+                // a lane's two 4-k groups (k8 = 0 and 8) are exactly the 8 consecutive operands of ONE 32x32x16 MFMA
+                g_bf16x8 bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) g_split3(bf[0][j], bf[1][j], bh[j], bm[j], bl[j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    g_bf16x8 ah, am, al;
+                    g_split3(af[0][i], af[1][i], ah, am, al);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            } else {
             read_frags(sa, sb, sp, 0, 0);
             g_lds_wait(); pin_frags(0);
             read_frags(sa, sb, sp, 8, 1);                                       // in flight under the first 16 MFMAs
             mfma_step(0);
             g_lds_wait(); pin_frags(1);
             mfma_step(1);
+            }
             if (c + 1 < nch) wait_prev(c + 2 < nch);                            // chunk c+1 has landed (this wave's part)
             __builtin_amdgcn_s_barrier();                                       // ... and everybody else's; stage st is free again
             st = st == 2 ? 0 : st + 1;
@@ -609,7 +657,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(long long total, int
     }
 }
 
-template <int BM, int BN, bool A_T, bool B_T>
+template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0>
 static int launch(const GemmArgs &a, hipStream_t st)
 {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -619,9 +667,9 @@ static int launch(const GemmArgs &a, hipStream_t st)
     const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + 32) * sizeof(float);
     const size_t lds = lds_reg > lds_dir ? lds_reg : lds_dir;
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T>,
+    if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EMUL>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T>), grid, dim3(G_THREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL>), grid, dim3(G_THREADS), lds, st, a);
     return cmf_launch_status();
 }
 
@@ -656,8 +704,10 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     if (err > 0) return err;
     const bool thin_done = (err == 0);
     const bool wide = N > 64, tall = M > 64;
+    static const bool emul = getenv("CMF_GEMM_MODE") && !strcmp(getenv("CMF_GEMM_MODE"), "bf16x3");       // experimental, opt-in
 #define CMF_PICK(AT, BT)                                                                                   \
-    (tall ? (wide ? launch<128, 128, AT, BT>(g, st) : launch<128, 64, AT, BT>(g, st))                      \
+    (tall ? (wide ? (emul ? launch<128, 128, AT, BT, 1>(g, st) : launch<128, 128, AT, BT>(g, st))          \
+                  : launch<128, 64, AT, BT>(g, st))                                                        \
           : (wide ? launch<64, 128, AT, BT>(g, st) : launch<64, 64, AT, BT>(g, st)))
     if (thin_done)         err = 0;
     else if (!a_t && b_t)  err = CMF_PICK(false, true);

@@ -3,9 +3,13 @@
 Floating-point kernel => tolerance, stated per check: fp32 MFMA is an exact fmaf chain, the only
 difference to torch is summation order: |err| <= 2e-6 * sum|a*b| (checked against an fp64 product).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -182,3 +186,43 @@ def test_thin_gemm_weight_gradient(dev, M, N, K):
     dW = gemm_dw(dZ, Zp, prob=(ea, ec))
     _check(dW, dZ.double().t() @ X.double(), dZ.double().abs().t() @ X.double().abs(), tol=4e-6)
     assert torch.equal(dW, gemm_dw(dZ, Zp, prob=(ea, ec)))            # deterministic
+
+
+def test_bf16x3_emulation_is_fp32_grade(dev):
+    """The opt-in main loop on the bf16 matrix cores (CMF_GEMM_MODE=bf16x3): exact 3-way split of
+    every fp32 operand, six bf16 MFMAs per 16 k.  Its error against an fp64 product must sit in the same bound as the
+    fp32 MFMA path's.  The mode is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = r'''
+import torch, sys
+sys.path.insert(0, %r)
+from cmflow_amd.fused import gemm
+from cmflow_amd.fused_blocks import gemm_dw
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+worst = 0.0
+for (M, N, K) in ((4096, 256, 512), (8192, 512, 256), (2048, 384, 1040)):
+    A = torch.randn(M, K, device=dev) * torch.logspace(-3, 3, K, device=dev)       # wide dynamic range across k
+    W = torch.randn(N, K, device=dev)
+    ref = A.double() @ W.double().t()
+    bound = A.double().abs() @ W.double().abs().t()
+    err = ((gemm(A, W).double() - ref).abs() / bound).max().item()
+    dZ = torch.randn(M, N, device=dev)
+    refx = dZ.double() @ W.double()
+    errx = ((gemm(dZ, W, b_t=False).double() - refx).abs() / (dZ.double().abs() @ W.double().abs())).max().item()
+    refw = dZ.double().t() @ A.double()
+    errw = ((gemm_dw(dZ, A).double() - refw).abs() / (dZ.double().abs().t() @ A.double().abs())).max().item()
+    worst = max(worst, err, errx, errw)
+print("WORST", worst)
+''' % REPO
+    env = dict(os.environ)
+    out = {}
+    for mode in ("bf16x3", "f32"):
+        env["CMF_GEMM_MODE"] = mode
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mode] = float(r.stdout.strip().split("WORST")[-1])
+    print("max |err| / (|A||B|): fp32 MFMA %.3g, bf16x3 %.3g" % (out["f32"], out["bf16x3"]))
+    assert out["f32"] < 2e-6 and out["bf16x3"] < 2e-6
+    assert out["bf16x3"] < 4 * out["f32"] + 1e-7
