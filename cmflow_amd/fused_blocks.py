@@ -643,7 +643,8 @@ class EncoderPlan:
             self.n_saved.append(ns.value); self.n_fwd.append(nf.value); self.n_bwd.append(nb.value)
             self.params.append(params); self.bns.append(bns)
         self.co = self.params[0][15].shape[0]
-        self.check_ptrs = [p[15].data_ptr() for p in self.params] + [p[0].data_ptr() for p in self.params]
+        self.modules = list(modules)
+        self.check_ptrs = self._live_ptrs()
         al = lambda v: (v + 63) // 64 * 64                          # keep every arena 256-byte aligned
         self.off_saved = [0]
         for v in self.n_saved:
@@ -654,9 +655,18 @@ class EncoderPlan:
         for v in self.n_bwd:
             self.off_bwd.append(self.off_bwd[-1] + al(v))
 
+    def _live_ptrs(self):
+        """Storage of representative tensors as the MODULES hold them now (the views kept in self.params would keep a
+        replaced storage alive and never change): first / last conv weight, first BN weight, last BN running mean."""
+        out = []
+        for m in self.modules:
+            out += [m.mlp_convs[0].weight.data_ptr(), m.mlp2_convs[-1].weight.data_ptr(), m.mlp_bns[0].weight.data_ptr(),
+                    m.mlp2_bns[-1].running_mean.data_ptr()]
+        return out
+
     def valid(self):
-        """Parameters are updated in place by optimizers and load_state_dict; .to()/.float() re-allocate them."""
-        return self.check_ptrs == [p[15].data_ptr() for p in self.params] + [p[0].data_ptr() for p in self.params]
+        """Parameters are updated in place by optimizers and load_state_dict; .to()/.float()/.data = ... re-allocate them."""
+        return self.check_ptrs == self._live_ptrs()
 
     def sinks_ready(self):
         """All parameter gradients can be accumulated in place (TrainStep's flat bucket).  The sink pointers are

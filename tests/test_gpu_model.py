@@ -264,3 +264,33 @@ def test_single_rank_rccl_all_reduce(dev, manifest, golden_dir, args):
         assert torch.equal(before, bucket.flat) and float(before.abs().sum()) > 0
     finally:
         dist.destroy_process_group()
+
+
+def test_encoder_plan_follows_parameter_reallocation_and_guards_grad_sinks(dev, manifest, golden_dir, args):
+    """The cached call plan of an encoder (fused_blocks.EncoderPlan) holds raw parameter pointers: it must notice when
+    the parameters are re-allocated, and the in-place gradient sinks must refuse to run once the .grad buffers they
+    point at are gone."""
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.train import TrainStep
+    net = CMFlow(args)
+    net.load_state_dict(_weights(manifest, golden_dir))
+    net = net.to(dev).train()
+    step = TrainStep(net, vr_thres=args.vr_thres)
+    b = {k: v.to(dev) for k, v in synth.make_batch(4, seed=5, train_extras=True).items()}
+    loss0, _, _, _ = step.forward_loss(b)
+    assert net.mse_layer2._plans, "the fused path did not build a call plan"
+    # re-allocate every parameter (what .to()/.half().float() do): same values, new storage
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    for p in net.parameters():
+        p.data = p.data.clone()
+    step2 = TrainStep(net, vr_thres=args.vr_thres)                 # fresh gradient bucket over the new storage
+    net.load_state_dict(sd)
+    loss1, _, _, _ = step2.forward_loss(b)
+    # BN running statistics moved by the first forward, batch statistics did not: train-mode outputs are identical
+    assert abs(loss0.item() - loss1.item()) < 1e-5 * max(1.0, abs(loss0.item()))
+    # sinks: dropping the .grad buffers between forward and backward must raise, not write through stale pointers
+    loss2, _, _, _ = step2.forward_loss(b)
+    for p in net.parameters():
+        p.grad = None
+    with pytest.raises(RuntimeError):
+        loss2.backward()
