@@ -661,7 +661,8 @@ class EncoderPlan:
         out = []
         for m in self.modules:
             out += [m.mlp_convs[0].weight.data_ptr(), m.mlp2_convs[-1].weight.data_ptr(), m.mlp_bns[0].weight.data_ptr(),
-                    m.mlp2_bns[-1].running_mean.data_ptr()]
+                    m.mlp2_bns[-1].running_mean.data_ptr(), m.mlp_bns[0].momentum, m.mlp_bns[0].eps,
+                    m.mlp2_bns[-1].momentum, m.radius, m.nsample]
         return out
 
     def valid(self):
