@@ -33,6 +33,8 @@ SIGNATURES = {
     "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
     "cmf_setconv_forward": [_vp, _vp],
     "cmf_setconv_backward": [_vp, _vp],
+    "cmf_setconv_bn_offsets": [_vp, _vp],
+    "cmf_bn_running_update": [_ci, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_forward_multi": [_ci, _vp, _vp],
     "cmf_setconv_backward_multi": [_ci, _vp, _vp],
     "cmf_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
@@ -73,6 +75,12 @@ class SetConvDesc(ctypes.Structure):
                 ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
                 ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("lddy", _ll), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
                 ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6)]
+
+
+class BnUpdateEntry(ctypes.Structure):
+    """cmf_bn_update_entry of include/cmflow_hip.h"""
+    _fields_ = [("rmean", _vp), ("rvar", _vp), ("nbt", _vp), ("C", _ci), ("momentum", _cf), ("eps", _cf),
+                ("count", ctypes.c_double), ("offset", _ll)]
 
 
 class RadarLossDesc(ctypes.Structure):

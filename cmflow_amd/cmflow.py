@@ -95,8 +95,8 @@ class CMFlow(nn.Module):
             f12 = self.mse_layer.forward_pm(torch.cat((x1, x2), dim=0), torch.nn.functional.pad(torch.cat((a1, a2), dim=0), (0, 1)))
             f1, f2 = f12[:B], f12[B:]
         elif self.path == "pm":                                 # one zero column: rows of 4 floats for the stacked first-conv GEMM
-            f1 = self.mse_layer.forward_pm(x1, torch.nn.functional.pad(a1, (0, 1)))        # (B,N,256)
-            f2 = self.mse_layer.forward_pm(x2, torch.nn.functional.pad(a2, (0, 1)))
+            f1, f2 = self.mse_layer.forward_pm_pair(x1, torch.nn.functional.pad(a1, (0, 1)),
+                                                    x2, torch.nn.functional.pad(a2, (0, 1)))   # (B,N,256) each
         else:
             f1 = self.mse_layer.forward_pm(x1, a1)
             f2 = self.mse_layer.forward_pm(x2, a2)

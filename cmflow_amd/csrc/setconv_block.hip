@@ -298,3 +298,46 @@ extern "C" int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, 
 {
     return setconv_multi(n, descs, streams, true);
 }
+
+// Float offsets of the per-layer BatchNorm blocks (mean | invstd | a | c, 4*C_l floats each) inside `saved`.
+extern "C" int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6)
+{
+    CMF_CHECK_ARG(d && offsets6);
+    const Layout L = make_layout(d, nullptr, nullptr, false);
+    for (int l = 0; l < 6; ++l) offsets6[l] = (long long)(L.bn[l] - (float *)nullptr);
+    return 0;
+}
+
+// Deferred running-statistics update for encoder calls that ran concurrently (two clouds through the same weight-shared
+// encoder, radarflow_util.py:111-118 called twice per step, cmflow.py:72-73): the block calls were issued with
+// rmean == NULL (batch statistics only) and the nn.BatchNorm2d momentum update is applied here once per call, in call
+// order, from the saved batch mean / invstd of each call.  One workgroup per table entry (= one BN layer of one scale).
+__global__ __launch_bounds__(64) void bn_running_update_kernel(const cmf_bn_update_entry *__restrict__ table, int n_calls,
+                                                              const float *__restrict__ saved0, const float *__restrict__ saved1)
+{
+    const cmf_bn_update_entry e = table[blockIdx.x];
+    const double mo = e.momentum, cnt = e.count;
+    for (int c = threadIdx.x; c < e.C; c += 64) {
+        double rm = e.rmean[c], rv = e.rvar[c];
+        for (int k = 0; k < n_calls; ++k) {
+            const float *s = (k == 0 ? saved0 : saved1) + e.offset;
+            const double mean = s[c], invstd = s[e.C + c];
+            double var = 1.0 / (invstd * invstd) - (double)e.eps;
+            if (var < 0.0) var = 0.0;
+            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            rm = (1.0 - mo) * rm + mo * mean;
+            rv = (1.0 - mo) * rv + mo * unbiased;
+        }
+        e.rmean[c] = (float)rm; e.rvar[c] = (float)rv;
+    }
+    if (threadIdx.x == 0 && e.nbt) *e.nbt += n_calls;
+}
+
+extern "C" int cmf_bn_running_update(int n_entries, const cmf_bn_update_entry *table, int n_calls, const float *saved0,
+                                     const float *saved1, void *stream)
+{
+    CMF_CHECK_ARG(n_entries >= 0 && n_calls >= 1 && n_calls <= 2 && (n_entries == 0 || (table && saved0 && (n_calls == 1 || saved1))));
+    if (n_entries == 0) return 0;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(n_entries), dim3(64), 0, (hipStream_t)stream, table, n_calls, saved0, saved1);
+    return cmf_launch_status();
+}

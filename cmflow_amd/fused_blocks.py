@@ -612,14 +612,22 @@ class EncoderPlan:
     then only sets the per-call pointers (xyz, y, saved, scratch, out) -- the Python work per encoder call drops
     from ~0.5 ms to a few tens of microseconds, which at N = 256 is what the GPU was waiting for."""
 
-    def __init__(self, modules, B, N, O1, training, device):
+    def __init__(self, modules, B, N, O1, training, device, clouds=1):
+        """clouds == 2: two calls of the (weight-shared) encoder issued CONCURRENTLY -- descriptors [0, ns) are the
+        first call, [ns, 2 ns) the second.  Their BN running-statistics updates are deferred (cmf_bn_running_update,
+        in call order) and the second call writes its parameter gradients to scratch tensors that are added to the
+        sinks afterwards (two kernels accumulating into one buffer from different streams would race)."""
         import ctypes
-        self.n = n = len(modules)
-        self.key = (B, N, O1, bool(training), str(device))
+        ns = len(modules)
+        self.ns, self.clouds = ns, clouds
+        self.n = n = ns * clouds
+        self.key = (B, N, O1, bool(training), str(device), clouds)
         self.descs = (_lib.SetConvDesc * n)()
         self.keep, self.params, self.bns = [], [], []
         self.n_saved, self.n_fwd, self.n_bwd = [], [], []
-        for i, m in enumerate(modules):
+        defer = clouds > 1 and training
+        for i in range(n):
+            m = modules[i % ns]
             params, bns = set_conv_params(m)
             d = self.descs[i]
             wx = params[0]
@@ -633,17 +641,39 @@ class EncoderPlan:
                 assert bn.momentum is not None, "cumulative moving average BN is not supported by the block call"
                 d.eps[l], d.momentum[l] = bn.eps, bn.momentum
                 d.gamma[l], d.beta[l] = bn.weight.data_ptr(), bn.bias.data_ptr()
-                d.rmean[l], d.rvar[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-                d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats) else None
+                d.rmean[l], d.rvar[l] = (None, None) if defer else (bn.running_mean.data_ptr(), bn.running_var.data_ptr())
+                d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats and not defer) else None
             d.wx, d.ldwx = wx.data_ptr(), wx.stride(0)
-            d.ldy = n * O1                                          # y is a column slice of the stacked (B,N,n*O1) GEMM output
-            ns, nf, nb = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
-            _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), ctypes.addressof(ns), ctypes.addressof(nf),
-                                             ctypes.addressof(nb)), "cmf_setconv_sizes")
-            self.n_saved.append(ns.value); self.n_fwd.append(nf.value); self.n_bwd.append(nb.value)
+            d.ldy = ns * O1                                         # y is a column slice of the stacked (B,N,ns*O1) GEMM output
+            c_s, c_f, c_b = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+            _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), ctypes.addressof(c_s), ctypes.addressof(c_f),
+                                             ctypes.addressof(c_b)), "cmf_setconv_sizes")
+            self.n_saved.append(c_s.value); self.n_fwd.append(c_f.value); self.n_bwd.append(c_b.value)
             self.params.append(params); self.bns.append(bns)
         self.co = self.params[0][15].shape[0]
         self.modules = list(modules)
+        self.update_table, self.temps = None, None
+        if defer:                                                   # one table entry per (scale, BN layer)
+            entries = (_lib.BnUpdateEntry * (ns * 6))()
+            offs = (ctypes.c_longlong * 6)()
+            base = 0
+            for i in range(ns):
+                _lib.check(L().cmf_setconv_bn_offsets(ctypes.addressof(self.descs[i]), ctypes.addressof(offs)), "cmf_setconv_bn_offsets")
+                for l, bn in enumerate(self.bns[i]):
+                    e = entries[i * 6 + l]
+                    e.rmean, e.rvar = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                    e.nbt = bn.num_batches_tracked.data_ptr() if bn.track_running_stats else None
+                    e.C, e.momentum, e.eps = bn.num_features, bn.momentum, bn.eps
+                    e.count = float(B * N * (modules[i].nsample if l < 3 else 1))
+                    e.offset = base + offs[l]
+                base += (self.n_saved[i] + 63) // 64 * 64          # same rounding as off_saved below
+            raw = bytes(entries)
+            self.update_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+            self.n_update = ns * 6
+            # gradient scratch of the second call, one tensor per parameter (views for the conv weights)
+            # (the xyz columns of the first conv are written into a full-size, zero-initialised weight-shaped tensor)
+            self.temps = [[torch.zeros_like(t._base) if j == 0 else torch.empty_like(t) for j, t in enumerate(p)]
+                          for p in self.params[:ns]]
         self.check_ptrs = self._live_ptrs()
         al = lambda v: (v + 63) // 64 * 64                          # keep every arena 256-byte aligned
         self.off_saved = [0]
@@ -654,6 +684,7 @@ class EncoderPlan:
             self.off_fwd.append(self.off_fwd[-1] + al(v))
         for v in self.n_bwd:
             self.off_bwd.append(self.off_bwd[-1] + al(v))
+        self.saved_per_cloud = self.off_saved[ns]                   # floats: the second call's arena starts here
 
     def _live_ptrs(self):
         """Storage of representative tensors as the MODULES hold them now (the views kept in self.params would keep a
@@ -683,17 +714,24 @@ class EncoderPlan:
                 probe.append(g.data_ptr())
         if getattr(self, "_sink_probe", None) == probe:
             return True
-        for d, params in zip(self.descs, self.params):
+        self.sink_list, self.temp_list = [], []
+        for i, (d, params) in enumerate(zip(self.descs, self.params)):
             wsink = self._wx_sink(params[0])
             sinks = [grad_sink(t) for t in params[1:]]
             if wsink is None or any(x is None for x in sinks):
                 self._sink_probe = None
                 return False
-            d.dwx, d.lddwx, d.acc_wx = wsink.data_ptr(), params[0].stride(0), 1
+            acc = 1
+            if i >= self.ns:                                        # second call: write to scratch, added to the sinks afterwards
+                tmp = self.temps[i - self.ns]
+                self.sink_list += [wsink] + sinks
+                self.temp_list += tmp
+                wsink, sinks, acc = tmp[0], tmp[1:], 0
+            d.dwx, d.lddwx, d.acc_wx = wsink.data_ptr(), params[0].stride(0), acc
             for j in range(5):
-                d.dw[j], d.acc_w[j] = sinks[2 + 3 * j].data_ptr(), 1
+                d.dw[j], d.acc_w[j] = sinks[2 + 3 * j].data_ptr(), acc
             for l in range(6):
-                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sinks[3 * l].data_ptr(), sinks[3 * l + 1].data_ptr(), 1
+                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sinks[3 * l].data_ptr(), sinks[3 * l + 1].data_ptr(), acc
         self._sink_probe = probe
         return True
 
@@ -802,6 +840,100 @@ class MultiScaleBlockFn(Function):
         return (None, dy_all, None, None, None, *(() if ctx.sink_mode else grads))
 
 
+class DualCloudBlockFn(Function):
+    """Both calls of a weight-shared encoder (cmflow.py:72-73: mse_layer(pc1), mse_layer(pc2)) as ONE autograd node:
+    2 x 4 scale chains on eight streams / host threads at once.  At N = 256 these chains are made of 5-40 us kernels on
+    a fraction of the chip; doubling the number of concurrent chains is free.  What made the two calls order-dependent
+    is handled outside the kernels: BN running statistics are updated afterwards in call order
+    (cmf_bn_running_update), and the second call's parameter gradients go to scratch tensors that are added to the
+    sinks in one multi-tensor add.  Training with in-place gradient sinks only (EncoderPlan clouds=2)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, y1, xyz2, y2, plan, streams):
+        import ctypes
+        B, N, _ = xyz1.shape
+        n, ns, co, dev = plan.n, plan.ns, plan.co, xyz1.device
+        xyz = (xyz1.contiguous(), xyz2.contiguous())
+        ys = (y1, y2)
+        o1 = plan.descs[0].O1
+        assert y1.is_contiguous() and y2.is_contiguous() and y1.shape[2] == ns * o1
+        main = torch.cuda.current_stream()
+        outs = [torch.empty(B * N, ns * co, dtype=_f32, device=dev) for _ in range(2)]
+        saved = torch.empty(2 * plan.saved_per_cloud, dtype=_f32, device=dev)
+        scratch = torch.empty(plan.off_fwd[-1], dtype=_f32, device=dev)
+        for i in range(n):
+            c, sc = divmod(i, ns)
+            d = plan.descs[i]
+            d.xyz, d.y = xyz[c].data_ptr(), ys[c].data_ptr() + 4 * sc * o1
+            d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_fwd[i]
+            d.out, d.ldo = outs[c].data_ptr() + 4 * sc * co, ns * co
+        sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
+        for st in streams:
+            st.wait_stream(main)
+        _lib.check(L().cmf_setconv_forward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_forward_multi")
+        for st in streams:
+            main.wait_stream(st)
+        if plan.update_table is not None:                           # running statistics: first call, then second call
+            _lib.check(L().cmf_bn_running_update(plan.n_update, plan.update_table.data_ptr(), 2, saved.data_ptr(),
+                                                 saved.data_ptr() + 4 * plan.saved_per_cloud, _lib.stream_ptr()),
+                       "cmf_bn_running_update")
+        ctx.plan, ctx.keep, ctx.streams = plan, (xyz, ys, saved), streams
+        return outs[0].view(B, N, ns * co), outs[1].view(B, N, ns * co)
+
+    @staticmethod
+    def backward(ctx, dout1, dout2):
+        import ctypes
+        plan, (xyz, ys, saved), streams = ctx.plan, ctx.keep, ctx.streams
+        n, ns, co = plan.n, plan.ns, plan.co
+        B, N, o1 = plan.descs[0].B, plan.descs[0].N, plan.descs[0].O1
+        dev = dout1.device
+        douts = []
+        for g in (dout1, dout2):
+            g = g.reshape(B * N, ns * co)
+            douts.append(g if (g.stride(1) == 1 and g.stride(0) % 4 == 0) else g.contiguous())
+        if not plan.sinks_ready():
+            raise RuntimeError("parameter .grad buffers disappeared between forward and backward")
+        main = torch.cuda.current_stream()
+        scratch = torch.empty(plan.off_bwd[-1], dtype=_f32, device=dev)
+        need = (ctx.needs_input_grad[1], ctx.needs_input_grad[3])
+        dys = [torch.empty(B, N, ns * o1, dtype=_f32, device=dev) if need[c] else None for c in range(2)]
+        for i in range(n):
+            c, sc = divmod(i, ns)
+            d = plan.descs[i]
+            d.xyz, d.y = xyz[c].data_ptr(), ys[c].data_ptr() + 4 * sc * o1
+            d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_bwd[i]
+            d.dout, d.lddout = douts[c].data_ptr() + 4 * sc * co, douts[c].stride(0)
+            d.dy, d.lddy = (dys[c].data_ptr() + 4 * sc * o1, ns * o1) if need[c] else (None, 0)
+        sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
+        for st in streams:
+            st.wait_stream(main)
+        _lib.check(L().cmf_setconv_backward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_backward_multi")
+        for st in streams:
+            main.wait_stream(st)
+        torch._foreach_add_(plan.sink_list, plan.temp_list)         # the second call's parameter gradients
+        return None, dys[0], None, dys[1], None, None
+
+
+def dual_cloud_set_conv(encoder, modules, streams, xyz1, y1, xyz2, y2):
+    """Both clouds through the weight-shared encoder concurrently; None when the preconditions (training, in-place
+    gradient sinks, equal shapes) do not hold and the caller should issue the two calls one after the other."""
+    if not torch.is_grad_enabled() or xyz1.shape != xyz2.shape or y1.shape != y2.shape:
+        return None
+    B, N, _ = xyz1.shape
+    o1 = y1.shape[2] // len(modules)
+    training = modules[0].mlp_bns[0].training
+    if not training:
+        return None
+    key = (B, N, o1, True, str(xyz1.device), 2)
+    plans = encoder.__dict__.setdefault("_plans", {})
+    plan = plans.get(key)
+    if plan is None or not plan.valid():
+        plan = plans[key] = EncoderPlan(modules, B, N, o1, True, xyz1.device, clouds=2)
+    if not plan.sinks_ready():
+        return None
+    return DualCloudBlockFn.apply(xyz1, y1.contiguous(), xyz2, y2.contiguous(), plan, streams)
+
+
 def set_conv_params(module):
     w2d = lambda conv: conv.weight.view(conv.weight.shape[0], conv.weight.shape[1])
     c, b = module.mlp_convs, module.mlp_bns
@@ -816,7 +948,7 @@ def multi_scale_set_conv(encoder, modules, streams, xyz_t, y_all):
     B, N, _ = xyz_t.shape
     o1 = y_all.shape[2] // len(modules)
     training = modules[0].mlp_bns[0].training
-    key = (B, N, o1, bool(training), str(xyz_t.device))
+    key = (B, N, o1, bool(training), str(xyz_t.device), 1)
     plans = encoder.__dict__.setdefault("_plans", {})
     plan = plans.get(key)
     if plan is None or not plan.valid():

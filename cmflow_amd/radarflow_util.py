@@ -149,8 +149,31 @@ class MultiScaleEncoder(nn.Module):
         return torch.cat(outs, dim=2)
 
     threaded_enqueue = True
+    def forward_pm_pair(self, xyz1_t, feats1, xyz2_t, feats2):
+        """Two calls of this (weight-shared) encoder -- forward_pm(xyz1_t, feats1), forward_pm(xyz2_t, feats2) in this
+        order as far as BN running statistics go -- issued concurrently when that is possible (fused path, training with
+        in-place gradient sinks: fused_blocks.DualCloudBlockFn)."""
+        fused = self.use_blocks and self.multi_stream and FB.USE_BLOCK_CALLS and self.threaded_enqueue and \
+            feats1.shape[2] % 4 == 0 and feats1.shape == feats2.shape
+        if fused and self.training:
+            ws = [sa.mlp_convs[0].weight for sa in self.ms_ls]
+            B, N, Kp = feats1.shape
+            y1 = FB.StackedFirstConvFn.apply(feats1.reshape(B * N, Kp), 0, 0, *ws).view(B, N, -1)
+            y2 = FB.StackedFirstConvFn.apply(feats2.reshape(B * N, Kp), 0, 0, *ws).view(B, N, -1)
+            if self._streams2 is None:
+                self._streams2 = [torch.cuda.Stream() for _ in range(2 * len(self.ms_ls))]
+            out = FB.dual_cloud_set_conv(self, list(self.ms_ls), self._streams2, xyz1_t, y1, xyz2_t, y2)
+            if out is not None:
+                return out
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+            return (FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz1_t, y1),
+                    FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz2_t, y2))
+        return self.forward_pm(xyz1_t, feats1), self.forward_pm(xyz2_t, feats2)
+
     multi_stream = True
     _streams = None
+    _streams2 = None
 
     use_blocks = True
 

@@ -230,6 +230,22 @@ typedef struct cmf_setconv_desc {
 int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
 int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
+/* Float offsets, inside `saved`, of the six per-layer BatchNorm blocks (mean | invstd | a | c, 4*C_l floats each). */
+int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6);
+
+/* Deferred nn.BatchNorm2d running-statistics update.  A weight-shared encoder is called twice per step
+ * (cmflow.py:72-73); to run the two calls CONCURRENTLY they are issued with rmean/rvar/nbt == NULL (batch statistics
+ * only) and the momentum updates are applied afterwards, in call order, from each call's saved batch mean / invstd.
+ * table (device memory): one entry per BN layer; offset = float offset of that layer's BN block inside a call's `saved`
+ * arena (saved0 = first call, saved1 = second call). */
+typedef struct cmf_bn_update_entry {
+    float *rmean, *rvar; long long *nbt;
+    int C; float momentum, eps; double count;      /* channels; bn.momentum, bn.eps; rows the statistics were taken over */
+    long long offset;
+} cmf_bn_update_entry;
+int cmf_bn_running_update(int n_entries, const cmf_bn_update_entry *table, int n_calls, const float *saved0,
+                          const float *saved1, void *stream);
+
 /* The independent scales of a MultiScaleEncoder (radarflow_util.py:101-118) in one call: descs[i] is issued on
  * streams[i] from its own host thread inside the library (n <= 16).  The caller orders the streams against its own
  * (events before and after); nothing is synchronised. */
