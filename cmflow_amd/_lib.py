@@ -37,6 +37,9 @@ SIGNATURES = {
     "cmf_bn_running_update": [_ci, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_forward_multi": [_ci, _vp, _vp],
     "cmf_setconv_backward_multi": [_ci, _vp, _vp],
+    "cmf_setconv_forward_on": [_ci, _vp, _vp, _vp],
+    "cmf_setconv_backward_on": [_ci, _vp, _vp, _vp],
+    "cmf_graph_stats": [_vp, _vp],
     "cmf_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_gather_points_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_furthest_point_sampling": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],

@@ -605,6 +605,9 @@ class SetConvBlockFn(Function):
         return (None, dy, None, None, None, None, *grads)
 
 
+import os as _os
+
+
 class EncoderPlan:
     """Everything about a MultiScaleEncoder call that does not change from step to step, built once per
     (batch, points, training, device): the four cmf_setconv_desc structs with geometry, hyper-parameters and the
@@ -744,6 +747,26 @@ class EncoderPlan:
         return None
 
 
+_LIB_FORK_JOIN = _os.environ.get("CMF_LIB_FORK_JOIN", "0") == "1"
+
+
+def _multi_call(backward, n, plan, sp, streams, main):
+    """Issue the n chains of a plan on their streams, forked from and joined back into `main`.  Default: fork / join with
+    torch stream waits around cmf_setconv_*_multi.  CMF_LIB_FORK_JOIN=1: the library does it (cmf_setconv_*_on; required
+    for the experimental hipGraph path, CMF_GRAPHS=1)."""
+    import ctypes
+    if _LIB_FORK_JOIN:
+        fn = L().cmf_setconv_backward_on if backward else L().cmf_setconv_forward_on
+        _lib.check(fn(n, ctypes.addressof(plan.descs), ctypes.addressof(sp), main.cuda_stream), "cmf_setconv_*_on")
+        return
+    for st in streams:
+        st.wait_stream(main)
+    fn = L().cmf_setconv_backward_multi if backward else L().cmf_setconv_forward_multi
+    _lib.check(fn(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_*_multi")
+    for st in streams:
+        main.wait_stream(st)
+
+
 class MultiScaleBlockFn(Function):
     """The four set-conv scales of a MultiScaleEncoder (radarflow_util.py:101-118) as one autograd node and ONE
     C-ABI call per direction (cmf_setconv_forward_multi / _backward_multi: each scale is issued on its own HIP
@@ -771,11 +794,7 @@ class MultiScaleBlockFn(Function):
             d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_fwd[i]
             d.out, d.ldo = out_all.data_ptr() + 4 * i * co, n * co
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
-        for st in streams:
-            st.wait_stream(main)
-        _lib.check(L().cmf_setconv_forward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_forward_multi")
-        for st in streams:
-            main.wait_stream(st)
+        _multi_call(False, n, plan, sp, streams, main)
         ctx.plan, ctx.keep, ctx.streams, ctx.sink_mode = plan, (xyz_t, y_all, saved), streams, sink_mode
         return out_all.view(B, N, n * co)
 
@@ -832,11 +851,7 @@ class MultiScaleBlockFn(Function):
         if ctx.sink_mode and any(t is not None for t in grads):
             raise RuntimeError("parameter .grad buffers disappeared between forward and backward")
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
-        for st in streams:
-            st.wait_stream(main)
-        _lib.check(L().cmf_setconv_backward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_backward_multi")
-        for st in streams:
-            main.wait_stream(st)
+        _multi_call(True, n, plan, sp, streams, main)
         return (None, dy_all, None, None, None, *(() if ctx.sink_mode else grads))
 
 
@@ -868,11 +883,7 @@ class DualCloudBlockFn(Function):
             d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_fwd[i]
             d.out, d.ldo = outs[c].data_ptr() + 4 * sc * co, ns * co
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
-        for st in streams:
-            st.wait_stream(main)
-        _lib.check(L().cmf_setconv_forward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_forward_multi")
-        for st in streams:
-            main.wait_stream(st)
+        _multi_call(False, n, plan, sp, streams, main)
         if plan.update_table is not None:                           # running statistics: first call, then second call
             _lib.check(L().cmf_bn_running_update(plan.n_update, plan.update_table.data_ptr(), 2, saved.data_ptr(),
                                                  saved.data_ptr() + 4 * plan.saved_per_cloud, _lib.stream_ptr()),
@@ -905,11 +916,7 @@ class DualCloudBlockFn(Function):
             d.dout, d.lddout = douts[c].data_ptr() + 4 * sc * co, douts[c].stride(0)
             d.dy, d.lddy = (dys[c].data_ptr() + 4 * sc * o1, ns * o1) if need[c] else (None, 0)
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
-        for st in streams:
-            st.wait_stream(main)
-        _lib.check(L().cmf_setconv_backward_multi(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_backward_multi")
-        for st in streams:
-            main.wait_stream(st)
+        _multi_call(True, n, plan, sp, streams, main)
         torch._foreach_add_(plan.sink_list, plan.temp_list)         # the second call's parameter gradients
         return None, dys[0], None, dys[1], None, None
 
