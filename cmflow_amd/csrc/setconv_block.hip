@@ -456,8 +456,10 @@ extern "C" int cmf_setconv_backward_on(int n, const cmf_setconv_desc *descs, voi
 extern "C" int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6)
 {
     CMF_CHECK_ARG(d && offsets6);
-    const Layout L = make_layout(d, nullptr, nullptr, false);
-    for (int l = 0; l < 6; ++l) offsets6[l] = (long long)(L.bn[l] - (float *)nullptr);
+    // lay the arena out over a fake non-null base (Bump hands out NULL for a NULL base) and subtract it again
+    float *const fake = reinterpret_cast<float *>(uintptr_t(1) << 40);
+    const Layout L = make_layout(d, fake, nullptr, false);
+    for (int l = 0; l < 6; ++l) offsets6[l] = (long long)(L.bn[l] - fake);
     return 0;
 }
 

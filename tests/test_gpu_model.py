@@ -294,3 +294,42 @@ def test_encoder_plan_follows_parameter_reallocation_and_guards_grad_sinks(dev, 
         p.grad = None
     with pytest.raises(RuntimeError):
         loss2.backward()
+
+
+def test_concurrent_first_encoder_equals_sequential_calls(dev, manifest, golden_dir, args, monkeypatch):
+    """The two calls of the weight-shared first encoder run concurrently as one node (DualCloudBlockFn: deferred BN
+    running-statistics update, scratch gradients for the second call).  One optimizer step must leave the network in
+    the same state as the two calls issued one after the other: every parameter, every BN buffer, the loss."""
+    from cmflow_amd import fused_blocks as FB
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.train import TrainStep
+    b = {k: v.to(dev) for k, v in synth.make_batch(8, seed=31, train_extras=True).items()}
+    states, losses, used = [], [], []
+    for concurrent in (True, False):
+        net = CMFlow(args)
+        net.load_state_dict(_weights(manifest, golden_dir))
+        net = net.to(dev).train()
+        step = TrainStep(net, vr_thres=args.vr_thres)
+        calls = []
+        real = FB.dual_cloud_set_conv
+        if concurrent:
+            monkeypatch.setattr(FB, "dual_cloud_set_conv", lambda *a: (calls.append(1), real(*a))[1])
+        else:
+            monkeypatch.setattr(FB, "dual_cloud_set_conv", lambda *a: None)
+        loss, _, _, _ = step(b)
+        monkeypatch.setattr(FB, "dual_cloud_set_conv", real)
+        used.append(len(calls))
+        losses.append(loss.item())
+        states.append({k: v.detach().clone() for k, v in net.state_dict().items()})
+    assert used == [1, 0]
+    assert abs(losses[0] - losses[1]) <= 1e-6 * max(1.0, abs(losses[1]))
+    for k, v in states[1].items():
+        a = states[0][k]
+        if v.dtype.is_floating_point:
+            # Adam's first step moves a weight by lr * sign(g): entries whose gradient is at rounding level may flip
+            tol = 2.1e-3 if (k.endswith("weight") or k.endswith("bias")) else 0.0
+            diff = (a - v).abs()
+            bad = diff > 1e-5 + 1e-5 * v.abs()
+            assert bad.float().mean().item() <= (0.02 if tol else 0.0) and diff.max().item() <= max(tol, 1e-5 + 1e-5 * v.abs().max().item()), k
+        else:
+            assert torch.equal(a, v), k                     # num_batches_tracked: +2 for the first encoder
