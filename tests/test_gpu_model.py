@@ -333,3 +333,33 @@ def test_concurrent_first_encoder_equals_sequential_calls(dev, manifest, golden_
             assert bad.float().mean().item() <= (0.02 if tol else 0.0) and diff.max().item() <= max(tol, 1e-5 + 1e-5 * v.abs().max().item()), k
         else:
             assert torch.equal(a, v), k                     # num_batches_tracked: +2 for the first encoder
+
+
+def test_all_bn_buffers_after_one_step_match_oracle(dev, manifest, golden_dir, args):
+    """Every BatchNorm buffer of the network (running_mean, running_var, num_batches_tracked: 156 tensors) after one
+    training step, HIP path vs the CPU oracle -- the goldens only pin a handful of them."""
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.train import TrainStep
+    sd = _weights(manifest, golden_dir)
+    ref = O.CMFlow(args)
+    ref.load_state_dict(sd)
+    ref.train()
+    net = CMFlow(args)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    b = synth.make_batch(4, seed=41, train_extras=True)
+    P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
+    TO.train_step(ref, torch.optim.Adam(ref.parameters(), lr=0.001, weight_decay=1e-4), b, P, Tcr)
+    TrainStep(net, vr_thres=args.vr_thres)({k: v.to(dev) for k, v in b.items()})
+    want, got = ref.state_dict(), net.state_dict()
+    n = 0
+    for k, v in want.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            g = got[k].cpu()
+            assert torch.isfinite(g).all(), k
+            np.testing.assert_allclose(g.numpy(), v.numpy(), rtol=2e-4, atol=2e-5 * float(v.abs().max()) + 1e-7, err_msg=k)
+            n += 1
+        elif k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v), k
+            n += 1
+    assert n >= 150
