@@ -205,31 +205,45 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
         for (int k = 0; k < 3; ++k) wx[j][k] = Wx[(size_t)(tm.col + j) * ldw + k];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     const long long row0 = (long long)blockIdx.x * PW_ROWS;
-    // 4 rows per step: the idx -> source-row dependent loads of 4 rows are in flight together
-    for (int rb = tm.r0; rb < PW_ROWS; rb += 4 * tm.rl) {
-        long long rows4[4]; int jj[4]; bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            rows4[u] = row0 + rb + u * tm.rl;
-            ok[u] = (rb + u * tm.rl < PW_ROWS) && rows4[u] < rows;
-            jj[u] = ok[u] ? idx[rows4[u]] : 0;
-        }
-        float4 v[4], cc[4]; float d[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long row = ok[u] ? rows4[u] : 0;
+    // Per-row quantities (source row, relative xyz) are computed ONCE per tile into LDS: with C = 512 the 128 threads
+    // that share a row used to issue the same idx load and six scalar xyz loads each -- nine memory instructions per
+    // useful 16-byte gather, and the kernel was bound by their issue rate (2.5 TB/s of stores at C = 512).
+    __shared__ float4 sd[PW_ROWS];
+    __shared__ long long ssrc[PW_ROWS];
+    for (int r = threadIdx.x; r < PW_ROWS; r += PW_THREADS) {
+        const long long row = row0 + r;
+        if (row < rows) {
+            const int j = idx[row];
             const long long bp = row / S;
             const int b = (int)(bp / P);
-            const float *xs = xyz_src + ((size_t)b * n_src + jj[u]) * 3;
+            const float *xs = xyz_src + ((size_t)b * n_src + j) * 3;
             const float *xc = xyz_ctr + (size_t)bp * 3;
-            d[u][0] = xs[0] - xc[0]; d[u][1] = xs[1] - xc[1]; d[u][2] = xs[2] - xc[2];
-            v[u] = *(const float4 *)(ysrc + ((size_t)b * n_src + jj[u]) * ld_src + tm.col);
+            const float4 d4 = make_float4(xs[0] - xc[0], xs[1] - xc[1], xs[2] - xc[2], 0.f);
+            sd[r] = d4;
+            ssrc[r] = (long long)b * n_src + j;
+            if (dxyz) *(float4 *)(dxyz + (size_t)row * 4) = d4;
+        }
+    }
+    __syncthreads();
+    // 4 rows per step: the gathers of 4 rows are in flight together
+    for (int rb = tm.r0; rb < PW_ROWS; rb += 4 * tm.rl) {
+        long long rows4[4]; bool ok[4];
+        float4 v[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * tm.rl;
+            rows4[u] = row0 + r;
+            ok[u] = (r < PW_ROWS) && rows4[u] < rows;
+            const long long src = ok[u] ? ssrc[r] : 0;
+            const long long bp = (ok[u] ? rows4[u] : 0) / S;
+            v[u] = *(const float4 *)(ysrc + (size_t)src * ld_src + tm.col);
             cc[u] = yctr ? *(const float4 *)(yctr + (size_t)bp * ld_ctr + tm.col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (!ok[u]) continue;
-            const float dx = d[u][0], dy = d[u][1], dz = d[u][2];
+            const float4 d4 = sd[rb + u * tm.rl];
+            const float dx = d4.x, dy = d4.y, dz = d4.z;
             float4 o = v[u];
             o.x += cc[u].x; o.y += cc[u].y; o.z += cc[u].z; o.w += cc[u].w;
             o.x += fmaf(wx[0][2], dz, fmaf(wx[0][1], dy, wx[0][0] * dx));
@@ -239,7 +253,6 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             if (act == 2) { o.x = o.x > 0.f ? o.x : 0.1f * o.x; o.y = o.y > 0.f ? o.y : 0.1f * o.y;
                             o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
             *(float4 *)(z + (size_t)rows4[u] * C + tm.col) = o;
-            if (dxyz && tm.col == 0) *(float4 *)(dxyz + (size_t)rows4[u] * 4) = make_float4(dx, dy, dz, 0.f);
             s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
             s2.x += o.x * o.x; s2.y += o.y * o.y; s2.z += o.z * o.z; s2.w += o.w * o.w;
             if (partial_x) {
