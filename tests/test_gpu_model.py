@@ -363,3 +363,47 @@ def test_all_bn_buffers_after_one_step_match_oracle(dev, manifest, golden_dir, a
             assert int(got[k]) == int(v), k
             n += 1
     assert n >= 150
+
+
+@pytest.mark.parametrize("B,N", [(1, 256), (3, 128), (2, 200), (5, 64)])
+def test_odd_shapes_match_oracle(dev, manifest, golden_dir, args, B, N):
+    """Batch sizes and cloud sizes other than the benchmark's (ragged tiles, N not a multiple of 64 or 128): forward in
+    eval mode and one training step (loss + gradient norms) against the CPU oracle."""
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.train import TrainStep
+    sd = _weights(manifest, golden_dir)
+    ref = O.CMFlow(args)
+    ref.load_state_dict(sd)
+    net = CMFlow(args)
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    b = synth.make_batch(B, N, seed=100 + B + N, train_extras=True)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    ref.eval(); net.eval()
+    with torch.no_grad():
+        want = ref(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+        got = net(bd["pc1"], bd["pc2"], bd["ft1"], bd["ft2"], None, "test")
+    flips = (got[3].cpu() != want[3])
+    assert flips.float().mean().item() <= 0.01                       # stat_cls against the 0.5 threshold
+    ok = ~flips.unsqueeze(1).expand(-1, 3, -1)
+    scale = max(1.0, float(want[0].abs().max()))
+    assert (got[0].cpu() - want[0])[ok].abs().max().item() <= 2e-4 * scale
+    assert (got[1].cpu() - want[1]).abs().max().item() <= 2e-4
+    if not flips.any():
+        np.testing.assert_allclose(got[2].cpu().numpy(), want[2].numpy(), rtol=3e-5, atol=2e-4)
+    ref.train(); net.train()
+    P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
+    opt = torch.optim.Adam(ref.parameters(), lr=0.001, weight_decay=1e-4)
+    loss_ref, _, _, _ = TO.train_step(ref, opt, b, P, Tcr)
+    step = TrainStep(net, vr_thres=args.vr_thres)
+    loss, _, _, _ = step.forward_loss(bd)
+    step.bucket.zero()
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 3e-4 * max(1.0, abs(loss_ref.item()))
+    gref = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    worst = 0.0
+    for k, p in net.named_parameters():
+        if k in gref:
+            a, r = float(p.grad.norm()), float(gref[k].norm())
+            worst = max(worst, abs(a - r) / max(r, 1e-3))
+    assert worst <= 2e-2, worst
