@@ -206,6 +206,9 @@ def main():
             achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         return {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
                 "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+                # PMC counters need rocprofv3 around the process; the per-launch FETCH_SIZE / WRITE_SIZE passes for this
+                # kernel are committed (traffic = algorithmic bytes within 9 %)
+                "traffic_profile": "profiles/r01_gemm_pmc.txt" if prof["kernel"] == "cmf_gemm" else "profiles/r01_op_bench_ballquery_group.md",
                 "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
                 "algorithmic_per_launch": per_launch,
                 "launch_filter": "launches >= %.0e units (cmflow_amd/_lib.py TRACK_MIN_UNITS)" %
