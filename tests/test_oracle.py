@@ -252,3 +252,23 @@ def test_raflow_oracle_train_step_matches_reference(golden_dir):
     for k in g:
         if k.startswith("after::"):
             np.testing.assert_allclose(params[k[7:]].detach().reshape(-1)[:64].numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_oracle_is_not_a_strawman(manifest, golden_dir, args):
+    """the CPU baseline bench.py reports (`cpu_baseline.kind == "port"`) must be in the same league as the
+    reference's own Python on the same cores.  tests/golden/ref_cpu_timing.json holds the reference's forward time
+    (B=1, 8 threads, this container, measured by make_golden.py); the oracle gets a generous 3x."""
+    import json
+    import time
+    ref = json.load(open(os.path.join(golden_dir, "ref_cpu_timing.json")))
+    torch.set_num_threads(ref["threads"])
+    net = _net(manifest, golden_dir, args).eval()
+    b = synth.make_batch(1, seed=3)
+    with torch.no_grad():
+        net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+            ts.append(time.perf_counter() - t0)
+    assert sorted(ts)[1] <= 3.0 * ref["ref_cpu_fwd_b1_s"], (ts, ref)
