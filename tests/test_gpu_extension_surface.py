@@ -87,3 +87,31 @@ def test_gather_and_interpolate(dev):
     gk = torch.zeros(B, C, M)
     orc.three_interpolate_grad_wrapper(B, C, n, M, go, idx3, w, gk)
     np.testing.assert_allclose(k.grad.cpu().numpy(), gk.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_integration_md_stub_runs_as_written(dev):
+    """The ctypes stub of INTEGRATION.md (seam 1: a drop-in `pointnet2_cuda.py`) is executed verbatim, only the library path
+    filled in, and its three wrappers are checked against the oracle."""
+    import os
+    import re
+    import types
+    from cmflow_amd import _lib
+    from oracle import ops as orc
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# pointnet2_cuda.py.*?```", text, flags=re.S).group(0)
+    code = code[len("```python\n"):-3].replace("/path/to/cmflow_amd/libcmflow_hip.so", _lib.SO_PATH)
+    mod = types.ModuleType("pointnet2_cuda_stub")
+    exec(compile(code, "INTEGRATION.md", "exec"), mod.__dict__)
+    xyz, new = _clouds(2, 200, 64, seed=9)
+    idx = torch.zeros(2, 64, 8, dtype=torch.int32, device=dev)
+    assert mod.ball_query_wrapper(2, 200, 64, 3.0, 8, new.to(dev), xyz.to(dev), idx) == 1
+    assert torch.equal(idx.cpu(), orc.ball_query(3.0, 8, xyz, new))
+    feats = torch.randn(2, 5, 200)
+    out = torch.empty(2, 5, 64, 8, device=dev)
+    mod.group_points_wrapper(2, 5, 200, 64, 8, feats.to(dev), idx, out)
+    assert torch.equal(out.cpu(), orc.group_points(feats, idx.cpu()))
+    go = torch.randn(2, 5, 64, 8)
+    gp = torch.zeros(2, 5, 200, device=dev)
+    mod.group_points_grad_wrapper(2, 5, 200, 64, 8, go.to(dev), idx, gp)
+    torch.testing.assert_close(gp.cpu(), orc.group_points_grad(go, idx.cpu(), 200), rtol=1e-5, atol=1e-5)
