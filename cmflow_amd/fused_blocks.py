@@ -1088,3 +1088,58 @@ class WeightedKSumFn(Function):
                        "cmf_group_rows_grad")
             dx = dp
         return dw, dx, None, None, None, db
+
+
+class WeightNetKSumFn(Function):
+    """cost[b,n,:] = sum_k relu(h[b,n,k,:] @ wl^T + bl) * x[...]: WeightedKSumFn with the last WeightNet layer
+    (radarflow_util.py:307-318, Conv2d(8, C, 1) + ReLU) recomputed inside the kernels, so the (B,N,K,C) weights and their
+    gradient are never materialised -- cmf_weightnet_ksum / cmf_weightnet_ksum_grad (csrc/wsum.hip).
+    h (B,N,K,8) hidden activation; x (B,N,K,C) dense, or (B,n_src,C) per-point rows with nbr; leaky / x_bias as in
+    WeightedKSumFn."""
+
+    @staticmethod
+    def supported(C, J):
+        return J == 8 and L().cmf_weightnet_ksum_tiles(int(C)) > 0
+
+    @staticmethod
+    def forward(ctx, h, wl, bl, x, nbr, leaky, x_bias=None):
+        B, N1, K, J = h.shape
+        C = wl.shape[0]
+        h, wl, bl, x = h.contiguous(), wl.contiguous(), bl.contiguous(), x.contiguous()
+        out = torch.empty(B, N1, C, dtype=_f32, device=h.device)
+        idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
+        n_src = nbr.n if nbr is not None else 0
+        _lib.check(L().cmf_weightnet_ksum(B * N1, K, C, N1, n_src, _p(h), _p(wl), _p(bl), _p(x), idx, _p(out), _lib.stream_ptr()),
+                   "cmf_weightnet_ksum")
+        ctx.saved = (h, wl, bl, x, nbr, int(bool(leaky)))
+        ctx.params = (wl, bl, x_bias)
+        return out
+
+    @staticmethod
+    def backward(ctx, dcost):
+        h, wl, bl, x, nbr, leaky = ctx.saved
+        B, N1, K, J = h.shape
+        C = wl.shape[0]
+        dev = h.device
+        dcost = dcost.contiguous()
+        dx = torch.empty(B, N1, K, C, dtype=_f32, device=dev)
+        dh = torch.empty_like(h)
+        part = torch.empty(L().cmf_weightnet_ksum_tiles(C), C * (J + 2), dtype=_f32, device=dev)
+        idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
+        n_src = nbr.n if nbr is not None else 0
+        _lib.check(L().cmf_weightnet_ksum_grad(B * N1, K, C, N1, n_src, leaky, _p(dcost), _p(h), _p(wl), _p(bl), _p(x), idx,
+                                               _p(dx), _p(dh), _p(part), _lib.stream_ptr()), "cmf_weightnet_ksum_grad")
+        sums = colsum_n(part)                                            # fixed-order sum of the per-workgroup partials
+        grads = [sums[:C * J].view(C, J), sums[C * J:C * J + C], sums[C * J + C:] if ctx.params[2] is not None else None]
+        sinks = [grad_sink(p) if p is not None else None for p in ctx.params]
+        pairs = [(s.view(-1), g.reshape(-1)) for s, g in zip(sinks, grads) if s is not None and g is not None]
+        if pairs:                                                        # straight into the parameters' .grad, one launch
+            torch._foreach_add_([s for s, _ in pairs], [g for _, g in pairs])
+        dwl, dbl, dxb = [None if (s is not None or g is None) else g for s, g in zip(sinks, grads)]
+        if nbr is not None:                                              # scatter the per-slot gradients back to the points
+            off, inv = nbr.inverse()
+            dp = torch.empty(B, nbr.n, C, dtype=_f32, device=dev)
+            _lib.check(L().cmf_group_rows_grad(B, nbr.n, C, C, N1 * K, 0, _p(dx), _p(off), _p(inv), _p(dp), _lib.stream_ptr()),
+                       "cmf_group_rows_grad")
+            dx = dp
+        return dh, dwl, dbl, dx, None, None, dxb

@@ -263,6 +263,21 @@ class WeightNet(nn.Module):
                 F.relu(F.linear(w, w2d(conv), conv.bias))
         return w
 
+    def weighted_ksum(self, dxyz, x, nbr, leaky, x_bias=None):
+        """sum_k WeightNet(dxyz)[b,n,k,:] * x[...] (radarflow_util.py:219-221,234-236) on the fused blocks.  With the
+        reference's hidden width (8) the last layer is evaluated inside the weighting kernels and the (B,N,K,C) weights
+        are never written; other widths materialise them."""
+        last = self.mlp_convs[-1]
+        if self.fuse_tail and FB.WeightNetKSumFn.supported(last.weight.shape[0], last.weight.shape[1]):
+            h = dxyz
+            for conv in list(self.mlp_convs)[:-1]:
+                h = FB.linear(h, w2d(conv), conv.bias, act=1)
+            return FB.WeightNetKSumFn.apply(h, w2d(last), last.bias, x, nbr, leaky, x_bias)
+        weights = self.forward_pm(dxyz, use_blocks=True, preact_grad=True)
+        return FB.WeightedKSumFn.apply(weights, x, nbr, leaky, True, x_bias)
+
+    fuse_tail = True
+
 
 class FeatureCorrelator(nn.Module):
     """radarflow_util.py:164-237 -- cost volume (point-to-patch, then patch-to-patch)."""
@@ -349,12 +364,10 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     p1 = FB.linear(f1, w0[:, :D1], c0.bias)
     p2 = FB.linear(f2, w0[:, D1:D1 + D2])
     x, dxyz = FB.CostVolumeMLPFn.apply(xyz1_t, xyz2_t, p1, p2, nbr, w0[:, D1 + D2:], w2d(c1), c1.bias, w2d(c2), c2.bias, True)
-    weights = self.weightnet1.forward_pm(dxyz, use_blocks=True, preact_grad=True)
-    p2p = FB.WeightedKSumFn.apply(weights, x, None, True, True, c2.bias)                   # sum_k weights * x
+    p2p = self.weightnet1.weighted_ksum(dxyz, x, None, True, c2.bias)                      # sum_k weights * x
     nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
     dxyz2 = F.pad(group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2), (0, 1))
-    weights = self.weightnet2.forward_pm(dxyz2, use_blocks=True, preact_grad=True)
-    return FB.WeightedKSumFn.apply(weights, p2p, nbr, False, True)                         # sum_k weights * p2p[idx]
+    return self.weightnet2.weighted_ksum(dxyz2, p2p, nbr, False)                           # sum_k weights * p2p[idx]
 
 
 FeatureCorrelator._forward_blocks = _fc_blocks

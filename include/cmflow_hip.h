@@ -275,6 +275,19 @@ int cmf_weighted_ksum(long long M, int K, int C, int n1, int n_src, const float 
 int cmf_weighted_ksum_grad_tiles(int C);
 int cmf_weighted_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *w,
                            const float *x, const int *idx, float *dw, float *dx, float *dx_colsum, void *stream);
+/* The same weighting with WeightNet's last layer (radarflow_util.py:307-318: Conv2d(8, C, 1) + ReLU) folded in: the
+ * weights are not an operand but recomputed where they are used, w[m,k,c] = relu(bl[c] + sum_j h[m,k,j] * Wl[c,j]) with
+ * h (M*K, 8) the hidden activation, Wl (C, 8), bl (C) -- the (M,K,C) weight tensor and its gradient never exist.
+ * C in {256, 512, 1024} (cmf_weightnet_ksum_tiles(C) > 0), M*K < 2^31, x / idx / leaky bit 0 as above.
+ * The gradient call writes dx (M,K,C), dh (M*K, 8) and one partial row per workgroup,
+ * part [cmf_weightnet_ksum_tiles(C)][C*8 + C + C] = sums of dWl (C,8) | dbl (C) | column sums of dx (C), to be reduced
+ * in fixed order with cmf_colsum. */
+int cmf_weightnet_ksum_tiles(int C);
+int cmf_weightnet_ksum(long long M, int K, int C, int n1, int n_src, const float *h, const float *Wl, const float *bl,
+                       const float *x, const int *idx, float *out, void *stream);
+int cmf_weightnet_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *h,
+                            const float *Wl, const float *bl, const float *x, const int *idx, float *dx, float *dh,
+                            float *part, void *stream);
 
 /* ---- the training step's loss -------------------------------------------------------------
  * RadarFlowLoss of losses/radar_loss.py:260-292 for model 'cmflow' / 'cmflow_t': SoftChamfer (:17-58),

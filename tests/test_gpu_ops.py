@@ -187,6 +187,66 @@ def test_product_refuses_cpu_tensors():
         ball_query(1.0, 2, x, x)
 
 
+@pytest.mark.parametrize("B,N1,N2,K,C", [(2, 64, 64, 8, 512), (3, 51, 70, 5, 256), (1, 33, 40, 16, 1024), (4, 256, 256, 8, 512)])
+def test_weightnet_ksum_matches_torch(dev, B, N1, N2, K, C):
+    """cmf_weightnet_ksum(_grad): the weighting with WeightNet's last conv + ReLU (radarflow_util.py:307-318) evaluated
+    inside the kernel, against the torch composition -- output, dx (dense and scattered), dh, and the conv's dW / db
+    and the producer-bias column sums; the fused and the materialised-weights host paths agree."""
+    from cmflow_amd.fused import Neighbors, group_rows
+    from cmflow_amd.fused_blocks import WeightNetKSumFn, WeightedKSumFn
+    assert WeightNetKSumFn.supported(C, 8) and not WeightNetKSumFn.supported(12, 8) and not WeightNetKSumFn.supported(C, 16)
+    g = torch.Generator().manual_seed(B + N1 + K + C)
+    mk = lambda *shape: torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+    # h, wl, bl on a dyadic grid: the pre-activation is then exact in any summation order, so the kernel and torch
+    # take the same side of the ReLU kink everywhere (a flipped slot would move dh / dwl / dbl by a whole term)
+    grid = lambda t, q: (torch.round(t * q) / q).to(dev).requires_grad_(True)
+    h = grid(torch.relu(torch.randn(B, N1, K, 8, generator=g)), 8)
+    wl, bl, xb = grid(torch.randn(C, 8, generator=g), 16), grid(torch.randn(C, generator=g), 16), mk(C)
+    go = torch.randn(B, N1, C, generator=g).to(dev)
+    leaves = [h, wl, bl, xb]
+
+    def grads_of(fn, x):
+        for t in leaves + [x]:
+            t.grad = None
+        out = fn()
+        out.backward(go)
+        return [out.detach()] + [t.grad.clone() if t.grad is not None else None for t in leaves + [x]]
+
+    def check(got, ref, leaky, x):
+        names = ["out", "dh", "dwl", "dbl", "dxb", "dx"]
+        for n, a, b in zip(names, got, ref):
+            if n == "dxb" and b is None:
+                continue
+            scale = float(b.abs().max()) + 1e-6
+            np.testing.assert_allclose(a.cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=2e-6, err_msg=n)
+
+    # dense x = leaky(z + xb): the kernel returns the gradient w.r.t. the pre-activation and its column sums as dxb
+    z = mk(B, N1, K, C)
+    for leaky in (True, False):
+        def ref_fn():
+            xa = torch.nn.functional.leaky_relu(z + xb, 0.1) if leaky else z + xb
+            return torch.sum(torch.relu(torch.nn.functional.linear(h, wl, bl)) * xa, dim=2)
+        ref = grads_of(ref_fn, z)
+        xa = (torch.nn.functional.leaky_relu(z + xb, 0.1) if leaky else z + xb).detach().requires_grad_(True)
+        got = grads_of(lambda: WeightNetKSumFn.apply(h, wl, bl, xa, None, leaky, xb), xa)
+        check(got, ref, leaky, z)
+        if not leaky:                                                    # unfused host path (materialised weights), same numbers
+            xa2 = xa.detach().requires_grad_(True)
+            w_mat = lambda: torch.relu(torch.nn.functional.linear(h, wl, bl))
+            got2 = grads_of(lambda: WeightedKSumFn.apply(w_mat(), xa2, None, False, False, None), xa2)
+            check(got2[:4] + [None] + got2[5:], ref[:4] + [None] + ref[5:], leaky, z)
+    # gathered x: per-point rows, gradient scattered back
+    p = mk(B, N2, C)
+    nbr = Neighbors(torch.randint(0, N2, (B, N1, K), generator=g, dtype=torch.int32).to(dev), N2)
+    ref = grads_of(lambda: torch.sum(torch.relu(torch.nn.functional.linear(h, wl, bl)) * group_rows(p, nbr), dim=2), p)
+    got = grads_of(lambda: WeightNetKSumFn.apply(h, wl, bl, p, nbr, False), p)
+    check(got, ref, False, p)
+    # run-to-run identical (fixed-order reductions)
+    again = grads_of(lambda: WeightNetKSumFn.apply(h, wl, bl, p, nbr, False), p)
+    for a, b in zip(got, again):
+        assert (a is None and b is None) or torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,N1,N2,K,C", [(2, 64, 64, 8, 512), (3, 50, 70, 5, 12), (1, 33, 33, 16, 64)])
 def test_weighted_ksum_matches_torch(dev, B, N1, N2, K, C):
     """cmf_weighted_ksum(_grad) (radarflow_util.py:219-221,234-236) against the torch expressions, dense and gathered."""
