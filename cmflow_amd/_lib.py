@@ -63,7 +63,9 @@ SIGNATURES = {
     "cmf_weighted_ksum_grad": [_ll, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_weightnet_ksum_tiles": [_ci],
     "cmf_weightnet_ksum": [_ll, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "cmf_weightnet_ksum_grad": [_ll, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_weightnet_ksum_grad": [_ll, _ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_global_max_cat": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _vp],
+    "cmf_global_max_cat_grad": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _ll, _vp],
     "cmf_radar_loss_workspace": [_ci, _ci],
     "cmf_radar_loss": [_vp, _vp],
     "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],

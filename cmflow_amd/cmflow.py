@@ -11,6 +11,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import fused_blocks as FB
 from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScaleEncoder, weighted_kabsch)
 
 
@@ -100,19 +101,30 @@ class CMFlow(nn.Module):
         else:
             f1 = self.mse_layer.forward_pm(x1, a1)
             f2 = self.mse_layer.forward_pm(x2, a2)
-        f1 = torch.cat((f1, f1.max(dim=1, keepdim=True)[0].expand(-1, f1.shape[1], -1)), dim=2)
-        f2 = torch.cat((f2, f2.max(dim=1, keepdim=True)[0].expand(-1, f2.shape[1], -1)), dim=2)
+        if self.path == "pm":
+            f1, f2 = FB.global_max_cat(f1), FB.global_max_cat(f2)                          # (B,N,512): features + global max
+        else:
+            f1 = torch.cat((f1, f1.max(dim=1, keepdim=True)[0].expand(-1, f1.shape[1], -1)), dim=2)
+            f2 = torch.cat((f2, f2.max(dim=1, keepdim=True)[0].expand(-1, f2.shape[1], -1)), dim=2)
         cor = self.fc_layer.forward_pm(x1, x2, f1, f2)                                     # (B,N,512)
-        # embeddings (B,N,1027) with one zero column so rows are 16-byte aligned for the GEMM (K = 1028)
-        emb = torch.cat((a1, f1, cor, torch.zeros_like(a1[:, :, :1])), dim=2) if self.path == "pm" else \
-            torch.cat((a1, f1, cor), dim=2)
-        prop = self._second_encoder().forward_pm(x1, emb)                                         # (B,N,256)
+        if self.path == "pm":
+            # embeddings as [f1 | cor | ft1 | zero pad], K = 1040: the columns that need a gradient come first (the
+            # data-gradient GEMM of the stacked first conv is 1024 wide and f1 / cor read their blocks of it in place),
+            # the raw input channels (cmflow.py:82 puts them first) go behind, rows padded to a multiple of 16 floats
+            n_grad, n_tail = f1.shape[2] + cor.shape[2], a1.shape[2]
+            pad = -(n_grad + n_tail) % 16
+            emb = torch.cat((f1, cor, a1, a1.new_zeros(a1.shape[0], a1.shape[1], pad)), dim=2)
+            prop = self._second_encoder().forward_pm(x1, emb, n_tail=n_tail, n_grad=n_grad)       # (B,N,256)
+        else:
+            prop = self._second_encoder().forward_pm(x1, torch.cat((a1, f1, cor), dim=2))
         self.last = {"pc1_features": f1[:, :, :256].transpose(1, 2), "pc2_features": f2[:, :, :256].transpose(1, 2),
                      "cor_features": cor.transpose(1, 2), "prop_features": prop.transpose(1, 2)}
         return prop.transpose(1, 2)
 
     def Backbone(self, pc1, pc2, feature1, feature2):
         prop_features = self._propagate(pc1, pc2, feature1, feature2)
+        if self.path == "pm":                                   # prop_features is the (B,256,N) view of point-major rows
+            return FB.global_max_cat(prop_features.transpose(1, 2)).transpose(1, 2)
         gfeat = torch.max(prop_features, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
         return torch.cat((prop_features, gfeat), dim=1)
 

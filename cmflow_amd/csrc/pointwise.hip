@@ -501,3 +501,114 @@ extern "C" int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, l
                        M, C, dU, z, ldz, a, mean, invstd, sums, (float)(1.0 / (double)M));
     return cmf_launch_status();
 }
+
+// ---- global feature: max over the points, broadcast back and concatenated ------------------------------------
+// cmflow.py:76-81,89-91 (Backbone): gfeat = max_n f[b,n,:]; out = cat(f, gfeat expanded over n).  As torch ops that is
+// a strided reduction, an expand and a cat in forward and a scatter + two adds + a reduction in backward; here one
+// kernel per direction.  A workgroup owns 64 channels of one sample: 16 threads (float4 each) span the channels, 16 row
+// groups walk the rows; partial results are folded across the row groups in LDS in fixed order.  arg keeps the FIRST row
+// attaining the maximum -- the row torch.max's gradient goes to.
+constexpr int GM_THREADS = 256;
+constexpr int GM_CH = 64;
+
+__global__ __launch_bounds__(GM_THREADS) void global_max_cat_kernel(
+    int N, int C, const float *__restrict__ f, long long ldf, float *__restrict__ out, long long ldo, int *__restrict__ arg)
+{
+    __shared__ float smax[GM_THREADS / 16][GM_CH];
+    __shared__ int sarg[GM_THREADS / 16][GM_CH];
+    const int b = blockIdx.y, c0 = blockIdx.x * GM_CH;
+    const int tc = (threadIdx.x % 16) * 4, rg = threadIdx.x / 16;
+    const int c = c0 + tc;
+    const bool live = c < C;
+    const float *fb = f + (long long)b * N * ldf;
+    float *ob = out + (long long)b * N * ldo;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int am[4] = {0, 0, 0, 0};
+    if (live)
+        for (int n = rg; n < N; n += GM_THREADS / 16) {
+            const float4 v = *(const float4 *)(fb + (long long)n * ldf + c);
+            *(float4 *)(ob + (long long)n * ldo + c) = v;
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (vv[i] > m[i]) { m[i] = vv[i]; am[i] = n; }
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { smax[rg][tc + i] = m[i]; sarg[rg][tc + i] = am[i]; }
+    __syncthreads();
+    if (threadIdx.x < GM_CH) {
+        float best = smax[0][threadIdx.x];
+        int ba = sarg[0][threadIdx.x];
+        for (int g = 1; g < GM_THREADS / 16; ++g) {
+            const float v = smax[g][threadIdx.x];
+            const int a = sarg[g][threadIdx.x];
+            if (v > best || (v == best && a < ba)) { best = v; ba = a; }
+        }
+        smax[0][threadIdx.x] = best;
+        if (c0 + (int)threadIdx.x < C) arg[(long long)b * C + c0 + threadIdx.x] = ba;
+    }
+    __syncthreads();
+    if (live) {
+        const float4 g = make_float4(smax[0][tc], smax[0][tc + 1], smax[0][tc + 2], smax[0][tc + 3]);
+        for (int n = rg; n < N; n += GM_THREADS / 16) *(float4 *)(ob + (long long)n * ldo + C + c) = g;
+    }
+}
+
+__global__ __launch_bounds__(GM_THREADS) void global_max_cat_grad_kernel(
+    int N, int C, const float *__restrict__ dout, long long ldd, const int *__restrict__ arg, float *__restrict__ df, long long ldf)
+{
+    __shared__ float ssum[GM_THREADS / 16][GM_CH];
+    const int b = blockIdx.y, c0 = blockIdx.x * GM_CH;
+    const int tc = (threadIdx.x % 16) * 4, rg = threadIdx.x / 16;
+    const int c = c0 + tc;
+    const bool live = c < C;
+    const float *db = dout + (long long)b * N * ldd;
+    float *fb = df + (long long)b * N * ldf;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int n = rg; n < N; n += GM_THREADS / 16) {
+            const float4 v = *(const float4 *)(db + (long long)n * ldd + C + c);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ssum[rg][tc + i] = s[i];
+    __syncthreads();
+    if (threadIdx.x < GM_CH) {
+        float t = ssum[0][threadIdx.x];
+        for (int g = 1; g < GM_THREADS / 16; ++g) t += ssum[g][threadIdx.x];
+        ssum[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (live) {
+        const int4 a = *(const int4 *)(arg + (long long)b * C + c);
+        const float4 g = make_float4(ssum[0][tc], ssum[0][tc + 1], ssum[0][tc + 2], ssum[0][tc + 3]);
+        for (int n = rg; n < N; n += GM_THREADS / 16) {
+            float4 v = *(const float4 *)(db + (long long)n * ldd + c);
+            if (n == a.x) v.x += g.x;
+            if (n == a.y) v.y += g.y;
+            if (n == a.z) v.z += g.z;
+            if (n == a.w) v.w += g.w;
+            *(float4 *)(fb + (long long)n * ldf + c) = v;
+        }
+    }
+}
+
+extern "C" int cmf_global_max_cat(int B, int N, int C, const float *f, long long ldf, float *out, long long ldo, int *arg, void *stream)
+{
+    CMF_CHECK_ARG(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && ldf >= C && ldo >= 2 * C && ldf % 4 == 0 && ldo % 4 == 0 && B < 65536);
+    if (B == 0) return 0;
+    CMF_CHECK_ARG(f && out && arg && (((uintptr_t)f | (uintptr_t)out | (uintptr_t)arg) & 15) == 0);
+    hipLaunchKernelGGL(global_max_cat_kernel, dim3(cmf_divup(C, GM_CH), B), dim3(GM_THREADS), 0, (hipStream_t)stream, N, C, f, ldf, out, ldo, arg);
+    return cmf_launch_status();
+}
+
+extern "C" int cmf_global_max_cat_grad(int B, int N, int C, const float *dout, long long ldd, const int *arg, float *df, long long ldf,
+                                       void *stream)
+{
+    CMF_CHECK_ARG(B >= 0 && N > 0 && C > 0 && C % 4 == 0 && ldf >= C && ldd >= 2 * C && ldf % 4 == 0 && ldd % 4 == 0 && B < 65536);
+    if (B == 0) return 0;
+    CMF_CHECK_ARG(dout && df && arg && (((uintptr_t)dout | (uintptr_t)df | (uintptr_t)arg) & 15) == 0);
+    hipLaunchKernelGGL(global_max_cat_grad_kernel, dim3(cmf_divup(C, GM_CH), B), dim3(GM_THREADS), 0, (hipStream_t)stream, N, C, dout, ldd, arg,
+                       df, ldf);
+    return cmf_launch_status();
+}

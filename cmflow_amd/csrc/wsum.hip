@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WS_THREADS) void wn_ksum_fwd_kernel(
 }
 
 __global__ __launch_bounds__(WS_THREADS, 3) void wn_ksum_bwd_kernel(
-    int M, int K, int C, int n1, int n_src, int leaky, const float *__restrict__ dcost, const float *__restrict__ h,
+    int M, int K, int C, int n1, int n_src, int leaky, const float *__restrict__ dcost, long long ldd, const float *__restrict__ h,
     const float *__restrict__ Wl, const float *__restrict__ bl, const float *__restrict__ x, const int *__restrict__ idx,
     float *__restrict__ dx, float *__restrict__ dh, float *__restrict__ part)
 {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wn_ksum_bwd_kernel(
 #pragma unroll
             for (int j = 0; j < WN_J; ++j) hv[j] = h[(long long)mk * WN_J + j];
             const long long row = idx ? (long long)(m / n1) * n_src + idx[mk] : mk;
-            const float4 g4 = *(const float4 *)(dcost + (long long)m * C + c);
+            const float4 g4 = *(const float4 *)(dcost + (long long)m * ldd + c);
             const float4 x4 = *(const float4 *)(x + row * C + c);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
             float pre[4], d[4];
@@ -329,15 +329,15 @@ extern "C" int cmf_weightnet_ksum(long long M, int K, int C, int n1, int n_src, 
     return cmf_launch_status();
 }
 
-extern "C" int cmf_weightnet_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *h,
+extern "C" int cmf_weightnet_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, long long ldd, const float *h,
                                        const float *Wl, const float *bl, const float *x, const int *idx, float *dx, float *dh,
                                        float *part, void *stream)
 {
     CMF_CHECK_ARG(M >= 0 && K > 0 && cmf_weightnet_ksum_tiles(C) > 0 && M * K < (1LL << 31));
-    CMF_CHECK_ARG(dcost && h && Wl && bl && x && dx && dh && part && (!idx || (n1 > 0 && n_src > 0)));
+    CMF_CHECK_ARG(dcost && h && Wl && bl && x && dx && dh && part && (!idx || (n1 > 0 && n_src > 0)) && ldd >= C && ldd % 4 == 0);
     CMF_CHECK_ARG((((uintptr_t)h | (uintptr_t)Wl | (uintptr_t)x | (uintptr_t)dcost | (uintptr_t)dx | (uintptr_t)dh | (uintptr_t)part) & 15) == 0);
     // M == 0 still launches: every workgroup writes its (zero) partial row
-    hipLaunchKernelGGL(wn_ksum_bwd_kernel, dim3(WN_TILES), dim3(WS_THREADS), 0, (hipStream_t)stream, (int)M, K, C, n1, n_src, leaky, dcost, h,
+    hipLaunchKernelGGL(wn_ksum_bwd_kernel, dim3(WN_TILES), dim3(WS_THREADS), 0, (hipStream_t)stream, (int)M, K, C, n1, n_src, leaky, dcost, ldd, h,
                        Wl, bl, x, idx, dx, dh, part);
     return cmf_launch_status();
 }

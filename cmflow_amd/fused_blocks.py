@@ -1121,13 +1121,15 @@ class WeightNetKSumFn(Function):
         B, N1, K, J = h.shape
         C = wl.shape[0]
         dev = h.device
-        dcost = dcost.contiguous()
+        if not (dcost.stride(2) == 1 and dcost.stride(0) == N1 * dcost.stride(1) and dcost.stride(1) % 4 == 0
+                and dcost.data_ptr() % 16 == 0):
+            dcost = dcost.contiguous()                                  # a column block of a wider gradient is read in place
         dx = torch.empty(B, N1, K, C, dtype=_f32, device=dev)
         dh = torch.empty_like(h)
         part = torch.empty(L().cmf_weightnet_ksum_tiles(C), C * (J + 2), dtype=_f32, device=dev)
         idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
         n_src = nbr.n if nbr is not None else 0
-        _lib.check(L().cmf_weightnet_ksum_grad(B * N1, K, C, N1, n_src, leaky, _p(dcost), _p(h), _p(wl), _p(bl), _p(x), idx,
+        _lib.check(L().cmf_weightnet_ksum_grad(B * N1, K, C, N1, n_src, leaky, dcost.data_ptr(), dcost.stride(1), _p(h), _p(wl), _p(bl), _p(x), idx,
                                                _p(dx), _p(dh), _p(part), _lib.stream_ptr()), "cmf_weightnet_ksum_grad")
         sums = colsum_n(part)                                            # fixed-order sum of the per-workgroup partials
         grads = [sums[:C * J].view(C, J), sums[C * J:C * J + C], sums[C * J + C:] if ctx.params[2] is not None else None]
@@ -1143,3 +1145,34 @@ class WeightNetKSumFn(Function):
                        "cmf_group_rows_grad")
             dx = dp
         return dh, dwl, dbl, dx, None, None, dxb
+
+
+class GlobalMaxCatFn(Function):
+    """(B,N,C) -> (B,N,2C) = cat(f, max over the points broadcast to every point): Backbone's global feature
+    (cmflow.py:76-81,89-91) in one kernel per direction -- cmf_global_max_cat(_grad), csrc/pointwise.hip.  The incoming
+    gradient may be a column block of a wider tensor (row-strided view); it is read in place."""
+
+    @staticmethod
+    def forward(ctx, f):
+        B, N, C = f.shape
+        f = f.contiguous()
+        out = torch.empty(B, N, 2 * C, dtype=_f32, device=f.device)
+        arg = torch.empty(B, C, dtype=torch.int32, device=f.device)
+        _lib.check(L().cmf_global_max_cat(B, N, C, _p(f), C, _p(out), 2 * C, _p(arg), _lib.stream_ptr()), "cmf_global_max_cat")
+        ctx.arg = arg
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C = ctx.arg.shape
+        N = dout.shape[1]
+        if not (dout.stride(2) == 1 and dout.stride(0) == N * dout.stride(1) and dout.stride(1) % 4 == 0 and dout.data_ptr() % 16 == 0):
+            dout = dout.contiguous()
+        df = torch.empty(B, N, C, dtype=_f32, device=dout.device)
+        _lib.check(L().cmf_global_max_cat_grad(B, N, C, dout.data_ptr(), dout.stride(1), _p(ctx.arg), _p(df), C, _lib.stream_ptr()),
+                   "cmf_global_max_cat_grad")
+        return df
+
+
+def global_max_cat(f):
+    return GlobalMaxCatFn.apply(f)

@@ -115,7 +115,11 @@ class MultiScaleEncoder(nn.Module):
             if self._streams is None:
                 self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
             return FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz_t, y_all)
-        assert n_tail == 0
+        if n_tail:                      # permuted layout handed to one of the unstacked paths: back to the module's own order
+            cin = self.ms_ls[0].mlp_convs[0].weight.shape[1] - 3
+            feats = torch.cat((feats[:, :, cin - n_tail:cin], feats[:, :, :cin - n_tail]), dim=2)
+            if self.use_blocks and cin % 4:
+                feats = F.pad(feats, (0, 4 - cin % 4))
         wf_all = torch.cat([w2d(sa.mlp_convs[0])[:, 3:] for sa in self.ms_ls], dim=0)
         if not self.use_blocks:
             y_all = F.linear(feats, wf_all)                               # (B,N,4*o1)

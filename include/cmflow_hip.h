@@ -281,13 +281,21 @@ int cmf_weighted_ksum_grad(long long M, int K, int C, int n1, int n_src, int lea
  * C in {256, 512, 1024} (cmf_weightnet_ksum_tiles(C) > 0), M*K < 2^31, x / idx / leaky bit 0 as above.
  * The gradient call writes dx (M,K,C), dh (M*K, 8) and one partial row per workgroup,
  * part [cmf_weightnet_ksum_tiles(C)][C*8 + C + C] = sums of dWl (C,8) | dbl (C) | column sums of dx (C), to be reduced
- * in fixed order with cmf_colsum. */
+ * in fixed order with cmf_colsum.  dcost has row stride ldd floats (>= C: it may be a column block of a wider gradient). */
 int cmf_weightnet_ksum_tiles(int C);
 int cmf_weightnet_ksum(long long M, int K, int C, int n1, int n_src, const float *h, const float *Wl, const float *bl,
                        const float *x, const int *idx, float *out, void *stream);
-int cmf_weightnet_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, const float *h,
+int cmf_weightnet_ksum_grad(long long M, int K, int C, int n1, int n_src, int leaky, const float *dcost, long long ldd, const float *h,
                             const float *Wl, const float *bl, const float *x, const int *idx, float *dx, float *dh,
                             float *part, void *stream);
+
+/* Global feature of Backbone (cmflow.py:76-81,89-91: torch.max over the points, expand, cat): out[b,n,0:C] = f[b,n,:],
+ * out[b,n,C:2C] = max_n' f[b,n',:], point-major rows with strides ldf / ldo floats (multiples of 4, so out may be a
+ * column block of a wider buffer); arg (B,C) int32 = first row attaining the maximum.  The gradient call returns
+ * df[b,n,c] = dout[b,n,c] + (n == arg[b,c]) * sum_n' dout[b,n',C+c].  C % 4 == 0, 16-byte aligned pointers. */
+int cmf_global_max_cat(int B, int N, int C, const float *f, long long ldf, float *out, long long ldo, int *arg, void *stream);
+int cmf_global_max_cat_grad(int B, int N, int C, const float *dout, long long ldd, const int *arg, float *df, long long ldf,
+                            void *stream);
 
 /* ---- the training step's loss -------------------------------------------------------------
  * RadarFlowLoss of losses/radar_loss.py:260-292 for model 'cmflow' / 'cmflow_t': SoftChamfer (:17-58),

@@ -187,6 +187,30 @@ def test_product_refuses_cpu_tensors():
         ball_query(1.0, 2, x, x)
 
 
+@pytest.mark.parametrize("B,N,C", [(64, 256, 256), (3, 77, 12), (2, 1, 64), (1, 300, 100)])
+def test_global_max_cat_matches_torch(dev, B, N, C):
+    """cmf_global_max_cat(_grad) (cmflow.py:76-81,89-91: max over the points + expand + cat) against the torch ops:
+    bit-exact output, gradient through a column block of a wider upstream gradient, first-row tie rule."""
+    from cmflow_amd.fused_blocks import global_max_cat
+    g = torch.Generator().manual_seed(B + N + C)
+    f = torch.randn(B, N, C, generator=g)
+    f[:, N // 2] = f[:, 0]                                                # duplicated point: ties between rows 0 and N//2
+    f = f.to(dev).requires_grad_(True)
+    wide = torch.randn(B, N, 2 * C + 8, generator=g).to(dev)             # upstream gradient lives in columns 4 : 4 + 2C
+    out = global_max_cat(f)
+    out.backward(wide[:, :, 4:4 + 2 * C])
+    got = f.grad.clone()
+    f.grad = None
+    ref = torch.cat((f, f.max(dim=1, keepdim=True)[0].expand(-1, N, -1)), dim=2)
+    assert torch.equal(out.detach(), ref.detach())
+    # torch's own backward of max may pick either of two tied rows; the rule here is the first one
+    gsum = wide[:, :, 4 + C:4 + 2 * C].sum(dim=1)
+    first = (f.detach() == f.detach().max(dim=1, keepdim=True)[0]).float().argmax(dim=1)      # (B,C) first maximal row
+    want = wide[:, :, 4:4 + C].clone()
+    want.scatter_add_(1, first.unsqueeze(1), gsum.unsqueeze(1))
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-5)
+
+
 @pytest.mark.parametrize("B,N1,N2,K,C", [(2, 64, 64, 8, 512), (3, 51, 70, 5, 256), (1, 33, 40, 16, 1024), (4, 256, 256, 8, 512)])
 def test_weightnet_ksum_matches_torch(dev, B, N1, N2, K, C):
     """cmf_weightnet_ksum(_grad): the weighting with WeightNet's last conv + ReLU (radarflow_util.py:307-318) evaluated
