@@ -53,6 +53,8 @@ SIGNATURES = {
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],
     "cmf_group_rows_grad_bn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _ci, _vp],
+    "cmf_group_rows_grad_bn_cf": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp,
+                                  _ci, _vp],
     "cmf_bn_relu_maxpool": [_ll, _ci, _ci, _vp, _vp, _vp, _vp, _ll, _vp, _vp],
     "cmf_maxpool_bwd": [_ll, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_affine_relu": [_ll, _ci, _vp, _ll, _vp, _vp, _vp, _ll, _vp],

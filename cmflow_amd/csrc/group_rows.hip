@@ -309,6 +309,94 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_kernel(
     }
 }
 
+// The same sums without reading z.  Every entry of inv(j) gathers the SAME source row, z[e,:] = y[j,:] + wx . d[e]
+// with d[e] = xyz_src[j] - xyz_ctr[e / S] (cmf_group_affine), so the z-dependent part of the sum has a closed form:
+//   sum_e (z[e,:] - mean) = cnt_j * (y[j,:] - mean) + wx . D_j,    D_j = sum_e d[e]   (3 floats per source point)
+//   grad_feat[b,j,:] = a * (sum_e dU[e,:] - cnt_j*s1/M - (invstd*s2/M) * (cnt_j*(y[j,:] - mean) + wx . D_j)).
+// Only dU is streamed (half the bytes of the kernel above); y, wx and the coordinates are per-point and cache-resident.
+__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
+    int n, int c, int entries, int S, int total_waves, const float *__restrict__ dU, const float *__restrict__ y, long long ldy,
+    const float *__restrict__ wx, long long ldw, const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
+    const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ sums, float inv_count,
+    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg)
+{
+    const int wave = (blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
+    if (wave >= total_waves) return;
+    const int lane = threadIdx.x % CMF_WAVE;
+    const int bs = wave / n, j = wave - bs * n;
+    const int *off = offsets + (size_t)bs * (n + 1);
+    const int beg = off[j], end = off[j + 1];
+    const int *lst = inv + (size_t)bs * entries;
+    const float *gu = dU + (size_t)bs * entries * c;
+    float *dst = grad_feat + ((size_t)bs * n + j) * ldg;
+    // D_j: lanes stride over the entries, then a fixed butterfly
+    float Dx = 0.f, Dy = 0.f, Dz = 0.f;
+    {
+        const float *xs = xyz_src + ((size_t)bs * n + j) * 3;
+        const float sx = xs[0], sy = xs[1], sz = xs[2];
+        const float *xc = xyz_ctr + (size_t)bs * (entries / S) * 3;
+        for (int t = beg + lane; t < end; t += CMF_WAVE) {
+            const int p = lst[t] / S;
+            Dx += sx - xc[p * 3]; Dy += sy - xc[p * 3 + 1]; Dz += sz - xc[p * 3 + 2];
+        }
+#pragma unroll
+        for (int m = CMF_WAVE / 2; m > 0; m >>= 1) { Dx += __shfl_xor(Dx, m, CMF_WAVE); Dy += __shfl_xor(Dy, m, CMF_WAVE); Dz += __shfl_xor(Dz, m, CMF_WAVE); }
+    }
+    const float cnt = (float)(end - beg);
+    for (int col = lane * 4; col < c; col += CMF_WAVE * 4) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = beg;
+        for (; t + 4 <= end; t += 4) {                      // 4 rows in flight; the sum keeps ascending entry order
+            const int e0 = lst[t], e1 = lst[t + 1], e2 = lst[t + 2], e3 = lst[t + 3];
+            const float4 u0 = *(const float4 *)(gu + (size_t)e0 * c + col), u1 = *(const float4 *)(gu + (size_t)e1 * c + col);
+            const float4 u2 = *(const float4 *)(gu + (size_t)e2 * c + col), u3 = *(const float4 *)(gu + (size_t)e3 * c + col);
+            acc.x += u0.x; acc.y += u0.y; acc.z += u0.z; acc.w += u0.w;
+            acc.x += u1.x; acc.y += u1.y; acc.z += u1.z; acc.w += u1.w;
+            acc.x += u2.x; acc.y += u2.y; acc.z += u2.z; acc.w += u2.w;
+            acc.x += u3.x; acc.y += u3.y; acc.z += u3.z; acc.w += u3.w;
+        }
+        for (; t < end; ++t) {
+            const float4 u0 = *(const float4 *)(gu + (size_t)lst[t] * c + col);
+            acc.x += u0.x; acc.y += u0.y; acc.z += u0.z; acc.w += u0.w;
+        }
+        const float4 sa = *(const float4 *)(a + col);
+        float r[4] = {acc.x, acc.y, acc.z, acc.w};
+        if (sums) {
+            const float4 t1 = *(const float4 *)(sums + col), t2 = *(const float4 *)(sums + c + col);
+            const float4 is = *(const float4 *)(invstd + col), mu = *(const float4 *)(mean + col);
+            const float4 yv = *(const float4 *)(y + ((size_t)bs * n + j) * ldy + col);
+            const float s1[4] = {t1.x, t1.y, t1.z, t1.w}, s2[4] = {t2.x, t2.y, t2.z, t2.w}, iv[4] = {is.x, is.y, is.z, is.w};
+            const float ym[4] = {yv.x - mu.x, yv.y - mu.y, yv.z - mu.z, yv.w - mu.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float *w = wx + (size_t)(col + i) * ldw;
+                const float zsum = cnt * ym[i] + (w[0] * Dx + w[1] * Dy + w[2] * Dz);
+                r[i] = r[i] - cnt * (s1[i] * inv_count) - (iv[i] * s2[i] * inv_count) * zsum;
+            }
+        }
+        *(float4 *)(dst + col) = make_float4(sa.x * r[0], sa.y * r[1], sa.z * r[2], sa.w * r[3]);
+    }
+}
+
+extern "C" int cmf_group_rows_grad_bn_cf(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,
+                                         const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
+                                         const float *a, const float *mean, const float *invstd, const float *sums,
+                                         float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && c % 4 == 0 && entries >= 0 && S > 0 && entries % S == 0 && ldg >= c && ldg % 4 == 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(dU && a && offsets && inv && grad_feat);
+    CMF_CHECK_ARG(!sums || (y && wx && xyz_src && xyz_ctr && mean && invstd && ldy >= c && ldy % 4 == 0 && ldw >= 3));
+    CMF_CHECK_ARG((((uintptr_t)dU | (uintptr_t)y | (uintptr_t)grad_feat | (uintptr_t)a) & 15) == 0);
+    const long long waves = (long long)b * n;
+    const int grid = (int)((waves * CMF_WAVE + GR_THREADS - 1) / GR_THREADS);
+    hipLaunchKernelGGL(group_rows_grad_bn_cf_kernel, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
+                       n, c, entries, S, (int)waves, dU, y, ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets, inv,
+                       grad_feat, ldg);
+    return cmf_launch_status();
+}
+
 extern "C" int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, const float *z,
                                       const float *a, const float *mean, const float *invstd, const float *sums,
                                       float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream)

@@ -256,9 +256,11 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
                                 (int)d->lddwx, d->acc_wx, st));
     if (d->dy) {
         CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
-        CMF_TRY(cmf_group_rows_grad_bn(d->B, d->N, O1, d->N * d->S, L.dU1, L.z1, b0 + 2 * O1, b0, b0 + O1,
-                                       d->training ? L.sums : nullptr, (float)(1.0 / (double)M), L.offsets, L.inv, d->dy,
-                                       d->lddy ? (int)d->lddy : O1, st));
+        // z1 rows of one source point differ only by wx . dxyz: the BN-backward part of the scatter has a closed form,
+        // so only dU1 is streamed (csrc/group_rows.hip)
+        CMF_TRY(cmf_group_rows_grad_bn_cf(d->B, d->N, O1, d->N * d->S, d->S, L.dU1, d->y, d->ldy, d->wx, d->ldwx, d->xyz, d->xyz,
+                                          b0 + 2 * O1, b0, b0 + O1, d->training ? L.sums : nullptr, (float)(1.0 / (double)M),
+                                          L.offsets, L.inv, d->dy, d->lddy ? (int)d->lddy : O1, st));
     }
     return 0;
 }

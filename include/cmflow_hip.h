@@ -167,6 +167,15 @@ int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, long long ld
 int cmf_group_rows_grad_bn(int b, int n, int c, int entries, const float *dU, const float *z,
                            const float *a, const float *mean, const float *invstd, const float *sums,
                            float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream);
+/* The same result without reading z, for z produced by cmf_group_affine from per-point rows: every entry e of inv(j)
+ * gathers the same source row, z[e,:] = y[j,:] + wx . (xyz_src[j] - xyz_ctr[e / S]), so
+ *   sum_e (z[e,:] - mean) = cnt_j*(y[j,:] - mean) + wx . D_j,   D_j = sum_e (xyz_src[j] - xyz_ctr[e / S]),
+ * and only dU is streamed.  y (b,n,c) rows with stride ldy, wx (c,3) rows with stride ldw, xyz_src (b,n,3),
+ * xyz_ctr (b, entries/S, 3); entries = centres * S in (centre, slot) order. */
+int cmf_group_rows_grad_bn_cf(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,
+                              const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
+                              const float *a, const float *mean, const float *invstd, const float *sums,
+                              float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream);
 
 /* dW_xyz of the set-conv's first conv from column sums only (no pass over the grouped tensor):
  *   dWx[c,k] = a_c*( q_k[c] - (s1_c/M)*u_k - (s2_c/M)*invstd_c*(tz_k[c] - mean_c*u_k) )

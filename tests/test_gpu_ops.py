@@ -187,6 +187,50 @@ def test_product_refuses_cpu_tensors():
         ball_query(1.0, 2, x, x)
 
 
+@pytest.mark.parametrize("B,N,S,C,r", [(4, 256, 16, 64, 6.0), (2, 100, 8, 32, 3.0), (3, 64, 32, 512, 50.0), (1, 50, 4, 8, 0.01)])
+def test_group_rows_grad_bn_closed_form(dev, B, N, S, C, r):
+    """Set-conv first-layer backward (radarflow_util.py:148-151): the scatter with the BN backward folded in, once
+    reading z (cmf_group_rows_grad_bn) and once from the closed form over per-point rows (cmf_group_rows_grad_bn_cf),
+    against the dense torch expression -- train-mode and eval-mode BN."""
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import Neighbors
+    from cmflow_amd.fused_blocks import group_affine
+    from cmflow_amd.pointnet2_utils import ball_query
+    L = _lib.lib()
+    p = lambda t, dt=None: _lib.dev_ptr(t, dt or t.dtype)
+    g = torch.Generator().manual_seed(N + S + C)
+    xyz = (torch.rand(B, N, 3, generator=g) * 20).to(dev)
+    y = torch.randn(B, N, C, generator=g).to(dev)
+    wx = torch.randn(C, 3, generator=g).to(dev)
+    idx = ball_query(r, S, xyz, xyz)                                     # repeated slots when the ball holds < S points
+    z, dxyz, _ = group_affine(y, None, xyz, xyz, wx, idx, act=0, stats=False)
+    M = B * N * S
+    dU = torch.randn(M, C, generator=g).to(dev)
+    zf = z.view(M, C)
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    a = (torch.rand(C, generator=g).to(dev) + 0.5) * invstd
+    zhat = (zf - mean) * invstd
+    sums = torch.stack((dU.sum(0), (dU * zhat).sum(0))).contiguous()
+    nbr = Neighbors(idx.int(), N)
+    off, inv = nbr.inverse()
+    for train in (True, False):
+        dZ = a * (dU - sums[0] / M - zhat * sums[1] / M) if train else a * dU
+        want = torch.zeros(B, N, C, device=dev, dtype=torch.float64)
+        want.scatter_add_(1, idx.long().view(B, N * S, 1).expand(-1, -1, C), dZ.view(B, N * S, C).double())
+        got_z = torch.empty(B, N, C, device=dev)
+        got_cf = torch.empty(B, N, C, device=dev)
+        sp = p(sums, torch.float32) if train else None
+        _lib.check(L.cmf_group_rows_grad_bn(B, N, C, N * S, p(dU), p(zf), p(a), p(mean), p(invstd), sp, 1.0 / M,
+                                            p(off), p(inv), p(got_z), C, _lib.stream_ptr()), "z")
+        _lib.check(L.cmf_group_rows_grad_bn_cf(B, N, C, N * S, S, p(dU), p(y), C, p(wx), 3, p(xyz), p(xyz), p(a), p(mean),
+                                               p(invstd), sp, 1.0 / M, p(off), p(inv), p(got_cf), C, _lib.stream_ptr()), "cf")
+        scale = float(want.abs().max())
+        for name, got in (("z", got_z), ("closed form", got_cf)):
+            err = float((got.double() - want).abs().max()) / scale
+            assert err < 2e-6, (name, train, err)
+
+
 @pytest.mark.parametrize("B,N,C", [(64, 256, 256), (3, 77, 12), (2, 1, 64), (1, 300, 100)])
 def test_global_max_cat_matches_torch(dev, B, N, C):
     """cmf_global_max_cat(_grad) (cmflow.py:76-81,89-91: max over the points + expand + cat) against the torch ops:
