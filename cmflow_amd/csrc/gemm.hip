@@ -151,7 +151,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     const int kc_begin = split * kchunks_per;
     const int kc_end = min(kchunks_total, kc_begin + kchunks_per);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave index in an SGPR: LDS-direct destinations and per-wave branches stay scalar
     const int wm = wid / WARPS_N, wn = wid % WARPS_N;
 
     // ---- staging maps ----
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         };
         int st = 0;
         for (int c = 0; c < nch; ++c) {
-            if (c + 2 < nch) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);       // (st + 2) % 3
+            if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);       // (st + 2) % 3
             const float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
             if (EMUL) {
                 read_frags(sa, sb, sp, 0, 0);
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             g_lds_wait(); pin_frags(1);
             mfma_step(1);
             }
-            if (c + 1 < nch) wait_prev(c + 2 < nch);                            // chunk c+1 has landed (this wave's part)
-            __builtin_amdgcn_s_barrier();                                       // ... and everybody else's; stage st is free again
+            if (c + 1 < nch && !(p.diag & 3)) wait_prev(c + 2 < nch);           // chunk c+1 has landed (this wave's part)
+            if (!(p.diag & 4)) __builtin_amdgcn_s_barrier();                    // ... and everybody else's; stage st is free again
             st = st == 2 ? 0 : st + 1;
         }
     } else
@@ -700,6 +700,8 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.accumulate = split_k > 1 ? 0 : accumulate;
     static const int no_direct = (getenv("CMF_GEMM_NO_DIRECT") && getenv("CMF_GEMM_NO_DIRECT")[0] == '1') ? 1 : 0;
     g.no_direct = no_direct;
+    static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
+    g.diag = diag_rt;
     int err = cmf_thin_gemm(g, a_t, b_t, st);            // narrow layers (<= 64 channels): barrier-free per-wave kernels
     if (err > 0) return err;
     const bool thin_done = (err == 0);

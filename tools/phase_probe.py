@@ -18,12 +18,18 @@ def hook(mod, name):
     mod.register_forward_hook(lambda m, i, o: mark(name + ":end"))
 # point-major path calls forward_pm, not forward: wrap them
 import types
-for name in ("mse_layer", "fc_layer", "mse_layer2", "fp", "mp"):
+def tag_bwd(r, n):                       # the gradient of a module's output arrives right before its backward runs
+    for t in (r if isinstance(r, tuple) else (r,)):
+        if torch.is_tensor(t) and t.requires_grad:
+            t.register_hook(lambda g, _n=n: mark(_n + ":grad_in"))
+            break
+for name, attr in (("mse_layer", "forward_pm_pair"), ("fc_layer", "forward_pm"), ("mse_layer2", "forward_pm"), ("fp", "forward_pm"),
+                   ("mp", "forward_pm")):
     m = getattr(net, name)
-    orig = m.forward_pm
+    orig = getattr(m, attr)
     def wrapped(*a, _o=orig, _n=name, **k):
-        mark(_n + ":begin"); r = _o(*a, **k); mark(_n + ":end"); return r
-    m.forward_pm = wrapped
+        mark(_n + ":begin"); r = _o(*a, **k); mark(_n + ":end"); tag_bwd(r, _n); return r
+    setattr(m, attr, wrapped)
 tot = {}
 for it in range(5):
     marks.clear()
