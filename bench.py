@@ -177,8 +177,11 @@ def main():
         torch.cuda.synchronize()
 
     if a.serial:
-        from cmflow_amd.radarflow_util import MultiScaleEncoder as _MSE
+        from cmflow_amd.radarflow_util import FeatureCorrelator as _FC, MultiScaleEncoder as _MSE
+        from cmflow_amd.cmflow import CMFlow as _CM
         _MSE.multi_stream = False
+        _FC.side_streams = False
+        _CM.head_streams = False
     for _ in range(a.warmup):
         one()
     track = a.track or ("cmf_group_points" if a.path == "ref" else "cmf_gemm")
@@ -219,10 +222,13 @@ def main():
     # the scales serialised (outside the timed region, not part of `value`) gives the kernel's own rate.
     iso = None
     if rank == 0 and a.path == "pm":
-        from cmflow_amd.radarflow_util import MultiScaleEncoder
+        from cmflow_amd.radarflow_util import FeatureCorrelator, MultiScaleEncoder
         for m in net.modules():
             if isinstance(m, MultiScaleEncoder):
                 m.multi_stream = False
+            if isinstance(m, FeatureCorrelator):
+                m.side_streams = False
+        net.head_streams = False
         one(); torch.cuda.synchronize()
         _lib.profile_begin(track, "hbm" if track == "cmf_group_points" else "mfma")
         for _ in range(3):

@@ -57,6 +57,9 @@ class CMFlow(nn.Module):
     def _declare_recurrent(self, width):
         pass
 
+    head_streams = True
+    _head_stream = None
+
     def _second_encoder(self):
         """The encoder over the flow embeddings (mse_layer2 here, fd_layer.mse in RaFlow)."""
         return self.mse_layer2
@@ -145,7 +148,22 @@ class CMFlow(nn.Module):
         return weighted_kabsch(A, B, W)
 
     def _heads(self, final_features, pc1, label_m, mode):
-        if self.path in ("pm", "pm_torch"):
+        if self.path == "pm" and self.head_streams and final_features.is_cuda:
+            # the two heads are independent chains of small GEMMs (N = 256: a third of the CUs each): the motion head
+            # runs on a side stream next to the flow head; autograd replays each backward on its forward stream
+            ff = final_features.transpose(1, 2)                       # (B,N,512) view
+            main = torch.cuda.current_stream()
+            if self._head_stream is None:
+                self._head_stream = FB.side_stream(0)
+            side = self._head_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                stat_cls = self.mp.forward_pm(ff).transpose(1, 2)
+            output = self.fp.forward_pm(ff).transpose(1, 2)
+            main.wait_stream(side)
+            ff.record_stream(side)
+            stat_cls.record_stream(main)
+        elif self.path in ("pm", "pm_torch"):
             ff = final_features.transpose(1, 2)                       # (B,N,512) view
             output = self.fp.forward_pm(ff).transpose(1, 2)
             stat_cls = self.mp.forward_pm(ff).transpose(1, 2)

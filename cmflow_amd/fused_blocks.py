@@ -12,6 +12,8 @@ Design (DESIGN.md "Fused path"):
   their epilogue; weight-gradient GEMMs contract over the positions with deterministic split-K and
   re-apply the producer's BN+ReLU to the saved Z in their B-operand prologue.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -62,6 +64,42 @@ def bn_fold(bn, partial, count):
                                   _p(bn.running_var), _p(st.mean), _p(st.invstd), _p(st.a), _p(st.c), None, _lib.stream_ptr())
     _lib.check(err, "cmf_bn_finalize")
     return st
+
+
+# ---- side streams ---------------------------------------------------------------------------------
+# Independent chains (the scales of an encoder, the two clouds, the two heads, the neighbourhood branch of the cost
+# volume) are issued on side streams so that their small kernels run next to other chains' large ones.  The HIP runtime
+# multiplexes all streams of a process onto a few hardware queues (4 by default); streams that land on the same queue
+# serialise against each other in creation order, and measured on MI355X more than 4 busy queues is far slower
+# (GPU_MAX_HW_QUEUES=5: 36 ms per step instead of 27) while 3 is faster than 4.  So the whole package shares ONE pool
+# of N_SIDE side streams (+ the caller's stream), and chains are dealt to them by size instead of each module
+# creating its own.
+N_SIDE = int(os.environ.get("CMF_SIDE_STREAMS", "3"))
+_side_pool = {}
+
+
+def side_stream(slot, device=None):
+    dev = torch.device(device if device is not None else torch.cuda.current_device())
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    pool = _side_pool.setdefault(key, [])
+    while len(pool) < N_SIDE:
+        pool.append(torch.cuda.Stream(device=key))
+    return pool[slot % N_SIDE]
+
+
+def scale_streams(n_scales, cloud=0):
+    """The side stream of each scale of a MultiScaleEncoder call (scales ordered by growing neighbourhood).  With four
+    scales on three streams the largest scale (half of the rows) shares its stream with the smallest; the second
+    cloud's call is rotated by one stream.  Measured against other deals of the same pool and against one stream per
+    chain (8 + 4 streams aliased onto the hardware queues by creation order): 26.3 vs 26.4-27.3 ms per step.
+    CMF_SCALE_SLOTS="a,b,c,d|e,f,g,h" overrides the deal (diagnostics)."""
+    if n_scales == 4 and os.environ.get("CMF_SCALE_SLOTS"):
+        slots = [int(v) for v in os.environ["CMF_SCALE_SLOTS"].split("|")[cloud % 2].split(",")]
+    elif n_scales == 4:
+        slots = ([0, 1, 2, 0], [1, 2, 0, 1])[cloud % 2]
+    else:
+        slots = [(i + cloud) % N_SIDE for i in range(n_scales)]
+    return [side_stream(s) for s in slots]
 
 
 def grad_sink(t):

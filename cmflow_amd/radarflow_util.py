@@ -9,6 +9,9 @@ contracts follow the reference; the hot inner loops run in libcmflow_hip.so:
   FeatureCorrelator (:164-237)  -> cmf_knn + cmf_group_points
   WeightedKabsch (models/cmflow.py:128-169) -> cmf_weighted_kabsch(+_grad)
 """
+import contextlib
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -113,7 +116,7 @@ class MultiScaleEncoder(nn.Module):
             y_all = FB.StackedFirstConvFn.apply(feats.reshape(B * N, Kp), n_tail, n_grad,
                                                 *[sa.mlp_convs[0].weight for sa in self.ms_ls]).view(B, N, -1)
             if self._streams is None:
-                self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+                self._streams = FB.scale_streams(len(self.ms_ls))
             return FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz_t, y_all)
         if n_tail:                      # permuted layout handed to one of the unstacked paths: back to the module's own order
             cin = self.ms_ls[0].mlp_convs[0].weight.shape[1] - 3
@@ -136,7 +139,7 @@ class MultiScaleEncoder(nn.Module):
         # fill 256 CUs (N = 256): run each scale on its own HIP stream so they overlap.  Autograd replays
         # each block's backward on the stream its forward ran on and orders the streams itself.
         if self._streams is None:
-            self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+            self._streams = FB.scale_streams(len(self.ms_ls))
         if FB.USE_BLOCK_CALLS and self.threaded_enqueue:
             # one host thread per scale as well: see fused_blocks.MultiScaleBlockFn
             return FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz_t, y_all)
@@ -165,12 +168,12 @@ class MultiScaleEncoder(nn.Module):
             y1 = FB.StackedFirstConvFn.apply(feats1.reshape(B * N, Kp), 0, 0, *ws).view(B, N, -1)
             y2 = FB.StackedFirstConvFn.apply(feats2.reshape(B * N, Kp), 0, 0, *ws).view(B, N, -1)
             if self._streams2 is None:
-                self._streams2 = [torch.cuda.Stream() for _ in range(2 * len(self.ms_ls))]
+                self._streams2 = FB.scale_streams(len(self.ms_ls), 0) + FB.scale_streams(len(self.ms_ls), 1)
             out = FB.dual_cloud_set_conv(self, list(self.ms_ls), self._streams2, xyz1_t, y1, xyz2_t, y2)
             if out is not None:
                 return out
             if self._streams is None:
-                self._streams = [torch.cuda.Stream() for _ in self.ms_ls]
+                self._streams = FB.scale_streams(len(self.ms_ls))
             return (FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz1_t, y1),
                     FB.multi_scale_set_conv(self, list(self.ms_ls), self._streams, xyz2_t, y2))
         return self.forward_pm(xyz1_t, feats1), self.forward_pm(xyz2_t, feats2)
@@ -267,18 +270,23 @@ class WeightNet(nn.Module):
                 F.relu(F.linear(w, w2d(conv), conv.bias))
         return w
 
-    def weighted_ksum(self, dxyz, x, nbr, leaky, x_bias=None):
+    def weighted_ksum(self, dxyz, x, nbr, leaky, x_bias=None, hidden=None):
         """sum_k WeightNet(dxyz)[b,n,k,:] * x[...] (radarflow_util.py:219-221,234-236) on the fused blocks.  With the
         reference's hidden width (8) the last layer is evaluated inside the weighting kernels and the (B,N,K,C) weights
         are never written; other widths materialise them."""
         last = self.mlp_convs[-1]
         if self.fuse_tail and FB.WeightNetKSumFn.supported(last.weight.shape[0], last.weight.shape[1]):
-            h = dxyz
-            for conv in list(self.mlp_convs)[:-1]:
-                h = FB.linear(h, w2d(conv), conv.bias, act=1)
+            h = hidden if hidden is not None else self.hidden_pm(dxyz)
             return FB.WeightNetKSumFn.apply(h, w2d(last), last.bias, x, nbr, leaky, x_bias)
-        weights = self.forward_pm(dxyz, use_blocks=True, preact_grad=True)
+        weights = FB.linear(hidden if hidden is not None else self.hidden_pm(dxyz), w2d(last), last.bias, act=1, preact_grad=True)
         return FB.WeightedKSumFn.apply(weights, x, nbr, leaky, True, x_bias)
+
+    def hidden_pm(self, dxyz):
+        """All layers but the last on the fused blocks: (B,N,K,3|4) -> (B,N,K,hidden)."""
+        h = dxyz
+        for conv in list(self.mlp_convs)[:-1]:
+            h = FB.linear(h, w2d(conv), conv.bias, act=1)
+        return h
 
     fuse_tail = True
 
@@ -364,14 +372,45 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     K = self.nsample
     c0, c1, c2 = self.mlp_convs
     w0 = w2d(c0)
+    # Two branches do not depend on the point-to-patch MLP: the per-point GEMM over the second cloud's features and the
+    # whole neighbourhood side of the patch-to-patch stage (kNN in cloud 1, relative coordinates, WeightNet's hidden
+    # layers).  They are small kernels; on side streams they run next to the large GEMMs of the main stream, and
+    # autograd replays their backward on the same streams.
+    side = self._side_streams() if (self.side_streams and xyz1_t.is_cuda) else None
+    main = torch.cuda.current_stream() if side else None
     nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])
+    if side:
+        for st in side:
+            st.wait_stream(main)
+    with torch.cuda.stream(side[0]) if side else contextlib.nullcontext():
+        p2 = FB.linear(f2, w0[:, D1:D1 + D2])
+    with torch.cuda.stream(side[1]) if side else contextlib.nullcontext():
+        nbr2 = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
+        dxyz2 = F.pad(group_rows(xyz1_t, nbr2) - xyz1_t.unsqueeze(2), (0, 1))
+        h2 = self.weightnet2.hidden_pm(dxyz2)
     p1 = FB.linear(f1, w0[:, :D1], c0.bias)
-    p2 = FB.linear(f2, w0[:, D1:D1 + D2])
+    if side:
+        main.wait_stream(side[0])
+        p2.record_stream(main); f2.record_stream(side[0])
     x, dxyz = FB.CostVolumeMLPFn.apply(xyz1_t, xyz2_t, p1, p2, nbr, w0[:, D1 + D2:], w2d(c1), c1.bias, w2d(c2), c2.bias, True)
     p2p = self.weightnet1.weighted_ksum(dxyz, x, None, True, c2.bias)                      # sum_k weights * x
-    nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
-    dxyz2 = F.pad(group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2), (0, 1))
-    return self.weightnet2.weighted_ksum(dxyz2, p2p, nbr, False)                           # sum_k weights * p2p[idx]
+    if side:
+        main.wait_stream(side[1])
+        xyz1_t.record_stream(side[1])
+        for t in (h2, dxyz2, nbr2.idx):
+            t.record_stream(main)
+    return self.weightnet2.weighted_ksum(dxyz2, p2p, nbr2, False, hidden=h2)               # sum_k weights * p2p[idx]
+
+
+def _fc_side_streams(self):
+    if self._side is None:
+        self._side = [FB.side_stream(0), FB.side_stream(1)]
+    return self._side
+
+
+FeatureCorrelator._side_streams = _fc_side_streams
+FeatureCorrelator._side = None
+FeatureCorrelator.side_streams = True
 
 
 FeatureCorrelator._forward_blocks = _fc_blocks
