@@ -116,16 +116,43 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
 
 #define CMF_TRY(call) do { int e_ = (call); if (e_) return e_; } while (0)
 
-// BN fold of layer l from `partial` (train) or running stats (eval) into L.bn[l]
+// Eval mode: the six folds depend on nothing the block computes (running statistics), so they are ONE launch at the head
+// of the chain instead of six tiny kernels between its GEMMs.  Same arithmetic as bn_finalize_kernel's eval branch.
+struct FoldAll { int C[6]; const float *gamma[6], *beta[6], *rmean[6], *rvar[6]; float eps[6]; float *out[6]; };
+
+__global__ __launch_bounds__(256) void bn_fold_eval_kernel(const FoldAll f)
+{
+    const int l = blockIdx.x, C = f.C[l];
+    float *b = f.out[l];
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const double mean = f.rmean[l][ch], var = f.rvar[l][ch];
+        const double invstd = 1.0 / sqrt(var + (double)f.eps[l]);
+        const double a = (f.gamma[l] ? (double)f.gamma[l][ch] : 1.0) * invstd;
+        b[ch] = (float)mean; b[C + ch] = (float)invstd; b[2 * C + ch] = (float)a;
+        b[3 * C + ch] = (float)((f.beta[l] ? (double)f.beta[l][ch] : 0.0) - mean * a);
+    }
+}
+
+int fold_all_eval(const cmf_setconv_desc *d, const Layout &L, void *st)
+{
+    FoldAll f;
+    for (int l = 0; l < 6; ++l) {
+        CMF_CHECK_ARG(d->rmean[l] && d->rvar[l]);
+        f.C[l] = chan(d, l); f.gamma[l] = d->gamma[l]; f.beta[l] = d->beta[l]; f.rmean[l] = d->rmean[l]; f.rvar[l] = d->rvar[l];
+        f.eps[l] = d->eps[l]; f.out[l] = L.bn[l];
+    }
+    hipLaunchKernelGGL(bn_fold_eval_kernel, dim3(6), dim3(256), 0, (hipStream_t)st, f);
+    return cmf_launch_status();
+}
+
+// BN fold of layer l from `partial` (train: batch statistics + running-stat update) into L.bn[l]; eval: done up front
 int fold(const cmf_setconv_desc *d, const Layout &L, int l, long long rows, void *st)
 {
+    if (!d->training) return 0;
     const int C = chan(d, l);
     float *b = L.bn[l];
-    if (d->training)
-        return cmf_bn_finalize(tiles128(rows), C, (double)rows, L.partial, d->gamma[l], d->beta[l], d->eps[l], d->momentum[l],
-                               d->rmean[l], d->rvar[l], b, b + C, b + 2 * C, b + 3 * C, d->nbt[l], st);
-    return cmf_bn_finalize(0, C, 1.0, nullptr, d->gamma[l], d->beta[l], d->eps[l], 0.f, d->rmean[l], d->rvar[l],
-                           b, b + C, b + 2 * C, b + 3 * C, nullptr, st);
+    return cmf_bn_finalize(tiles128(rows), C, (double)rows, L.partial, d->gamma[l], d->beta[l], d->eps[l], d->momentum[l],
+                           d->rmean[l], d->rvar[l], b, b + C, b + 2 * C, b + 3 * C, d->nbt[l], st);
 }
 
 // Z_out = act_{l_in}(Z_in) @ W^T (+ statistics), Z_in activated by BN layer l_in (or already active if l_in < 0)
@@ -197,6 +224,7 @@ extern "C" int cmf_setconv_forward(const cmf_setconv_desc *d, void *st)
     const long long P = (long long)d->B * d->N, M = P * d->S;
     const int O1 = d->O1, C2 = d->C[0], C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
     // idx is pre-zeroed like the reference's BallQuery.forward (every point is its own neighbour here, but keep the contract)
+    if (!d->training) CMF_TRY(fold_all_eval(d, L, st));
     CMF_TRY((int)hipMemsetAsync(L.idx, 0, M * sizeof(int), (hipStream_t)st));
     CMF_TRY(cmf_ball_query(d->B, d->N, d->N, d->radius, d->S, d->xyz, d->xyz, L.idx, st));
     CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,

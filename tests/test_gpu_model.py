@@ -335,6 +335,42 @@ def test_concurrent_first_encoder_equals_sequential_calls(dev, manifest, golden_
             assert torch.equal(a, v), k                     # num_batches_tracked: +2 for the first encoder
 
 
+def test_side_streams_do_not_change_results(dev, manifest, golden_dir, args):
+    """The motion head and the cost volume's neighbourhood branch / second per-point GEMM run on the shared pool of side
+    streams (fused_blocks.side_stream), next to the encoder scales.  The kernels are the same ones and deterministic,
+    so outputs, loss and all gradients must be BIT-identical to the same step with those branches on the caller's
+    stream -- a missing stream dependency shows up here as a difference (or as garbage)."""
+    from cmflow_amd import fused_blocks as FB
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.radarflow_util import FeatureCorrelator
+    from cmflow_amd.train import TrainStep
+    assert FB.side_stream(0) is FB.side_stream(FB.N_SIDE) and len({FB.side_stream(i) for i in range(FB.N_SIDE)}) == FB.N_SIDE
+    assert [s is FB.side_stream(i) for s, i in zip(FB.scale_streams(4, 0), (0, 1, 2, 0))] == [True] * 4
+    b = {k: v.to(dev) for k, v in synth.make_batch(8, seed=77, train_extras=True).items()}
+    results = []
+    for side in (True, False, True):
+        net = CMFlow(args)
+        net.load_state_dict(_weights(manifest, golden_dir))
+        net = net.to(dev).train()
+        net.head_streams = side
+        for m in net.modules():
+            if isinstance(m, FeatureCorrelator):
+                m.side_streams = side
+        step = TrainStep(net, vr_thres=args.vr_thres)
+        for _ in range(2):                                  # second pass: warm plans, re-used streams and cached blocks
+            loss, items, outs, labels = step.forward_loss(b)
+            step.bucket.zero()
+            loss.backward()
+        torch.cuda.synchronize()
+        results.append(([o.detach().clone() for o in outs[:3]], loss.detach().clone(), step.bucket.flat.detach().clone()))
+    ref = results[1]
+    for got in (results[0], results[2]):
+        for a, r in zip(got[0], ref[0]):
+            assert torch.equal(a, r)
+        assert torch.equal(got[1], ref[1])
+        assert torch.equal(got[2], ref[2])
+
+
 def test_all_bn_buffers_after_one_step_match_oracle(dev, manifest, golden_dir, args):
     """Every BatchNorm buffer of the network (running_mean, running_var, num_batches_tracked: 156 tensors) after one
     training step, HIP path vs the CPU oracle -- the goldens only pin a handful of them."""
