@@ -235,13 +235,14 @@ def main():
             one()
         iso = roofline_of(_lib.profile_end())
         if iso:
-            iso["note"] = "3 extra steps with the encoder scales serialised on one stream (outside the timed region)"
+            iso["note"] = "3 extra steps with every chain on one stream (outside the timed region): the kernel's own rate"
 
     if rank == 0:
         pairs = a.batch * world * a.steps
         roof = roofline_of(prof)
         if roof:
-            roof["note"] = "durations include contention from kernels of the 3 other encoder-scale streams"
+            roof["note"] = ("independent chains run on 3 side streams next to the caller's: a bracketed launch shares the chip with "
+                            "kernels (often other cmf_gemm launches) of the other streams, so its duration is a contended one")
         cpu = None
         if not a.no_cpu_baseline:
             cpu = cpu_baseline(a.mode, a.model)
