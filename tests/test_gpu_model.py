@@ -443,3 +443,28 @@ def test_odd_shapes_match_oracle(dev, manifest, golden_dir, args, B, N):
             a, r = float(p.grad.norm()), float(gref[k].norm())
             worst = max(worst, abs(a - r) / max(r, 1e-3))
     assert worst <= 2e-2, worst
+
+
+def test_dense_cloud_forward_matches_oracle(dev, manifest, golden_dir, args):
+    """BASELINE config 5's cloud size through the WHOLE model (N = 4096 LiDAR-like points; the op-level roofline run of
+    that config is tools/op_bench.py): forward in eval mode against the CPU oracle -- flow within 1e-4, identical
+    static masks, transform within 1e-4.  Exercises the large-N paths (multi-wave ball query with spilled hit lists,
+    count/fill inverse index, 16-row LDS tiles of the global max, kNN over 4096 candidates)."""
+    from cmflow_amd.cmflow import CMFlow
+    sd = _weights(manifest, golden_dir)
+    ref = O.CMFlow(args)
+    ref.load_state_dict(sd)
+    ref.eval()
+    net = CMFlow(args)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    b = synth.make_batch(1, N=4096, seed=2025, lidar=True)
+    with torch.no_grad():
+        want = ref(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+        got = net(*(b[k].to(dev) for k in ("pc1", "pc2", "ft1", "ft2")), None, "test")
+    flips = got[3].cpu() != want[3]
+    assert int(flips.sum()) <= 2                                  # a score within rounding of the threshold may flip
+    epe = (got[0].cpu() - want[0]).norm(dim=1)
+    assert float(epe[~flips].max()) < 1e-4
+    assert float((got[1].cpu() - want[1]).abs().max()) < 1e-4
+    assert float((got[2].cpu() - want[2]).abs().max()) < 1e-4
