@@ -21,18 +21,20 @@ class FlatGradBucket:
         p0 = self.params[0]
         self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
         off = 0
+        self.views = []
         for p in self.params:
             k = p.numel()
             p.grad = self.flat[off:off + k].view_as(p)        # gradients accumulate in place into the bucket
+            self.views.append(p.grad)
             off += k
         self.numel = n
 
     def zero(self):
-        """optimizer.zero_grad() equivalent that keeps the views (set_to_none would break them)."""
+        """optimizer.zero_grad() equivalent that keeps the views (set_to_none would break them).  The check is an
+        identity comparison per parameter (this runs on the host between forward and backward, every step)."""
         self.flat.zero_()
-        for p in self.params:
-            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr() or \
-                    p.grad.data_ptr() >= self.flat.data_ptr() + self.flat.numel() * self.flat.element_size():
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
                 raise RuntimeError("a gradient left the flat bucket (zero_grad(set_to_none=True)?)")
 
     def all_reduce_mean(self, group=None, force=False):
