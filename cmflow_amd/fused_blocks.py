@@ -74,7 +74,7 @@ def bn_fold(bn, partial, count):
 # (GPU_MAX_HW_QUEUES=5: 36 ms per step instead of 27) while 3 is faster than 4.  So the whole package shares ONE pool
 # of N_SIDE side streams (+ the caller's stream), and chains are dealt to them by size instead of each module
 # creating its own.
-N_SIDE = int(os.environ.get("CMF_SIDE_STREAMS", "3"))
+N_SIDE = max(1, int(os.environ.get("CMF_SIDE_STREAMS", "3")))
 _side_pool = {}
 
 
