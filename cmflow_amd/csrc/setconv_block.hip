@@ -252,6 +252,11 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     const long long P = (long long)d->B * d->N, M = P * d->S;
     const int O1 = d->O1, C2 = d->C[0], C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
     const float *b5 = L.bn[5], *b2 = L.bn[2];
+    // The inverse index of the grouping is only needed by the scatter at the very end, but its kernel wants most of a
+    // CU's LDS (one workgroup per sample, 132 KB at N = 256): issued there it has to wait until a CU has drained the
+    // GEMM workgroups of the other chains -- up to a tile's duration on the critical tail of the chain.  Issued first
+    // it runs next to the small per-point kernels and is long done when the scatter needs it.
+    if (d->dy) CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
     // layer 6 .. 4 (per point)
     CMF_TRY(cmf_act_bwd_stats(P, C6, d->dout, d->lddout, L.z6, C6, b5 + 2 * C6, b5 + 3 * C6, b5, b5 + C6, L.t6, L.partial, st));
     CMF_TRY(bn_bwd(d, L, 5, P, L.t6, L.z6, st));
@@ -283,7 +288,6 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
         CMF_TRY(cmf_setconv_dwx(O1, (float)(1.0 / (double)M), d->training, L.sums, L.fwd_sums, b0 + 2 * O1, b0, b0 + O1, d->dwx,
                                 (int)d->lddwx, d->acc_wx, st));
     if (d->dy) {
-        CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
         // z1 rows of one source point differ only by wx . dxyz: the BN-backward part of the scatter has a closed form,
         // so only dU1 is streamed (csrc/group_rows.hip)
         CMF_TRY(cmf_group_rows_grad_bn_cf(d->B, d->N, O1, d->N * d->S, d->S, L.dU1, d->y, d->ldy, d->wx, d->ldwx, d->xyz, d->xyz,

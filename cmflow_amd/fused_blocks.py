@@ -1052,6 +1052,7 @@ class CostVolumeMLPFn(Function):
     def backward(ctx, dx3, _ddxyz):
         nbr, dxyz, x1, x2, x3, w2, w3, (B, N1, K, C), N2 = ctx.saved
         M = B * N1 * K
+        off, inv = nbr.inverse()            # wants most of a CU's LDS: issued ahead of the GEMMs, not behind them
         dx3 = dx3.reshape(M, -1)
         # leaky'(z) has the sign of the stored activation
         dz3 = dx3.contiguous() if ctx.preact_grad else torch.where(x3 > 0, dx3, 0.1 * dx3)
@@ -1066,7 +1067,6 @@ class CostVolumeMLPFn(Function):
         dz1 = gemm(dz2, w2, b_t=False, bwd=(2, x1))
         dwd = gemm_dw(dz1, dxyz.view(-1, 4))[:, :3]
         dp1 = dz1.view(B, N1, K, C).sum(dim=2)
-        off, inv = nbr.inverse()
         dp2 = torch.empty(B, N2, C, dtype=_f32, device=dz1.device)
         err = L().cmf_group_rows_grad(B, N2, C, C, N1 * K, 0, _p(dz1), _p(off), _p(inv), _p(dp2), _lib.stream_ptr())
         _lib.check(err, "cmf_group_rows_grad")
