@@ -126,11 +126,19 @@ def main():
     if world != a.gpus:
         print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
     import torch.distributed as dist
+    # CMF_BENCH_ONE_GPU=1: every rank on cuda:0 over gloo -- exercises the multi-rank control flow (collectives entered by
+    # all ranks, one JSON line, clean exit) on a 1-GPU box; its numbers mean nothing (tests/test_gpu_model.py)
+    one_gpu = os.environ.get("CMF_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
 
@@ -220,8 +228,9 @@ def main():
     # In the timed region the four scales of an encoder run on four HIP streams, so a bracketed launch shares
     # the chip with kernels of the other streams and its duration is a contended one.  A short extra pass with
     # the scales serialised (outside the timed region, not part of `value`) gives the kernel's own rate.
+    # Every rank runs it: a training step contains the gradient all-reduce, a collective all ranks must enter.
     iso = None
-    if rank == 0 and a.path == "pm":
+    if a.path == "pm":
         from cmflow_amd.radarflow_util import FeatureCorrelator, MultiScaleEncoder
         for m in net.modules():
             if isinstance(m, MultiScaleEncoder):
@@ -244,7 +253,7 @@ def main():
             roof["note"] = ("independent chains run on 3 side streams next to the caller's: a bracketed launch shares the chip with "
                             "kernels (often other cmf_gemm launches) of the other streams, so its duration is a contended one")
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:           # the CPU leg is timed at N=1 only
             cpu = cpu_baseline(a.mode, a.model)
         line = {
             "metric": "frame-pairs/sec %s %s" % ({"cmflow": "CMFlow", "cmflow_t": "CMFlow-T", "raflow": "RaFlow"}[a.model],
@@ -266,6 +275,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        fence()                                             # leave together
         dist.destroy_process_group()
 
 

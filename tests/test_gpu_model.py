@@ -468,3 +468,28 @@ def test_dense_cloud_forward_matches_oracle(dev, manifest, golden_dir, args):
     assert float(epe[~flips].max()) < 1e-4
     assert float((got[1].cpu() - want[1]).abs().max()) < 1e-4
     assert float((got[2].cpu() - want[2]).abs().max()) < 1e-4
+
+
+def test_bench_two_ranks_control_flow(dev):
+    """bench.py under torch.distributed.run with two ranks (both on cuda:0 over gloo, CMF_BENCH_ONE_GPU=1): every
+    collective of the script -- parameter broadcast, the gradient all-reduce inside every step INCLUDING the extra
+    isolated-roofline steps after the timed region, the max-over-ranks of the time -- is entered by both ranks, rank 0
+    prints exactly one JSON line, and both processes exit cleanly (a rank-0-only training step would hang here)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CMF_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["cpu_baseline"] is None
+    assert rec["roofline"] is not None and rec["roofline_isolated"] is not None and rec["value"] > 0
