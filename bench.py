@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this stack (already exported on the pool)
+
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
