@@ -94,15 +94,15 @@ extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *part
 // acc0 / acc1 (optional): accumulate columns [0,C) into acc0 and [C,2C) into acc1 -- the BN-backward sums go
 // straight into beta.grad / gamma.grad (one launch instead of a reduction plus two tiny torch adds).
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
-                                                              int C, float *__restrict__ acc0, float *__restrict__ acc1)
+                                                              int C, float *__restrict__ acc0, float *__restrict__ acc1, int store = 0)
 {
     __shared__ double sh[FIN_COLS * FIN_LANES];
     const int col = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
     const double s = fin_reduce(tiles, C2, col, partial, sh);
     if (threadIdx.x < FIN_COLS && col < C2) {
         out[col] = (float)s;
-        if (acc0 && col < C) acc0[col] += (float)s;
-        if (acc1 && col >= C && col < 2 * C) acc1[col - C] += (float)s;
+        if (acc0 && col < C) acc0[col] = store ? (float)s : acc0[col] + (float)s;
+        if (acc1 && col >= C && col < 2 * C) acc1[col - C] = store ? (float)s : acc1[col - C] + (float)s;
     }
 }
 
@@ -119,6 +119,16 @@ extern "C" int cmf_colsum(int tiles, int ncols, const float *partial, float *out
     CMF_CHECK_ARG(tiles > 0 && ncols > 0 && partial && out);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(ncols, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
                        tiles, ncols, partial, out, C, acc0, acc1);
+    return cmf_launch_status();
+}
+
+// internal (csrc/setconv_block.hip): the same reduction with the first 2*C columns STORED to dst0 / dst1 instead of added --
+// a block whose BN gradients go to caller buffers gets them from this launch instead of two device-to-device copies
+int cmf_colsum_store(int tiles, int ncols, const float *partial, float *out, int C, float *dst0, float *dst1, void *stream)
+{
+    CMF_CHECK_ARG(tiles > 0 && ncols > 0 && partial && out);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(ncols, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
+                       tiles, ncols, partial, out, C, dst0, dst1, 1);
     return cmf_launch_status();
 }
 

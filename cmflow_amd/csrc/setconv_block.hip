@@ -116,6 +116,11 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
 
 #define CMF_TRY(call) do { int e_ = (call); if (e_) return e_; } while (0)
 
+}  // namespace
+// csrc/pointwise.hip (internal): cmf_colsum with the first 2*C columns stored to dst0 / dst1
+int cmf_colsum_store(int tiles, int ncols, const float *partial, float *out, int C, float *dst0, float *dst1, void *stream);
+namespace {
+
 // Eval mode: the six folds depend on nothing the block computes (running statistics), so they are ONE launch at the head
 // of the chain instead of six tiny kernels between its GEMMs.  Same arithmetic as bn_finalize_kernel's eval branch.
 struct FoldAll { int C[6]; const float *gamma[6], *beta[6], *rmean[6], *rvar[6]; float eps[6]; float *out[6]; };
@@ -195,12 +200,9 @@ int bn_bwd(const cmf_setconv_desc *d, const Layout &L, int l, long long rows, fl
 {
     const int C = chan(d, l);
     const float *b = L.bn[l];
-    float *accb = d->acc_bn[l] ? d->dbeta[l] : nullptr, *accg = d->acc_bn[l] ? d->dgamma[l] : nullptr;
-    CMF_TRY(cmf_colsum_finalize(tiles128(rows), C, L.partial, L.sums, accb, accg, st));
-    if (!d->acc_bn[l]) {
-        if (d->dbeta[l]) CMF_TRY((int)hipMemcpyAsync(d->dbeta[l], L.sums, C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
-        if (d->dgamma[l]) CMF_TRY((int)hipMemcpyAsync(d->dgamma[l], L.sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
-    }
+    // the two sums land in the caller's dbeta / dgamma from the same launch: added (gradient sinks) or stored
+    if (d->acc_bn[l]) CMF_TRY(cmf_colsum_finalize(tiles128(rows), C, L.partial, L.sums, d->dbeta[l], d->dgamma[l], st));
+    else CMF_TRY(cmf_colsum_store(tiles128(rows), 2 * C, L.partial, L.sums, C, d->dbeta[l], d->dgamma[l], st));
     return cmf_bn_bwd_apply(rows, C, dU, z, C, b + 2 * C, b, b + C, d->training ? L.sums : nullptr, st);
 }
 
@@ -278,12 +280,8 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     CMF_TRY(dx_gemm(d, L, M, C2, O1, L.dU2, d->w[0], L.z1, 0, L.dU1, L.dxyz, st));
     // first layer: sums {s1,s2,q0,q1,q2}; dgamma/dbeta; dW_xyz from sums; BN backward folded into the scatter
     const float *b0 = L.bn[0];
-    float *accb = d->acc_bn[0] ? d->dbeta[0] : nullptr, *accg = d->acc_bn[0] ? d->dgamma[0] : nullptr;
-    CMF_TRY(cmf_colsum(tiles128(M), 5 * O1, L.partial, L.sums, O1, accb, accg, st));
-    if (!d->acc_bn[0]) {
-        if (d->dbeta[0]) CMF_TRY((int)hipMemcpyAsync(d->dbeta[0], L.sums, O1 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
-        if (d->dgamma[0]) CMF_TRY((int)hipMemcpyAsync(d->dgamma[0], L.sums + O1, O1 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)st));
-    }
+    if (d->acc_bn[0]) CMF_TRY(cmf_colsum(tiles128(M), 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));
+    else CMF_TRY(cmf_colsum_store(tiles128(M), 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));
     if (d->dwx)
         CMF_TRY(cmf_setconv_dwx(O1, (float)(1.0 / (double)M), d->training, L.sums, L.fwd_sums, b0 + 2 * O1, b0, b0 + O1, d->dwx,
                                 (int)d->lddwx, d->acc_wx, st));
