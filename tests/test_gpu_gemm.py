@@ -186,6 +186,14 @@ def test_thin_gemm_weight_gradient(dev, M, N, K):
     dW = gemm_dw(dZ, Zp, prob=(ea, ec))
     _check(dW, dZ.double().t() @ X.double(), dZ.double().abs().t() @ X.double().abs(), tol=4e-6)
     assert torch.equal(dW, gemm_dw(dZ, Zp, prob=(ea, ec)))            # deterministic
+    # the same slabs accumulated into a row-strided buffer (gradient sinks: the [:, 3:] block of a conv weight's .grad)
+    from cmflow_amd.fused import gemm
+    from cmflow_amd.fused_blocks import dw_split
+    base = torch.randn(N, K + 4, generator=g).to(dev)
+    acc = base.clone()
+    gemm(dZ, Zp, a_t=True, b_t=False, prob=(ea, ec), split_k=dw_split(M, N, K), out=acc[:, 4:], accumulate=True)
+    assert torch.equal(acc[:, :4], base[:, :4])
+    np.testing.assert_allclose(acc[:, 4:].cpu().numpy(), (base[:, 4:] + dW).cpu().numpy(), rtol=1e-6, atol=1e-4 * float(dW.abs().max()))
 
 
 def test_bf16x3_emulation_is_fp32_grade(dev):
