@@ -541,7 +541,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float qs[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    const bool want_q = want_stats && p.bwd_mode == 1 && p.dxyz != nullptr;
+    const bool want_q = want_stats && p.bwd_mode != 0 && p.dxyz != nullptr;    // + column sums of out * dxyz_k: the xyz-weight gradient
     const int nstat = want_q ? 5 : 2;
 #pragma unroll
     for (int band = 0; band < WARPS_M; ++band) {
@@ -580,8 +580,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                         x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
                         s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
                         if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
-                    } else if (p.bwd_mode == 2) { x = z[q] > 0.f ? x : 0.1f * x; if (want_stats) s1[q] += x; }   // column sums: bias gradient
-                    else if (p.bwd_mode == 3) { x = z[q] > 0.f ? x : 0.f; if (want_stats) s1[q] += x; }
+                    } else if (p.bwd_mode == 2 || p.bwd_mode == 3) {
+                        x = z[q] > 0.f ? x : (p.bwd_mode == 2 ? 0.1f * x : 0.f);
+                        if (want_stats) s1[q] += x;                                           // column sums: bias gradient
+                        if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
+                    }
                     else if (want_stats) { s1[q] += x; s2[q] += x * x; }
                     v[q] = x;
                 }

@@ -95,9 +95,10 @@ int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, int accumulat
  *   bias [N], act: 0 none / 1 relu / 2 leaky(0.1) / 3 sigmoid
  *   stats: [ceil(M/128)][2][N] per-row-tile partial (sum, sum of squares) of the stored C
  *   bwd_mode 1: C = acc * [ea[n]*Z + ec[n] > 0], stats <- partial (sum C, sum C*(Z-emean)*einvstd)
- *   dxyz (bwd_mode 1, optional): rows of (dx,dy,dz,0) per output row; stats becomes [tiles][5][N] with the
- *                three extra partials sum C*d_k -- the set-conv's dW_xyz comes out of the epilogue
- *   bwd_mode 2: C = acc * (Z > 0 ? 1 : 0.1)        bwd_mode 3: C = acc * [Z > 0]
+ *   dxyz (bwd_mode 1, 2 or 3 with stats, optional): rows of (dx,dy,dz,0) per output row; stats becomes [tiles][5][N]
+ *                with the three extra partials sum C*d_k -- the xyz-weight gradient of the set-conv's / cost volume's
+ *                first conv comes out of the epilogue instead of a 4-column GEMM over the same rows
+ *   bwd_mode 2: C = acc * (Z > 0 ? 1 : 0.1)        bwd_mode 3: C = acc * [Z > 0]     (stats: column sums of C in row 0)
  *   split_k > 1: contraction split over split_k slabs in `workspace` ([split_k][M][N] floats),
  *                summed in a fixed order by a second kernel (deterministic weight gradients)
  *   accumulate: C += result
