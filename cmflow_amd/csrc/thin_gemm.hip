@@ -35,7 +35,7 @@ __device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[N
 {
     const int h = lane >> 5, cl = lane & 31;
     const bool want_stats = p.stats != nullptr;
-    const bool want_q = want_stats && p.bwd_mode == 1 && p.dxyz != nullptr;
+    const bool want_q = want_stats && p.bwd_mode != 0 && p.dxyz != nullptr;
     const int nstat = want_q ? 5 : 2;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -58,8 +58,11 @@ __device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[N
                         x = (fmaf(ea, z, ec) > 0.f) ? x : 0.f;
                         s1 += x; s2 += x * ((z - em) * ei);
                         if (want_q) { const float4 d = *(const float4 *)(p.dxyz + (long long)m * 4); q0 += x * d.x; q1 += x * d.y; q2 += x * d.z; }
-                    } else if (p.bwd_mode == 2) { x = z > 0.f ? x : 0.1f * x; if (want_stats) s1 += x; }
-                    else { x = z > 0.f ? x : 0.f; if (want_stats) s1 += x; }
+                    } else {
+                        x = z > 0.f ? x : (p.bwd_mode == 2 ? 0.1f * x : 0.f);
+                        if (want_stats) s1 += x;
+                        if (want_q) { const float4 d = *(const float4 *)(p.dxyz + (long long)m * 4); q0 += x * d.x; q1 += x * d.y; q2 += x * d.z; }
+                    }
                 } else if (want_stats) { s1 += x; s2 += x * x; }
                 float *dst = p.C + (long long)m * p.ldc + n;
                 *dst = p.accumulate ? *dst + x : x;

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wn_ksum_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < WN_J; ++j) dW[i][j] = 0.f;
     float db[4] = {0.f, 0.f, 0.f, 0.f}, cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float dbh = 0.f;                                    // threads tid < R*8: column sum of the masked dh they write
     const int MK = M * K;
     int it = 0;
     for (int row0 = (int)blockIdx.x * R; row0 < MK; row0 += (int)gridDim.x * R, ++it) {
@@ -287,12 +288,27 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wn_ksum_bwd_kernel(
             if (row0 + rr < MK) {
                 float s = sred[it & 1][rr * wpr][j];
                 for (int w = 1; w < wpr; ++w) s += sred[it & 1][rr * wpr + w][j];
+                if (leaky & 4) {                        // h is a stored ReLU activation: gradient w.r.t. its pre-activation
+                    s = h[(long long)(row0 + rr) * WN_J + j] > 0.f ? s : 0.f;
+                    dbh += s;
+                }
                 dh[(long long)(row0 + rr) * WN_J + j] = s;
             }
         }
     }
-    // fold the R thread groups that own the same channels, then one [C*8 | C | C] partial row per workgroup
-    float *prow = part + (long long)blockIdx.x * (C * (WN_J + 2));
+    // fold the R thread groups that own the same channels, then one [C*8 | C | C | 8] partial row per workgroup
+    float *prow = part + (long long)blockIdx.x * (C * (WN_J + 2) + WN_J);
+    {
+        __syncthreads();
+        float *fl = (float *)fold;
+        if (tid < R * WN_J) fl[tid] = dbh;
+        __syncthreads();
+        if (tid < WN_J) {
+            float t = fl[tid];
+            for (int rr = 1; rr < R; ++rr) t += fl[rr * WN_J + tid];
+            prow[C * (WN_J + 2) + tid] = t;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
         float4 v;

@@ -283,9 +283,14 @@ class LinearFn(Function):
     Operands whose row stride is not a multiple of 4 floats are copied into padded buffers."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, act, preact_grad=False):
+    def forward(ctx, x, w, bias, act, preact_grad=False, in_bias=None):
         # preact_grad: the consumer hands back the gradient w.r.t. the pre-activation (WeightedKSumFn relu_w=True)
+        # in_bias: x is the stored ReLU activation of a layer with this bias that was built with preact_grad=True and a
+        # detached bias: the input gradient is then formed w.r.t. that layer's pre-activation (mask in the GEMM epilogue)
+        # and its column sums -- the producer's bias gradient -- are returned for in_bias, instead of a compare, a
+        # multiply and a reduction as separate torch kernels in the producer's backward
         ctx.preact_grad = preact_grad
+        ctx.in_bias = in_bias
         ok = x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[1] % 4 == 0
         x2 = x if ok else _pad_cols(x)
         w2 = _pad_cols(w)
@@ -307,16 +312,23 @@ class LinearFn(Function):
             dy = torch.where(y > 0, dy, 0.1 * dy)
         elif ctx.act == 3:
             dy = dy * y * (1 - y)
-        dx = dw = db = None
+        dx = dw = db = dib = None
         dyp = _pad_cols(dy)                                             # (M, N4)
         if ctx.needs_input_grad[0]:
             wp = w2 if dyp.shape[1] == N else torch.nn.functional.pad(w2, (0, 0, 0, dyp.shape[1] - N))
-            dx = gemm(dyp, wp, b_t=False)[:, :K]
+            if ctx.in_bias is not None:
+                dx, part = gemm(dyp, wp, b_t=False, bwd=(3, x2), stats=True)
+                sink = grad_sink(ctx.in_bias)
+                sums = colsum_n(part, K, sink, None)
+                dib = None if sink is not None else sums[0, :K]
+                dx = dx[:, :K]
+            else:
+                dx = gemm(dyp, wp, b_t=False)[:, :K]
         if ctx.needs_input_grad[1]:
             dw = gemm_dw(dyp, x2)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, dib
 
 
 class StackedFirstConvFn(Function):
@@ -399,10 +411,10 @@ def _pad_cols(t):
     return buf
 
 
-def linear(x, w, bias=None, act=0, preact_grad=False):
+def linear(x, w, bias=None, act=0, preact_grad=False, in_bias=None):
     """(..., K) -> (..., N) through cmf_gemm"""
     shp = x.shape
-    y = LinearFn.apply(x.reshape(-1, shp[-1]), w, bias, act, preact_grad)
+    y = LinearFn.apply(x.reshape(-1, shp[-1]), w, bias, act, preact_grad, in_bias)
     return y.view(*shp[:-1], w.shape[0])
 
 
@@ -1142,7 +1154,9 @@ class WeightNetKSumFn(Function):
         return J == 8 and L().cmf_weightnet_ksum_tiles(int(C)) > 0
 
     @staticmethod
-    def forward(ctx, h, wl, bl, x, nbr, leaky, x_bias=None):
+    def forward(ctx, h, wl, bl, x, nbr, leaky, x_bias=None, h_bias=None):
+        # h_bias: h is the stored ReLU activation of a layer with this bias (built with preact_grad=True and a detached
+        # bias): the gradient returned for h is w.r.t. that layer's pre-activation and its column sums go to h_bias
         B, N1, K, J = h.shape
         C = wl.shape[0]
         h, wl, bl, x = h.contiguous(), wl.contiguous(), bl.contiguous(), x.contiguous()
@@ -1151,8 +1165,8 @@ class WeightNetKSumFn(Function):
         n_src = nbr.n if nbr is not None else 0
         _lib.check(L().cmf_weightnet_ksum(B * N1, K, C, N1, n_src, _p(h), _p(wl), _p(bl), _p(x), idx, _p(out), _lib.stream_ptr()),
                    "cmf_weightnet_ksum")
-        ctx.saved = (h, wl, bl, x, nbr, int(bool(leaky)))
-        ctx.params = (wl, bl, x_bias)
+        ctx.saved = (h, wl, bl, x, nbr, int(bool(leaky)) | (4 if h_bias is not None else 0))
+        ctx.params = (wl, bl, x_bias, h_bias)
         return out
 
     @staticmethod
@@ -1166,25 +1180,26 @@ class WeightNetKSumFn(Function):
             dcost = dcost.contiguous()                                  # a column block of a wider gradient is read in place
         dx = torch.empty(B, N1, K, C, dtype=_f32, device=dev)
         dh = torch.empty_like(h)
-        part = torch.empty(L().cmf_weightnet_ksum_tiles(C), C * (J + 2), dtype=_f32, device=dev)
+        part = torch.empty(L().cmf_weightnet_ksum_tiles(C), C * (J + 2) + J, dtype=_f32, device=dev)
         idx = _lib.dev_ptr(nbr.idx, torch.int32) if nbr is not None else None
         n_src = nbr.n if nbr is not None else 0
         _lib.check(L().cmf_weightnet_ksum_grad(B * N1, K, C, N1, n_src, leaky, dcost.data_ptr(), dcost.stride(1), _p(h), _p(wl), _p(bl), _p(x), idx,
                                                _p(dx), _p(dh), _p(part), _lib.stream_ptr()), "cmf_weightnet_ksum_grad")
         sums = colsum_n(part)                                            # fixed-order sum of the per-workgroup partials
-        grads = [sums[:C * J].view(C, J), sums[C * J:C * J + C], sums[C * J + C:] if ctx.params[2] is not None else None]
+        grads = [sums[:C * J].view(C, J), sums[C * J:C * J + C], sums[C * J + C:C * J + 2 * C] if ctx.params[2] is not None else None,
+                 sums[C * (J + 2):] if ctx.params[3] is not None else None]
         sinks = [grad_sink(p) if p is not None else None for p in ctx.params]
         pairs = [(s.view(-1), g.reshape(-1)) for s, g in zip(sinks, grads) if s is not None and g is not None]
         if pairs:                                                        # straight into the parameters' .grad, one launch
             torch._foreach_add_([s for s, _ in pairs], [g for _, g in pairs])
-        dwl, dbl, dxb = [None if (s is not None or g is None) else g for s, g in zip(sinks, grads)]
+        dwl, dbl, dxb, dhb = [None if (s is not None or g is None) else g for s, g in zip(sinks, grads)]
         if nbr is not None:                                              # scatter the per-slot gradients back to the points
             off, inv = nbr.inverse()
             dp = torch.empty(B, nbr.n, C, dtype=_f32, device=dev)
             _lib.check(L().cmf_group_rows_grad(B, nbr.n, C, C, N1 * K, 0, _p(dx), _p(off), _p(inv), _p(dp), _lib.stream_ptr()),
                        "cmf_group_rows_grad")
             dx = dp
-        return dh, dwl, dbl, dx, None, None, dxb
+        return dh, dwl, dbl, dx, None, None, dxb, dhb
 
 
 class GlobalMaxCatFn(Function):

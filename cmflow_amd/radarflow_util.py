@@ -277,16 +277,36 @@ class WeightNet(nn.Module):
         last = self.mlp_convs[-1]
         if self.fuse_tail and FB.WeightNetKSumFn.supported(last.weight.shape[0], last.weight.shape[1]):
             h = hidden if hidden is not None else self.hidden_pm(dxyz)
-            return FB.WeightNetKSumFn.apply(h, w2d(last), last.bias, x, nbr, leaky, x_bias)
+            return FB.WeightNetKSumFn.apply(h, w2d(last), last.bias, x, nbr, leaky, x_bias, self._hidden_bias())
         weights = FB.linear(hidden if hidden is not None else self.hidden_pm(dxyz), w2d(last), last.bias, act=1, preact_grad=True)
         return FB.WeightedKSumFn.apply(weights, x, nbr, leaky, True, x_bias)
 
     def hidden_pm(self, dxyz):
-        """All layers but the last on the fused blocks: (B,N,K,3|4) -> (B,N,K,hidden)."""
-        h = dxyz
-        for conv in list(self.mlp_convs)[:-1]:
-            h = FB.linear(h, w2d(conv), conv.bias, act=1)
+        """All layers but the last on the fused blocks: (B,N,K,3|4) -> (B,N,K,hidden).  With the fused tail every ReLU
+        mask and bias gradient of the chain is produced by the kernel that consumes the layer's output (the weighting
+        kernel for the last hidden layer, the data-gradient GEMM epilogue of layer i+1 for layer i): the layers are
+        built with detached biases and preact_grad=True, the real biases ride along as in_bias / h_bias."""
+        convs = list(self.mlp_convs)[:-1]
+        if not (self.fuse_tail and self._hidden_bias() is not None):
+            h = dxyz
+            for conv in convs:
+                h = FB.linear(h, w2d(conv), conv.bias, act=1)
+            return h
+        h, prev = dxyz, None
+        for conv in convs:
+            h = FB.linear(h, w2d(conv), conv.bias.detach(), act=1, preact_grad=True, in_bias=prev)
+            prev = conv.bias
         return h
+
+    def _hidden_bias(self):
+        """Bias of the last hidden layer when the fused chain applies (tail fused and every hidden width a multiple of 4)."""
+        convs = list(self.mlp_convs)
+        last = convs[-1]
+        if not (self.fuse_tail and FB.WeightNetKSumFn.supported(last.weight.shape[0], last.weight.shape[1])):
+            return None
+        if any(c.weight.shape[0] % 4 for c in convs[:-1]) or len(convs) < 2:
+            return None
+        return convs[-2].bias
 
     fuse_tail = True
 

@@ -290,8 +290,10 @@ int cmf_weighted_ksum_grad(long long M, int K, int C, int n1, int n_src, int lea
  * h (M*K, 8) the hidden activation, Wl (C, 8), bl (C) -- the (M,K,C) weight tensor and its gradient never exist.
  * C in {256, 512, 1024} (cmf_weightnet_ksum_tiles(C) > 0), M*K < 2^31, x / idx / leaky bit 0 as above.
  * The gradient call writes dx (M,K,C), dh (M*K, 8) and one partial row per workgroup,
- * part [cmf_weightnet_ksum_tiles(C)][C*8 + C + C] = sums of dWl (C,8) | dbl (C) | column sums of dx (C), to be reduced
- * in fixed order with cmf_colsum.  dcost has row stride ldd floats (>= C: it may be a column block of a wider gradient). */
+ * part [cmf_weightnet_ksum_tiles(C)][C*8 + C + C + 8] = sums of dWl (C,8) | dbl (C) | column sums of dx (C) | column sums
+ * of dh (8), to be reduced in fixed order with cmf_colsum.  leaky bit 2 (value 4): h is itself a stored ReLU activation
+ * (WeightNet's second hidden layer) -- dh is then masked by h > 0, i.e. it is the gradient w.r.t. that layer's
+ * pre-activation and its column sums are that layer's bias gradient.  dcost has row stride ldd floats (>= C: it may be a column block of a wider gradient). */
 int cmf_weightnet_ksum_tiles(int C);
 int cmf_weightnet_ksum(long long M, int K, int C, int n1, int n_src, const float *h, const float *Wl, const float *bl,
                        const float *x, const int *idx, float *out, void *stream);

@@ -315,6 +315,57 @@ def test_weightnet_ksum_matches_torch(dev, B, N1, N2, K, C):
         assert (a is None and b is None) or torch.equal(a, b)
 
 
+@pytest.mark.parametrize("gather", [False, True])
+def test_weightnet_chain_gradients_match_torch(dev, gather):
+    """WeightNet (radarflow_util.py:287-318: 3 -> 8 -> 8 -> 512 with ReLUs) through the fused chain: the last layer lives
+    inside the weighting kernels, and every hidden layer's ReLU mask and bias gradient is produced by the kernel that
+    consumes its output (weighting backward for the second hidden layer, the data-gradient GEMM epilogue for the first).
+    Output and the gradients of all six parameters and of x against plain torch autograd.  All WeightNet operands sit on
+    dyadic grids so that every pre-activation is exact in any summation order (no ReLU-kink ambiguity)."""
+    from cmflow_amd.fused import Neighbors, group_rows
+    from cmflow_amd.radarflow_util import WeightNet
+    B, N, K, C = 3, 96, 8, 512
+    g = torch.Generator().manual_seed(5 + int(gather))
+    wn = WeightNet(3, C).to(dev)
+    assert wn._hidden_bias() is wn.mlp_convs[1].bias
+    with torch.no_grad():
+        for conv, q in zip(wn.mlp_convs, (2, 2, 4)):
+            conv.weight.copy_((torch.round(torch.randn(conv.weight.shape, generator=g) * q) / q).clamp(-2, 2))
+            conv.bias.copy_(torch.round(torch.randn(conv.bias.shape, generator=g) * q) / q)
+    dxyz = torch.nn.functional.pad((torch.round(torch.randn(B, N, K, 3, generator=g) * 4) / 4).clamp(-3, 3), (0, 1)).to(dev)
+    go = torch.randn(B, N, C, generator=g).to(dev)
+    if gather:
+        x = torch.randn(B, N, C, generator=g).to(dev).requires_grad_(True)
+        nbr = Neighbors(torch.randint(0, N, (B, N, K), generator=g, dtype=torch.int32).to(dev), N)
+    else:
+        x = torch.randn(B, N, K, C, generator=g).to(dev).requires_grad_(True)
+        nbr = None
+    params = [p for conv in wn.mlp_convs for p in (conv.weight, conv.bias)]
+
+    def run(fn):
+        for t in params + [x]:
+            t.grad = None
+        out = fn()
+        out.backward(go)
+        return [out.detach()] + [t.grad.clone() for t in params + [x]]
+
+    def torch_path():
+        w = dxyz[..., :3]
+        for conv in wn.mlp_convs:
+            w = torch.relu(torch.nn.functional.linear(w, conv.weight.view(conv.weight.shape[0], -1), conv.bias))
+        return torch.sum(w * (group_rows(x, nbr) if gather else x), dim=2)
+
+    ref = run(torch_path)
+    got = run(lambda: wn.weighted_ksum(dxyz, x, nbr, False))
+    names = ["out", "w1", "b1", "w2", "b2", "w3", "b3", "dx"]
+    for n, a, b in zip(names, got, ref):
+        scale = float(b.abs().max()) + 1e-6
+        np.testing.assert_allclose(a.reshape(b.shape).cpu().numpy() / scale, b.cpu().numpy() / scale, rtol=0, atol=3e-6, err_msg=n)
+    again = run(lambda: wn.weighted_ksum(dxyz, x, nbr, False))
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,N1,N2,K,C", [(2, 64, 64, 8, 512), (3, 50, 70, 5, 12), (1, 33, 33, 16, 64)])
 def test_weighted_ksum_matches_torch(dev, B, N1, N2, K, C):
     """cmf_weighted_ksum(_grad) (radarflow_util.py:219-221,234-236) against the torch expressions, dense and gathered."""
