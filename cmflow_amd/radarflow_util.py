@@ -398,11 +398,11 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     # autograd replays their backward on the same streams.
     side = self._side_streams() if (self.side_streams and xyz1_t.is_cuda) else None
     main = torch.cuda.current_stream() if side else None
-    nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])
     if side:
         for st in side:
             st.wait_stream(main)
     with torch.cuda.stream(side[0]) if side else contextlib.nullcontext():
+        nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])     # needed after p1: off the main stream too
         p2 = FB.linear(f2, w0[:, D1:D1 + D2])
     with torch.cuda.stream(side[1]) if side else contextlib.nullcontext():
         nbr2 = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
@@ -411,7 +411,8 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     p1 = FB.linear(f1, w0[:, :D1], c0.bias)
     if side:
         main.wait_stream(side[0])
-        p2.record_stream(main); f2.record_stream(side[0])
+        p2.record_stream(main); nbr.idx.record_stream(main); f2.record_stream(side[0])
+        xyz1_t.record_stream(side[0]); xyz2_t.record_stream(side[0])
     x, dxyz = FB.CostVolumeMLPFn.apply(xyz1_t, xyz2_t, p1, p2, nbr, w0[:, D1 + D2:], w2d(c1), c1.bias, w2d(c2), c2.bias, True)
     p2p = self.weightnet1.weighted_ksum(dxyz, x, None, True, c2.bias)                      # sum_k weights * x
     if side:
