@@ -1,0 +1,43 @@
+"""Kernel-time breakdown of the second encoder alone (forward + backward, train-mode BN) at B=64, N=256."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from cmflow_amd import synth
+from cmflow_amd.cmflow import CMFlow
+from cmflow_amd.train import TrainStep
+dev = torch.device("cuda:0")
+net = CMFlow(bench.Args()); net.load_state_dict(bench.load_weights("cmflow")); net = net.to(dev).train()
+step = TrainStep(net)
+b = {k: v.to(dev) for k, v in synth.make_batch(64, seed=1).items()}
+x1 = b["pc1"].transpose(1, 2).contiguous()
+g = torch.Generator().manual_seed(0)
+emb = torch.randn(64, 256, 1040, generator=g).to(dev)
+emb[:, :, 1027:] = 0
+emb.requires_grad_(True)
+go = torch.randn(64, 256, 256, generator=g).to(dev)
+net._set_blocks(True)
+
+
+def one():
+    net.mse_layer2.forward_pm(x1, emb, n_tail=3, n_grad=1024).backward(go)
+
+
+for _ in range(3):
+    one()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    one()
+e1.record(); torch.cuda.synchronize()
+print("second encoder fwd+bwd: %.2f ms" % (e0.elapsed_time(e1) / 10))
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    for _ in range(5):
+        one()
+    torch.cuda.synchronize()
+rows = [(e.device_time_total / 5, e.count / 5, e.key) for e in prof.key_averages() if e.device_time_total > 0]
+rows.sort(reverse=True)
+print("sum of kernel time per call: %.2f ms" % (sum(r[0] for r in rows) / 1e3))
+for t, c, k in rows[:30]:
+    print("%8.1f us  n=%5.1f  avg %6.1f us  %s" % (t, c, t / c, k[:100]))
