@@ -24,9 +24,13 @@ class CMFlow(nn.Module):
     path = "pm"
 
     def _set_blocks(self, on):
+        # called every forward: walking ~400 submodules costs 0.7 ms of host time, so only when the setting changes
+        if getattr(self, "_blocks_on", None) is on:
+            return
         for m in self.modules():
             if hasattr(m, "use_blocks"):
                 m.use_blocks = on
+        self._blocks_on = on
 
     def __init__(self, args):
         super().__init__()
