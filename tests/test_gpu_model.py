@@ -136,16 +136,21 @@ def test_forward_matches_oracle_fresh_inputs(dev, manifest, golden_dir, args):
 
 
 @pytest.mark.parametrize("path", ["pm", "pm_py", "pm_torch", "ref"])
-def test_train_step_matches_reference_golden(path, dev, manifest, golden_dir, args):
+@pytest.mark.parametrize("case", ["cmflow_train_synth_b4", "cmflow_train_evalbn_synth_b4"])
+def test_train_step_matches_reference_golden(case, path, dev, manifest, golden_dir, args):
     """Rows a3 + a15('train') + losses + Adam against the reference's own train step
-    (main_util.py:63-76 run behind the shims, tests/golden/make_golden.py)."""
+    (main_util.py:63-76 run behind the shims, tests/golden/make_golden.py).  `evalbn`: the same step with the network
+    in eval mode -- the regime of every CMFlow epoch after the first (train_one_epoch never calls net.train(),
+    main_util.py:39-76,96): BN normalises with its running statistics, gradients flow, buffers must not move."""
     from cmflow_amd.cmflow import CMFlow
     from cmflow_amd.train import TrainStep
-    g = _load(golden_dir, "cmflow_train_synth_b4")
+    g = _load(golden_dir, case)
     net = CMFlow(args)
     _set_path(net, path)
     net.load_state_dict(_weights(manifest, golden_dir))
-    net = net.to(dev).train()
+    net = net.to(dev)
+    net.eval() if "evalbn" in case else net.train()
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
     batch = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc1", "pc2", "ft1", "ft2", "gt_trans", "flow_label", "fg_mask",
                                                             "interval", "radar_u", "radar_v", "opt_flow")}
     step = TrainStep(net, vr_thres=args.vr_thres)
@@ -153,9 +158,9 @@ def test_train_step_matches_reference_golden(path, dev, manifest, golden_dir, ar
     step.bucket.zero()
     loss.backward()
     assert np.array_equal(dyn.cpu().numpy(), g["dyn_mask"]) and np.array_equal(mseg.cpu().numpy(), g["mseg_gt"])
-    assert abs(loss.item() - float(g["loss"])) < 2e-4
+    assert abs(loss.item() - float(g["loss"])) < 2e-4 * max(1.0, abs(float(g["loss"])))
     for k, v in items.items():
-        assert abs(v.item() - float(g["item_" + k])) < 2e-4, k
+        assert abs(v.item() - float(g["item_" + k])) < 2e-4 * max(1.0, abs(float(g["item_" + k]))), k
     assert _epe(outs[0].detach().cpu().numpy(), g["sf_agg"]) < 1e-4
     np.testing.assert_allclose(outs[2].detach().cpu().numpy(), g["pre_trans"], rtol=2e-5, atol=1e-4)
     params = dict(net.named_parameters())
@@ -174,6 +179,8 @@ def test_train_step_matches_reference_golden(path, dev, manifest, golden_dir, ar
     for k in g:
         if k.startswith("after::"):
             np.testing.assert_allclose(sd[k[7:]].reshape(-1)[:64].cpu().numpy(), g[k], rtol=1e-3, atol=1e-4, err_msg=k)
+    if "evalbn" in case:
+        assert all(torch.equal(sd[k], v) for k, v in before.items())            # eval-mode BN never moves its buffers
 
 
 def test_full_size_properties(dev, manifest, golden_dir, args):
@@ -198,6 +205,132 @@ def test_full_size_properties(dev, manifest, golden_dir, args):
     eye = torch.eye(3, dtype=torch.float64, device=dev).expand(64, 3, 3)
     assert torch.allclose(R @ R.transpose(1, 2), eye, atol=1e-5)
     assert torch.all(torch.abs(torch.linalg.det(R).abs() - 1) < 1e-5)
+
+
+def _bench_setup(dev, train):
+    """Exactly bench.py's rank-0 workload: its weights (load_weights), its batch (seed 1234, B=64, N=256), its Args."""
+    import bench
+    from cmflow_amd.cmflow import CMFlow
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    sd = bench.load_weights("cmflow")
+    ref = O.CMFlow(bench.Args())
+    ref.load_state_dict(sd)
+    net = CMFlow(bench.Args())
+    net.load_state_dict(sd)
+    net = net.to(dev)
+    (ref.train(), net.train()) if train else (ref.eval(), net.eval())
+    b = synth.make_batch(64, seed=1234, train_extras=True)
+    return ref, net, b, {k: v.to(dev) for k, v in b.items()}
+
+
+def _rot_angle(Ra, Rb):
+    """Angle (rad) of Ra Rb^T, fp64, from the skew part (accurate for tiny angles)."""
+    D = Ra.double() @ Rb.double().transpose(1, 2)
+    skew = 0.5 * (D - D.transpose(1, 2))
+    return torch.sqrt(skew[:, 2, 1] ** 2 + skew[:, 0, 2] ** 2 + skew[:, 1, 0] ** 2)
+
+
+def _check_transform(got, want, pc1, weight):
+    """SURVEY 8d asks pre_trans <= 1e-4.  R meets an absolute bound (rotation error <= 2e-6 rad, entries <= 1e-5).  t does
+    NOT have an absolute fp32 bound at this size: t = cB - R cA (models/cmflow.py:163) with |cA| ~ 50 m, so a rotation
+    difference dR between two correct fp32 evaluations moves t by up to |dR| |cA| (3e-6 rad * 50 m = 1.5e-4).  The
+    bound that holds for every correct implementation is the conditioned one:
+        |dt| <= 1e-4 + |dR|_2 * |cA|        
+    weight: the normalised Kabsch weights (B,N) the reference uses for the centroid (:137-139)."""
+    got, want = got.double().cpu(), want.double()
+    ang = _rot_angle(got[:, :3, :3], want[:, :3, :3])
+    assert float(ang.max()) <= 2e-6, float(ang.max())
+    assert float((got[:, :3, :3] - want[:, :3, :3]).abs().max()) <= 1e-5
+    cA = (pc1.double() * weight.double().unsqueeze(1)).sum(dim=2)                     # (B,3)
+    dR = torch.linalg.matrix_norm(got[:, :3, :3] - want[:, :3, :3], ord=2)
+    dt = (got[:, :3, 3] - want[:, :3, 3]).norm(dim=1)
+    bound = 1e-4 + dR * cA.norm(dim=1)
+    assert bool((dt <= bound).all()), (float(dt.max()), float(bound.min()))
+    assert torch.equal(got[:, 3], want[:, 3])                                          # bottom row 0 0 0 1 exactly
+    return float(ang.max()), float(dt.max())
+
+
+def test_full_size_forward_matches_oracle(dev):
+    """BASELINE config 2 at its own size -- bench.py's batch (B=64, N=256, seed 1234) and weights, eval mode -- HIP
+    path vs the CPU oracle, with the bound of every quantity of SURVEY 8d written out:
+      ball-query idx (4 radii x 2 clouds) and kNN idx/dist: bit-exact;  EPE mean <= 1e-4;  stat_cls max <= 1e-4;
+      mask equal wherever the oracle's score is further than 1e-4 (the stat_cls bound) from the threshold;
+      rotation <= 2e-6 rad;  translation in the conditioned form of _check_transform."""
+    from cmflow_amd import pointnet2_utils as pu, radarflow_util as ru
+    from oracle import ops
+    ref, net, b, bd = _bench_setup(dev, train=False)
+    for c in ("pc1", "pc2"):
+        xyz = b[c].transpose(1, 2).contiguous()
+        for r, ns in ((2.0, 4), (4.0, 8), (8.0, 16), (16.0, 32)):
+            got = pu.ball_query(r, ns, xyz.to(dev), xyz.to(dev)).cpu()
+            assert torch.equal(got, ops.ball_query(r, ns, xyz, xyz)), (c, r)
+    x1, x2 = b["pc1"].transpose(1, 2).contiguous(), b["pc2"].transpose(1, 2).contiguous()
+    for db, q in ((x2, x1), (x1, x1)):
+        gi, gd = ru.knn_point(8, db.to(dev), q.to(dev), return_dist=True)
+        wi, wd = ops.knn(8, db, q, return_dist=True)
+        assert torch.equal(gi.cpu().int(), wi) and torch.equal(gd.cpu(), wd)
+    with torch.no_grad():
+        want = ref(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
+        got = net(bd["pc1"], bd["pc2"], bd["ft1"], bd["ft2"], None, "test")
+    sf, cls, trans, mask = (t.cpu() for t in got)
+    assert float((cls - want[1]).abs().max()) <= 1e-4
+    flips = mask != want[3]
+    near = (want[1].squeeze(1) - 0.5).abs() <= 1e-4
+    assert not bool((flips & ~near).any()), int(flips.sum())
+    epe = (sf - want[0]).norm(dim=1)
+    assert float(epe[~flips].mean()) <= 1e-4
+    score = want[1].squeeze(1) + 1e-4                                                   # models/cmflow.py:105-107
+    ang, dt = _check_transform(trans, want[2], b["pc1"], score / score.sum(dim=1, keepdim=True))
+    # the per-point bound follows the transform's: a static point's flow is (T - I) p, |p| up to ~95 m
+    assert float(epe[~flips].max()) <= 1e-4 + 2e-6 * 100.0 + dt
+    print("full-size fwd: EPE mean %.3g max %.3g, stat_cls %.3g, flips %d, rot %.3g rad, dt %.3g m"
+          % (float(epe.mean()), float(epe.max()), float((cls - want[1]).abs().max()), int(flips.sum()), ang, dt))
+
+
+def test_full_size_train_step_matches_oracle(dev):
+    """BASELINE config 3 (the headline) at its own size: one training step of bench.py's batch and weights, train-mode
+    BN, 7 losses -- loss within 2e-4, every loss item within 2e-4, labels bit-equal, outputs as in the forward test,
+    EVERY parameter's gradient norm within 1e-2 relative (the fp32 gradient noise floor of this net is ~1e-3, DESIGN.md
+    section 4), never-used parameters without gradient, and all BN running statistics after the step."""
+    from cmflow_amd.train import TrainStep
+    ref, net, b, bd = _bench_setup(dev, train=True)
+    P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
+
+    class NoStep:                                                   # keep the oracle's pre-step weights and its .grad
+        def zero_grad(self): ref.zero_grad()
+        def step(self): pass
+    loss_ref, items_ref, out_ref, (dyn_ref, mseg_ref) = TO.train_step(ref, NoStep(), b, P, Tcr)
+    step = TrainStep(net, vr_thres=0.3)
+    loss, items, outs, (dyn, mseg) = step.forward_loss(bd)
+    step.bucket.zero()
+    loss.backward()
+    assert torch.equal(dyn.cpu(), dyn_ref) and torch.equal(mseg.cpu(), mseg_ref)
+    assert abs(loss.item() - loss_ref.item()) <= 2e-4 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    for k, v in items.items():
+        assert abs(v.item() - items_ref[k]) <= 2e-4 * max(1.0, abs(items_ref[k])), (k, v.item(), items_ref[k])
+    assert torch.equal(outs[3].cpu(), out_ref[3])                   # train mode: the mask comes from the labels
+    assert float((outs[1].detach().cpu() - out_ref[1].detach()).abs().max()) <= 1e-4
+    score = mseg_ref + 1e-4                                         # train mode: the labels are the Kabsch scores (:181-185)
+    ang, dt = _check_transform(outs[2].detach(), out_ref[2].detach(), b["pc1"], score / score.sum(dim=1, keepdim=True))
+    epe = (outs[0].detach().cpu() - out_ref[0].detach()).norm(dim=1)
+    assert float(epe.mean()) <= 1e-4 and float(epe.max()) <= 1e-4 + 2e-6 * 100.0 + dt
+    gref = {k: p.grad for k, p in ref.named_parameters()}
+    worst, n = ("", 0.0), 0
+    for k, p in net.named_parameters():
+        if gref[k] is None:
+            assert p.grad is None, k
+            continue
+        a, r = float(p.grad.norm()), float(gref[k].norm())
+        rel = abs(a - r) / max(r, 1e-3)
+        worst = max(worst, (k, rel), key=lambda t: t[1])
+        n += 1
+    assert n >= 360 and worst[1] <= 1e-2, worst
+    want, have = ref.state_dict(), net.state_dict()
+    for k, v in want.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(have[k].cpu().numpy(), v.numpy(), rtol=2e-4, atol=2e-5 * float(v.abs().max()) + 1e-7, err_msg=k)
+    print("full-size train: loss %.6f vs %.6f, worst grad-norm rel err %.3g (%s), rot %.3g rad, dt %.3g m"
+          % (loss.item(), loss_ref.item(), worst[1], worst[0], ang, dt))
 
 
 def test_cmflow_t_clip_training_matches_oracle(dev, manifest_t, golden_dir, args):

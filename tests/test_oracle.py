@@ -96,10 +96,15 @@ def test_cmflow_t_matches_reference(manifest_t, golden_dir, args):
         np.testing.assert_allclose(o[4].numpy(), g[tag + "_gfeat"], rtol=0, atol=1e-5)
 
 
-def test_train_step_matches_reference(manifest, golden_dir, args):
-    """Rows a3 + a15('train') + the 7 loss terms + Adam: main_util.py:63-76 sequence."""
-    g = _load(golden_dir, "cmflow_train_synth_b4")
-    net = _net(manifest, golden_dir, args).train()
+@pytest.mark.parametrize("case", ["cmflow_train_synth_b4", "cmflow_train_evalbn_synth_b4"])
+def test_train_step_matches_reference(case, manifest, golden_dir, args):
+    """Rows a3 + a15('train') + the 7 loss terms + Adam: main_util.py:63-76 sequence.  The `evalbn` case is the same
+    step with the network left in eval mode -- what every CMFlow epoch after the first trains in (train_one_epoch never
+    calls net.train(), main_util.py:39-76; eval_one_epoch leaves net.eval(), :96): BN uses and keeps its running stats."""
+    g = _load(golden_dir, case)
+    net = _net(manifest, golden_dir, args)
+    net.eval() if "evalbn" in case else net.train()
+    before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
     batch = {k: torch.from_numpy(g[k]) for k in ("pc1", "pc2", "ft1", "ft2", "gt_trans", "flow_label", "fg_mask",
                                                    "interval", "radar_u", "radar_v", "opt_flow")}
     P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
@@ -128,6 +133,8 @@ def test_train_step_matches_reference(manifest, golden_dir, args):
     for k in g:
         if k.startswith("after::"):
             np.testing.assert_allclose(sd[k[7:]].reshape(-1)[:64].numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    if "evalbn" in case:
+        assert all(torch.equal(sd[k], v) for k, v in before.items())            # eval-mode BN never moves its buffers
 
 
 def test_kabsch_kat(golden_dir):
