@@ -8,11 +8,15 @@ Adam) on synthetic N=256 radar clouds at B=64 per GPU (BASELINE.json metric / co
 
 One process per GPU; batches shard over ranks (weak scaling: 64 pairs per GPU); the only
 collective is one RCCL all-reduce of the flat gradient bucket per step.  Rank 0 prints ONE
-JSON line.  `roofline` is measured live with HIP events around every launch of the dominant
-hand-written kernel (cmf_gemm, the fp32 MFMA GEMM behind every 1x1 conv) inside the timed region:
-achieved = sum of 2*M*N*K over its launches / sum of their durations, peak = 157.3 TFLOP/s dense
-fp32 MFMA; `--track cmf_group_points` reports the HBM-bound grouping kernel of the unfused path
-instead.  `cpu_baseline` is the CPU oracle ("port") timed on this box's host cores on a bounded sample.
+JSON line.  `roofline` is measured live with HIP events around every launch >= 1 GFLOP of the dominant
+hand-written kernel (cmf_gemm, the fp32 MFMA GEMM behind every 1x1 conv) inside the timed region --
+the events are recorded INSIDE the library on the launch stream, so the GEMMs of the set-conv block
+calls count too; `flop_share` is the share of all cmf_gemm FLOPs the bracketed launches carry:
+achieved = sum of 2*M*N*K over those launches / sum of their durations, peak = 157.3 TFLOP/s dense
+fp32 MFMA.  `roofline_hbm` (N=1 only, after the timed region): the drop-in ball_query + group_points
+(+ group_points_grad) kernels at the op shapes of SURVEY 8d against the 8 TB/s HBM peak.
+`cpu_baseline` is the CPU oracle ("port") timed on this box's host cores on a bounded sample of the
+same workload; `cpu_baseline_config1` is BASELINE config 1 (B=1 forward, eval mode) on the same oracle.
 """
 import argparse
 import json
@@ -46,7 +50,7 @@ def load_weights(model_name):
     return synth.synth_state_dict(man, seed=1234, calib=calib if os.path.exists(calib) else None)
 
 
-def cpu_baseline(mode, model_name, budget_s=20.0):
+def cpu_baseline(mode, model_name, budget_s=20.0, B=4):
     """The CPU oracle (a port: own torch-CPU restatement + C ops) on this box's host cores."""
     from cmflow_amd import synth
     from oracle import cmflow_oracle as O
@@ -61,7 +65,6 @@ def cpu_baseline(mode, model_name, budget_s=20.0):
     torch.set_num_threads(cores)
     net = {"cmflow": O.CMFlow, "cmflow_t": O.CMFlow_T, "raflow": O.RaFlow}[model_name](Args())
     net.load_state_dict(load_weights(model_name))
-    B = 4
     b = synth.make_batch(B, seed=1, train_extras=True)
     P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
     if mode == "train":
@@ -106,6 +109,63 @@ def cpu_baseline(mode, model_name, budget_s=20.0):
             "sample": "%d steps of B=%d N=256 %s (%s), median; oracle/ torch-CPU + C ops" % (len(times), B, model_name, what)}
 
 
+def hbm_op_rooflines(dev, iters=20):
+    """The drop-in kernels of the boundary (cmf_ball_query, cmf_group_points, cmf_group_points_grad through the C-ABI)
+    at the op-level shapes of SURVEY 8d / BASELINE.md section 4, inputs resident in HBM.  Per op: `iters` back-to-back
+    launches between one HIP event pair on the launch stream (kernel duration incl. the ~1.5 us launch gap).
+    Algorithmic bytes (every tensor touched once):
+      ball_query+group = 2*B*N*12 (xyz, centres) + B*C*N*4 (features) + B*M*K*4 (idx) + B*(3+C)*M*K*4 (grouped out)
+                         over t(ball_query) + t(group xyz) + t(group features)
+      group_grad       = B*C*M*K*4 (grad_out) + B*M*K*4 (idx) + B*C*N*4 (grad_points)"""
+    from cmflow_amd import _lib, synth
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    rows = []
+    for (B, N, K, r, lidar), Cs in (((64, 256, 32, 2.0, False), (3, 64, 1027)), ((32, 4096, 64, 2.0, True), (64, 128))):
+        xyz = synth.make_batch(B, N=N, seed=1234, lidar=lidar)["pc1"].to(dev)          # (B,3,N) channel-major
+        xyz_t = xyz.transpose(1, 2).contiguous()                                        # (B,N,3)
+        idx = torch.zeros(B, N, K, dtype=torch.int32, device=dev)
+        gx = torch.empty(B, 3, N, K, device=dev)
+        bq = lambda: _lib.check(L.cmf_ball_query(B, N, N, r, K, xyz_t.data_ptr(), xyz_t.data_ptr(), idx.data_ptr(), st), "bq")
+        t_bq = timed(bq)
+        t_gx = timed(lambda: _lib.check(L.cmf_group_points(B, 3, N, N, K, xyz.data_ptr(), idx.data_ptr(), gx.data_ptr(), st), "gx"))
+        for C in Cs:
+            feats = torch.randn(B, C, N, device=dev)
+            out = torch.empty(B, C, N, K, device=dev)
+            t_gf = timed(lambda: _lib.check(L.cmf_group_points(B, C, N, N, K, feats.data_ptr(), idx.data_ptr(), out.data_ptr(), st), "gf"))
+            out.normal_()
+            gp = torch.zeros(B, C, N, device=dev)
+            t_gg = timed(lambda: _lib.check(L.cmf_group_points_grad(B, C, N, N, K, out.data_ptr(), idx.data_ptr(), gp.data_ptr(), st), "gg"))
+            nb = 2 * B * N * 12 + B * C * N * 4 + B * N * K * 4 + B * (3 + C) * N * K * 4
+            ng = B * C * N * K * 4 + B * N * K * 4 + B * C * N * 4
+            t_f = t_bq + t_gx + t_gf
+            rows.append({"shape_BNKC": [B, N, K, C],
+                         "ball_query+group": {"bytes": nb, "us": round(t_f * 1e6, 1), "achieved": round(nb / t_f / 1e9, 1),
+                                              "frac": round(nb / t_f / 1e9 / HBM_PEAK_GBS, 4),
+                                              "us_parts": [round(t * 1e6, 1) for t in (t_bq, t_gx, t_gf)]},
+                         "group_grad": {"bytes": ng, "us": round(t_gg * 1e6, 1), "achieved": round(ng / t_gg / 1e9, 1),
+                                        "frac": round(ng / t_gg / 1e9 / HBM_PEAK_GBS, 4)}})
+            del feats, out, gp
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "traffic_profile": "profiles/r02_op_hbm_pmc.md",
+            "kernels": ["ball_query_kernel", "group_points_kernel", "group_points_grad_*_kernel"],
+            "method": "%d back-to-back launches per op between one HIP event pair; bytes = SURVEY 8d algorithmic bytes" % iters,
+            "rows": rows}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +180,10 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="diagnostic: encoder scales on ONE stream (per-kernel durations free of contention)")
     ap.add_argument("--track", choices=["cmf_gemm", "cmf_group_points"], default=None)
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="diagnostic at N=1: run the RCCL all-reduce of the gradient bucket (world size 1) inside every step")
+    ap.add_argument("--no-op-rooflines", action="store_true", help="skip the roofline_hbm op benchmarks after the timed region")
+    ap.add_argument("--clip", type=int, default=5, help="cmflow_t: frames per mini-clip (clip_util.py:34-62)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,6 +199,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world == 1 and a.force_allreduce:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if one_gpu:
@@ -157,17 +225,26 @@ def main():
     net.path = a.path
     broadcast_module(net)
     batch = {k: v.to(dev) for k, v in synth.make_batch(a.batch, seed=1234 + rank, train_extras=True).items()}
+    # CMFlow-T trains on mini-clips (clip_util.py:34-62): `--clip` consecutive frames, the GRU state handed from frame to
+    # frame as gfeat.detach() (:54), one optimizer step per frame, gfeat = None at the first frame of a clip (:51-52).
+    # A bench "step" is one frame; the clip's frames are distinct resident batches.
+    clip = [batch] + [{k: v.to(dev) for k, v in synth.make_batch(a.batch, seed=1234 + rank + 1000 * f, train_extras=True).items()}
+                      for f in range(1, a.clip if (a.model == "cmflow_t" and a.mode == "train") else 1)]
+    frame = [0]
 
     if a.mode == "train":
         net.train()
         # RaFlow's purely self-supervised loss diverges within a few Adam steps on seeded random weights (NaN -> the
         # CPU SVD of the baseline leg throws): same work per step with a small learning rate
         step = TrainStep(net, vr_thres=Args.vr_thres, lr=1e-6 if a.model == "raflow" else 0.001)
+        step.force_allreduce = bool(a.force_allreduce)
 
         def one():
-            if a.model == "cmflow_t":
+            f = frame[0] % len(clip)
+            if a.model == "cmflow_t" and f == 0:
                 step.reset_clip()
-            step(batch)
+            step(clip[f])
+            frame[0] += 1
     else:
         net.eval()
 
@@ -194,6 +271,7 @@ def main():
         _CM.head_streams = False
     for _ in range(a.warmup):
         one()
+    frame[0] = 0                                     # the timed region starts at the first frame of a clip
     track = a.track or ("cmf_group_points" if a.path == "ref" else "cmf_gemm")
     _lib.profile_begin(track, "hbm" if track == "cmf_group_points" else "mfma")   # HIP-event pairs around every launch
     fence()
@@ -217,15 +295,20 @@ def main():
             achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        return {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
-                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
-                # PMC counters need rocprofv3 around the process; the per-launch FETCH_SIZE / WRITE_SIZE passes for this
-                # kernel are committed (traffic = algorithmic bytes within 9 %)
-                "traffic_profile": "profiles/r01_gemm_pmc.txt" if prof["kernel"] == "cmf_gemm" else "profiles/r01_op_bench_ballquery_group.md",
-                "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
-                "algorithmic_per_launch": per_launch,
-                "launch_filter": "launches >= %.0e units (cmflow_amd/_lib.py TRACK_MIN_UNITS)" %
-                                 _lib.TRACK_MIN_UNITS.get(prof["kernel"], 0.0)}
+        out = {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
+               "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+               # PMC counters need rocprofv3 around the process; the per-launch FETCH_SIZE / WRITE_SIZE passes for this
+               # kernel are committed (separate --pmc runs, gfx950 x2 correction on FETCH_SIZE)
+               "traffic_profile": "profiles/r02_gemm_pmc.txt" if prof["kernel"] == "cmf_gemm" else "profiles/r02_op_hbm_pmc.md",
+               "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
+               "algorithmic_per_launch": per_launch,
+               "launch_filter": "every tiled-kernel launch >= %.0e flop, bracketed inside libcmflow_hip.so (block-internal "
+                                "GEMMs included); thin (<= 64-channel) kernels are counted in flop_share only" %
+                                _lib.TRACK_MIN_UNITS.get(prof["kernel"], 0.0)}
+        if prof.get("units_all"):
+            out["flop_share"] = round(prof["units"] / prof["units_all"], 4)
+            out["launches_all"] = prof["launches_all"]
+        return out
 
     # In the timed region the four scales of an encoder run on four HIP streams, so a bracketed launch shares
     # the chip with kernels of the other streams and its duration is a contended one.  A short extra pass with
@@ -254,9 +337,13 @@ def main():
         if roof:
             roof["note"] = ("independent chains run on 3 side streams next to the caller's: a bracketed launch shares the chip with "
                             "kernels (often other cmf_gemm launches) of the other streams, so its duration is a contended one")
-        cpu = None
+        cpu = cpu1 = hbm = None
+        if world == 1 and not a.no_op_rooflines:
+            hbm = hbm_op_rooflines(dev)
         if not a.no_cpu_baseline and world == 1:           # the CPU leg is timed at N=1 only
             cpu = cpu_baseline(a.mode, a.model)
+            # BASELINE config 1 (the reference's own CPU-runnable case): one frame pair, forward, eval mode (main_util.py:142)
+            cpu1 = cpu_baseline("fwd", a.model, budget_s=8.0, B=1)
         line = {
             "metric": "frame-pairs/sec %s %s" % ({"cmflow": "CMFlow", "cmflow_t": "CMFlow-T", "raflow": "RaFlow"}[a.model],
                                                    "fwd+bwd" if a.mode == "train" else "fwd"),
@@ -268,9 +355,14 @@ def main():
                                     (a.model, ("fwd+bwd training (3 self-supervised losses + Adam, train-mode BN)" if a.model == "raflow"
                                                else "fwd+bwd training (7 cross-modal losses + Adam, train-mode BN)")
                                      if a.mode == "train" else "fwd-only inference (eval-mode BN)", a.batch,
-                                     a.batch * world, "; dp%d RCCL grad all-reduce" % world if world > 1 else "")),
+                                     a.batch * world,
+                                     ("; %d-frame mini-clips, GRU state handed over detached, optimizer step per frame" % len(clip)
+                                      if len(clip) > 1 else "") +
+                                     ("; dp%d RCCL grad all-reduce" % world if world > 1 else "") +
+                                     ("; RCCL all-reduce of the gradient bucket forced at world size 1" if a.force_allreduce and world == 1 else ""))),
                        "parallelism": "dp%d" % world},
-            "roofline": roof, "roofline_isolated": iso, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_isolated": iso, "roofline_hbm": hbm, "cpu_baseline": cpu,
+            "cpu_baseline_config1": cpu1,
             # model-level rate against the reference's ALGORITHMIC work (25.52 GFLOP per frame pair forward,
             # x3 for fwd+bwd) -- the build's hoisted first convs execute fewer FLOPs than that
             "algorithmic_model_tflops": round(pairs / dt * 25.52e9 * (3.0 if a.mode == "train" else 1.0) / 1e12, 2),
@@ -278,6 +370,7 @@ def main():
         print(json.dumps(line))
     if world > 1:
         fence()                                             # leave together
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

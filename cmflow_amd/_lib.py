@@ -30,6 +30,8 @@ SIGNATURES = {
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
+    "cmf_gemm_profile_begin": [ctypes.c_double],
+    "cmf_gemm_profile_end": [_vp, _vp, _vp, _vp, _vp],
     "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
     "cmf_setconv_forward": [_vp, _vp],
     "cmf_setconv_backward": [_vp, _vp],
@@ -163,17 +165,25 @@ def check(err, what):
 
 
 # ---- live per-kernel timing for bench.py's `roofline` object ---------------------------------
-# HIP events recorded on the launch stream (torch's current stream) around every launch of ONE
-# tracked kernel inside the timed region.  `units` = algorithmic bytes (bound "hbm") or flops
-# (bound "mfma") of that launch, as defined in DESIGN.md.
+# cmf_gemm (bound "mfma", units = 2*M*N*K flop): bracketed INSIDE the library (cmf_gemm_profile_begin/_end, csrc/gemm.hip)
+# with HIP events on the stream each launch goes to, so the GEMMs issued by cmf_setconv_forward/_backward on the side
+# streams are covered exactly like the ones issued from Python.  Any other kernel (cmf_group_points, bound "hbm", units =
+# algorithmic bytes): HIP events recorded here on torch's current stream around the Python-level launch (`tracked`).
 TRACKED_KERNEL = ("cmf_gemm", "mfma")        # the dominant kernel of the training step (profiles/)
 _prof = None
+
+# Only launches of at least this many algorithmic units are bracketed: an event pair costs a few microseconds of stream
+# time, which would distort the step if the ~150 thin / small GEMM launches of a step were bracketed too.  The share of
+# the FLOPs the bracketed launches carry is reported next to the result (`flop_share`).
+TRACK_MIN_UNITS = {"cmf_gemm": 1.0e9, "cmf_group_points": 0.0}
 
 
 def profile_begin(kernel=None, bound=None):
     global _prof
     k, b = TRACKED_KERNEL
     _prof = {"kernel": kernel or k, "bound": bound or b, "events": [], "units": 0.0}
+    if _prof["kernel"] == "cmf_gemm":
+        check(lib().cmf_gemm_profile_begin(TRACK_MIN_UNITS["cmf_gemm"]), "cmf_gemm_profile_begin")
 
 
 def profile_end():
@@ -181,20 +191,22 @@ def profile_end():
     p, _prof = _prof, None
     if p is None:
         return None
+    if p["kernel"] == "cmf_gemm":
+        n, n_all = ctypes.c_longlong(), ctypes.c_longlong()
+        ms, fl, fl_all = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(lib().cmf_gemm_profile_end(ctypes.addressof(n), ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n_all),
+                                         ctypes.addressof(fl_all)), "cmf_gemm_profile_end")
+        return {"kernel": "cmf_gemm", "bound": p["bound"], "launches": n.value, "ms": ms.value, "units": fl.value,
+                "launches_all": n_all.value, "units_all": fl_all.value}
     torch.cuda.synchronize()
     ms = sum(s.elapsed_time(e) for s, e in p["events"])
     return {"kernel": p["kernel"], "bound": p["bound"], "launches": len(p["events"]), "ms": ms, "units": p["units"]}
 
 
-# Only launches of at least this many algorithmic units are bracketed: an event pair costs ~10 us of
-# stream time, which would distort the step time if all ~250 GEMM launches of a step were bracketed.
-# For cmf_gemm the threshold selects the 128x128-tile instantiations that carry > 95 % of the FLOPs.
-TRACK_MIN_UNITS = {"cmf_gemm": 2.0e9, "cmf_group_points": 0.0}
-
-
 def tracked(name, units, fn):
-    """Run fn() (one kernel launch); time it with a HIP event pair if `name` is the tracked kernel."""
-    if _prof is None or name != _prof["kernel"] or units < TRACK_MIN_UNITS.get(name, 0.0):
+    """Run fn() (one kernel launch); time it with a HIP event pair if `name` is the tracked kernel (cmf_gemm is timed by
+    the library itself)."""
+    if _prof is None or name != _prof["kernel"] or name == "cmf_gemm" or units < TRACK_MIN_UNITS.get(name, 0.0):
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()

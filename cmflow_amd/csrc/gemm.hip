@@ -18,6 +18,7 @@
 // * XCD-aware tile order: the column tiles that share an A row-panel run back to back on ONE XCD
 //   (blockIdx -> XCD is round-robin), so the panel is fetched from HBM once and re-read from L2.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include "cmf_common.h"
@@ -700,6 +701,88 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(long long total
     }
 }
 
+// ---- live timing of the tiled kernel (bench.py's `roofline` object) ------------------------------------------------
+// Between cmf_gemm_profile_begin and _end every launch of gemm_kernel whose 2*M*N*K reaches `min_flops` is bracketed by
+// a HIP event pair recorded on the stream the kernel is launched on -- inside the library, so the launches issued from
+// cmf_setconv_forward / _backward (on side streams, from the block calls' host threads) are covered like the ones a
+// caller issues directly.  The FLOPs of ALL launches (thin kernels included) are counted next to the bracketed ones,
+// so the caller can state which share of the work the measured launches carry.
+#include <mutex>
+#include <vector>
+namespace {
+struct GemmProfile {
+    std::mutex mu;
+    bool on = false;
+    double min_flops = 0.0, flops_timed = 0.0, flops_all = 0.0;
+    long long launches_all = 0;
+    size_t used = 0;
+    std::vector<hipEvent_t> events;                  // pairs: [2i] before, [2i+1] after; kept across sessions
+};
+GemmProfile g_gprof;
+
+// -> index of the event pair to record around this launch, or -1
+long long gprof_open(double flops, hipStream_t st)
+{
+    if (!g_gprof.on) return -1;
+    std::lock_guard<std::mutex> lock(g_gprof.mu);
+    if (!g_gprof.on) return -1;
+    g_gprof.flops_all += flops;
+    ++g_gprof.launches_all;
+    if (flops < g_gprof.min_flops) return -1;
+    if (g_gprof.used * 2 == g_gprof.events.size()) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        g_gprof.events.push_back(a); g_gprof.events.push_back(b);
+    }
+    const size_t i = g_gprof.used++;
+    g_gprof.flops_timed += flops;
+    (void)hipEventRecord(g_gprof.events[2 * i], st);
+    return (long long)i;
+}
+void gprof_count(double flops)
+{
+    if (!g_gprof.on) return;
+    std::lock_guard<std::mutex> lock(g_gprof.mu);
+    g_gprof.flops_all += flops;
+    ++g_gprof.launches_all;
+}
+void gprof_close(long long i, hipStream_t st)
+{
+    if (i < 0) return;
+    std::lock_guard<std::mutex> lock(g_gprof.mu);
+    (void)hipEventRecord(g_gprof.events[2 * (size_t)i + 1], st);
+}
+}  // namespace
+
+extern "C" int cmf_gemm_profile_begin(double min_flops)
+{
+    std::lock_guard<std::mutex> lock(g_gprof.mu);
+    g_gprof.on = true; g_gprof.min_flops = min_flops; g_gprof.flops_timed = g_gprof.flops_all = 0.0;
+    g_gprof.launches_all = 0; g_gprof.used = 0;
+    return 0;
+}
+
+// Synchronises the device, sums the bracketed durations.  Any output pointer may be NULL.
+extern "C" int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed, double *flops_timed, long long *launches_all,
+                                    double *flops_all)
+{
+    std::lock_guard<std::mutex> lock(g_gprof.mu);
+    g_gprof.on = false;
+    if (hipDeviceSynchronize() != hipSuccess) return (int)hipGetLastError();
+    double ms = 0.0;
+    for (size_t i = 0; i < g_gprof.used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_gprof.events[2 * i], g_gprof.events[2 * i + 1]) != hipSuccess) return (int)hipGetLastError();
+        ms += t;
+    }
+    if (launches_timed) *launches_timed = (long long)g_gprof.used;
+    if (ms_timed) *ms_timed = ms;
+    if (flops_timed) *flops_timed = g_gprof.flops_timed;
+    if (launches_all) *launches_all = g_gprof.launches_all;
+    if (flops_all) *flops_all = g_gprof.flops_all;
+    return 0;
+}
+
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0>
 static int launch(const GemmArgs &a, hipStream_t st)
 {
@@ -709,10 +792,20 @@ static int launch(const GemmArgs &a, hipStream_t st)
     const size_t lds_reg = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
     const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + 32) * sizeof(float);
     const size_t lds = lds_reg > lds_dir ? lds_reg : lds_dir;
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EMUL>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    // the dynamic-LDS limit is a per-device attribute of the function: set once per (instantiation, device); cmf_gemm is
+    // entered concurrently by the host threads of cmf_setconv_*_multi, hence the atomics
+    static std::atomic<unsigned> set_mask[4];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (dev >= 128 || !(set_mask[dev >> 5].load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EMUL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return (int)hipGetLastError();
+        if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
+    }
+    const long long pe = gprof_open(2.0 * a.M * a.N * a.K, st);
     hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL>), grid, dim3(G_THREADS), lds, st, a);
+    gprof_close(pe, st);
     return cmf_launch_status();
 }
 
@@ -748,6 +841,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     int err = cmf_thin_gemm(g, a_t, b_t, st);            // narrow layers (<= 64 channels): barrier-free per-wave kernels
     if (err > 0) return err;
     const bool thin_done = (err == 0);
+    if (thin_done) gprof_count(2.0 * M * N * K);         // thin kernels: counted in flops_all, never bracketed
     const bool wide = N > 64, tall = M > 64;
     static const bool emul = getenv("CMF_GEMM_MODE") && !strcmp(getenv("CMF_GEMM_MODE"), "bf16x3");       // experimental, opt-in
 #define CMF_PICK(AT, BT)                                                                                   \

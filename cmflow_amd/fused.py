@@ -126,11 +126,10 @@ def gemm(A, B, *, a_t=False, b_t=True, out=None, pro=None, prob=None, bias=None,
         mode, Z = bwd[0], bwd[1]
         if mode == 1:
             ea, ec, em, ei = bwd[2:6]
-    units = 2.0 * M * N * K
-    err = _lib.tracked("cmf_gemm", units, lambda: _lib.lib().cmf_gemm(
+    err = _lib.lib().cmf_gemm(
         M, N, K, int(a_t), int(b_t), A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), out.data_ptr(), out.stride(0),
         _p(pro[0]) if pro else None, _p(pro[1]) if pro else None, _p(prob[0]) if prob else None,
         _p(prob[1]) if prob else None, _p(bias), act, _p(st), mode, _p(Z), Z.stride(0) if Z is not None else 0,
-        _p(ea), _p(ec), _p(em), _p(ei), _p(dxyz), split_k, _p(ws), int(accumulate), _lib.stream_ptr()))
+        _p(ea), _p(ec), _p(em), _p(ei), _p(dxyz), split_k, _p(ws), int(accumulate), _lib.stream_ptr())
     _lib.check(err, "cmf_gemm")
     return (out, st) if st is not None else out

@@ -87,6 +87,17 @@ def side_stream(slot, device=None):
     return pool[slot % N_SIDE]
 
 
+def join_side_streams(main=None):
+    """Make `main` (default: the current stream) wait for everything queued on the pool's side streams.  The backward
+    kernels of chains that ran on a side stream accumulate parameter gradients straight into the flat bucket (grad_sink)
+    without passing through autograd's AccumulateGrad, so autograd does not know those streams wrote the leaves: whoever
+    reads the bucket next (all-reduce, optimizer) on `main` must be ordered behind the pool explicitly."""
+    main = main or torch.cuda.current_stream()
+    for pool in _side_pool.values():
+        for st in pool:
+            main.wait_stream(st)
+
+
 def scale_streams(n_scales, cloud=0):
     """The side stream of each scale of a MultiScaleEncoder call (scales ordered by growing neighbourhood).  With four
     scales on three streams the largest scale (half of the rows) shares its stream with the smallest; the second
@@ -365,8 +376,12 @@ class StackedFirstConvFn(Function):
         dfeats = None
         if ctx.needs_input_grad[0]:
             ng = ctx.n_grad if ctx.n_grad else Kp
-            dfeats = torch.empty(M, Kp, dtype=_f32, device=dy.device)          # columns >= ng: raw input channels, never read
+            dfeats = torch.empty(M, Kp, dtype=_f32, device=dy.device)
             gemm(dy, wf[:, :ng], b_t=False, out=dfeats[:, :ng])
+            if ng < Kp:
+                # columns >= ng are declared gradient-free by the caller (raw input channels + zero pad); the model never
+                # reads them, but a caller whose tail DOES require grad must see zeros, not uninitialised memory
+                dfeats[:, ng:].zero_()
         dwf = gemm_dw(dy, feats)                                                 # (n*O1, Kp)
         grads, r0 = [], 0
         for w in ctx.weights:
@@ -740,13 +755,17 @@ class EncoderPlan:
         self.saved_per_cloud = self.off_saved[ns]                   # floats: the second call's arena starts here
 
     def _live_ptrs(self):
-        """Storage of representative tensors as the MODULES hold them now (the views kept in self.params would keep a
-        replaced storage alive and never change): first / last conv weight, first BN weight, last BN running mean."""
+        """Storage of EVERY tensor the descriptors point at, as the MODULES hold them now (the views kept in self.params
+        would keep a replaced storage alive and never change), plus the hyper-parameters baked into the descriptors:
+        ~30 pointers per scale, compared as one list per call."""
         out = []
         for m in self.modules:
-            out += [m.mlp_convs[0].weight.data_ptr(), m.mlp2_convs[-1].weight.data_ptr(), m.mlp_bns[0].weight.data_ptr(),
-                    m.mlp2_bns[-1].running_mean.data_ptr(), m.mlp_bns[0].momentum, m.mlp_bns[0].eps,
-                    m.mlp2_bns[-1].momentum, m.radius, m.nsample]
+            for conv in list(m.mlp_convs) + list(m.mlp2_convs):
+                out.append(conv.weight.data_ptr())
+            for bn in list(m.mlp_bns) + list(m.mlp2_bns):
+                out += [bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                        bn.num_batches_tracked.data_ptr(), bn.momentum, bn.eps]
+            out += [m.radius, m.nsample]
         return out
 
     def valid(self):

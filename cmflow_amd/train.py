@@ -10,6 +10,7 @@ import torch
 
 from . import synth
 from .dp import FlatGradBucket
+from .fused_blocks import join_side_streams
 from .losses import RadarFlowLoss, make_labels
 
 
@@ -28,6 +29,8 @@ class TrainStep:
         # the scales of an encoder run on side streams while the gradient bucket lives on the main stream
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.gfeat = None
+        # diagnostics (bench.py --force-allreduce): run the gradient all-reduce even with a single rank
+        self.force_allreduce = False
 
     def reset_clip(self):
         """clip_util.py:51-52: the first frame of a mini-clip starts from gfeat=None."""
@@ -54,6 +57,8 @@ class TrainStep:
         loss, items, outs, labels = self.forward_loss(batch)
         self.bucket.zero()
         loss.backward()
-        self.bucket.all_reduce_mean()
+        if loss.is_cuda:
+            join_side_streams()                     # gradient sinks written on side streams (fused_blocks.grad_sink)
+        self.bucket.all_reduce_mean(force=self.force_allreduce)
         self.opt.step()
         return loss.detach(), items, outs, labels

@@ -112,6 +112,16 @@ int cmf_gemm(int M, int N, int K, int a_t, int b_t,
              const float *dxyz, int split_k, float *workspace, int accumulate, void *stream);
 int cmf_gemm_tiles_m(int M);
 
+/* Live timing of the tiled GEMM kernel for bench.py's `roofline` object.  Between _begin and _end every launch of the
+ * tiled kernel with 2*M*N*K >= min_flops is bracketed by a HIP event pair on the stream it is launched on -- inside
+ * the library, so launches issued by cmf_setconv_forward/_backward count like direct cmf_gemm calls.  _end synchronises
+ * the device and returns the number of bracketed launches, the sum of their durations (ms) and of their FLOPs, and the
+ * launch count / FLOPs of ALL cmf_gemm calls in the window (thin kernels included): the share the measurement covers.
+ * Not re-entrant (one window at a time); every output pointer may be NULL. */
+int cmf_gemm_profile_begin(double min_flops);
+int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed, double *flops_timed, long long *launches_all,
+                         double *flops_all);
+
 /* ---- BatchNorm / activation / pooling kernels around the GEMMs (point-major) ---------------------- *
  * Per-channel reductions use a partial buffer [ceil(rows/128)][2][C] (no atomics, fixed order). */
 

@@ -1,0 +1,69 @@
+"""Worker of tests/test_gpu_model.py::test_two_rank_cmflow_step_matches_single_rank_shards -- one rank of a 2-rank
+data-parallel CMFlow training step (both ranks on cuda:0 over gloo: the GPU box has one GPU; the collective semantics
+are backend-independent, RCCL itself is exercised with world size 1 by test_single_rank_rccl_all_reduce).
+
+    python -m torch.distributed.run --nproc-per-node 2 ... tests/dp_worker.py OUT_DIR
+
+Each rank takes its shard of the global batch (dp.shard_batch, as nn.DataParallel's scatter: models/model.py:40-42),
+runs forward / loss / backward, keeps a copy of its LOCAL gradient bucket, all-reduces (mean), steps Adam, and saves
+what the test compares.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    out_dir = sys.argv[1]
+    global_b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    import bench
+    from cmflow_amd import synth
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.dp import broadcast_module, shard_batch
+    from cmflow_amd.train import TrainStep
+
+    net = CMFlow(bench.Args())
+    net.load_state_dict(bench.load_weights("cmflow"))
+    net = net.to(dev).train()
+    if rank != 0:                                   # replicas must come out of the broadcast identical, whatever they held
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.01)
+    broadcast_module(net)
+    gb = synth.make_batch(global_b, seed=777, train_extras=True)
+    b = {k: v.to(dev) for k, v in shard_batch(gb, rank, world).items()}
+    step = TrainStep(net, vr_thres=bench.Args.vr_thres)
+    loss, items, outs, _ = step.forward_loss(b)
+    step.bucket.zero()
+    loss.backward()
+    from cmflow_amd.fused_blocks import join_side_streams
+    join_side_streams()
+    local = step.bucket.flat.detach().clone()
+    step.bucket.all_reduce_mean()
+    averaged = step.bucket.flat.detach().clone()
+    step.opt.step()
+    torch.cuda.synchronize()
+    sd = net.state_dict()
+    torch.save({"local": local.cpu(), "averaged": averaged.cpu(), "loss": loss.detach().cpu(),
+                "outs": [o.detach().cpu() for o in outs[:3]],
+                "params": {k: v.detach().cpu() for k, v in net.named_parameters()},
+                "buffers": {k: v.detach().cpu() for k, v in sd.items() if "running_" in k or "num_batches" in k}},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        json.dump({"world": world, "global_b": global_b}, open(os.path.join(out_dir, "done.json"), "w"))
+
+
+if __name__ == "__main__":
+    main()

@@ -626,3 +626,62 @@ def test_bench_two_ranks_control_flow(dev):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["cpu_baseline"] is None
     assert rec["roofline"] is not None and rec["roofline_isolated"] is not None and rec["value"] > 0
+
+
+def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path):
+    """SURVEY 8e's parity check on the REAL model: a 2-rank data-parallel training step (both ranks on cuda:0 over gloo,
+    tests/dp_worker.py; global B=8 -> 4+4) against single-process runs on each shard.
+      * rank r's forward outputs, loss and LOCAL gradient bucket == a single-process run on shard r (same kernels:
+        <= 1e-6 relative; bit-equal in practice -- the kernels are deterministic);
+      * the all-reduced bucket is identical on both ranks and == the mean of the two single-process buckets;
+      * parameters after the Adam step are bit-identical across ranks;
+      * BN running statistics are PER RANK (each rank == the single-process run on its shard), which is what
+        nn.DataParallel's replicas do as well (models/model.py:40-42: only replica 0's buffers persist)."""
+    import socket
+    import subprocess
+    import sys
+    import bench
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.dp import shard_batch
+    from cmflow_amd.train import TrainStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dp_worker.py"), str(tmp_path), "8"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(2)]
+    assert torch.equal(ranks[0]["averaged"], ranks[1]["averaged"])
+    for k, v in ranks[0]["params"].items():
+        assert torch.equal(v, ranks[1]["params"][k]), k
+
+    def close(a, b, what):
+        a, b = a.double(), b.double()
+        assert float((a - b).abs().max()) <= 1e-6 * max(1e-30, float(b.abs().max())), what
+        return bool(torch.equal(a, b))
+
+    gb = synth.make_batch(8, seed=777, train_extras=True)
+    singles, exact = [], True
+    for r in range(2):
+        net = CMFlow(bench.Args())
+        net.load_state_dict(bench.load_weights("cmflow"))
+        net = net.to(dev).train()
+        step = TrainStep(net, vr_thres=bench.Args.vr_thres)
+        loss, _, outs, _ = step.forward_loss({k: v.to(dev) for k, v in shard_batch(gb, r, 2).items()})
+        step.bucket.zero()
+        loss.backward()
+        torch.cuda.synchronize()
+        exact &= close(ranks[r]["loss"], loss.detach().cpu(), "loss")
+        for a, b in zip(ranks[r]["outs"], outs[:3]):
+            exact &= close(a, b.detach().cpu(), "outputs of rank %d" % r)
+        exact &= close(ranks[r]["local"], step.bucket.flat.cpu(), "local gradient bucket of rank %d" % r)
+        have = net.state_dict()
+        for k, v in ranks[r]["buffers"].items():
+            exact &= close(v, have[k].cpu(), k)
+        singles.append(step.bucket.flat.cpu().double())
+    mean = (singles[0] + singles[1]) / 2
+    assert float((ranks[0]["averaged"].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
+    assert float(ranks[0]["local"].abs().sum()) > 0 and not torch.equal(ranks[0]["local"], ranks[1]["local"])
+    print("2-rank CMFlow step vs single-rank shards: bit-identical" if exact else "2-rank CMFlow step vs single-rank shards: within 1e-6")
