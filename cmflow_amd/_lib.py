@@ -30,6 +30,8 @@ SIGNATURES = {
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
+    "cmf_gemm_trace_arm": [],
+    "cmf_gemm_trace_read": [_vp, _ll],
     "cmf_gemm_profile_begin": [ctypes.c_double],
     "cmf_gemm_profile_end": [_vp, _vp, _vp, _vp, _vp],
     "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
@@ -75,7 +77,7 @@ SIGNATURES = {
     "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
     "cmf_eval_metrics": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _cf, _cf, _vp, _vp, _vp],
 }
-RESTYPES = {"cmf_radar_loss_workspace": _ll}
+RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_gemm_trace_read": _ll}
 
 
 class SetConvDesc(ctypes.Structure):

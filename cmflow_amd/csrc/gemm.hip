@@ -82,6 +82,12 @@ __device__ __forceinline__ float g_lds_read32(unsigned addr)
 }
 __device__ __forceinline__ void g_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void g_pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void g_keep(const f32x16 &v) { asm volatile("" :: "v"(v)); }
+__device__ __forceinline__ unsigned long long g_where()         // HW_REG_XCC_ID[3:0] << 32 | HW_REG_HW_ID
+{
+    return ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) |
+           (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+}
 
 // A_T: A stored [K][M] (contraction-major) instead of [M][K].  B_T: B stored [N][K] (i.e. W[out][in],
 // the forward layout) instead of [K][N].
@@ -147,6 +153,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             if (tm >= tiles_m || slot / tiles_n >= per) return;
         }
     }
+    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
     const int kchunks_total = (p.K + G_BK - 1) / G_BK;
     const int kchunks_per = (kchunks_total + p.split_k - 1) / p.split_k;
     const int kc_begin = split * kchunks_per;
@@ -520,6 +527,14 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         }
     }
 
+    const unsigned long long t_main = p.trace ? wall_clock64() : 0ull;
+    if (p.diag & 8) {                                   // timing diagnostic: no epilogue at all (accumulators kept live)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) g_keep(acc[i][j]);
+        return;
+    }
     // ---- epilogue ----
     // The accumulators (C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)) are
     // transposed through LDS so that every global access of the epilogue is a coalesced 16-byte access:
@@ -618,6 +633,11 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             for (int g = 0; g < RPP; ++g) sum += red[(g * nstat + which) * BN + cc];
             if (n0 + cc < p.N) p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
         }
+    }
+    if (p.trace && tid == 0) {
+        unsigned long long *r = p.trace + 4ull * blockIdx.x;
+        r[0] = t_start; r[1] = t_main; r[2] = wall_clock64();
+        r[3] = g_where();
     }
 }
 
@@ -754,6 +774,22 @@ void gprof_close(long long i, hipStream_t st)
 }
 }  // namespace
 
+// ---- diagnostics: per-workgroup timeline of the NEXT tiled launch (tools/gemm_timeline.py) -------------------------
+namespace {
+unsigned long long *g_trace_buf = nullptr;
+long long g_trace_cap = 0, g_trace_n = 0;
+bool g_trace_armed = false;
+}
+extern "C" int cmf_gemm_trace_arm(void) { g_trace_armed = true; return 0; }
+// Copies the records of the traced launch (4 x u64 per workgroup) to host memory; returns the workgroup count.
+extern "C" long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    const long long n = g_trace_n < max_workgroups ? g_trace_n : max_workgroups;
+    if (n > 0 && host_out && hipMemcpy(host_out, g_trace_buf, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return g_trace_n;
+}
+
 extern "C" int cmf_gemm_profile_begin(double min_flops)
 {
     std::lock_guard<std::mutex> lock(g_gprof.mu);
@@ -804,6 +840,23 @@ static int launch(const GemmArgs &a, hipStream_t st)
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
     const long long pe = gprof_open(2.0 * a.M * a.N * a.K, st);
+    if (g_trace_armed) {                                 // diagnostics only: one launch, single-threaded use
+        g_trace_armed = false;
+        if ((long long)grid.x > g_trace_cap) {
+            if (g_trace_buf) (void)hipFree(g_trace_buf);
+            g_trace_cap = grid.x;
+            if (hipMalloc((void **)&g_trace_buf, (size_t)g_trace_cap * 32) != hipSuccess) { g_trace_buf = nullptr; g_trace_cap = 0; }
+        }
+        if (g_trace_buf) {
+            (void)hipMemsetAsync(g_trace_buf, 0, (size_t)grid.x * 32, st);
+            g_trace_n = grid.x;
+            GemmArgs t = a;
+            t.trace = g_trace_buf;
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL>), grid, dim3(G_THREADS), lds, st, t);
+            gprof_close(pe, st);
+            return cmf_launch_status();
+        }
+    }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL>), grid, dim3(G_THREADS), lds, st, a);
     gprof_close(pe, st);
     return cmf_launch_status();
@@ -838,6 +891,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.no_direct = no_direct;
     static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
     g.diag = diag_rt;
+    g.trace = nullptr;
     int err = cmf_thin_gemm(g, a_t, b_t, st);            // narrow layers (<= 64 channels): barrier-free per-wave kernels
     if (err > 0) return err;
     const bool thin_done = (err == 0);

@@ -29,7 +29,9 @@ struct GemmArgs {
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
     int no_direct;              // diagnostics (env CMF_GEMM_NO_DIRECT=1): register-staged main loop everywhere
-    int diag;                   // timing diagnostics, results invalid (env CMF_GEMM_DIAG_RT bits: 1 no loads in the loop, 2 no vmcnt waits, 4 no barrier)
+    int diag;                   // timing diagnostics, results invalid (env CMF_GEMM_DIAG_RT bits: 1 no loads in the loop, 2 no vmcnt waits, 4 no barrier,
+                                // 8 no epilogue (nothing stored))
+    unsigned long long *trace;  // diagnostics (cmf_gemm_trace): per workgroup {t_start, t_mainloop_end, t_end (100 MHz wall clock), xcc_id << 32 | hw_id}
 };
 
 // thin_gemm.hip: returns -1 when the shape is not handled there

@@ -118,6 +118,11 @@ int cmf_gemm_tiles_m(int M);
  * the device and returns the number of bracketed launches, the sum of their durations (ms) and of their FLOPs, and the
  * launch count / FLOPs of ALL cmf_gemm calls in the window (thin kernels included): the share the measurement covers.
  * Not re-entrant (one window at a time); every output pointer may be NULL. */
+/* Diagnostics (tools/gemm_timeline.py): _arm makes the NEXT tiled launch record, per workgroup, {start, end of main loop,
+ * end} on the 100 MHz wall clock and (xcc_id << 32 | HW_ID); _read synchronises and copies the 4 x u64 records to host
+ * memory, returning the workgroup count of that launch. */
+int cmf_gemm_trace_arm(void);
+long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups);
 int cmf_gemm_profile_begin(double min_flops);
 int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed, double *flops_timed, long long *launches_all,
                          double *flops_all);
