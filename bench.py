@@ -175,11 +175,10 @@ def main():
     ap.add_argument("--model", choices=["cmflow", "cmflow_t", "raflow"], default="cmflow")
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", choices=["pm", "pm_torch", "ref"], default="pm",
-                    help="pm: fused point-major HIP path (product); ref: unfused reference-layout ops")
+    ap.add_argument("--path", choices=["pm", "pm_torch"], default="pm",
+                    help="pm: fused point-major HIP path (product); pm_torch: same layout, dense math through torch (debugging)")
     ap.add_argument("--serial", action="store_true",
                     help="diagnostic: encoder scales on ONE stream (per-kernel durations free of contention)")
-    ap.add_argument("--track", choices=["cmf_gemm", "cmf_group_points"], default=None)
     ap.add_argument("--force-allreduce", action="store_true",
                     help="diagnostic at N=1: run the RCCL all-reduce of the gradient bucket (world size 1) inside every step")
     ap.add_argument("--no-op-rooflines", action="store_true", help="skip the roofline_hbm op benchmarks after the timed region")
@@ -272,8 +271,7 @@ def main():
     for _ in range(a.warmup):
         one()
     frame[0] = 0                                     # the timed region starts at the first frame of a clip
-    track = a.track or ("cmf_group_points" if a.path == "ref" else "cmf_gemm")
-    _lib.profile_begin(track, "hbm" if track == "cmf_group_points" else "mfma")   # HIP-event pairs around every launch
+    _lib.profile_begin()                            # HIP-event pairs around every cmf_gemm launch >= 1 GFLOP, inside the library
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -299,7 +297,7 @@ def main():
                "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
                # PMC counters need rocprofv3 around the process; the per-launch FETCH_SIZE / WRITE_SIZE passes for this
                # kernel are committed (separate --pmc runs, gfx950 x2 correction on FETCH_SIZE)
-               "traffic_profile": "profiles/r02_gemm_pmc.txt" if prof["kernel"] == "cmf_gemm" else "profiles/r02_op_hbm_pmc.md",
+               "traffic_profile": "profiles/r02_gemm_pmc.txt",
                "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
                "algorithmic_per_launch": per_launch,
                "launch_filter": "every tiled-kernel launch >= %.0e flop, bracketed inside libcmflow_hip.so (block-internal "
@@ -324,7 +322,7 @@ def main():
                 m.side_streams = False
         net.head_streams = False
         one(); torch.cuda.synchronize()
-        _lib.profile_begin(track, "hbm" if track == "cmf_group_points" else "mfma")
+        _lib.profile_begin()
         for _ in range(3):
             one()
         iso = roofline_of(_lib.profile_end())

@@ -166,54 +166,31 @@ def check(err, what):
         raise RuntimeError("%s failed: hipError_t %d" % (what, err))
 
 
-# ---- live per-kernel timing for bench.py's `roofline` object ---------------------------------
-# cmf_gemm (bound "mfma", units = 2*M*N*K flop): bracketed INSIDE the library (cmf_gemm_profile_begin/_end, csrc/gemm.hip)
-# with HIP events on the stream each launch goes to, so the GEMMs issued by cmf_setconv_forward/_backward on the side
-# streams are covered exactly like the ones issued from Python.  Any other kernel (cmf_group_points, bound "hbm", units =
-# algorithmic bytes): HIP events recorded here on torch's current stream around the Python-level launch (`tracked`).
-TRACKED_KERNEL = ("cmf_gemm", "mfma")        # the dominant kernel of the training step (profiles/)
-_prof = None
-
-# Only launches of at least this many algorithmic units are bracketed: an event pair costs a few microseconds of stream
-# time, which would distort the step if the ~150 thin / small GEMM launches of a step were bracketed too.  The share of
-# the FLOPs the bracketed launches carry is reported next to the result (`flop_share`).
-TRACK_MIN_UNITS = {"cmf_gemm": 1.0e9, "cmf_group_points": 0.0}
+# ---- live timing of the dominant kernel for bench.py's `roofline` object ---------------------------------------
+# cmf_gemm (bound "mfma", units = 2*M*N*K flop) is bracketed INSIDE the library (cmf_gemm_profile_begin/_end,
+# csrc/gemm.hip) with HIP events on the stream each launch goes to, so the GEMMs issued by cmf_setconv_forward/_backward
+# on the side streams are covered exactly like the ones issued from Python.
+# Only launches of at least this many flops are bracketed: an event pair costs a few microseconds of stream time, which
+# would distort the step if the ~150 thin / small GEMM launches of a step were bracketed too.  The share of the FLOPs
+# the bracketed launches carry is reported next to the result (`flop_share`).
+TRACK_MIN_UNITS = {"cmf_gemm": 1.0e9}
+_prof_open = False
 
 
-def profile_begin(kernel=None, bound=None):
-    global _prof
-    k, b = TRACKED_KERNEL
-    _prof = {"kernel": kernel or k, "bound": bound or b, "events": [], "units": 0.0}
-    if _prof["kernel"] == "cmf_gemm":
-        check(lib().cmf_gemm_profile_begin(TRACK_MIN_UNITS["cmf_gemm"]), "cmf_gemm_profile_begin")
+def profile_begin():
+    global _prof_open
+    check(lib().cmf_gemm_profile_begin(TRACK_MIN_UNITS["cmf_gemm"]), "cmf_gemm_profile_begin")
+    _prof_open = True
 
 
 def profile_end():
-    global _prof
-    p, _prof = _prof, None
-    if p is None:
+    global _prof_open
+    if not _prof_open:
         return None
-    if p["kernel"] == "cmf_gemm":
-        n, n_all = ctypes.c_longlong(), ctypes.c_longlong()
-        ms, fl, fl_all = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        check(lib().cmf_gemm_profile_end(ctypes.addressof(n), ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n_all),
-                                         ctypes.addressof(fl_all)), "cmf_gemm_profile_end")
-        return {"kernel": "cmf_gemm", "bound": p["bound"], "launches": n.value, "ms": ms.value, "units": fl.value,
-                "launches_all": n_all.value, "units_all": fl_all.value}
-    torch.cuda.synchronize()
-    ms = sum(s.elapsed_time(e) for s, e in p["events"])
-    return {"kernel": p["kernel"], "bound": p["bound"], "launches": len(p["events"]), "ms": ms, "units": p["units"]}
-
-
-def tracked(name, units, fn):
-    """Run fn() (one kernel launch); time it with a HIP event pair if `name` is the tracked kernel (cmf_gemm is timed by
-    the library itself)."""
-    if _prof is None or name != _prof["kernel"] or name == "cmf_gemm" or units < TRACK_MIN_UNITS.get(name, 0.0):
-        return fn()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    r = fn()
-    e.record()
-    _prof["events"].append((s, e))
-    _prof["units"] += units
-    return r
+    _prof_open = False
+    n, n_all = ctypes.c_longlong(), ctypes.c_longlong()
+    ms, fl, fl_all = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    check(lib().cmf_gemm_profile_end(ctypes.addressof(n), ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n_all),
+                                     ctypes.addressof(fl_all)), "cmf_gemm_profile_end")
+    return {"kernel": "cmf_gemm", "bound": "mfma", "launches": n.value, "ms": ms.value, "units": fl.value,
+            "launches_all": n_all.value, "units_all": fl_all.value}

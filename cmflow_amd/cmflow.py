@@ -18,9 +18,9 @@ from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScale
 class CMFlow(nn.Module):
     score_eps = 1e-4            # models/cmflow.py:105; CMFlow_T has none (cmflow_t.py:119)
     # "pm": point-major fused path on the hand-written GEMM / BN / pooling kernels (default).
-    # "pm_torch": same layout and hoisting, dense math through torch (debug reference).
-    # "ref": the reference's op sequence in its own (B,C,N,ns) layout over the drop-in kernels
-    # (QueryAndGroup + 1x1 convs) -- kept as the unfused roofline/parity reference.
+    # "pm_torch": same layout and hoisting, dense math through torch (debugging aid).
+    # (The reference's own op sequence in its (B,C,N,ns) layout over the drop-in kernels is a test fixture:
+    # the oracle's modules bound to pointnet2_utils, tests/hip_ops.py.)
     path = "pm"
 
     def _set_blocks(self, on):
@@ -76,22 +76,10 @@ class CMFlow(nn.Module):
 
     def _propagate(self, pc1, pc2, feature1, feature2):
         """cmflow.py:59-88: everything of Backbone up to prop_features."""
-        if self.path in ("pm", "pm_torch"):
-            self._set_blocks(self.path == "pm")
-            return self._propagate_pm(pc1, pc2, feature1, feature2)
-        N = pc1.size(2)
-        pc1_features = self.mse_layer(pc1, feature1)
-        pc2_features = self.mse_layer(pc2, feature2)
-        gfeat_1 = torch.max(pc1_features, -1)[0].unsqueeze(2).expand(-1, -1, N)
-        gfeat_2 = torch.max(pc2_features, -1)[0].unsqueeze(2).expand(-1, -1, pc2.size(2))
-        pc1_features = torch.cat((pc1_features, gfeat_1), dim=1)
-        pc2_features = torch.cat((pc2_features, gfeat_2), dim=1)
-        cor_features = self.fc_layer(pc1, pc2, pc1_features, pc2_features)
-        embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
-        prop_features = self._second_encoder()(pc1, embeddings)
-        self.last = {"pc1_features": pc1_features[:, :256], "pc2_features": pc2_features[:, :256],
-                     "cor_features": cor_features, "prop_features": prop_features}
-        return prop_features
+        if self.path not in ("pm", "pm_torch"):
+            raise ValueError("unknown path %r (pm | pm_torch)" % (self.path,))
+        self._set_blocks(self.path == "pm")
+        return self._propagate_pm(pc1, pc2, feature1, feature2)
 
     def _propagate_pm(self, pc1, pc2, feature1, feature2):
         """Same computation in point-major layout; returns prop_features as (B,256,N)."""
@@ -167,13 +155,10 @@ class CMFlow(nn.Module):
             main.wait_stream(side)
             ff.record_stream(side)
             stat_cls.record_stream(main)
-        elif self.path in ("pm", "pm_torch"):
+        else:
             ff = final_features.transpose(1, 2)                       # (B,N,512) view
             output = self.fp.forward_pm(ff).transpose(1, 2)
             stat_cls = self.mp.forward_pm(ff).transpose(1, 2)
-        else:
-            output = self.fp(final_features)
-            stat_cls = self.mp(final_features)
         if (mode == 'train') and (label_m is not None):
             scores = label_m.unsqueeze(1)
         else:

@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -110,8 +111,20 @@ __device__ __forceinline__ void g_split3(const f32x4 a, const f32x4 b, g_bf16x8 
     }
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0>
-__global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
+// 0 raw store (split-K slabs, plain GEMM); 1 forward (bias / none-ReLU-leaky activation / BN statistics); 2 backward
+// through BN + ReLU; 3 backward through (leaky) ReLU
+__host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
+{
+    if (p.split_k > 1) return 0;
+    if (p.bwd_mode == 1) return 2;
+    if (p.bwd_mode) return 3;
+    return (p.bias || p.act || p.stats) ? 1 : 0;
+}
+
+// EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
+// kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
+template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
+__global__ __launch_bounds__(G_THREADS, (BM == 128 && BN == 128) ? (EPI <= 1 ? 3 : 2) : 3) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -548,17 +561,137 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
     const int col = (tid % TPR) * 4, n = n0 + col;
     const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)Cout) % 16 == 0) && (n + 3 < p.N) &&
                      (!p.bwd_mode || (p.ldz % 4 == 0 && ((uintptr_t)p.Z) % 16 == 0));
-    float bias[4] = {0, 0, 0, 0}, ea[4] = {0, 0, 0, 0}, ec[4] = {0, 0, 0, 0}, em[4] = {0, 0, 0, 0}, ei[4] = {0, 0, 0, 0};
+    // per-column constants: c0 = bias (forward; the backward modes carry neither bias nor activation) or ea (mode 1)
+    float c0[4] = {0, 0, 0, 0}, ec[4] = {0, 0, 0, 0}, em[4] = {0, 0, 0, 0}, ei[4] = {0, 0, 0, 0};
     if (p.split_k == 1)
         for (int q = 0; q < 4; ++q)
             if (n + q < p.N) {
-                if (p.bias) bias[q] = p.bias[n + q];
-                if (p.bwd_mode == 1) { ea[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
+                if (p.bwd_mode == 1) { c0[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
+                else if (p.bias && p.bwd_mode == 0) c0[q] = p.bias[n + q];
             }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float qs[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const bool want_q = want_stats && p.bwd_mode != 0 && p.dxyz != nullptr;    // + column sums of out * dxyz_k: the xyz-weight gradient
     const int nstat = want_q ? 5 : 2;
+    // One output row of the epilogue: activation / backward mask, statistics, store.  z: the producer's stored
+    // pre-activation (backward modes), dd: the row's (dx,dy,dz,0).
+    auto finish_row = [&](float (&v)[4], const float (&z)[4], const float4 dd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = p.bwd_mode ? v[q] : act_fn(v[q] + c0[q], p.act);
+            if (p.bwd_mode == 1) {
+                x = (fmaf(c0[q], z[q], ec[q]) > 0.f) ? x : 0.f;
+                s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
+                if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
+            } else if (p.bwd_mode == 2 || p.bwd_mode == 3) {
+                x = z[q] > 0.f ? x : (p.bwd_mode == 2 ? 0.1f * x : 0.f);
+                if (want_stats) s1[q] += x;                                           // column sums: bias gradient
+                if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
+            }
+            else if (want_stats) { s1[q] += x; s2[q] += x * x; }
+            v[q] = x;
+        }
+    };
+    // workgroup barrier for LDS traffic only: __syncthreads() carries a fence that also waits for every outstanding
+    // global store (vmcnt(0))
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // ---- fast path (workgroup-uniform): interior tile, 16-byte aligned rows, no read-modify-write of C ----
+    // gfx950 counts loads AND stores in one in-order counter (vmcnt): a load issued after a store cannot be awaited
+    // without awaiting that store's acknowledgement from L2 (1-3 us under load), and __syncthreads() waits for every
+    // outstanding store too.  The straightforward row loop (load Z row, compute, store, next row) therefore ran as a
+    // chain of 16 store round trips: ~40 us per tile, as long as the whole K = 256 main loop (measured per workgroup,
+    // tools/gemm_timeline.py).  Here every global load of the epilogue is issued BEFORE the first store -- the
+    // producer's Z tile into registers, the dxyz rows into LDS -- the row loops are straight-line code, and the
+    // workgroup barriers are plain s_barrier behind an LDS-only wait.
+    const bool fast_epi = (p.ldc % 4 == 0) && (((uintptr_t)Cout) % 16 == 0) && (n0 + BN <= p.N) && (m0 + BM <= p.M) &&
+                          !(p.accumulate && p.split_k == 1) && p.act != 3 &&
+                          (!p.bwd_mode || (p.ldz % 4 == 0 && ((uintptr_t)p.Z) % 16 == 0));
+    // Bands of 32 rows (one MFMA tile row of the owning waves): 4 (BN = 128) or 2 (BN = 64) rows per thread and band.
+    //   transpose -> read rows from LDS -> [Z(band) has landed] compute -> ISSUE Z(band+1) -> store band
+    // so the only loads ever waited on are older than every outstanding store.  Band 0 is peeled and the other bands are
+    // a real loop: every path into the loop body then has the same queue shape (NIT loads, NIT stores), which lets the
+    // compiler's waitcnt pass emit vmcnt(NIT) instead of the vmcnt(0) a merged state forces.  The body is instantiated
+    // per epilogue KIND (0 raw store: split-K slabs / plain GEMM; 1 forward: bias, none / ReLU / leaky activation as one
+    // slope select, BN statistics; 2 backward through BN + ReLU with the two BN sums; 3 backward through (leaky) ReLU with
+    // column sums) and selected once per workgroup -- with the modes decided per element the body is thousands of
+    // instructions and 140 registers.
+    auto fast_epilogue = [&](auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool USE_Z = KIND >= 2;
+        constexpr int NB = BM / 32, NIT = 32 / RPP;
+        static_assert(32 % RPP == 0 && NIT >= 1 && TM <= 2, "band rows");
+        const int rr = tid / TPR;
+        f32x4 zp[NIT];
+        const float *zrow = p.Z + (long long)(m0 + rr) * p.ldz + n;
+        float *crow = Cout + (long long)(m0 + rr) * p.ldc + n;
+        auto load_z = [&](int band) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) zp[it] = *(const f32x4 *)(zrow + (long long)(band * 32 + it * RPP) * p.ldz);
+        };
+        if (USE_Z) load_z(0);
+        float *dq = smem + 32 * T_LD;                                           // [BM][4] behind the transposition tile
+        const bool wq = USE_Z && want_q;
+        if (wq && tid < BM) *(f32x4 *)(dq + tid * 4) = *(const f32x4 *)(p.dxyz + (long long)(m0 + tid) * 4);
+        const float slope = KIND == 1 ? (p.act == 1 ? 0.f : (p.act == 2 ? 0.1f : 1.f)) : (p.bwd_mode == 2 ? 0.1f : 0.f);
+        auto spill_tile = [&](const f32x16 (&a)[TN]) {                          // this wave's 32 rows x WN columns -> LDS
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * T_LD + wn * WN + j * 32 + (lane & 31)] = a[j][r];
+        };
+        auto do_band = [&](int band) {
+            if (wm == band / TM) {
+                if (TM == 1 || (band % TM) == 0) spill_tile(acc[0]); else spill_tile(acc[TM - 1]);
+            }
+            lds_barrier();
+            f32x4 t4[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) t4[it] = *(const f32x4 *)(tile + (rr + it * RPP) * T_LD + col);
+            if (KIND != 0) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                    if (wq) d4 = *(const f32x4 *)(dq + (band * 32 + rr + it * RPP) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float x = t4[it][q];
+                        if (KIND == 1) {
+                            x += c0[q];
+                            x = x > 0.f ? x : slope * x;
+                            s1[q] += x; s2[q] += x * x;
+                        } else if (KIND == 2) {
+                            const float z = zp[it][q];
+                            x = (fmaf(c0[q], z, ec[q]) > 0.f) ? x : 0.f;
+                            s1[q] += x; s2[q] += x * ((z - em[q]) * ei[q]);
+                        } else {
+                            x = zp[it][q] > 0.f ? x : slope * x;
+                            s1[q] += x;
+                        }
+                        if (wq) { qs[0][q] += x * d4.x; qs[1][q] += x * d4.y; qs[2][q] += x * d4.z; }
+                        t4[it][q] = x;
+                    }
+                }
+            }
+            if (USE_Z && band + 1 < NB) load_z(band + 1);                       // issued ahead of this band's stores
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) *(f32x4 *)(crow + (long long)(band * 32 + it * RPP) * p.ldc) = t4[it];
+        };
+        do_band(0);
+#pragma unroll 1
+        for (int band = 1; band < NB; ++band) {
+            lds_barrier();                               // previous band fully consumed
+            do_band(band);
+        }
+        if (want_stats) lds_barrier();                   // all tile reads done: the LDS is reused for the column reduction
+    };
+    if (fast_epi && epilogue_kind(p) == EPI) {
+        fast_epilogue(std::integral_constant<int, EPI>{});
+    } else {
 #pragma unroll
     for (int band = 0; band < WARPS_M; ++band) {
         if (band > 0) __syncthreads();                   // previous band fully consumed
@@ -589,21 +722,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
                     if (vec) { const float4 z4 = *(const float4 *)zp; z[0] = z4.x; z[1] = z4.y; z[2] = z4.z; z[3] = z4.w; }
                     else for (int q = 0; q < 4; ++q) if (n + q < p.N) z[q] = zp[q];
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float x = act_fn(v[q] + bias[q], p.act);
-                    if (p.bwd_mode == 1) {
-                        x = (fmaf(ea[q], z[q], ec[q]) > 0.f) ? x : 0.f;
-                        s1[q] += x; s2[q] += x * ((z[q] - em[q]) * ei[q]);
-                        if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
-                    } else if (p.bwd_mode == 2 || p.bwd_mode == 3) {
-                        x = z[q] > 0.f ? x : (p.bwd_mode == 2 ? 0.1f * x : 0.f);
-                        if (want_stats) s1[q] += x;                                           // column sums: bias gradient
-                        if (want_q) { qs[0][q] += x * dd.x; qs[1][q] += x * dd.y; qs[2][q] += x * dd.z; }
-                    }
-                    else if (want_stats) { s1[q] += x; s2[q] += x * x; }
-                    v[q] = x;
-                }
+                finish_row(v, z, dd);
             }
             float *dst = Cout + (long long)m * p.ldc + n;
             if (vec) {
@@ -616,8 +735,9 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
             }
         }
     }
+    if (want_stats) __syncthreads();                     // all tile reads done: reuse LDS for the column reduction
+    }
     if (want_stats) {
-        __syncthreads();                                 // all tile reads done: reuse LDS for the column reduction
         float *red = smem;                               // [RPP][nstat][BN]
         const int rg = tid / TPR;
         *(float4 *)(red + (rg * nstat + 0) * BN + col) = make_float4(s1[0], s1[1], s1[2], s1[3]);
@@ -625,7 +745,7 @@ __global__ __launch_bounds__(G_THREADS) void gemm_kernel(const GemmArgs p)
         if (want_q)
             for (int k = 0; k < 3; ++k)
                 *(float4 *)(red + (rg * nstat + 2 + k) * BN + col) = make_float4(qs[k][0], qs[k][1], qs[k][2], qs[k][3]);
-        __syncthreads();
+        lds_barrier();
         for (int c = tid; c < nstat * BN; c += G_THREADS) {
             const int which = c / BN, cc = c % BN;
             float sum = 0.f;
@@ -819,7 +939,7 @@ extern "C" int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed,
     return 0;
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0>
+template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
 static int launch(const GemmArgs &a, hipStream_t st)
 {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -835,7 +955,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
     (void)hipGetDevice(&dev);
     const unsigned bit = 1u << (dev & 31);
     if (dev >= 128 || !(set_mask[dev >> 5].load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EMUL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EMUL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return (int)hipGetLastError();
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
@@ -852,12 +972,12 @@ static int launch(const GemmArgs &a, hipStream_t st)
             g_trace_n = grid.x;
             GemmArgs t = a;
             t.trace = g_trace_buf;
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL>), grid, dim3(G_THREADS), lds, st, t);
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL, EPI>), grid, dim3(G_THREADS), lds, st, t);
             gprof_close(pe, st);
             return cmf_launch_status();
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL>), grid, dim3(G_THREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL, EPI>), grid, dim3(G_THREADS), lds, st, a);
     gprof_close(pe, st);
     return cmf_launch_status();
 }
@@ -876,6 +996,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     CMF_CHECK_ARG(!(a_t && pro_a));                                  // A prologue needs the [M][K] layout
     CMF_CHECK_ARG(!(b_t && prob_a));
     CMF_CHECK_ARG(split_k == 1 || (workspace && !stats && !bwd_mode && !bias && !act));
+    CMF_CHECK_ARG(!bwd_mode || (!bias && !act));                     // a backward epilogue is mask * accumulator
     // 16-byte vector loads need aligned rows
     CMF_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0));
     CMF_CHECK_ARG(!pro_a || (((uintptr_t)pro_a | (uintptr_t)pro_c) % 16 == 0));
@@ -898,15 +1019,19 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     if (thin_done) gprof_count(2.0 * M * N * K);         // thin kernels: counted in flops_all, never bracketed
     const bool wide = N > 64, tall = M > 64;
     static const bool emul = getenv("CMF_GEMM_MODE") && !strcmp(getenv("CMF_GEMM_MODE"), "bf16x3");       // experimental, opt-in
-#define CMF_PICK(AT, BT)                                                                                   \
-    (tall ? (wide ? (emul ? launch<128, 128, AT, BT, 1>(g, st) : launch<128, 128, AT, BT>(g, st))          \
-                  : launch<128, 64, AT, BT>(g, st))                                                        \
-          : (wide ? launch<64, 128, AT, BT>(g, st) : launch<64, 64, AT, BT>(g, st)))
+    // instantiated (layout, kind) pairs: forward GEMMs (A[M][K], W[N][K]) carry kind 0 / 1, data gradients (dZ[M][N], W[N][K])
+    // kind 0 / 2 / 3, weight gradients and the rest kind 0; any other pairing runs the kind-0 kernel, whose generic loop
+    // handles every epilogue
+    const int kind = epilogue_kind(g);
+#define CMF_PICK(AT, BT, EP)                                                                               \
+    (tall ? (wide ? (emul ? launch<128, 128, AT, BT, 1, EP>(g, st) : launch<128, 128, AT, BT, 0, EP>(g, st)) \
+                  : launch<128, 64, AT, BT, 0, EP>(g, st))                                                 \
+          : (wide ? launch<64, 128, AT, BT, 0, EP>(g, st) : launch<64, 64, AT, BT, 0, EP>(g, st)))
     if (thin_done)         err = 0;
-    else if (!a_t && b_t)  err = CMF_PICK(false, true);
-    else if (!a_t && !b_t) err = CMF_PICK(false, false);
-    else if (a_t && !b_t)  err = CMF_PICK(true, false);
-    else                   err = CMF_PICK(true, true);
+    else if (!a_t && b_t)  err = kind == 1 ? CMF_PICK(false, true, 1) : CMF_PICK(false, true, 0);
+    else if (!a_t && !b_t) err = kind == 2 ? CMF_PICK(false, false, 2) : (kind == 3 ? CMF_PICK(false, false, 3) : CMF_PICK(false, false, 0));
+    else if (a_t && !b_t)  err = CMF_PICK(true, false, 0);
+    else                   err = CMF_PICK(true, true, 0);
 #undef CMF_PICK
     if (err) return err;
     if (split_k > 1) {

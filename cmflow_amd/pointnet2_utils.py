@@ -32,10 +32,7 @@ def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     """lib/src/group_points.cpp (group_points_wrapper_fast)."""
     args = (b, c, n, npoints, nsample, _lib.dev_ptr(points, _f32), _lib.dev_ptr(idx, _i32), _lib.dev_ptr(out, _f32),
             _lib.stream_ptr())
-    # algorithmic bytes (DESIGN.md): features once + idx once + grouped output once
-    nbytes = 4.0 * (b * c * n + b * npoints * nsample + b * c * npoints * nsample)
-    err = _lib.tracked("cmf_group_points", nbytes, lambda: _lib.lib().cmf_group_points(*args))
-    _lib.check(err, "cmf_group_points")
+    _lib.check(_lib.lib().cmf_group_points(*args), "cmf_group_points")
     return 1
 
 

@@ -1,13 +1,20 @@
 """Host-side mirror of the reference's building blocks (utils/model_utils/radarflow_util.py).
 
-Module names, constructor arguments, parameter names (=> state_dict keys) and tensor
-contracts follow the reference; the hot inner loops run in libcmflow_hip.so:
+Module names, constructor arguments, parameter names (=> state_dict keys) and the tensor contracts of
+``forward`` (channel-major (B,C,N) in and out) follow the reference.  The computation does not: every
+``forward`` is an adapter onto the point-major path (``forward_pm``: rows = points, hoisted first conv,
+fused grouping / BN / pooling kernels of libcmflow_hip.so), so a caller that uses a block on its own gets
+the same kernels the whole model runs on.
 
   knn_point (:88-99)            -> cmf_knn            (canonical distance + ordered top-k)
-  index_points_group (:52-63)   -> cmf_group_points   (+ cmf_group_points_grad in backward)
-  PointLocalFeature (:121-162)  -> QueryAndGroup over cmf_ball_query / cmf_group_points
-  FeatureCorrelator (:164-237)  -> cmf_knn + cmf_group_points
+  index_points_group (:52-63)   -> cmf_group_rows     (+ cmf_group_rows_grad in backward)
+  PointLocalFeature (:121-162)  -> cmf_setconv_forward/_backward (ball query, group, 6 x conv+BN+ReLU, max)
+  FeatureCorrelator (:164-237)  -> cmf_knn, cmf_group_affine, cmf_gemm, cmf_weightnet_ksum
   WeightedKabsch (models/cmflow.py:128-169) -> cmf_weighted_kabsch(+_grad)
+
+The reference's own op sequence in its (B,C,N,ns) layout over the drop-in kernels (cmf_ball_query /
+cmf_group_points / cmf_group_points_grad through ``pointnet2_utils``) is exercised by the tests with the
+oracle's modules bound to those ops (tests/hip_ops.py), not from this package.
 """
 import contextlib
 import os
@@ -26,19 +33,19 @@ _f32, _i32 = torch.float32, torch.int32
 
 
 def square_distance(src, dst):
-    """radarflow_util.py:8-30: (B,N,C),(B,M,C) -> (B,N,M) squared distances, clamped at 0."""
-    B, N, _ = src.shape
-    _, M, _ = dst.shape
-    dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
-    dist += torch.sum(src ** 2, -1).view(B, N, 1)
-    dist += torch.sum(dst ** 2, -1).view(B, 1, M)
-    return torch.clamp_min(dist, 0.0)
+    """radarflow_util.py:8-30: (B,N,C),(B,M,C) -> (B,N,M) squared distances |s|^2 + |d|^2 - 2 s.d, clamped at 0.
+    Evaluated as ((-2 s.d) + |s|^2) + |d|^2 -- the operation order of the reference expression, which the canonical
+    distance of the kNN kernel and of the oracle reproduces bit for bit."""
+    cross = torch.matmul(src, dst.transpose(1, 2)).mul_(-2.0)
+    cross.add_(src.square().sum(-1).unsqueeze(2)).add_(dst.square().sum(-1).unsqueeze(1))
+    return cross.clamp_min_(0.0)
 
 
 def index_points_group(points, knn_idx):
-    """radarflow_util.py:52-63: points (B,N,C), knn_idx (B,N,K) -> (B,N,K,C)."""
-    points_flipped = points.permute(0, 2, 1).contiguous()
-    return pointutils.grouping_operation(points_flipped, knn_idx.int().contiguous()).permute(0, 2, 3, 1)
+    """radarflow_util.py:52-63: points (B,N,C), knn_idx (B,S,K) -> (B,S,K,C).  Rows are contiguous in this layout, so
+    the gather is the point-major row copy (cmf_group_rows; backward: segmented sum over the inverse index) -- the
+    reference transposes to (B,C,N), gathers per channel and transposes back."""
+    return group_rows(points, Neighbors(knn_idx.int().contiguous(), points.shape[1]))
 
 
 def knn_point(nsample, xyz, new_xyz, return_dist=False):
@@ -93,6 +100,15 @@ def weighted_kabsch(A, B, W):
     return _WeightedKabsch.apply(A, B, W)
 
 
+def _rows(t, pad4=False):
+    """(B,C,N) channel-major -> (B,N,C) point-major rows (contiguous); pad4: zero columns up to a multiple of 4 floats
+    (16-byte rows for the stacked first-conv GEMM)."""
+    r = t.transpose(1, 2)
+    if pad4 and r.shape[2] % 4:
+        return F.pad(r, (0, -r.shape[2] % 4))
+    return r.contiguous()
+
+
 class MultiScaleEncoder(nn.Module):
     """radarflow_util.py:101-118"""
 
@@ -103,7 +119,8 @@ class MultiScaleEncoder(nn.Module):
             self.ms_ls.append(PointLocalFeature(radius[l], nsample[l], in_channel=in_channel, mlp=mlp, mlp2=mlp2))
 
     def forward(self, xyz, features):
-        return torch.cat([sa(xyz, features) for sa in self.ms_ls], dim=1)
+        """Reference contract (:111-118): xyz (B,3,N), features (B,C,N) -> (B, 64*scales, N)."""
+        return self.forward_pm(_rows(xyz), _rows(features, pad4=self.use_blocks)).transpose(1, 2)
 
     def forward_pm(self, xyz_t, feats, n_tail=0, n_grad=0):
         """Point-major: xyz_t (B,N,3), feats (B,N,C) -> (B,N,4*64).  The feature half of the four
@@ -209,15 +226,16 @@ class PointLocalFeature(nn.Module):
             last_channel = out_channel
         self.queryandgroup = pointutils.QueryAndGroup(radius, nsample)
 
+    use_blocks = True
+
     def forward(self, xyz, points):
-        xyz_t = xyz.permute(0, 2, 1).contiguous()
-        new_points = self.queryandgroup(xyz_t, xyz_t, points.contiguous())
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            new_points = F.relu(bn(conv(new_points)))
-        new_points = torch.max(new_points, -1)[0].unsqueeze(2)
-        for conv, bn in zip(self.mlp2_convs, self.mlp2_bns):
-            new_points = F.relu(bn(conv(new_points)))
-        return new_points.squeeze(2)
+        """Reference contract (:144-162): xyz (B,3,N), points (B,C,N) -> (B,64,N).  The feature columns of the first
+        conv are applied per point (one GEMM), the rest is the fused block."""
+        xyz_t, feats = _rows(xyz), _rows(points)
+        wf = w2d(self.mlp_convs[0])[:, 3:]
+        if self.use_blocks:
+            return FB.set_conv(self, xyz_t, FB.linear(feats, wf)).transpose(1, 2)
+        return self.forward_pm(xyz_t, F.linear(feats, wf)).transpose(1, 2)
 
     def forward_pm(self, xyz_t, y):
         """Point-major set-conv.  xyz_t (B,N,3); y (B,N,O1) = feats @ W_f^T, the feature half of
@@ -254,10 +272,8 @@ class WeightNet(nn.Module):
                 p._cmf_unused = True
 
     def forward(self, localized_xyz):
-        weights = localized_xyz
-        for i, conv in enumerate(self.mlp_convs):
-            weights = F.relu(self.mlp_bns[i](conv(weights))) if self.bn else F.relu(conv(weights))
-        return weights
+        """Reference contract (:307-318): (B,3,K,N) -> (B,out,K,N)."""
+        return self.forward_pm(localized_xyz.permute(0, 3, 2, 1), use_blocks=localized_xyz.is_cuda).permute(0, 3, 2, 1)
 
     def forward_pm(self, dxyz, use_blocks=False, preact_grad=False):
         """dxyz (B,N,K,3) -> (B,N,K,out).  preact_grad: the consumer (WeightedKSumFn relu_w=True) returns the gradient
@@ -332,30 +348,8 @@ class FeatureCorrelator(nn.Module):
         self.relu = nn.ReLU(inplace=True) if not use_leaky else nn.LeakyReLU(0.1, inplace=True)
 
     def forward(self, xyz1, xyz2, points1, points2):
-        B, C, N1 = xyz1.shape
-        _, D1, _ = points1.shape
-        xyz1 = xyz1.permute(0, 2, 1)
-        xyz2 = xyz2.permute(0, 2, 1)
-        points1 = points1.permute(0, 2, 1)
-        points2 = points2.permute(0, 2, 1)
-
-        knn_idx = knn_point(self.nsample, xyz2, xyz1)
-        neighbor_xyz = index_points_group(xyz2, knn_idx)
-        direction_xyz = neighbor_xyz - xyz1.view(B, N1, 1, C)
-        grouped_points2 = index_points_group(points2, knn_idx)
-        grouped_points1 = points1.view(B, N1, 1, D1).repeat(1, 1, self.nsample, 1)
-        new_points = torch.cat([grouped_points1, grouped_points2, direction_xyz], dim=-1).permute(0, 3, 2, 1)
-        for i, conv in enumerate(self.mlp_convs):
-            new_points = self.relu(self.mlp_bns[i](conv(new_points))) if self.bn else self.relu(conv(new_points))
-        weights = self.weightnet1(direction_xyz.permute(0, 3, 2, 1))
-        point_to_patch_cost = torch.sum(weights * new_points, dim=2)
-
-        knn_idx = knn_point(self.nsample, xyz1, xyz1)
-        neighbor_xyz = index_points_group(xyz1, knn_idx)
-        direction_xyz = neighbor_xyz - xyz1.view(B, N1, 1, C)
-        weights = self.weightnet2(direction_xyz.permute(0, 3, 2, 1))
-        grouped = index_points_group(point_to_patch_cost.permute(0, 2, 1), knn_idx)
-        return torch.sum(weights * grouped.permute(0, 3, 2, 1), dim=2)
+        """Reference contract (:185-237): xyz (B,3,N), points (B,D,N) -> patch-to-patch cost (B,mlp[-1],N1)."""
+        return self.forward_pm(_rows(xyz1), _rows(xyz2), _rows(points1), _rows(points2)).transpose(1, 2)
 
     def forward_pm(self, xyz1_t, xyz2_t, f1, f2):
         """Point-major cost volume.  xyz*_t (B,N,3), f1/f2 (B,N,D) -> (B,N,512).  The first conv
@@ -452,10 +446,8 @@ class FlowHead(nn.Module):
         self.conv2 = nn.Conv2d(mlp[-1], 3, 1, bias=False)
 
     def forward(self, feat):
-        feat = feat.unsqueeze(3)
-        for conv in self.sf_mlp:
-            feat = conv(feat)
-        return self.conv2(feat).squeeze(3)
+        """Reference contract (:253-261): (B,C,N) -> (B,3,N)."""
+        return self.forward_pm(feat.transpose(1, 2)).transpose(1, 2)
 
     def forward_pm(self, feat):
         """feat (B,N,512) -> (B,N,3)"""
@@ -484,10 +476,8 @@ class MotionHead(nn.Module):
         self.m = nn.Sigmoid()
 
     def forward(self, feat):
-        feat = feat.unsqueeze(3)
-        for conv in self.sf_mlp:
-            feat = conv(feat)
-        return self.m(self.conv2(feat)).squeeze(3)
+        """Reference contract (:276-285): (B,C,N) -> (B,1,N) in (0,1)."""
+        return self.forward_pm(feat.transpose(1, 2)).transpose(1, 2)
 
     def forward_pm(self, feat):
         """feat (B,N,512) -> (B,N,1)"""
@@ -518,7 +508,10 @@ class FlowDecoder(nn.Module):
         self.fp = FlowPredictor(in_channel=sf_inch, mlp=[int(sf_inch / 2), int(sf_inch / 4), int(sf_inch / 8)])
 
     def forward(self, pc1, feature1, pc1_features, cor_features):
-        embeddings = torch.cat((feature1, pc1_features, cor_features), dim=1)
-        prop_features = self.mse(pc1, embeddings)
-        gfeat = torch.max(prop_features, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
-        return self.fp(torch.cat((prop_features, gfeat), dim=1))
+        """Reference contract (:339-350): (B,3,N), (B,3,N), (B,512,N), (B,512,N) -> flow (B,3,N)."""
+        emb = torch.cat((_rows(feature1), _rows(pc1_features), _rows(cor_features)), dim=2)
+        prop = self.mse.forward_pm(_rows(pc1), F.pad(emb, (0, -emb.shape[2] % 4)) if self.mse.use_blocks else emb)
+        if self.mse.use_blocks:
+            return self.fp.forward_pm(FB.global_max_cat(prop)).transpose(1, 2)
+        glob = prop.max(dim=1, keepdim=True)[0].expand(-1, prop.shape[1], -1)
+        return self.fp.forward_pm(torch.cat((prop, glob), dim=2)).transpose(1, 2)

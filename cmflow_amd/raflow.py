@@ -34,9 +34,7 @@ class RaFlow(CMFlow):
     def ROFE_module(self, pc1, pc2, feature1, feature2):
         """raflow.py:46-76"""
         final_features = self.Backbone(pc1, pc2, feature1, feature2)          # (B,512,N): prop features + global max
-        if self.path in ("pm", "pm_torch"):
-            return self.fd_layer.fp.forward_pm(final_features.transpose(1, 2)).transpose(1, 2)
-        return self.fd_layer.fp(final_features)
+        return self.fd_layer.fp.forward_pm(final_features.transpose(1, 2)).transpose(1, 2)
 
     @staticmethod
     def rigid_transform_torch(A, B, M):

@@ -194,7 +194,7 @@ class MotionHead(_Head):
 
 def rigid_to_flow(pc, trans):
     """models/cmflow.py:51-55 / utils/util.py:184-189"""
-    h = torch.cat((pc, torch.ones((pc.size(0), 1, pc.size(2)), dtype=pc.dtype)), dim=1)
+    h = torch.cat((pc, torch.ones((pc.size(0), 1, pc.size(2)), dtype=pc.dtype, device=pc.device)), dim=1)
     return torch.matmul(trans, h)[:, :3] - pc
 
 
@@ -214,7 +214,7 @@ def weighted_kabsch(A, B, W):
     Vc[:, 2, :] *= -d.view(b, 1)
     R = torch.matmul(Vc, U.transpose(2, 1).contiguous())
     t = torch.matmul(-R, cA) + cB
-    last = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=A.dtype).repeat(b, 1).view(b, 1, 4)
+    last = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=A.dtype, device=A.device).repeat(b, 1).view(b, 1, 4)
     return torch.cat((torch.cat((R, t), dim=2), last), dim=1)
 
 
@@ -298,7 +298,7 @@ class CMFlow_T(CMFlow):
         prop = self._embed(pc1, pc2, feature1, feature2)
         gfeat = torch.max(prop, -1)[0]
         if gfeat_prev is None:
-            gfeat_prev = torch.zeros(gfeat.shape, dtype=gfeat.dtype)
+            gfeat_prev = torch.zeros(gfeat.shape, dtype=gfeat.dtype, device=gfeat.device)
         gnew = self.gru(gfeat.unsqueeze(0), gfeat_prev.unsqueeze(0))[0].squeeze(0)
         return torch.cat((prop, gnew.unsqueeze(2).expand(-1, -1, pc1.size(2))), dim=1), gnew
 
@@ -355,7 +355,7 @@ class RaFlow(nn.Module):
     def SFR_module(self, output, pc1, feature1, interval):
         N = pc1.size(2)
         warp = pc1 + output
-        trans = rigid_transform_masked(pc1, warp, torch.ones(pc1.size(0), N, dtype=pc1.dtype))
+        trans = rigid_transform_masked(pc1, warp, torch.ones(pc1.size(0), N, dtype=pc1.dtype, device=pc1.device))
         sf_rg = rigid_to_flow(pc1, trans)
         vel = feature1[:, 0]
         proj = torch.sum(sf_rg * pc1, dim=1) / torch.norm(pc1, dim=1)

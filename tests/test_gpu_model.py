@@ -35,11 +35,20 @@ def _weights(manifest, golden_dir, t=False):
                                   calib=os.path.join(golden_dir, "bn_calib_cmflow_t.npz" if t else "bn_calib_cmflow.npz"))
 
 
-def _set_path(net, path):
-    """pm: fused path with one C-ABI call per set-conv block; pm_py: same kernels sequenced from Python."""
+def _build(path, args, sd, dev, monkeypatch):
+    """pm: the product (fused point-major path, one C-ABI call per set-conv block); pm_py: same kernels sequenced from
+    Python; pm_torch: same layout, dense math through torch; ref: the reference's own op sequence in its (B,C,N,ns)
+    layout -- the oracle's modules on the GPU with their native ops bound to the DROP-IN kernels (tests/hip_ops.py)."""
     from cmflow_amd import fused_blocks as FB
-    FB.USE_BLOCK_CALLS = (path != "pm_py")
+    from cmflow_amd.cmflow import CMFlow
+    if path == "ref":
+        import hip_ops
+        return hip_ops.reference_layout_net(O.CMFlow, args, sd, dev, monkeypatch)
+    monkeypatch.setattr(FB, "USE_BLOCK_CALLS", path != "pm_py")
+    net = CMFlow(args)
     net.path = "pm" if path == "pm_py" else path
+    net.load_state_dict(sd)
+    return net.to(dev)
 
 
 def _epe(a, b):
@@ -48,14 +57,10 @@ def _epe(a, b):
 
 @pytest.mark.parametrize("path", ["pm", "pm_py", "pm_torch", "ref"])
 @pytest.mark.parametrize("case", EVAL_CASES)
-def test_forward_matches_reference_golden(case, path, dev, manifest, golden_dir, args):
-    from cmflow_amd.cmflow import CMFlow
+def test_forward_matches_reference_golden(case, path, dev, manifest, golden_dir, args, monkeypatch):
     from cmflow_amd import pointnet2_utils as pu, radarflow_util as ru
     g = _load(golden_dir, case)
-    net = CMFlow(args)
-    _set_path(net, path)
-    net.load_state_dict(_weights(manifest, golden_dir))
-    net = net.to(dev).eval()
+    net = _build(path, args, _weights(manifest, golden_dir), dev, monkeypatch).eval()
     # record what crosses the op boundary, in call order
     bq, knn = [], []
     bq0, knn0 = pu.ball_query, ru.knn_point
@@ -137,18 +142,14 @@ def test_forward_matches_oracle_fresh_inputs(dev, manifest, golden_dir, args):
 
 @pytest.mark.parametrize("path", ["pm", "pm_py", "pm_torch", "ref"])
 @pytest.mark.parametrize("case", ["cmflow_train_synth_b4", "cmflow_train_evalbn_synth_b4"])
-def test_train_step_matches_reference_golden(case, path, dev, manifest, golden_dir, args):
+def test_train_step_matches_reference_golden(case, path, dev, manifest, golden_dir, args, monkeypatch):
     """Rows a3 + a15('train') + losses + Adam against the reference's own train step
     (main_util.py:63-76 run behind the shims, tests/golden/make_golden.py).  `evalbn`: the same step with the network
     in eval mode -- the regime of every CMFlow epoch after the first (train_one_epoch never calls net.train(),
     main_util.py:39-76,96): BN normalises with its running statistics, gradients flow, buffers must not move."""
-    from cmflow_amd.cmflow import CMFlow
     from cmflow_amd.train import TrainStep
     g = _load(golden_dir, case)
-    net = CMFlow(args)
-    _set_path(net, path)
-    net.load_state_dict(_weights(manifest, golden_dir))
-    net = net.to(dev)
+    net = _build(path, args, _weights(manifest, golden_dir), dev, monkeypatch)
     net.eval() if "evalbn" in case else net.train()
     before = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
     batch = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc1", "pc2", "ft1", "ft2", "gt_trans", "flow_label", "fg_mask",
@@ -324,7 +325,7 @@ def test_full_size_train_step_matches_oracle(dev):
         rel = abs(a - r) / max(r, 1e-3)
         worst = max(worst, (k, rel), key=lambda t: t[1])
         n += 1
-    assert n >= 360 and worst[1] <= 1e-2, worst
+    assert n >= 180 and worst[1] <= 1e-2, worst        # 182 parameter tensors receive a gradient
     want, have = ref.state_dict(), net.state_dict()
     for k, v in want.items():
         if k.endswith("running_mean") or k.endswith("running_var"):

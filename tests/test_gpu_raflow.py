@@ -1,6 +1,7 @@
 """GPU: RaFlow (cmflow_amd.raflow) against the goldens of the reference's models/raflow.py --
 evaluation (strict and loose inlier threshold: both branches of the SFR module) and one self-supervised train
-step -- on the fused point-major path and on the reference-layout path."""
+step -- on the fused point-major path ("pm") and on the reference's own op sequence over the drop-in kernels ("ref":
+the oracle's RaFlow on the GPU with its native ops bound to libcmflow_hip.so, tests/hip_ops.py)."""
 import json
 import os
 
@@ -26,21 +27,26 @@ class A:
     rigid_thres = 0.15
 
 
-def _net(golden_dir, dev, path, thres=0.15):
+def _net(golden_dir, dev, path, monkeypatch, thres=0.15):
     man = json.load(open(os.path.join(golden_dir, "state_manifest_raflow.json")))
     a = A()
     a.rigid_thres = thres
+    sd = synth.synth_state_dict(man, seed=1234, calib=os.path.join(golden_dir, "bn_calib_raflow.npz"))
+    if path == "ref":
+        import hip_ops
+        from oracle import cmflow_oracle as O
+        return hip_ops.reference_layout_net(O.RaFlow, a, sd, dev, monkeypatch)
     net = RaFlow(a)
     net.path = path
-    net.load_state_dict(synth.synth_state_dict(man, seed=1234, calib=os.path.join(golden_dir, "bn_calib_raflow.npz")))
+    net.load_state_dict(sd)
     return net.to(dev)
 
 
 @pytest.mark.parametrize("path", ["pm", "ref"])
 @pytest.mark.parametrize("tag,thres", [("raflow_eval_synth_b2", 0.15), ("raflow_eval_synth_b4_loose", 2.0)])
-def test_raflow_eval_matches_reference(dev, golden_dir, path, tag, thres):
+def test_raflow_eval_matches_reference(dev, golden_dir, path, tag, thres, monkeypatch):
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
-    net = _net(golden_dir, dev, path, thres).eval()
+    net = _net(golden_dir, dev, path, monkeypatch, thres).eval()
     with torch.no_grad():
         out, sf, trans, mask_s = net(*(torch.from_numpy(g[k]).to(dev) for k in ("pc1", "pc2", "ft1", "ft2", "interval")))
     flips = (mask_s.cpu().numpy() != g["mask_s"])
@@ -53,9 +59,9 @@ def test_raflow_eval_matches_reference(dev, golden_dir, path, tag, thres):
 
 
 @pytest.mark.parametrize("path", ["pm", "ref"])
-def test_raflow_train_step_matches_reference(dev, golden_dir, path):
+def test_raflow_train_step_matches_reference(dev, golden_dir, path, monkeypatch):
     g = np.load(os.path.join(golden_dir, "raflow_train_synth_b4.npz"))
-    net = _net(golden_dir, dev, path).train()
+    net = _net(golden_dir, dev, path, monkeypatch).train()
     step = TrainStep(net)
     assert step.self_supervised
     batch = {k: torch.from_numpy(g[k]).to(dev) for k in ("pc1", "pc2", "ft1", "ft2", "interval")}
