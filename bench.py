@@ -25,6 +25,10 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this stack (already exported on the pool)
+# stdout carries exactly ONE line (the JSON record): libraries that print to the C-level stdout (RCCL's version banner at
+# communicator creation) are sent to stderr, and the record is written to the saved descriptor at the end
+_RESULT_FD = os.dup(1)
+os.dup2(2, 1)
 
 import torch
 
@@ -109,6 +113,24 @@ def cpu_baseline(mode, model_name, budget_s=20.0, B=4):
             "sample": "%d steps of B=%d N=256 %s (%s), median; oracle/ torch-CPU + C ops" % (len(times), B, model_name, what)}
 
 
+def gemm_shape_table(prof, title):
+    """Markdown table of the bracketed cmf_gemm launches grouped by (shape, layout, epilogue kind)."""
+    rows = []
+    for (M, N, K, layout, kind, split, bm, bn), (n, ms) in prof["shapes"].items():
+        fl = 2.0 * M * N * K * n
+        rows.append((ms, "| %d x %d x %d | %s | %s | %d | %dx%d | %d | %.3f | %.1f | %.3f |" % (
+            M, N, K, ("A[M,K] W[N,K]", "A[M,K] B[K,N]", "A[K,M] B[K,N]", "A[K,M] B[N,K]")[(1, 0, 2, 3)[layout]],
+            ("store", "fwd bias/act/stats", "bwd BN+ReLU", "bwd (leaky) ReLU")[kind], split, bm, bn, n, ms,
+            fl / (ms * 1e-3) / 1e12, fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS)))
+    rows.sort(reverse=True)
+    tot_ms = prof["ms"]
+    head = ("### %s\n\n%d launches, %.2f ms, %.1f TFLOP/s = %.3f of %.1f\n\n| M x N x K | operands | epilogue | split-K | tile | launches | "
+            "ms (sum) | TFLOP/s | of peak |\n|---|---|---|---|---|---|---|---|---|\n"
+            % (title, prof["launches"], tot_ms, prof["units"] / (tot_ms * 1e-3) / 1e12,
+               prof["units"] / (tot_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+    return head + "\n".join(r for _, r in rows) + "\n"
+
+
 def hbm_op_rooflines(dev, iters=20):
     """The drop-in kernels of the boundary (cmf_ball_query, cmf_group_points, cmf_group_points_grad through the C-ABI)
     at the op-level shapes of SURVEY 8d / BASELINE.md section 4, inputs resident in HBM.  Per op: `iters` back-to-back
@@ -183,6 +205,7 @@ def main():
                     help="diagnostic at N=1: run the RCCL all-reduce of the gradient bucket (world size 1) inside every step")
     ap.add_argument("--no-op-rooflines", action="store_true", help="skip the roofline_hbm op benchmarks after the timed region")
     ap.add_argument("--clip", type=int, default=5, help="cmflow_t: frames per mini-clip (clip_util.py:34-62)")
+    ap.add_argument("--gemm-table", default=None, help="write a markdown table of the bracketed cmf_gemm launches by shape to this file")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -312,7 +335,7 @@ def main():
     # the chip with kernels of the other streams and its duration is a contended one.  A short extra pass with
     # the scales serialised (outside the timed region, not part of `value`) gives the kernel's own rate.
     # Every rank runs it: a training step contains the gradient all-reduce, a collective all ranks must enter.
-    iso = None
+    iso = iso_prof = None
     if a.path == "pm":
         from cmflow_amd.radarflow_util import FeatureCorrelator, MultiScaleEncoder
         for m in net.modules():
@@ -325,7 +348,8 @@ def main():
         _lib.profile_begin()
         for _ in range(3):
             one()
-        iso = roofline_of(_lib.profile_end())
+        iso_prof = _lib.profile_end()
+        iso = roofline_of(iso_prof)
         if iso:
             iso["note"] = "3 extra steps with every chain on one stream (outside the timed region): the kernel's own rate"
 
@@ -365,7 +389,13 @@ def main():
             # x3 for fwd+bwd) -- the build's hoisted first convs execute fewer FLOPs than that
             "algorithmic_model_tflops": round(pairs / dt * 25.52e9 * (3.0 if a.mode == "train" else 1.0) / 1e12, 2),
         }
-        print(json.dumps(line))
+        if a.gemm_table:
+            with open(a.gemm_table, "w") as f:
+                f.write(gemm_shape_table(prof, "timed region (chains on the side-stream pool: durations are contended)"))
+                if iso_prof:
+                    f.write("\n" + gemm_shape_table(iso_prof, "3 extra steps with every chain on one stream (the kernel's own rate)"))
+        sys.stdout.flush()
+        os.write(_RESULT_FD, (json.dumps(line) + "\n").encode())
     if world > 1:
         fence()                                             # leave together
     if dist.is_initialized():

@@ -34,6 +34,7 @@ SIGNATURES = {
     "cmf_gemm_trace_read": [_vp, _ll],
     "cmf_gemm_profile_begin": [ctypes.c_double],
     "cmf_gemm_profile_end": [_vp, _vp, _vp, _vp, _vp],
+    "cmf_gemm_profile_records": [_vp, _ll],
     "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
     "cmf_setconv_forward": [_vp, _vp],
     "cmf_setconv_backward": [_vp, _vp],
@@ -77,7 +78,13 @@ SIGNATURES = {
     "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
     "cmf_eval_metrics": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _cf, _cf, _vp, _vp, _vp],
 }
-RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_gemm_trace_read": _ll}
+RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_gemm_trace_read": _ll, "cmf_gemm_profile_records": _ll}
+
+
+class GemmLaunchRecord(ctypes.Structure):
+    """cmf_gemm_launch_record of include/cmflow_hip.h"""
+    _fields_ = [("M", _ci), ("N", _ci), ("K", _ci), ("layout", _ci), ("split_k", _ci), ("kind", _ci), ("bm", _ci), ("bn", _ci),
+                ("ms", _cf)]
 
 
 class SetConvDesc(ctypes.Structure):
@@ -192,5 +199,13 @@ def profile_end():
     ms, fl, fl_all = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     check(lib().cmf_gemm_profile_end(ctypes.addressof(n), ctypes.addressof(ms), ctypes.addressof(fl), ctypes.addressof(n_all),
                                      ctypes.addressof(fl_all)), "cmf_gemm_profile_end")
+    recs = (GemmLaunchRecord * max(1, n.value))()
+    lib().cmf_gemm_profile_records(ctypes.addressof(recs), n.value)
+    shapes = {}
+    for r in recs[:n.value]:
+        key = (r.M, r.N, r.K, r.layout, r.kind, r.split_k, r.bm, r.bn)
+        e = shapes.setdefault(key, [0, 0.0])
+        e[0] += 1
+        e[1] += r.ms
     return {"kernel": "cmf_gemm", "bound": "mfma", "launches": n.value, "ms": ms.value, "units": fl.value,
-            "launches_all": n_all.value, "units_all": fl_all.value}
+            "launches_all": n_all.value, "units_all": fl_all.value, "shapes": shapes}

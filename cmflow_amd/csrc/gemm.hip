@@ -31,6 +31,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CMF_GEMM_DIAG 0
 #endif
 constexpr int G_THREADS = 256;
+#ifndef CMF_GEMM_W3
+#define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
+#endif
 #ifndef CMF_GEMM_BK
 #define CMF_GEMM_BK 16
 #endif
@@ -124,7 +127,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
-__global__ __launch_bounds__(G_THREADS, (BM == 128 && BN == 128) ? (EPI <= 1 ? 3 : 2) : 3) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 1 || CMF_GEMM_W3) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 && BN == 128) ? (EPI <= 1 ? 3
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool USE_Z = KIND >= 2;
         constexpr int NB = BM / 32, NIT = 32 / RPP;
-        static_assert(32 % RPP == 0 && NIT >= 1 && TM <= 2, "band rows");
+        static_assert(32 % RPP == 0 && NIT >= 1 && TM <= 4, "band rows");
         const int rr = tid / TPR;
         f32x4 zp[NIT];
         const float *zrow = p.Z + (long long)(m0 + rr) * p.ldz + n;
@@ -646,7 +649,11 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 && BN == 128) ? (EPI <= 1 ? 3
         };
         auto do_band = [&](int band) {
             if (wm == band / TM) {
-                if (TM == 1 || (band % TM) == 0) spill_tile(acc[0]); else spill_tile(acc[TM - 1]);
+                const int ti = band % TM;                // static accumulator index per branch (a dynamic one would go to scratch)
+                if (ti == 0) spill_tile(acc[0]);
+                else if (TM > 1 && ti == 1) spill_tile(acc[1 % TM]);
+                else if (TM > 2 && ti == 2) spill_tile(acc[2 % TM]);
+                else if (TM > 3) spill_tile(acc[3 % TM]);
             }
             lds_barrier();
             f32x4 t4[NIT];
@@ -751,7 +758,15 @@ __global__ __launch_bounds__(G_THREADS, (BM == 128 && BN == 128) ? (EPI <= 1 ? 3
             float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < RPP; ++g) sum += red[(g * nstat + which) * BN + cc];
-            if (n0 + cc < p.N) p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
+            // partial sums are consumed per 128-row tile (cmf_gemm_tiles_m): a 256-row tile stores its sums in the first of
+            // its two slots and zeros in the second
+            constexpr int SPT = BM > 128 ? BM / 128 : 1;
+            if (n0 + cc < p.N) {
+                p.stats[(((long long)tm * SPT) * nstat + which) * p.N + n0 + cc] = sum;
+#pragma unroll
+                for (int e = 1; e < SPT; ++e)
+                    if ((long long)(tm * SPT + e) * 128 < p.M) p.stats[(((long long)tm * SPT + e) * nstat + which) * p.N + n0 + cc] = 0.f;
+            }
         }
     }
     if (p.trace && tid == 0) {
@@ -857,11 +872,12 @@ struct GemmProfile {
     long long launches_all = 0;
     size_t used = 0;
     std::vector<hipEvent_t> events;                  // pairs: [2i] before, [2i+1] after; kept across sessions
+    std::vector<cmf_gemm_launch_record> recs;        // one per bracketed launch (shape, layout, epilogue kind)
 };
 GemmProfile g_gprof;
 
 // -> index of the event pair to record around this launch, or -1
-long long gprof_open(double flops, hipStream_t st)
+long long gprof_open(double flops, hipStream_t st, const GemmArgs *a = nullptr, int layout = 0, int bm = 0, int bn = 0)
 {
     if (!g_gprof.on) return -1;
     std::lock_guard<std::mutex> lock(g_gprof.mu);
@@ -876,6 +892,10 @@ long long gprof_open(double flops, hipStream_t st)
     }
     const size_t i = g_gprof.used++;
     g_gprof.flops_timed += flops;
+    if (g_gprof.recs.size() <= i) g_gprof.recs.resize(i + 1);
+    cmf_gemm_launch_record &r = g_gprof.recs[i];
+    r.M = a ? a->M : 0; r.N = a ? a->N : 0; r.K = a ? a->K : 0; r.layout = layout; r.split_k = a ? a->split_k : 0;
+    r.kind = a ? epilogue_kind(*a) : 0; r.bm = bm; r.bn = bn; r.ms = 0.f;
     (void)hipEventRecord(g_gprof.events[2 * i], st);
     return (long long)i;
 }
@@ -930,6 +950,7 @@ extern "C" int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed,
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_gprof.events[2 * i], g_gprof.events[2 * i + 1]) != hipSuccess) return (int)hipGetLastError();
         ms += t;
+        g_gprof.recs[i].ms = t;
     }
     if (launches_timed) *launches_timed = (long long)g_gprof.used;
     if (ms_timed) *ms_timed = ms;
@@ -937,6 +958,15 @@ extern "C" int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed,
     if (launches_all) *launches_all = g_gprof.launches_all;
     if (flops_all) *flops_all = g_gprof.flops_all;
     return 0;
+}
+
+// The records of the bracketed launches of the last closed window (call after cmf_gemm_profile_end); returns their number.
+extern "C" long long cmf_gemm_profile_records(cmf_gemm_launch_record *out, long long max_records)
+{
+    std::lock_guard<std::mutex> lock(g_gprof.mu);
+    const long long n = (long long)g_gprof.used < max_records ? (long long)g_gprof.used : max_records;
+    for (long long i = 0; i < n && out; ++i) out[i] = g_gprof.recs[(size_t)i];
+    return (long long)g_gprof.used;
 }
 
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
@@ -959,7 +989,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
                                 (int)lds) != hipSuccess) return (int)hipGetLastError();
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
-    const long long pe = gprof_open(2.0 * a.M * a.N * a.K, st);
+    const long long pe = gprof_open(2.0 * a.M * a.N * a.K, st, &a, (A_T ? 2 : 0) | (B_T ? 1 : 0), BM, BN);
     if (g_trace_armed) {                                 // diagnostics only: one launch, single-threaded use
         g_trace_armed = false;
         if ((long long)grid.x > g_trace_cap) {
@@ -1023,6 +1053,8 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     // kind 0 / 2 / 3, weight gradients and the rest kind 0; any other pairing runs the kind-0 kernel, whose generic loop
     // handles every epilogue
     const int kind = epilogue_kind(g);
+    // [256 x 128 tiles at 2 workgroups per CU (wave tile 128 x 64) were measured against this: 107 vs 118 TF on
+    //  524288 x 256 x 512, 26.2 vs 24.6 ms per training step -- two waves per SIMD do not cover each other's stalls.]
 #define CMF_PICK(AT, BT, EP)                                                                               \
     (tall ? (wide ? (emul ? launch<128, 128, AT, BT, 1, EP>(g, st) : launch<128, 128, AT, BT, 0, EP>(g, st)) \
                   : launch<128, 64, AT, BT, 0, EP>(g, st))                                                 \

@@ -30,7 +30,7 @@ struct GemmArgs {
     int accumulate;             // C += result (beta = 1)
     int no_direct;              // diagnostics (env CMF_GEMM_NO_DIRECT=1): register-staged main loop everywhere
     int diag;                   // timing diagnostics, results invalid (env CMF_GEMM_DIAG_RT bits: 1 no loads in the loop, 2 no vmcnt waits, 4 no barrier,
-                                // 8 no epilogue (nothing stored))
+                                // 8 no epilogue (nothing stored), 16 epilogue at raised wave priority)
     unsigned long long *trace;  // diagnostics (cmf_gemm_trace): per workgroup {t_start, t_mainloop_end, t_end (100 MHz wall clock), xcc_id << 32 | hw_id}
 };
 

@@ -301,7 +301,71 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
 // as they take to enqueue, so one host thread cannot keep four streams fed.  Stream ordering against the
 // caller's stream is the caller's business (events before / after the call); nothing is synchronised here.
 // ---------------------------------------------------------------------------------------------------------------
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <vector>
+
+namespace {
+// Persistent host threads for the chains of a multi-scale call: a chain is ~20 / ~45 launches, i.e. a few hundred
+// microseconds of enqueueing -- creating and joining a std::thread per chain and call (up to 7 spawns, ~6 calls per step)
+// costs a comparable amount.  Workers are created on first use, sleep on a condition variable between calls and are
+// never destroyed (the pool is leaked on purpose: joining threads during static destruction races with the HIP
+// runtime's own teardown).
+struct ChainWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool pending = false, done = true;
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return pending; });
+                j = std::move(job);
+                pending = false;
+            }
+            j();
+            {
+                std::lock_guard<std::mutex> lk(m);
+                done = true;
+            }
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            pending = true;
+            done = false;
+        }
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return done; });
+    }
+};
+std::mutex g_pool_mutex;                                 // one multi-scale call at a time uses the pool
+std::vector<ChainWorker *> *g_pool = nullptr;
+
+ChainWorker *chain_worker(size_t i)
+{
+    if (!g_pool) g_pool = new std::vector<ChainWorker *>();
+    while (g_pool->size() <= i) {
+        ChainWorker *w = new ChainWorker();
+        std::thread(&ChainWorker::loop, w).detach();
+        g_pool->push_back(w);
+    }
+    return (*g_pool)[i];
+}
+}  // namespace
 
 static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *streams, bool backward)
 {
@@ -309,14 +373,16 @@ static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *stre
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
     int err[16] = {0};
-    std::thread th[16];
     auto run = [&](int i) {
         if (i > 0 && hipSetDevice(dev) != hipSuccess) { err[i] = (int)hipGetLastError(); return; }
         err[i] = backward ? cmf_setconv_backward(&descs[i], streams[i]) : cmf_setconv_forward(&descs[i], streams[i]);
     };
-    for (int i = 1; i < n; ++i) th[i] = std::thread(run, i);
-    if (n > 0) run(0);                                  // the calling thread takes the first scale
-    for (int i = 1; i < n; ++i) th[i].join();
+    {
+        std::lock_guard<std::mutex> pool_lock(g_pool_mutex);
+        for (int i = 1; i < n; ++i) chain_worker((size_t)i - 1)->submit([&run, i] { run(i); });
+        if (n > 0) run(0);                                  // the calling thread takes the first scale
+        for (int i = 1; i < n; ++i) chain_worker((size_t)i - 1)->wait();
+    }
     for (int i = 0; i < n; ++i) if (err[i]) return err[i];
     return 0;
 }

@@ -123,9 +123,18 @@ int cmf_gemm_tiles_m(int M);
  * memory, returning the workgroup count of that launch. */
 int cmf_gemm_trace_arm(void);
 long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups);
+typedef struct cmf_gemm_launch_record {
+    int M, N, K;          /* as passed to cmf_gemm (C is M x N, contraction K) */
+    int layout;           /* bit 1: a_t, bit 0: b_t */
+    int split_k, kind;    /* epilogue kind: 0 raw store, 1 forward (bias/act/stats), 2 backward BN+ReLU, 3 backward (leaky) ReLU */
+    int bm, bn;           /* block tile */
+    float ms;             /* duration between the two events */
+} cmf_gemm_launch_record;
 int cmf_gemm_profile_begin(double min_flops);
 int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed, double *flops_timed, long long *launches_all,
                          double *flops_all);
+/* per-launch records of the last closed window (shape, layout, kind, duration); returns the number available */
+long long cmf_gemm_profile_records(cmf_gemm_launch_record *out, long long max_records);
 
 /* ---- BatchNorm / activation / pooling kernels around the GEMMs (point-major) ---------------------- *
  * Per-channel reductions use a partial buffer [ceil(rows/128)][2][C] (no atomics, fixed order). */
