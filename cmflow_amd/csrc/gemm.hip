@@ -34,6 +34,9 @@ constexpr int G_THREADS = 256;
 #ifndef CMF_GEMM_W3
 #define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
 #endif
+#ifndef CMF_GEMM_DEFAULT_MODE
+#define CMF_GEMM_DEFAULT_MODE 0           // see cmf_gemm_set_mode
+#endif
 #ifndef CMF_GEMM_BK
 #define CMF_GEMM_BK 16
 #endif
@@ -115,19 +118,20 @@ __device__ __forceinline__ void g_split3(const f32x4 a, const f32x4 b, g_bf16x8 
 }
 
 // 0 raw store (split-K slabs, plain GEMM); 1 forward (bias / none-ReLU-leaky activation / BN statistics); 2 backward
-// through BN + ReLU; 3 backward through (leaky) ReLU
+// through BN + ReLU; 3 backward through (leaky) ReLU; 4 / 5 = 2 / 3 with the three dxyz column sums
 __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 {
     if (p.split_k > 1) return 0;
-    if (p.bwd_mode == 1) return 2;
-    if (p.bwd_mode) return 3;
+    const int q = (p.stats && p.dxyz) ? 2 : 0;
+    if (p.bwd_mode == 1) return 2 + q;
+    if (p.bwd_mode) return 3 + q;
     return (p.bias || p.act || p.stats) ? 1 : 0;
 }
 
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
-__global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 1 || CMF_GEMM_W3) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 3 || CMF_GEMM_W3) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -565,13 +569,8 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
     const bool vec = (p.ldc % 4 == 0) && (((uintptr_t)Cout) % 16 == 0) && (n + 3 < p.N) &&
                      (!p.bwd_mode || (p.ldz % 4 == 0 && ((uintptr_t)p.Z) % 16 == 0));
     // per-column constants: c0 = bias (forward; the backward modes carry neither bias nor activation) or ea (mode 1)
+    // (generic loop only: the fast path keeps them in LDS)
     float c0[4] = {0, 0, 0, 0}, ec[4] = {0, 0, 0, 0}, em[4] = {0, 0, 0, 0}, ei[4] = {0, 0, 0, 0};
-    if (p.split_k == 1)
-        for (int q = 0; q < 4; ++q)
-            if (n + q < p.N) {
-                if (p.bwd_mode == 1) { c0[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
-                else if (p.bias && p.bwd_mode == 0) c0[q] = p.bias[n + q];
-            }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     float qs[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     const bool want_q = want_stats && p.bwd_mode != 0 && p.dxyz != nullptr;    // + column sums of out * dxyz_k: the xyz-weight gradient
@@ -624,7 +623,7 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
     // instructions and 140 registers.
     auto fast_epilogue = [&](auto kind_c) {
         constexpr int KIND = decltype(kind_c)::value;
-        constexpr bool USE_Z = KIND >= 2;
+        constexpr bool USE_Z = KIND >= 2, WQ = KIND >= 4, BNR = KIND == 2 || KIND == 4;
         constexpr int NB = BM / 32, NIT = 32 / RPP;
         static_assert(32 % RPP == 0 && NIT >= 1 && TM <= 4, "band rows");
         const int rr = tid / TPR;
@@ -637,8 +636,15 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
         };
         if (USE_Z) load_z(0);
         float *dq = smem + 32 * T_LD;                                           // [BM][4] behind the transposition tile
-        const bool wq = USE_Z && want_q;
-        if (wq && tid < BM) *(f32x4 *)(dq + tid * 4) = *(const f32x4 *)(p.dxyz + (long long)(m0 + tid) * 4);
+        float *cst = dq + BM * 4;                                               // [4][BN] column constants (kinds >= 1)
+        if (WQ && tid < BM) *(f32x4 *)(dq + tid * 4) = *(const f32x4 *)(p.dxyz + (long long)(m0 + tid) * 4);
+        // the per-column constants live in LDS and are re-read per band: kept in registers for the whole epilogue they
+        // (16) and the statistics (8-20) pushed the backward kinds to 150 registers = 2 workgroups per CU
+        if (KIND == 1 && tid < BN) cst[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+        if (BNR && tid < BN) {
+            cst[tid] = p.ea[n0 + tid]; cst[BN + tid] = p.ec[n0 + tid];
+            cst[2 * BN + tid] = p.emean[n0 + tid]; cst[3 * BN + tid] = p.einvstd[n0 + tid];
+        }
         const float slope = KIND == 1 ? (p.act == 1 ? 0.f : (p.act == 2 ? 0.1f : 1.f)) : (p.bwd_mode == 2 ? 0.1f : 0.f);
         auto spill_tile = [&](const f32x16 (&a)[TN]) {                          // this wave's 32 rows x WN columns -> LDS
 #pragma unroll
@@ -660,26 +666,29 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
 #pragma unroll
             for (int it = 0; it < NIT; ++it) t4[it] = *(const f32x4 *)(tile + (rr + it * RPP) * T_LD + col);
             if (KIND != 0) {
+                f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, k2 = k0, k3 = k0;
+                if (KIND == 1 || BNR) k0 = *(const f32x4 *)(cst + col);
+                if (BNR) { k1 = *(const f32x4 *)(cst + BN + col); k2 = *(const f32x4 *)(cst + 2 * BN + col); k3 = *(const f32x4 *)(cst + 3 * BN + col); }
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
-                    if (wq) d4 = *(const f32x4 *)(dq + (band * 32 + rr + it * RPP) * 4);
+                    if (WQ) d4 = *(const f32x4 *)(dq + (band * 32 + rr + it * RPP) * 4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float x = t4[it][q];
                         if (KIND == 1) {
-                            x += c0[q];
+                            x += k0[q];
                             x = x > 0.f ? x : slope * x;
                             s1[q] += x; s2[q] += x * x;
-                        } else if (KIND == 2) {
+                        } else if (BNR) {
                             const float z = zp[it][q];
-                            x = (fmaf(c0[q], z, ec[q]) > 0.f) ? x : 0.f;
-                            s1[q] += x; s2[q] += x * ((z - em[q]) * ei[q]);
+                            x = (fmaf(k0[q], z, k1[q]) > 0.f) ? x : 0.f;
+                            s1[q] += x; s2[q] += x * ((z - k2[q]) * k3[q]);
                         } else {
                             x = zp[it][q] > 0.f ? x : slope * x;
                             s1[q] += x;
                         }
-                        if (wq) { qs[0][q] += x * d4.x; qs[1][q] += x * d4.y; qs[2][q] += x * d4.z; }
+                        if (WQ) { qs[0][q] += x * d4.x; qs[1][q] += x * d4.y; qs[2][q] += x * d4.z; }
                         t4[it][q] = x;
                     }
                 }
@@ -699,6 +708,12 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
     if (fast_epi && epilogue_kind(p) == EPI) {
         fast_epilogue(std::integral_constant<int, EPI>{});
     } else {
+    if (p.split_k == 1)
+        for (int q = 0; q < 4; ++q)
+            if (n + q < p.N) {
+                if (p.bwd_mode == 1) { c0[q] = p.ea[n + q]; ec[q] = p.ec[n + q]; em[q] = p.emean[n + q]; ei[q] = p.einvstd[n + q]; }
+                else if (p.bias && p.bwd_mode == 0) c0[q] = p.bias[n + q];
+            }
 #pragma unroll
     for (int band = 0; band < WARPS_M; ++band) {
         if (band > 0) __syncthreads();                   // previous band fully consumed
@@ -1012,6 +1027,26 @@ static int launch(const GemmArgs &a, hipStream_t st)
     return cmf_launch_status();
 }
 
+// Arithmetic of the interior-tile main loop of the 128 x 128 kernels: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products),
+// 1 = "bf16x3": every fp32 operand split exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16 k with fp32
+// accumulation (fp32-grade: the dropped terms are below 2^-26 |a||b|).  Initial value from CMF_GEMM_MODE.
+namespace {
+int initial_gemm_mode()
+{
+    const char *e = getenv("CMF_GEMM_MODE");
+    if (e && !strcmp(e, "bf16x3")) return 1;
+    if (e && (!strcmp(e, "fp32") || !strcmp(e, "f32"))) return 0;
+    return CMF_GEMM_DEFAULT_MODE;
+}
+std::atomic<int> g_gemm_mode{initial_gemm_mode()};
+}
+extern "C" int cmf_gemm_set_mode(int mode)
+{
+    if (mode != 0 && mode != 1) return -1;
+    return g_gemm_mode.exchange(mode);
+}
+extern "C" int cmf_gemm_get_mode(void) { return g_gemm_mode.load(); }
+
 extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
                         const float *A, long long lda, const float *B, long long ldb, float *C, long long ldc,
                         const float *pro_a, const float *pro_c, const float *prob_a, const float *prob_c,
@@ -1048,7 +1083,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     const bool thin_done = (err == 0);
     if (thin_done) gprof_count(2.0 * M * N * K);         // thin kernels: counted in flops_all, never bracketed
     const bool wide = N > 64, tall = M > 64;
-    static const bool emul = getenv("CMF_GEMM_MODE") && !strcmp(getenv("CMF_GEMM_MODE"), "bf16x3");       // experimental, opt-in
+    const bool emul = g_gemm_mode.load(std::memory_order_relaxed) == 1;
     // instantiated (layout, kind) pairs: forward GEMMs (A[M][K], W[N][K]) carry kind 0 / 1, data gradients (dZ[M][N], W[N][K])
     // kind 0 / 2 / 3, weight gradients and the rest kind 0; any other pairing runs the kind-0 kernel, whose generic loop
     // handles every epilogue
@@ -1061,7 +1096,8 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
           : (wide ? launch<64, 128, AT, BT, 0, EP>(g, st) : launch<64, 64, AT, BT, 0, EP>(g, st)))
     if (thin_done)         err = 0;
     else if (!a_t && b_t)  err = kind == 1 ? CMF_PICK(false, true, 1) : CMF_PICK(false, true, 0);
-    else if (!a_t && !b_t) err = kind == 2 ? CMF_PICK(false, false, 2) : (kind == 3 ? CMF_PICK(false, false, 3) : CMF_PICK(false, false, 0));
+    else if (!a_t && !b_t) err = kind == 2 ? CMF_PICK(false, false, 2) : kind == 3 ? CMF_PICK(false, false, 3) :
+                                 kind == 4 ? CMF_PICK(false, false, 4) : kind == 5 ? CMF_PICK(false, false, 5) : CMF_PICK(false, false, 0);
     else if (a_t && !b_t)  err = CMF_PICK(true, false, 0);
     else                   err = CMF_PICK(true, true, 0);
 #undef CMF_PICK

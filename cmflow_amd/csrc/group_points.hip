@@ -182,7 +182,7 @@ __device__ __forceinline__ int gg_block_scan(int v, int *wsum, int &block_total)
 
 template <int E>
 __global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_bal_kernel(
-    int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ offsets,
+    int c, int n, int total, int ch_per_wg, const float *__restrict__ grad_out, const int *__restrict__ offsets,
     const int *__restrict__ inv, float *__restrict__ grad_points)
 {
     constexpr int RS = GG_THREADS * E + 4;                          // row buffer: entries + one zero slot (padding reads)
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_bal_kernel(
     int *scan = rank_of + n;                                        // [4]   scratch for the block scans
     const int tid = threadIdx.x;
     const int bs = blockIdx.x;
-    const int c0 = blockIdx.y * GG_CH;
-    const int nch = min(GG_CH, c - c0);
+    const int c0 = blockIdx.y * ch_per_wg;
+    const int nch = min(ch_per_wg, c - c0);
     const int *off = offsets + (size_t)bs * (n + 1);
     const int *lst = inv + (size_t)bs * total;
     const float *g = grad_out + ((size_t)bs * c + c0) * total;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_points_grad_generic_kernel(
 }
 
 template <int E>
-static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int total, const float *grad_out,
+static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int total, int ch_per_wg, const float *grad_out,
                        const int *offsets, const int *inv, float *grad_points)
 {
     static bool attr_set = false;
@@ -409,8 +409,8 @@ static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int 
                                   ((GG_THREADS * E + 4) + 3 * GG_MAX_N_BAL + GG_THREADS + 16) * 4);
         attr_set = true;
     }
-    hipLaunchKernelGGL(group_points_grad_bal_kernel<E>, grid, dim3(GG_THREADS), lds, st, c, n, total, grad_out, offsets, inv,
-                       grad_points);
+    hipLaunchKernelGGL(group_points_grad_bal_kernel<E>, grid, dim3(GG_THREADS), lds, st, c, n, total, ch_per_wg, grad_out, offsets,
+                       inv, grad_points);
 }
 
 extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
@@ -442,14 +442,19 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     int err = cmf_build_inverse_rows(b, n, npoints, nsample, idx, offsets, inv, stream, (int)total);
     if (!err) {
         if (balanced) {
-            const dim3 grid(b, cmf_divup(c, GG_CH));
+            // channels per workgroup: the per-sample index set-up costs about two channel rows, so more channels amortise
+            // it -- but (b, c / 16) workgroups leave the chip empty for narrow features (b = 64, c = 64: 256 workgroups,
+            // one per CU, 145 us for 140 MB); aim at >= 1024 workgroups, at least 4 channels each
+            int ch_per_wg = GG_CH;
+            while (ch_per_wg > 4 && (long long)b * cmf_divup(c, ch_per_wg) < 1024) ch_per_wg /= 2;
+            const dim3 grid(b, cmf_divup(c, ch_per_wg));
             const int e_need = (int)cmf_divup(total, GG_THREADS);
             const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
             const size_t lds = (size_t)((GG_THREADS * E + 4) + 3 * n + GG_THREADS + 16) * 4;
-            if (E == 4) launch_bal<4>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
-            else if (E == 8) launch_bal<8>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
-            else if (E == 16) launch_bal<16>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
-            else launch_bal<32>(grid, lds, st, c, n, (int)total, grad_out, offsets, inv, grad_points);
+            if (E == 4) launch_bal<4>(grid, lds, st, c, n, (int)total, ch_per_wg, grad_out, offsets, inv, grad_points);
+            else if (E == 8) launch_bal<8>(grid, lds, st, c, n, (int)total, ch_per_wg, grad_out, offsets, inv, grad_points);
+            else if (E == 16) launch_bal<16>(grid, lds, st, c, n, (int)total, ch_per_wg, grad_out, offsets, inv, grad_points);
+            else launch_bal<32>(grid, lds, st, c, n, (int)total, ch_per_wg, grad_out, offsets, inv, grad_points);
         } else {
             hipLaunchKernelGGL(group_points_grad_generic_kernel, dim3(b, c), dim3(GG_THREADS), 0, st,
                                c, n, (int)total, grad_out, offsets, inv, grad_points);

@@ -14,6 +14,18 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+def gemm_mode(request):
+    """Every kernel-level check runs under both arithmetic modes of the tiled kernel's main loop (cmf_gemm_set_mode)."""
+    from cmflow_amd import _lib
+    if request.param == "bf16x3" and "emulation_is_fp32_grade" in request.node.name:
+        pytest.skip("compares the two modes itself (child processes)")
+    prev = _lib.set_gemm_mode(request.param)
+    yield request.param
+    _lib.set_gemm_mode(prev)
+
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()

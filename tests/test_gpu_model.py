@@ -25,6 +25,18 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+def gemm_mode(request):
+    """Every model-level parity test runs under both arithmetic modes of cmf_gemm's main loop (cmf_gemm_set_mode): the
+    fp32 MFMA and the fp32-grade 3-way bf16 split.  Same goldens, same oracle, same tolerances."""
+    from cmflow_amd import _lib
+    if request.param == "bf16x3" and any(k in request.node.name for k in ("-ref", "-pm_torch", "rccl", "[ref", "[pm_torch")):
+        pytest.skip("path without cmf_gemm: one mode is enough")
+    prev = _lib.set_gemm_mode(request.param)
+    yield request.param
+    _lib.set_gemm_mode(prev)
+
+
 def _load(golden_dir, name):
     with np.load(os.path.join(golden_dir, name + ".npz")) as z:
         return {k: z[k] for k in z.files}
@@ -604,7 +616,7 @@ def test_dense_cloud_forward_matches_oracle(dev, manifest, golden_dir, args):
     assert float((got[2].cpu() - want[2]).abs().max()) < 1e-4
 
 
-def test_bench_two_ranks_control_flow(dev):
+def test_bench_two_ranks_control_flow(dev, gemm_mode):
     """bench.py under torch.distributed.run with two ranks (both on cuda:0 over gloo, CMF_BENCH_ONE_GPU=1): every
     collective of the script -- parameter broadcast, the gradient all-reduce inside every step INCLUDING the extra
     isolated-roofline steps after the timed region, the max-over-ranks of the time -- is entered by both ranks, rank 0
@@ -617,7 +629,7 @@ def test_bench_two_ranks_control_flow(dev):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, CMF_BENCH_ONE_GPU="1")
+    env = dict(os.environ, CMF_BENCH_ONE_GPU="1", CMF_GEMM_MODE=gemm_mode)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
@@ -629,7 +641,7 @@ def test_bench_two_ranks_control_flow(dev):
     assert rec["roofline"] is not None and rec["roofline_isolated"] is not None and rec["value"] > 0
 
 
-def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path):
+def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path, gemm_mode):
     """SURVEY 8e's parity check on the REAL model: a 2-rank data-parallel training step (both ranks on cuda:0 over gloo,
     tests/dp_worker.py; global B=8 -> 4+4) against single-process runs on each shard.
       * rank r's forward outputs, loss and LOCAL gradient bucket == a single-process run on shard r (same kernels:
@@ -651,7 +663,7 @@ def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "dp_worker.py"), str(tmp_path), "8"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, CMF_GEMM_MODE=gemm_mode))
     assert out.returncode == 0, out.stderr[-3000:]
     ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(2)]
     assert torch.equal(ranks[0]["averaged"], ranks[1]["averaged"])

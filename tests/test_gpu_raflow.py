@@ -22,6 +22,17 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+def gemm_mode(request):
+    """Both arithmetic modes of cmf_gemm's main loop (cmf_gemm_set_mode), same goldens and tolerances."""
+    from cmflow_amd import _lib
+    if request.param == "bf16x3" and "ref" in request.node.name:
+        pytest.skip("path without cmf_gemm: one mode is enough")
+    prev = _lib.set_gemm_mode(request.param)
+    yield request.param
+    _lib.set_gemm_mode(prev)
+
+
 class A:
     num_points = 256
     rigid_thres = 0.15
