@@ -31,6 +31,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CMF_GEMM_DIAG 0
 #endif
 constexpr int G_THREADS = 256;
+#ifndef CMF_EMUL_DIAG
+#define CMF_EMUL_DIAG 0                   // diagnostics of the bf16x3 loop (tools/diag builds)
+#endif
 #ifndef CMF_GEMM_W3
 #define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
 #endif
@@ -131,7 +134,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
-__global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 3 || CMF_GEMM_W3) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 3)) ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 3 || CMF_GEMM_W3) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -464,6 +467,27 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
                 for (int i = 0; i < TM; ++i) {
                     g_bf16x8 ah, am, al;
                     g_split3(af[0][i], af[1][i], ah, am, al);
+#if CMF_EMUL_DIAG == 1
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#elif CMF_EMUL_DIAG == 2
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#if CMF_EMUL_DIAG == 4
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+                    continue;
+#elif CMF_EMUL_DIAG == 5
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].x, bf[w][j].x, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].y, bf[w][j].y, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].z, bf[w][j].z, acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].w, bf[w][j].w, acc[i][j], 0, 0, 0);
+                        }
+                    continue;
+#endif
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
@@ -472,7 +496,13 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+#if CMF_EMUL_DIAG == 6
+                        asm volatile("s_nop 7" ::: "memory");
+#endif
                     }
+#if CMF_EMUL_DIAG == 7
+                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
                 }
             } else {
             read_frags(sa, sb, sp, 0, 0);
@@ -705,7 +735,7 @@ __global__ __launch_bounds__(G_THREADS, BM == 256 ? 2 : ((BM == 128 && BN == 128
         }
         if (want_stats) lds_barrier();                   // all tile reads done: the LDS is reused for the column reduction
     };
-    if (fast_epi && epilogue_kind(p) == EPI) {
+    if (fast_epi && epilogue_kind(p) == EPI && CMF_EMUL_DIAG != 8) {
         fast_epilogue(std::integral_constant<int, EPI>{});
     } else {
     if (p.split_k == 1)

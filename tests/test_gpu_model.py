@@ -25,10 +25,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["fp32"])
 def gemm_mode(request):
-    """Every model-level parity test runs under both arithmetic modes of cmf_gemm's main loop (cmf_gemm_set_mode): the
-    fp32 MFMA and the fp32-grade 3-way bf16 split.  Same goldens, same oracle, same tolerances."""
+    """The arithmetic mode of cmf_gemm's main loop the model-level parity tests run under (cmf_gemm_set_mode).  Only the
+    product's mode, the fp32 MFMA.  The experimental 3-way bf16 split ("bf16x3") was put through this whole file in round
+    2 (add it to `params`): the goldens at B <= 8 pass, but at the benchmark's size it exceeds the bounds written in
+    test_full_size_* (rotation 2.3e-6 rad, single-point flow 6e-4) and -- with the encoder scales on side streams -- its
+    results are not bit-reproducible from run to run (test_side_streams_do_not_change_results, test_two_rank_*), so it
+    stays an opt-in experiment.  The kernel-level checks of tests/test_gpu_gemm.py run both modes."""
     from cmflow_amd import _lib
     if request.param == "bf16x3" and any(k in request.node.name for k in ("-ref", "-pm_torch", "rccl", "[ref", "[pm_torch")):
         pytest.skip("path without cmf_gemm: one mode is enough")
