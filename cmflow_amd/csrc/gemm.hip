@@ -578,6 +578,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
     }
 
     const unsigned long long t_main = p.trace ? wall_clock64() : 0ull;
+    unsigned long long t_e[3] = {0ull, 0ull, 0ull};     // trace: first transposition visible, band-0 stores issued, last band done
     if (p.diag & 8) {                                   // timing diagnostic: no epilogue at all (accumulators kept live)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
                 else if (TM > 3) spill_tile(acc[3 % TM]);
             }
             lds_barrier();
+            if (p.trace && band == 0) t_e[0] = wall_clock64();
             f32x4 t4[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) t4[it] = *(const f32x4 *)(tile + (rr + it * RPP) * T_LD + col);
@@ -728,11 +730,13 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
             for (int it = 0; it < NIT; ++it) *(f32x4 *)(crow + (long long)(band * 32 + it * RPP) * p.ldc) = t4[it];
         };
         do_band(0);
+        if (p.trace) t_e[1] = wall_clock64();
 #pragma unroll 1
         for (int band = 1; band < NB; ++band) {
             lds_barrier();                               // previous band fully consumed
             do_band(band);
         }
+        if (p.trace) t_e[2] = wall_clock64();
         if (want_stats) lds_barrier();                   // all tile reads done: the LDS is reused for the column reduction
     };
     if (fast_epi && epilogue_kind(p) == EPI && CMF_EMUL_DIAG != 8) {
@@ -815,9 +819,9 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
         }
     }
     if (p.trace && tid == 0) {
-        unsigned long long *r = p.trace + 4ull * blockIdx.x;
+        unsigned long long *r = p.trace + 8ull * blockIdx.x;
         r[0] = t_start; r[1] = t_main; r[2] = wall_clock64();
-        r[3] = g_where();
+        r[3] = g_where(); r[4] = t_e[0]; r[5] = t_e[1]; r[6] = t_e[2]; r[7] = 0ull;
     }
 }
 
@@ -966,12 +970,12 @@ long long g_trace_cap = 0, g_trace_n = 0;
 bool g_trace_armed = false;
 }
 extern "C" int cmf_gemm_trace_arm(void) { g_trace_armed = true; return 0; }
-// Copies the records of the traced launch (4 x u64 per workgroup) to host memory; returns the workgroup count.
+// Copies the records of the traced launch (8 x u64 per workgroup) to host memory; returns the workgroup count.
 extern "C" long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups)
 {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     const long long n = g_trace_n < max_workgroups ? g_trace_n : max_workgroups;
-    if (n > 0 && host_out && hipMemcpy(host_out, g_trace_buf, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n > 0 && host_out && hipMemcpy(host_out, g_trace_buf, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return g_trace_n;
 }
 
@@ -1040,10 +1044,10 @@ static int launch(const GemmArgs &a, hipStream_t st)
         if ((long long)grid.x > g_trace_cap) {
             if (g_trace_buf) (void)hipFree(g_trace_buf);
             g_trace_cap = grid.x;
-            if (hipMalloc((void **)&g_trace_buf, (size_t)g_trace_cap * 32) != hipSuccess) { g_trace_buf = nullptr; g_trace_cap = 0; }
+            if (hipMalloc((void **)&g_trace_buf, (size_t)g_trace_cap * 64) != hipSuccess) { g_trace_buf = nullptr; g_trace_cap = 0; }
         }
         if (g_trace_buf) {
-            (void)hipMemsetAsync(g_trace_buf, 0, (size_t)grid.x * 32, st);
+            (void)hipMemsetAsync(g_trace_buf, 0, (size_t)grid.x * 64, st);
             g_trace_n = grid.x;
             GemmArgs t = a;
             t.trace = g_trace_buf;

@@ -413,6 +413,30 @@ static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int 
                        inv, grad_points);
 }
 
+#include <map>
+#include <mutex>
+#include <tuple>
+void *cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, hipStream_t, int>, std::pair<void *, size_t>> *table =
+        new std::map<std::tuple<int, hipStream_t, int>, std::pair<void *, size_t>>();      // leaked on purpose (runtime teardown order)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto &e = (*table)[std::make_tuple(dev, stream, slot)];
+    if (e.second < bytes) {
+        // the old buffer may still be in use by queued work of this stream: drain the stream before replacing it (rare:
+        // sizes only grow)
+        if (e.first) { (void)hipStreamSynchronize(stream); (void)hipFree(e.first); e = {nullptr, 0}; }
+        void *p = nullptr;
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e = {p, want};
+    }
+    return e.first;
+}
+
 extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
                                      const float *grad_out, const int *idx, float *grad_points, void *stream)
 {
@@ -433,11 +457,10 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
                            (size_t)GA_CH * n * sizeof(float), st, c, n, (int)total, grad_out, idx, grad_points);
         return cmf_launch_status();
     }
-    // stream-ordered scratch for the inverse index (nothing is retained after the call)
-    int *scratch = nullptr;
+    // per-stream library scratch for the inverse index (cmf_common.h)
     const size_t n_off = (size_t)b * (n + 1), n_inv = (size_t)b * total;
-    hipError_t e = hipMallocAsync((void **)&scratch, (n_off + n_inv) * sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
+    int *scratch = (int *)cmf_stream_scratch(st, 0, (n_off + n_inv) * sizeof(int));
+    if (!scratch) return (int)hipErrorOutOfMemory;
     int *offsets = scratch, *inv = scratch + n_off;
     int err = cmf_build_inverse_rows(b, n, npoints, nsample, idx, offsets, inv, stream, (int)total);
     if (!err) {
@@ -461,6 +484,5 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         }
         err = cmf_launch_status();
     }
-    (void)hipFreeAsync(scratch, st);
     return err;
 }

@@ -219,15 +219,12 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
         const int seg = (cmf_divup(n, BQM_NW) + 3) / 4 * 4;
         const long long wgs = (long long)grid.x * grid.y;
         if (wgs > 3 * 256) {                                     // enough workgroups for LDS capacity to limit occupancy
-            unsigned short *scratch = nullptr;
             const size_t bytes = (size_t)wgs * BQM_NW * BQ_MAX_NS_LDS * CMF_WAVE * sizeof(unsigned short);
-            hipError_t e = hipMallocAsync((void **)&scratch, bytes, (hipStream_t)stream);
-            if (e != hipSuccess) return (int)e;
+            unsigned short *scratch = (unsigned short *)cmf_stream_scratch((hipStream_t)stream, 1, bytes);   // per-stream library scratch
+            if (!scratch) return (int)hipErrorOutOfMemory;
             hipLaunchKernelGGL(ball_query_multi_kernel<true>, grid, dim3(BQM_NW * CMF_WAVE), 0, (hipStream_t)stream,
                                n, m, radius * radius, nsample, seg, new_xyz, xyz, idx, scratch);
-            const int err = cmf_launch_status();
-            (void)hipFreeAsync(scratch, (hipStream_t)stream);
-            return err;
+            return cmf_launch_status();
         }
         hipLaunchKernelGGL(ball_query_multi_kernel<false>, grid, dim3(BQM_NW * CMF_WAVE), 0, (hipStream_t)stream,
                            n, m, radius * radius, nsample, seg, new_xyz, xyz, idx, (unsigned short *)nullptr);

@@ -8,7 +8,12 @@
  *     enqueued asynchronously, nothing is synchronised, nothing is retained after return --
  *     same threading model as the reference wrappers, which enqueue on
  *     at::cuda::getCurrentCUDAStream() (lib/src/ball_query.cpp:22).
- *   - the caller allocates every buffer, outputs included (lib/pointnet2_utils.py:200-202,246-248).
+ *   - the caller allocates every buffer, outputs included (lib/pointnet2_utils.py:200-202,246-248).  Two entry points
+ *     need working memory their reference signature has no argument for and take it from a library-owned scratch, one
+ *     buffer per (device, stream), allocated with hipMalloc on first use, grown on demand and kept for the life of the
+ *     process: cmf_ball_query (spilled hit lists when nsample > 32 and more than 768 workgroups: 32 KB per workgroup,
+ *     64 MB at b = 32, m = 4096) and cmf_group_points_grad (inverse index: 4 * b * (n + 1 + npoints * nsample) bytes).
+ *     Nothing else is retained between calls.
  *   - return value: hipError_t as int (0 = hipSuccess).  The reference launchers print and
  *     exit(-1) on a launch failure (lib/src/ball_query_gpu.cu:62-66); this library reports the
  *     error to the caller instead.  Invalid arguments return hipErrorInvalidValue (1).
@@ -124,8 +129,9 @@ int cmf_gemm_get_mode(void);
  * launch count / FLOPs of ALL cmf_gemm calls in the window (thin kernels included): the share the measurement covers.
  * Not re-entrant (one window at a time); every output pointer may be NULL. */
 /* Diagnostics (tools/gemm_timeline.py): _arm makes the NEXT tiled launch record, per workgroup, {start, end of main loop,
- * end} on the 100 MHz wall clock and (xcc_id << 32 | HW_ID); _read synchronises and copies the 4 x u64 records to host
- * memory, returning the workgroup count of that launch. */
+ * end} on the 100 MHz wall clock, (xcc_id << 32 | HW_ID) and three epilogue stamps (first transposition visible, band-0 stores
+ * issued, last band done); _read synchronises and copies the 8 x u64 records to host memory, returning the workgroup
+ * count of that launch. */
 int cmf_gemm_trace_arm(void);
 long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups);
 typedef struct cmf_gemm_launch_record {

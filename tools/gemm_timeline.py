@@ -35,12 +35,16 @@ L = _lib.lib()
 L.cmf_gemm_trace_arm()
 fn()
 n = L.cmf_gemm_trace_read(None, 0)
-buf = np.zeros((n, 4), dtype=np.uint64)
+buf = np.zeros((n, 8), dtype=np.uint64)
 L.cmf_gemm_trace_read(buf.ctypes.data_as(ctypes.c_void_p), n)
 live = buf[:, 2] > 0
 rec = buf[live]
 t0 = rec[:, 0].min()
 start, main, end = ((rec[:, i] - t0).astype(np.float64) * 0.01 for i in range(3))      # us (100 MHz clock)
+ep = [(rec[:, i] - t0).astype(np.float64) * 0.01 for i in (4, 5, 6)]
+if (rec[:, 4] > 0).all():
+    print("epilogue stages (us, mean): transposition of band 0 visible %.2f | band 0 computed + stored %.2f | remaining bands %.2f | statistics + exit %.2f"
+          % ((ep[0] - main).mean(), (ep[1] - ep[0]).mean(), (ep[2] - ep[1]).mean(), (end - ep[2]).mean()))
 hw = rec[:, 3]
 xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
 hwid = (hw & np.uint64(0xFFFFFFFF)).astype(np.int64)

@@ -1,36 +1,48 @@
-"""Probe for the HBM-bound kernels of the point-major path (used under rocprofv3 --kernel-trace / --pmc): the second
-encoder's largest scale (r = 16 m, 32 slots: 524288 neighbour rows at B = 64) forward + backward through the Python-
-sequenced block (same kernels as the C-ABI block call), 3 repetitions.  Prints the algorithmic bytes per launch of each
-kernel (every tensor touched once) as JSON for tools/pm_table.py."""
+"""Probe for the HBM-bound kernels of the point-major path (used under rocprofv3 --kernel-trace / --pmc): each kernel is
+launched 3 times in a fixed order at the shapes of the second encoder's largest scale (r = 16 m, 32 slots: M = 524288
+neighbour rows, P = 16384 points at B = 64).  Prints, as JSON for tools/pm_table.py, the launch order and the algorithmic
+bytes per launch (every tensor touched once)."""
 import json, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-from cmflow_amd import synth, fused_blocks as FB
-from cmflow_amd.cmflow import CMFlow
+from cmflow_amd import _lib, synth, fused_blocks as FB, pointnet2_utils as pu
+from cmflow_amd.fused import Neighbors
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-net = CMFlow(bench.Args()); net.load_state_dict(bench.load_weights("cmflow")); net = net.to(dev).train()
-sa = net.mse_layer2.ms_ls[3]                       # r = 16, nsample = 32; channels 1030 -> 512 -> 256 -> 64 | 64 -> 64 -> 64
-B, N, S = 64, 256, sa.nsample
-xyz = synth.make_batch(B, seed=1234)["pc1"].to(dev).transpose(1, 2).contiguous()
-y = torch.randn(B, N, 512, device=dev, requires_grad=True)
-FB.USE_BLOCK_CALLS = False
-for _ in range(3):
-    out = FB.set_conv(sa, xyz, y)
-    out.backward(torch.randn_like(out))
-torch.cuda.synchronize()
+L = _lib.lib()
+B, N, S = 64, 256, 32
 M, P = B * N * S, B * N
-alg = {
-    # gather y[idx] (sources L2-resident: 33 MB), write z1 (M x 512) + dxyz (M x 4); idx (M) read
-    "group_affine_kernel": 4 * M * 512 + 16 * M + 4 * M + 4 * P * 512,
-    # read z3 (M x 64), write x (P x 64) + argmax (P x 64 bytes)
-    "bn_relu_maxpool_kernel": 4 * M * 64 + 4 * P * 64 + P * 64,
-    # read z3 (M x 64) + dx (P x 64) + argmax, write dU3 (M x 64)
-    "maxpool_bwd_kernel": 8 * M * 64 + 4 * P * 64 + P * 64,
-    # in place on dU (M x C) with z (M x C): read 2, write 1 -- C = 64 (layer 3) and 256 (layer 2)
-    "bn_bwd_apply_kernel@64": 12 * M * 64,
-    "bn_bwd_apply_kernel@256": 12 * M * 256,
-    # read dU1 (M x 512) + inverse index (M), write dy (P x 512); y / xyz re-read per point
-    "group_rows_grad_bn_cf_kernel": 4 * M * 512 + 4 * M + 8 * P * 512,
-}
-print("ALG " + json.dumps(alg))
+xyz = synth.make_batch(B, seed=1234)["pc1"].to(dev).transpose(1, 2).contiguous()
+idx = pu.ball_query(16.0, S, xyz, xyz)
+nbr = Neighbors(idx, N)
+off, inv = nbr.inverse()
+st = FB.BNState()
+def bnstate(C):
+    s = FB.BNState(); buf = torch.rand(4, C, device=dev) + 0.5
+    s.mean, s.invstd, s.a, s.c = buf[0], buf[1], buf[2], buf[3]; s.training = True; s.count = M
+    return s
+seq = []
+def rep(name, nbytes, fn):
+    for _ in range(3):
+        fn()
+    seq.append((name, nbytes))
+y = torch.randn(B, N, 512, device=dev); wx = torch.randn(512, 3, device=dev)
+rep("group_affine_kernel", 4 * M * 512 + 16 * M + 4 * M + 4 * P * 512,
+    lambda: FB.group_affine(y, None, xyz, xyz, wx, idx, act=0, stats=True, extra=True))
+z3 = torch.randn(P, S, 64, device=dev); s64 = bnstate(64)
+rep("bn_relu_maxpool_kernel", 4 * M * 64 + 4 * P * 64 + P * 64, lambda: FB.bn_relu_maxpool(z3, s64))
+x, am = FB.bn_relu_maxpool(z3, s64); dx = torch.randn(P, 64, device=dev)
+rep("maxpool_bwd_kernel", 8 * M * 64 + 4 * P * 64 + P * 64, lambda: FB.maxpool_bwd(dx, z3, s64, am))
+for C in (256, 64):
+    dU = torch.randn(M, C, device=dev); z = torch.randn(M, C, device=dev); s = bnstate(C)
+    sums = torch.randn(2, C, device=dev)
+    rep("bn_bwd_apply_kernel", 12 * M * C, lambda: _lib.check(L.cmf_bn_bwd_apply(M, C, dU.data_ptr(), z.data_ptr(), C, s.a.data_ptr(),
+        s.mean.data_ptr(), s.invstd.data_ptr(), sums.data_ptr(), _lib.stream_ptr()), "bn_bwd_apply"))
+    del dU, z
+dU1 = torch.randn(M, 512, device=dev); s512 = bnstate(512); sums5 = torch.randn(5, 512, device=dev)
+dy = torch.empty(B, N, 512, device=dev)
+rep("group_rows_grad_bn_cf_kernel", 4 * M * 512 + 4 * M + 8 * P * 512,
+    lambda: _lib.check(L.cmf_group_rows_grad_bn_cf(B, N, 512, N * S, S, dU1.data_ptr(), y.data_ptr(), 512, wx.data_ptr(), 3, xyz.data_ptr(),
+        xyz.data_ptr(), s512.a.data_ptr(), s512.mean.data_ptr(), s512.invstd.data_ptr(), sums5.data_ptr(), 1.0 / M, off.data_ptr(),
+        inv.data_ptr(), dy.data_ptr(), 512, _lib.stream_ptr()), "group_rows_grad_bn_cf"))
+torch.cuda.synchronize()
+print("SEQ " + json.dumps(seq))
