@@ -382,6 +382,219 @@ __global__ __launch_bounds__(GA_THREADS) void group_points_grad_stream_kernel(
     for (int i = tid; i < nch * n; i += GA_THREADS) gp[i] += acc[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Long rows (N = 4096 x K = 64: 262 144 entries = 1 MB per (sample, channel) row), deterministic.
+// The row is cut into TILES of 8192 consecutive entries and each tile gets its own small inverse index, built once per
+// call and shared by all channels (gpg_tile_index_kernel): the tile's entries sorted by target with a stable 4-bit
+// LSD radix sort in LDS (16-bit keys; equal targets keep position order), the sorted POSITIONS (uint16), a bit per
+// sorted entry marking the end of a target's run, the target of every run, and for every 16-entry chunk the chunk in
+// which the run that is open at its start began.  The scatter kernel (gpg_tiled_kernel) then works like the balanced
+// kernel above, tile after tile: a workgroup owns (sample, 4 channels) and keeps acc[4][n] in LDS; per tile and channel
+// it stages the 8192 floats of the row (coalesced 16-byte loads, the next ones already in flight), every thread gathers
+// its 16 sorted entries from LDS, forms the segmented sums, runs that cross chunks are stitched from the chunk tails in
+// fixed order, and the one thread that holds a run's end adds the run's sum to acc[target] -- a target has exactly one
+// run per tile, so no atomics, and the order of every addition is fixed: bit-reproducible.  It is the default only where
+// the LDS-atomic kernel below does not fit (n > 8192) and otherwise opt-in: see the dispatch in cmf_group_points_grad.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GT_THREADS = 512;
+constexpr int GT_E = 16;                               // sorted entries per thread
+constexpr int GT_TILE = GT_THREADS * GT_E;             // 8192 entries
+constexpr int GT_CH = 4;                               // channels per workgroup
+// per-tile index record, in 16-bit words: pos[TILE] | seg_target[TILE] | mask[THREADS] | rank0[THREADS] | ostart[THREADS] | nseg, pad
+constexpr int GT_REC = 2 * GT_TILE + 3 * GT_THREADS + 16;
+
+__device__ __forceinline__ int gt_block_scan(int v, int *wsum, int &block_total)      // inclusive, 512 threads (8 waves)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    __syncthreads();
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < GT_THREADS / 64; ++w) {
+        const int x = wsum[w];
+        if (w < wave) add += x;
+        tot += x;
+    }
+    block_total = tot;
+    return v + add;
+}
+
+__global__ __launch_bounds__(GT_THREADS) void gpg_tile_index_kernel(int total, int tiles, int key_bits,
+                                                                   const int *__restrict__ idx, unsigned short *__restrict__ rec_all)
+{
+    __shared__ unsigned short skey[GT_TILE + 1], spos[GT_TILE];
+    __shared__ unsigned short cnt[16][GT_THREADS + 2];
+    __shared__ int scan[GT_THREADS / 64];
+    __shared__ unsigned short runstart[GT_THREADS];
+    const int tid = threadIdx.x, tile = blockIdx.x, bs = blockIdx.y;
+    const int *ix = idx + (size_t)bs * total + (size_t)tile * GT_TILE;
+    const int len = min(GT_TILE, total - tile * GT_TILE);
+    unsigned short *rec = rec_all + ((size_t)bs * tiles + tile) * GT_REC;
+    unsigned key[GT_E], pos[GT_E];
+#pragma unroll
+    for (int i = 0; i < GT_E; ++i) {
+        const int e = tid * GT_E + i;
+        key[i] = e < len ? (unsigned)ix[e] : 0xFFFFu;            // entries past the row's end sort last
+        pos[i] = e < len ? (unsigned)e : (unsigned)GT_TILE;      // ... and read the zero slot behind the staged row
+    }
+    for (int shift = 0; shift < key_bits; shift += 4) {          // stable LSD radix sort, 4 bits per pass
+#pragma unroll
+        for (int d = 0; d < 16; ++d) cnt[d][tid] = 0;
+#pragma unroll
+        for (int i = 0; i < GT_E; ++i) ++cnt[(key[i] >> shift) & 15][tid];       // own column: no conflicts between threads
+        __syncthreads();
+        // exclusive scan over the counters in (digit, thread) order: thread t takes the 16 consecutive counters t*16 ..
+        int loc[16], run = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int f = tid * 16 + q; loc[q] = run; run += cnt[f / GT_THREADS][f % GT_THREADS]; }
+        int tot;
+        const int base = gt_block_scan(run, scan, tot) - run;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int f = tid * 16 + q; cnt[f / GT_THREADS][f % GT_THREADS] = (unsigned short)(base + loc[q]); }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < GT_E; ++i) {
+            const int d = (key[i] >> shift) & 15;
+            const int dst = cnt[d][tid]++;
+            skey[dst] = (unsigned short)key[i]; spos[dst] = (unsigned short)pos[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < GT_E; ++i) { key[i] = skey[tid * GT_E + i]; pos[i] = spos[tid * GT_E + i]; }
+        __syncthreads();
+    }
+    // run ends: sorted entry i ends its target's run when the next sorted key differs (padding keys end nothing)
+    if (tid == 0) skey[GT_TILE] = 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < GT_E; ++i) skey[tid * GT_E + i] = (unsigned short)key[i];
+    __syncthreads();
+    unsigned mask = 0;
+    bool inner = false;                                            // a run starts inside this chunk
+#pragma unroll
+    for (int i = 0; i < GT_E; ++i) {
+        const unsigned nxt = skey[tid * GT_E + i + 1];
+        if (key[i] != 0xFFFFu && key[i] != nxt) mask |= 1u << i;
+        if (i + 1 < GT_E && key[i] != key[i + 1]) inner = true;
+    }
+    int tot;
+    const int rank0 = gt_block_scan(__popc(mask), scan, tot) - __popc(mask);
+    // runstart[t]: the chunk in which the run holding chunk t's LAST entry began (serial only through all-equal chunks)
+    runstart[tid] = (unsigned short)(inner ? tid : 0xFFFF);
+    __syncthreads();
+    if (tid == 0)
+        for (int t = 0; t < GT_THREADS; ++t)
+            if (runstart[t] == 0xFFFF)
+                runstart[t] = (unsigned short)((t > 0 && skey[t * GT_E - 1] == skey[t * GT_E]) ? runstart[t - 1] : t);
+    __syncthreads();
+    const int ostart = (tid > 0 && skey[tid * GT_E - 1] == (unsigned short)key[0]) ? runstart[tid - 1] : tid;
+    unsigned short *r_pos = rec, *r_seg = rec + GT_TILE, *r_mask = rec + 2 * GT_TILE;
+    unsigned short *r_rank = r_mask + GT_THREADS, *r_ost = r_rank + GT_THREADS;
+    int rk = rank0;
+#pragma unroll
+    for (int i = 0; i < GT_E; ++i) {
+        r_pos[tid * GT_E + i] = (unsigned short)pos[i];
+        if ((mask >> i) & 1u) r_seg[rk++] = (unsigned short)key[i];
+    }
+    r_mask[tid] = (unsigned short)mask; r_rank[tid] = (unsigned short)rank0; r_ost[tid] = (unsigned short)ostart;
+    if (tid == 0) r_ost[GT_THREADS] = (unsigned short)tot;
+}
+
+__global__ __launch_bounds__(GT_THREADS) void gpg_tiled_kernel(int c, int n, int total, int tiles, int nch_wg,
+                                                              const float *__restrict__ grad_out,
+                                                              const unsigned short *__restrict__ rec_all, float *__restrict__ grad_points)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *acc = sm;                                        // [nch_wg][n]
+    float *row = acc + (size_t)nch_wg * n;                  // [TILE + 4]: staged row tile + a zero slot
+    float *tails = row + GT_TILE + 4;                       // [THREADS]
+    unsigned short *seg = reinterpret_cast<unsigned short *>(tails + GT_THREADS);      // [TILE] targets of this tile's runs
+    const int tid = threadIdx.x, bs = blockIdx.x;
+    const int c0 = blockIdx.y * nch_wg, nch = min(nch_wg, c - c0);
+    const float *g = grad_out + ((size_t)bs * c + c0) * total;
+    float *gp = grad_points + ((size_t)bs * c + c0) * n;
+    for (int i = tid; i < nch_wg * n; i += GT_THREADS) acc[i] = 0.f;
+    if (tid == 0) row[GT_TILE] = 0.f;
+    const bool vec = (total & 3) == 0 && ((uintptr_t)grad_out & 15) == 0;
+    constexpr int V = GT_E / 4;
+    auto fetch = [&](int tile, int ch, float4 (&r)[V]) {    // this thread's part of the tile's row for channel ch
+        const float *src = g + (size_t)ch * total + (size_t)tile * GT_TILE;
+        const int len = min(GT_TILE, total - tile * GT_TILE);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int i = (v * GT_THREADS + tid) * 4;
+            if (vec) r[v] = i < len ? *(const float4 *)(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                r[v].x = i < len ? src[i] : 0.f;         r[v].y = i + 1 < len ? src[i + 1] : 0.f;
+                r[v].z = i + 2 < len ? src[i + 2] : 0.f; r[v].w = i + 3 < len ? src[i + 3] : 0.f;
+            }
+        }
+    };
+    float4 nxt[V];
+    fetch(0, 0, nxt);
+    for (int tile = 0; tile < tiles; ++tile) {
+        const unsigned short *rec = rec_all + ((size_t)bs * tiles + tile) * GT_REC;
+        unsigned pos2[GT_E / 2];
+#pragma unroll
+        for (int k = 0; k < GT_E / 2; ++k) pos2[k] = reinterpret_cast<const unsigned *>(rec)[tid * (GT_E / 2) + k];
+        const unsigned mask = rec[2 * GT_TILE + tid];
+        const int rank0 = rec[2 * GT_TILE + GT_THREADS + tid], ostart = rec[2 * GT_TILE + 2 * GT_THREADS + tid];
+        const int nseg = rec[2 * GT_TILE + 3 * GT_THREADS];
+        __syncthreads();                                    // previous tile's runs are finished with `seg`
+        for (int i = tid; i < (nseg + 1) / 2; i += GT_THREADS)
+            reinterpret_cast<unsigned *>(seg)[i] = reinterpret_cast<const unsigned *>(rec + GT_TILE)[i];
+        for (int ch = 0; ch < nch; ++ch) {
+            // stage the row tile (every read of the previous one is done: barrier at the end of the last iteration)
+#pragma unroll
+            for (int v = 0; v < V; ++v) *(float4 *)(row + (v * GT_THREADS + tid) * 4) = nxt[v];
+            const bool last = (ch + 1 == nch);
+            if (!(last && tile + 1 == tiles)) fetch(last ? tile + 1 : tile, last ? 0 : ch + 1, nxt);      // in flight during the reduction
+            __syncthreads();
+            float val[GT_E];
+#pragma unroll
+            for (int k = 0; k < GT_E; ++k) {
+                const unsigned pp = pos2[k / 2];
+                val[k] = row[(k & 1) ? (pp >> 16) : (pp & 0xffffu)];
+            }
+            // segmented sums of this chunk: `head` = up to the first run end, `run` = after the last one
+            float run = 0.f, head = 0.f;
+            bool first = true;
+            float ends[GT_E];                               // sum of the run ending at sorted entry k (valid where mask bit k)
+#pragma unroll
+            for (int k = 0; k < GT_E; ++k) {
+                run += val[k];
+                ends[k] = run;
+                if ((mask >> k) & 1u) { if (first) { head = run; first = false; } run = 0.f; }
+            }
+            tails[tid] = run;                               // (a chunk without any run end: its whole sum)
+            __syncthreads();
+            // every run end adds its run to acc: the first one of a chunk collects the tails of the chunks the run crossed
+            float *a = acc + (size_t)ch * n;
+            int rk = rank0;
+            bool f2 = true;
+#pragma unroll
+            for (int k = 0; k < GT_E; ++k)
+                if ((mask >> k) & 1u) {
+                    float sum = ends[k];
+                    if (f2) {
+                        float carry = 0.f;
+                        for (int q = ostart; q < tid; ++q) carry += tails[q];
+                        sum = carry + head;
+                        f2 = false;
+                    }
+                    a[seg[rk++]] += sum;
+                }
+            __syncthreads();                                // tails / row reusable
+        }
+    }
+    for (int i = tid; i < nch * n; i += GT_THREADS) gp[i] += acc[i];
+}
+
 // generic fall-back (any n): thread per target over the inverse index, row read through the caches
 __global__ __launch_bounds__(GG_THREADS) void group_points_grad_generic_kernel(
     int c, int n, int total, const float *__restrict__ grad_out, const int *__restrict__ offsets,
@@ -413,6 +626,7 @@ static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int 
                        inv, grad_points);
 }
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -446,7 +660,30 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     CMF_CHECK_ARG(grad_out && idx && grad_points && n > 0 && total < (1LL << 31));
     hipStream_t st = (hipStream_t)stream;
     const bool balanced = total <= GG_THREADS * GG_MAX_E && n <= GG_MAX_N_BAL;
-    if (!balanced && (size_t)GA_CH * n * sizeof(float) <= 128 * 1024) {
+    // Long rows: the deterministic tiled kernel is opt-in (CMF_GROUP_GRAD_DETERMINISTIC=1).  Measured at BASELINE config 5,
+    // (32,4096,64,64 / 128): 1747 / 3330 us against 1079 / 2148 us for the LDS-atomic kernel below -- with ~2 entries per
+    // target and tile nearly every second sorted entry ends a run, so the per-run work (target lookup + accumulate) and
+    // the two barriers per (tile, channel) at one workgroup per CU cost more than the same-address conflicts they remove.
+    static const bool deterministic = getenv("CMF_GROUP_GRAD_DETERMINISTIC") && getenv("CMF_GROUP_GRAD_DETERMINISTIC")[0] == '1';
+    const bool stream_fits = (size_t)GA_CH * n * sizeof(float) <= 128 * 1024;
+    if (!balanced && n <= 16384 && (deterministic || !stream_fits)) {
+        // per-tile inverse index (library scratch) + tiled deterministic scatter
+        const int tiles = cmf_divup(total, GT_TILE);
+        int key_bits = 4;
+        while ((1 << key_bits) < n) key_bits += 4;
+        unsigned short *rec = (unsigned short *)cmf_stream_scratch(st, 0, (size_t)b * tiles * GT_REC * sizeof(unsigned short));
+        if (!rec) return (int)hipErrorOutOfMemory;
+        hipLaunchKernelGGL(gpg_tile_index_kernel, dim3(tiles, b), dim3(GT_THREADS), 0, st, (int)total, tiles, key_bits, idx, rec);
+        int nch_wg = GT_CH;
+        while (nch_wg > 1 && (size_t)nch_wg * n * sizeof(float) > 64 * 1024) nch_wg /= 2;
+        const size_t lds = ((size_t)nch_wg * n + GT_TILE + 4 + GT_THREADS) * sizeof(float) + GT_TILE * sizeof(unsigned short);
+        static bool attr_t = false;
+        if (!attr_t) { (void)hipFuncSetAttribute((const void *)gpg_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_t = true; }
+        hipLaunchKernelGGL(gpg_tiled_kernel, dim3(b, cmf_divup(c, nch_wg)), dim3(GT_THREADS), lds, st, c, n, (int)total, tiles, nch_wg,
+                           grad_out, rec, grad_points);
+        return cmf_launch_status();
+    }
+    if (!balanced && stream_fits) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)group_points_grad_stream_kernel,

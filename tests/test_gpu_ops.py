@@ -56,7 +56,8 @@ def test_ball_query_edge_cases(dev):
 @pytest.mark.parametrize("B,C,N,P,S", [(4, 3, 256, 256, 4), (2, 64, 256, 256, 32), (2, 1027, 256, 256, 8),
                                        (1, 5, 100, 37, 3), (1, 2, 5000, 64, 16), (2, 9, 4096, 512, 64),
                                        (2, 33, 256, 256, 16), (1, 20, 300, 250, 32), (1, 2, 35000, 16, 8),
-                                       (1, 17, 700, 1, 1)])
+                                       (1, 17, 700, 1, 1), (2, 6, 4096, 4096, 64), (1, 5, 4096, 1000, 37),
+                                       (1, 3, 9000, 2000, 9)])
 def test_group_points_and_grad(dev, B, C, N, P, S):
     from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
     g = torch.Generator().manual_seed(B + C + N)
@@ -69,10 +70,10 @@ def test_group_points_and_grad(dev, B, C, N, P, S):
     gp = torch.zeros(B, C, N, device=dev)
     ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp)
     ref = orc.group_points_grad(go, idx, N)
-    # the reference's atomicAdd order is undefined; ours is a fixed chunked order (rows <= 8192 entries) or LDS
-    # atomics (longer rows): equal to the oracle's scan-order sum to fp32 rounding of the partial sums
+    # the reference's atomicAdd order is undefined; ours is a fixed chunked order (balanced kernel: rows <= 8192 entries;
+    # tiled kernel: longer rows, n <= 16384): equal to the oracle's scan-order sum to fp32 rounding of the partial sums
     np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(S * P / N + 1) ** 0.5 * 4)
-    if P * S <= 8192 and N <= 4096:                                   # balanced kernel: bit-reproducible run to run
+    if (P * S <= 8192 and N <= 4096) or 8192 < N <= 16384:             # balanced / tiled kernels: bit-reproducible run to run
         gp2 = torch.zeros(B, C, N, device=dev)
         ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp2)
         assert torch.equal(gp2.cpu(), gp.cpu())
@@ -403,3 +404,30 @@ def test_weighted_ksum_matches_torch(dev, B, N1, N2, K, C):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(gw.cpu().numpy(), w.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(gp.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_group_points_grad_long_rows_real_indices(dev):
+    """BASELINE config 5's row length (N = 4096, K = 64: 262 144 entries per row) with real ball-query indices -- first-hit
+    padding gives long runs of equal targets.  The deterministic tiled kernel (opt-in, CMF_GROUP_GRAD_DETERMINISTIC=1: read
+    once per process, so a child process) against the oracle, twice (bit-reproducible); the default kernel against the
+    oracle."""
+    import subprocess, sys, os
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    from cmflow_amd import synth
+    if os.environ.get("CMF_GROUP_GRAD_DETERMINISTIC") != "1":
+        env = dict(os.environ, CMF_GROUP_GRAD_DETERMINISTIC="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__ + "::test_group_points_grad_long_rows_real_indices",
+                            "-m", "gpu"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    xyz = synth.make_batch(2, N=4096, seed=9, lidar=True)["pc1"].permute(0, 2, 1).contiguous()
+    idx = orc.ball_query(2.0, 64, xyz, xyz)
+    go = torch.randn(2, 7, 4096, 64, generator=torch.Generator().manual_seed(4))
+    ref = orc.group_points_grad(go, idx, 4096)
+    outs = []
+    for _ in range(2):
+        gp = torch.zeros(2, 7, 4096, device=dev)
+        ext.group_points_grad_wrapper(2, 7, 4096, 4096, 64, go.to(dev), idx.to(dev), gp)
+        outs.append(gp.cpu())
+    if os.environ.get("CMF_GROUP_GRAD_DETERMINISTIC") == "1":
+        assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
