@@ -82,3 +82,19 @@ def test_product_fails_loudly_without_gpu():
                lambda: weighted_kabsch(torch.zeros(1, 3, 8), torch.zeros(1, 3, 8), torch.ones(1, 8) / 8)):
         with pytest.raises(RuntimeError):
             fn()
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """The descriptor structs are filled in from Python: their ctypes mirrors must have the C layout (size and the offset
+    of the last member) -- a field appended on one side only would shift every pointer behind it."""
+    from cmflow_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cmflow_hip.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(cmf_setconv_desc), offsetof(cmf_setconv_desc, acc_bn),'
+                   ' sizeof(cmf_bn_update_entry), offsetof(cmf_bn_update_entry, offset), sizeof(cmf_gemm_launch_record)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_lib.SetConvDesc), _lib.SetConvDesc.acc_bn.offset, ctypes.sizeof(_lib.BnUpdateEntry),
+            _lib.BnUpdateEntry.offset.offset, ctypes.sizeof(_lib.GemmLaunchRecord)]
+    assert got == want
