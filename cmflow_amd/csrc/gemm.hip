@@ -905,6 +905,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(long long total
     }
 }
 
+// C[M][N] (+)= the sum of `split_k` slabs [M][N] in slab order (internal; also used by thin_gemm.hip)
+int cmf_splitk_reduce(int M, int N, int split_k, const float *workspace, float *C, long long ldc, int accumulate, hipStream_t st)
+{
+    const long long total = (long long)M * N;
+    if (N % 4 == 0 && ldc % 4 == 0 && total <= 16384 && split_k >= 4 * SKW_LANES && (((uintptr_t)C | (uintptr_t)workspace) & 15) == 0) {
+        hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((total / 4 + SKW_OUT - 1) / SKW_OUT)), dim3(256), 0, st,
+                           total, split_k, N, ldc, accumulate, workspace, C);
+        return cmf_launch_status();
+    }
+    const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, total, split_k, N, ldc, accumulate, workspace, C);
+    return cmf_launch_status();
+}
+
 // ---- live timing of the tiled kernel (bench.py's `roofline` object) ------------------------------------------------
 // Between cmf_gemm_profile_begin and _end every launch of gemm_kernel whose 2*M*N*K reaches `min_flops` is bracketed by
 // a HIP event pair recorded on the stream the kernel is launched on -- inside the library, so the launches issued from
@@ -962,6 +976,7 @@ void gprof_close(long long i, hipStream_t st)
     (void)hipEventRecord(g_gprof.events[2 * (size_t)i + 1], st);
 }
 }  // namespace
+void cmf_gemm_count_flops(double flops) { gprof_count(flops); }     // thin_gemm.hip's fused layer (counted, never bracketed)
 
 // ---- diagnostics: per-workgroup timeline of the NEXT tiled launch (tools/gemm_timeline.py) -------------------------
 namespace {
@@ -1136,17 +1151,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     else                   err = CMF_PICK(true, true, 0);
 #undef CMF_PICK
     if (err) return err;
-    if (split_k > 1) {
-        const long long total = (long long)M * N;
-        if (N % 4 == 0 && ldc % 4 == 0 && total <= 16384 && split_k >= 4 * SKW_LANES && (((uintptr_t)C | (uintptr_t)workspace) & 15) == 0) {
-            hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((total / 4 + SKW_OUT - 1) / SKW_OUT)), dim3(256), 0, st,
-                               total, split_k, N, ldc, accumulate, workspace, C);
-            return cmf_launch_status();
-        }
-        const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, total, split_k, N, ldc, accumulate, workspace, C);
-        return cmf_launch_status();
-    }
+    if (split_k > 1) return cmf_splitk_reduce(M, N, split_k, workspace, C, ldc, accumulate, st);
     return 0;
 }
 

@@ -36,3 +36,6 @@ struct GemmArgs {
 
 // thin_gemm.hip: returns -1 when the shape is not handled there
 int cmf_thin_gemm(const GemmArgs &g, int a_t, int b_t, hipStream_t st);
+// gemm.hip: C[M][N] (+)= sum of split_k slabs [M][N], fixed order
+int cmf_splitk_reduce(int M, int N, int split_k, const float *workspace, float *C, long long ldc, int accumulate, hipStream_t st);
+void cmf_gemm_count_flops(double flops);

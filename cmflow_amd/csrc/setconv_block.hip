@@ -8,6 +8,7 @@
 // those of cmflow_amd/fused_blocks.py (SetConvFn), which remains the readable specification.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -195,15 +196,26 @@ int dx_gemm(const cmf_setconv_desc *d, const Layout &L, long long rows, int cout
                     1, x, cin, b + 2 * C, b + 3 * C, b, b + C, dxyz, 1, nullptr, 0, st);
 }
 
-// BN backward of layer l on dU (in place -> dZ); dgamma/dbeta into the descriptor's targets
-int bn_bwd(const cmf_setconv_desc *d, const Layout &L, int l, long long rows, float *dU, const float *z, void *st)
+// One backward layer: the BN-backward sums of layer l_out (dgamma / dbeta), then dZ -> dW (+ dU of the layer below).
+// Narrow layers run the fused single-pass kernel (cmf_thin_bwd_layer: dZ is never stored); the wide ones of the second
+// encoder the BN backward in place followed by the two tiled GEMMs.  CMF_THIN_FUSED=0 forces the three-kernel form.
+int bwd_layer(const cmf_setconv_desc *d, const Layout &L, int l_out, long long rows, int cout, int cin, float *dU, const float *z_out,
+              const float *w, const float *x, int l_in, float *dU_in, const float *dxyz, float *dw, int acc_w, void *st)
 {
-    const int C = chan(d, l);
-    const float *b = L.bn[l];
-    // the two sums land in the caller's dbeta / dgamma from the same launch: added (gradient sinks) or stored
-    if (d->acc_bn[l]) CMF_TRY(cmf_colsum_finalize(tiles128(rows), C, L.partial, L.sums, d->dbeta[l], d->dgamma[l], st));
-    else CMF_TRY(cmf_colsum_store(tiles128(rows), 2 * C, L.partial, L.sums, C, d->dbeta[l], d->dgamma[l], st));
-    return cmf_bn_bwd_apply(rows, C, dU, z, C, b + 2 * C, b, b + C, d->training ? L.sums : nullptr, st);
+    const float *b = L.bn[l_out];
+    if (d->acc_bn[l_out]) CMF_TRY(cmf_colsum_finalize(tiles128(rows), cout, L.partial, L.sums, d->dbeta[l_out], d->dgamma[l_out], st));
+    else CMF_TRY(cmf_colsum_store(tiles128(rows), 2 * cout, L.partial, L.sums, cout, d->dbeta[l_out], d->dgamma[l_out], st));
+    static const bool fused = !(getenv("CMF_THIN_FUSED") && getenv("CMF_THIN_FUSED")[0] == '0');
+    if (fused && cmf_thin_bwd_supported(cout, cin)) {
+        const float *bi = l_in >= 0 ? L.bn[l_in] : nullptr;
+        const int ci = l_in >= 0 ? chan(d, l_in) : 0;
+        return cmf_thin_bwd_layer(rows, cout, cin, dU, cout, z_out, cout, b + 2 * cout, b, b + cout, d->training ? L.sums : nullptr,
+                                  w, cin, x, cin, l_in >= 0 ? 1 : 0, bi ? bi + 2 * ci : nullptr, bi ? bi + 3 * ci : nullptr, bi,
+                                  bi ? bi + ci : nullptr, dxyz, dU_in, cin, l_in >= 0 ? L.partial : nullptr, dw, cin, acc_w, L.splitk, st);
+    }
+    CMF_TRY(cmf_bn_bwd_apply(rows, cout, dU, z_out, cout, b + 2 * cout, b, b + cout, d->training ? L.sums : nullptr, st));
+    CMF_TRY(dw_gemm(d, L, rows, cout, cin, dU, x, l_in, dw, acc_w, st));
+    return dx_gemm(d, L, rows, cout, cin, dU, w, x, l_in, dU_in, dxyz, st);
 }
 
 }  // namespace
@@ -261,23 +273,13 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     if (d->dy) CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
     // layer 6 .. 4 (per point)
     CMF_TRY(cmf_act_bwd_stats(P, C6, d->dout, d->lddout, L.z6, C6, b5 + 2 * C6, b5 + 3 * C6, b5, b5 + C6, L.t6, L.partial, st));
-    CMF_TRY(bn_bwd(d, L, 5, P, L.t6, L.z6, st));
-    CMF_TRY(dw_gemm(d, L, P, C6, C5, L.t6, L.z5, 4, d->dw[4], d->acc_w[4], st));
-    CMF_TRY(dx_gemm(d, L, P, C6, C5, L.t6, d->w[4], L.z5, 4, L.t5, nullptr, st));
-    CMF_TRY(bn_bwd(d, L, 4, P, L.t5, L.z5, st));
-    CMF_TRY(dw_gemm(d, L, P, C5, C4, L.t5, L.z4, 3, d->dw[3], d->acc_w[3], st));
-    CMF_TRY(dx_gemm(d, L, P, C5, C4, L.t5, d->w[3], L.z4, 3, L.t4, nullptr, st));
-    CMF_TRY(bn_bwd(d, L, 3, P, L.t4, L.z4, st));
-    CMF_TRY(dw_gemm(d, L, P, C4, C3, L.t4, L.x, -1, d->dw[2], d->acc_w[2], st));
-    CMF_TRY(dx_gemm(d, L, P, C4, C3, L.t4, d->w[2], L.x, -1, L.dx, nullptr, st));
+    CMF_TRY(bwd_layer(d, L, 5, P, C6, C5, L.t6, L.z6, d->w[4], L.z5, 4, L.t5, nullptr, d->dw[4], d->acc_w[4], st));
+    CMF_TRY(bwd_layer(d, L, 4, P, C5, C4, L.t5, L.z5, d->w[3], L.z4, 3, L.t4, nullptr, d->dw[3], d->acc_w[3], st));
+    CMF_TRY(bwd_layer(d, L, 3, P, C4, C3, L.t4, L.z4, d->w[2], L.x, -1, L.dx, nullptr, d->dw[2], d->acc_w[2], st));
     // max over the ball, layers 3 .. 1 (per neighbour slot)
     CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
-    CMF_TRY(bn_bwd(d, L, 2, M, L.dU3, L.z3, st));
-    CMF_TRY(dw_gemm(d, L, M, C3, C2, L.dU3, L.z2, 1, d->dw[1], d->acc_w[1], st));
-    CMF_TRY(dx_gemm(d, L, M, C3, C2, L.dU3, d->w[1], L.z2, 1, L.dU2, nullptr, st));
-    CMF_TRY(bn_bwd(d, L, 1, M, L.dU2, L.z2, st));
-    CMF_TRY(dw_gemm(d, L, M, C2, O1, L.dU2, L.z1, 0, d->dw[0], d->acc_w[0], st));
-    CMF_TRY(dx_gemm(d, L, M, C2, O1, L.dU2, d->w[0], L.z1, 0, L.dU1, L.dxyz, st));
+    CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));
+    CMF_TRY(bwd_layer(d, L, 1, M, C2, O1, L.dU2, L.z2, d->w[0], L.z1, 0, L.dU1, L.dxyz, d->dw[0], d->acc_w[0], st));
     // first layer: sums {s1,s2,q0,q1,q2}; dgamma/dbeta; dW_xyz from sums; BN backward folded into the scatter
     const float *b0 = L.bn[0];
     if (d->acc_bn[0]) CMF_TRY(cmf_colsum(tiles128(M), 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));

@@ -312,3 +312,359 @@ int cmf_thin_gemm(const GemmArgs &g, int a_t, int b_t, hipStream_t st)
     }
     return -1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// One backward layer of a narrow [linear + BN + ReLU] stack in ONE pass over the rows (cmf_thin_bwd_layer).
+//
+// As separate kernels the layer is: BN backward in place (read dU, read z, write dZ), the weight gradient (read dZ, read
+// the layer input) and the data gradient (read dZ, read the input again for its ReLU mask, write dU_in): 8 row streams
+// for the 4 that are needed.  With <= 64 channels all of it is HBM time, so here a workgroup walks its rows once:
+//   dZ      = a (dU - s1/M - zhat s2/M)                 formed in registers from dU and z, never stored
+//   dU_in   = mask_in(dZ @ W)  (+ the BN-backward partial sums of the layer below, + the dxyz sums)      [thin_dx's part]
+//   slab    = sum over the workgroup's rows of dZ^T act_in(x)                                            [thin_dw's part]
+// dZ is needed with lanes <-> rows for the first product and lanes <-> channels for the second; the second read of dU / z
+// comes from the cache (the same wave touched those lines a few hundred cycles earlier).  The input x is read once, in
+// the accumulator layout (lane = channel, registers = rows): it is the mask of the first product's epilogue and, after
+// the activation, the B operand of the second, whose contraction index (the row pair of one MFMA step) may be
+// assigned freely: register r pairs rows rho(r) and rho(r) + 4, exactly the rows the accumulator layout keeps in r.
+// ---------------------------------------------------------------------------------------------------------------
+struct ThinBwdArgs {
+    long long rows; int cout, cin;
+    const float *dU; long long lddu;               // [rows][cout] gradient w.r.t. the layer's BN output, masked by its ReLU
+    const float *z; long long ldz;                 // [rows][cout] the layer's pre-BN output
+    const float *a, *mean, *invstd, *sums;         // BN of the layer; sums = (s1, s2)[2][cout] or null (eval: dZ = a dU)
+    float inv_count;
+    const float *w; long long ldw;                 // [cout][cin]
+    const float *x; long long ldx;                 // [rows][cin] layer input: pre-BN output of the layer below (in_mode 1) or activated (0)
+    int in_mode;
+    const float *a_in, *c_in, *mean_in, *invstd_in;
+    const float *dxyz;                             // in_mode 1, optional
+    float *dx; long long lddx;                     // [rows][cin] or null (no data gradient, no statistics)
+    float *stats;                                  // in_mode 1: [tiles128][2 or 5][cin]
+    float *slabs;                                  // [gridDim.x][cout][cin] or null (no weight gradient)
+    int tiles_per_wg;
+};
+
+// LDS of the fused layer
+template <int NTO, int NTI>
+struct ThinBwdLds {
+    static constexpr int LDO = NTO * 32 + 4;
+    static constexpr int RED = 2 * NTO * NTI * 16 * CMF_WAVE, DZT = 4 * 32 * LDO;
+    float tile[RED > DZT ? RED : DZT];     // per-wave dZ tile [32 rows][cout]; after the row loop the cross-wave sums of the slab
+    float wt[NTI * 32 * LDO];              // the weight transposed ([cin][cout]): B operand of the data gradient as one 16-byte read
+    float4 dq[4][32];                      // per wave: dxyz of its rows
+    float sred[2][4][5][NTI * 32];         // two buffers of per-wave column sums
+    float ko[4][NTO * 32], ki[4][NTI * 32];// layer: a, mean, invstd * s2 / M, s1 / M; input layer: a, c, mean, invstd
+};
+
+__device__ __forceinline__ float tb_ld(const float *base, unsigned byte_off) { return *(const float *)((const char *)base + byte_off); }
+__device__ __forceinline__ float4 tb_ld4(const float *base, unsigned byte_off) { return *(const float4 *)((const char *)base + byte_off); }
+
+// One 128-row tile (32 rows per wave).  FULL: every row and channel of the tile exists -- no predicates around the loads.
+// Tile bases are wave-uniform (scalar registers); everything per lane is a 32-bit BYTE offset from them.
+// MODE >= 0 fixes the run-time switches at compile time (both products wanted; bit 0: train-mode BN, bit 1: in_mode,
+// bit 2: dxyz sums): the chain of a set-conv block only uses those; MODE < 0 reads them from the arguments.
+template <int NTO, int NTI, bool FULL, int MODE>
+__device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<NTO, NTI> &S, f32x16 (&accw)[NTO][NTI], long long tile,
+                                              unsigned live, int parity, int lane, int wave)
+{
+    constexpr int LDO = ThinBwdLds<NTO, NTI>::LDO;
+    const int h = lane >> 5, cl = lane & 31;
+    const bool train = MODE >= 0 ? (MODE & 1) != 0 : p.sums != nullptr;
+    const int in_mode = MODE >= 0 ? (MODE >> 1) & 1 : p.in_mode;
+    const bool want_q = MODE >= 0 ? (MODE & 4) != 0 : (p.in_mode == 1 && p.dxyz != nullptr);
+    const bool has_dx = MODE >= 0 || p.dx != nullptr, has_dw = MODE >= 0 || p.slabs != nullptr;
+    const int nstat = want_q ? 5 : 2;
+    const int ks = FULL ? NTO * 4 : p.cout >> 3;
+    const unsigned cin = (unsigned)p.cin;
+    const float *dUt = p.dU + tile * 128 * p.lddu, *zt = train ? p.z + tile * 128 * p.ldz : nullptr;
+    const float *xt = p.x + tile * 128 * p.ldx;
+    float *dxt = has_dx ? p.dx + tile * 128 * p.lddx : nullptr;
+    float *dzt = S.tile + wave * 32 * LDO;
+    const unsigned w0 = (unsigned)wave * 32u;
+    const unsigned ldxb = (unsigned)p.ldx * 4u, lddxb = (unsigned)p.lddx * 4u;
+    // ---- layer input in the accumulator layout (lane = channel, register r = rows rho(r) + 4h): mask of the data
+    //      gradient, B operand of the weight gradient.  Issued first: it is consumed last. ----
+    float xc[NTI][16];
+    const unsigned xo = (w0 + 4u * h) * ldxb + (unsigned)cl * 4u;
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned rho = (unsigned)((r & 3) + 8 * (r >> 2));
+            if (FULL) xc[j][r] = tb_ld(xt, xo + rho * ldxb + j * 128u);
+            else {
+                const unsigned m = w0 + rho + 4u * h, n = (unsigned)(j * 32 + cl);
+                xc[j][r] = (m < live && n < cin) ? tb_ld(xt, xo + rho * ldxb + j * 128u) : 0.f;
+            }
+        }
+    if (want_q && lane < 32) {
+        const unsigned m = w0 + (unsigned)lane;
+        S.dq[wave][lane] = (FULL || m < live) ? *(const float4 *)(p.dxyz + (tile * 128 + m) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // ---- dZ of the wave's 32 rows, rows on the lanes: A operand of the data gradient; parked in LDS for the second product ----
+    const unsigned mrow = w0 + (unsigned)(lane & 31);
+    const bool ok = FULL || mrow < live;
+    const unsigned ou = ((ok ? mrow : 0u) * (unsigned)p.lddu + 4u * h) * 4u, oz = ((ok ? mrow : 0u) * (unsigned)p.ldz + 4u * h) * 4u;
+    f32x16 acc[NTI];
+#pragma unroll
+    for (int j = 0; j < NTI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    constexpr int CH = NTO * 4;                  // every k step of the tile is loaded up front: one exposed load latency per tile
+    for (int kb = 0; kb < ks; kb += CH) {
+        float4 dv[CH], zv[CH];
+#pragma unroll
+        for (int ku = 0; ku < CH; ++ku) {
+            const int k8 = kb + ku;
+            dv[ku] = zv[ku] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k8 < ks) {
+                dv[ku] = tb_ld4(dUt, ou + 32u * k8);
+                if (train) zv[ku] = tb_ld4(zt, oz + 32u * k8);
+            }
+        }
+#pragma unroll
+        for (int ku = 0; ku < CH; ++ku) {
+            const int k8 = kb + ku;
+            if (k8 >= ks) break;
+            const int k = 8 * k8 + 4 * h;
+            float4 d = dv[ku];
+            const float4 sa = *(const float4 *)&S.ko[0][k];
+            if (train) {
+                const float4 v = zv[ku];
+                const float4 mu = *(const float4 *)&S.ko[1][k], u = *(const float4 *)&S.ko[2][k], t1 = *(const float4 *)&S.ko[3][k];
+                d.x = sa.x * (d.x - t1.x - (v.x - mu.x) * u.x);
+                d.y = sa.y * (d.y - t1.y - (v.y - mu.y) * u.y);
+                d.z = sa.z * (d.z - t1.z - (v.z - mu.z) * u.z);
+                d.w = sa.w * (d.w - t1.w - (v.w - mu.w) * u.w);
+            } else { d.x *= sa.x; d.y *= sa.y; d.z *= sa.z; d.w *= sa.w; }
+            if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (has_dw) *(float4 *)(dzt + (lane & 31) * LDO + k) = d;
+            if (has_dx) {
+#pragma unroll
+                for (int j = 0; j < NTI; ++j) {
+                    const float4 b = *(const float4 *)&S.wt[(j * 32 + cl) * LDO + k];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, b.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.y, b.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.z, b.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.w, b.w, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (has_dx) {
+        // epilogue of the data gradient: ReLU mask of the layer below, its BN-backward partial sums, store
+        float (*sr)[5][NTI * 32] = S.sred[parity];
+        const unsigned so = (w0 + 4u * h) * lddxb + (unsigned)cl * 4u;
+#pragma unroll
+        for (int j = 0; j < NTI; ++j) {
+            const unsigned n = (unsigned)(j * 32 + cl);
+            const bool nok = FULL || n < cin;
+            const float ia = S.ki[0][j * 32 + cl], ic = S.ki[1][j * 32 + cl], im = S.ki[2][j * 32 + cl], ii = S.ki[3][j * 32 + cl];
+            float s1 = 0.f, s2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned rho = (unsigned)((r & 3) + 8 * (r >> 2)), mr = rho + 4u * h;
+                if (FULL || (w0 + mr < live && nok)) {
+                    float v = acc[j][r];
+                    if (in_mode == 1) {
+                        const float zz = xc[j][r];
+                        v = (fmaf(ia, zz, ic) > 0.f) ? v : 0.f;
+                        s1 += v; s2 += v * ((zz - im) * ii);
+                        if (want_q) { const float4 dd = S.dq[wave][mr]; q0 += v * dd.x; q1 += v * dd.y; q2 += v * dd.z; }
+                    }
+                    *(float *)((char *)dxt + (so + rho * lddxb + j * 128u)) = v;
+                }
+            }
+            if (in_mode == 1) {
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (want_q) { q0 += __shfl_xor(q0, 32, 64); q1 += __shfl_xor(q1, 32, 64); q2 += __shfl_xor(q2, 32, 64); }
+                if (lane < 32) {
+                    sr[wave][0][j * 32 + cl] = s1; sr[wave][1][j * 32 + cl] = s2;
+                    if (want_q) { sr[wave][2][j * 32 + cl] = q0; sr[wave][3][j * 32 + cl] = q1; sr[wave][4][j * 32 + cl] = q2; }
+                }
+            }
+        }
+        if (in_mode == 1) {
+            __syncthreads();                // one barrier per tile: the buffer written now is read below, the other one two tiles apart
+            for (int i = threadIdx.x; i < nstat * p.cin; i += TG_THREADS) {
+                const int which = i / p.cin, n = i - which * p.cin;
+                p.stats[(tile * nstat + which) * p.cin + n] = sr[0][which][n] + sr[1][which][n] + sr[2][which][n] + sr[3][which][n];
+            }
+        }
+    }
+    if (has_dw) {
+        // ---- weight gradient: channels on the lanes, MFMA step r contracts the row pair (rho(r), rho(r) + 4) ----
+        if (in_mode == 1) {
+#pragma unroll
+            for (int j = 0; j < NTI; ++j) {
+                const float ia = S.ki[0][j * 32 + cl], ic = S.ki[1][j * 32 + cl];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xc[j][r] = fmaxf(fmaf(ia, xc[j][r], ic), 0.f);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *src = dzt + ((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + cl;
+#pragma unroll
+            for (int i = 0; i < NTO; ++i) {
+                const float dz = src[i * 32];
+#pragma unroll
+                for (int j = 0; j < NTI; ++j)
+                    accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, xc[j][r], accw[i][j], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// FULL (decided by the host): rows % 128 == 0, cout == NTO * 32, cin == NTI * 32 -- the kernel then contains no ragged-edge code
+template <int NTO, int NTI, int MODE, bool FULL>
+__global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_layer_kernel(const ThinBwdArgs p)
+{
+    constexpr int LDO = ThinBwdLds<NTO, NTI>::LDO;
+    __shared__ ThinBwdLds<NTO, NTI> S;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, cl = lane & 31;
+    const bool train = p.sums != nullptr;
+    if (threadIdx.x < NTO * 32) {
+        const int n = threadIdx.x;
+        const bool ok = n < p.cout;
+        S.ko[0][n] = ok ? p.a[n] : 0.f;
+        S.ko[1][n] = (ok && train) ? p.mean[n] : 0.f;
+        S.ko[2][n] = (ok && train) ? p.invstd[n] * (p.sums[p.cout + n] * p.inv_count) : 0.f;
+        S.ko[3][n] = (ok && train) ? p.sums[n] * p.inv_count : 0.f;
+    } else if (threadIdx.x >= 64 && threadIdx.x < 64 + NTI * 32) {
+        const int n = threadIdx.x - 64;
+        const bool ok = n < p.cin && p.in_mode == 1;
+        S.ki[0][n] = ok ? p.a_in[n] : 0.f; S.ki[1][n] = ok ? p.c_in[n] : 0.f;
+        S.ki[2][n] = ok ? p.mean_in[n] : 0.f; S.ki[3][n] = ok ? p.invstd_in[n] : 0.f;
+    }
+    if (p.dx)
+        for (int i = threadIdx.x; i < NTO * 32 * NTI * 32; i += TG_THREADS) {
+            const int k = i / (NTI * 32), n = i - k * (NTI * 32);
+            S.wt[n * LDO + k] = (k < p.cout && n < p.cin) ? p.w[(long long)k * p.ldw + n] : 0.f;
+        }
+    __syncthreads();
+    f32x16 accw[NTO][NTI];
+#pragma unroll
+    for (int i = 0; i < NTO; ++i)
+#pragma unroll
+        for (int j = 0; j < NTI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accw[i][j][r] = 0.f;
+    for (int t = 0; t < p.tiles_per_wg; ++t) {
+        const long long tile = (long long)blockIdx.x * p.tiles_per_wg + t;
+        if (tile * 128 >= p.rows) break;                                         // uniform over the workgroup
+        const long long left = p.rows - tile * 128;
+        thin_bwd_tile<NTO, NTI, FULL, MODE>(p, S, accw, tile, (FULL || left >= 128) ? 128u : (unsigned)left, t & 1, lane, wave);
+    }
+    if (!p.slabs) return;
+    __syncthreads();                                                             // the dZ tiles are dead: LDS becomes the reduction buffer
+    float (*red)[NTO * NTI * 16 * CMF_WAVE] = (float (*)[NTO * NTI * 16 * CMF_WAVE])S.tile;
+    // fixed-order reduction of the four waves: (w2, w3) -> LDS, added by (w0, w1); w1 -> LDS, added by w0
+    auto put = [&](float *dst) {
+#pragma unroll
+        for (int i = 0; i < NTO; ++i)
+#pragma unroll
+            for (int j = 0; j < NTI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[((i * NTI + j) * 16 + r) * CMF_WAVE + lane] = accw[i][j][r];
+    };
+    auto add = [&](const float *src) {
+#pragma unroll
+        for (int i = 0; i < NTO; ++i)
+#pragma unroll
+            for (int j = 0; j < NTI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[i][j][r] += src[((i * NTI + j) * 16 + r) * CMF_WAVE + lane];
+    };
+    if (wave >= 2) put(red[wave - 2]);
+    __syncthreads();
+    if (wave < 2) add(red[wave]);
+    __syncthreads();
+    if (wave == 1) put(red[0]);
+    __syncthreads();
+    if (wave != 0) return;
+    add(red[0]);
+    float *slab = p.slabs + (long long)blockIdx.x * p.cout * p.cin;
+#pragma unroll
+    for (int i = 0; i < NTO; ++i)
+#pragma unroll
+        for (int j = 0; j < NTI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = j * 32 + cl;
+                if (n < p.cout && k < p.cin) slab[(long long)n * p.cin + k] = accw[i][j][r];
+            }
+}
+
+// slabs of the fused layer for `rows` rows: workgroups take whole 128-row tiles, at most 1024 of them (the rule of
+// dw_split's thin branch, rounded to tiles -- never more slabs than dw_split sizes the workspace for)
+extern "C" int cmf_thin_bwd_slabs(long long rows, int *tiles_per_wg)
+{
+    const long long tiles = (rows + 127) / 128;
+    // two workgroups are resident per CU (register budget of 2 waves per SIMD): at most one round of 512 workgroups, each
+    // walking its share of the tiles -- 1024 slabs of 4 tiles ran 1.33 rounds, a third of the chip idle in the second
+    long long split = rows / 128 < 512 ? rows / 128 : 512;                       // <= dw_split's thin rule max(2, min(rows / 128, 1024))
+    if (split < 2) split = 2;
+    const long long tpw = (tiles + split - 1) / split;
+    if (tiles_per_wg) *tiles_per_wg = (int)tpw;
+    return (int)((tiles + tpw - 1) / tpw);
+}
+
+extern "C" int cmf_thin_bwd_supported(int cout, int cin)
+{
+    return cout >= 8 && cout <= 64 && cout % 8 == 0 && cin >= 1 && cin <= 64;
+}
+
+extern "C" int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float *dU, long long lddu, const float *z, long long ldz,
+                                  const float *a, const float *mean, const float *invstd, const float *sums,
+                                  const float *w, long long ldw, const float *x, long long ldx, int in_mode,
+                                  const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in, const float *dxyz,
+                                  float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
+                                  void *stream)
+{
+    CMF_CHECK_ARG(rows >= 0 && cmf_thin_bwd_supported(cout, cin) && (in_mode == 0 || in_mode == 1));
+    if (rows == 0) return 0;
+    CMF_CHECK_ARG(dU && a && w && x && (!sums || (z && mean && invstd)) && (dx || dw));
+    CMF_CHECK_ARG(lddu % 4 == 0 && (uintptr_t)dU % 16 == 0 && (!sums || (ldz % 4 == 0 && (uintptr_t)z % 16 == 0)));
+    CMF_CHECK_ARG(((uintptr_t)a | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)sums) % 16 == 0);
+    CMF_CHECK_ARG(in_mode == 0 || !dx || (a_in && c_in && mean_in && invstd_in && stats));
+    CMF_CHECK_ARG(in_mode == 0 || a_in && c_in);
+    CMF_CHECK_ARG(!dw || slabs);
+    ThinBwdArgs p;
+    p.rows = rows; p.cout = cout; p.cin = cin; p.dU = dU; p.lddu = lddu; p.z = z; p.ldz = ldz;
+    p.a = a; p.mean = mean; p.invstd = invstd; p.sums = sums; p.inv_count = (float)(1.0 / (double)rows);
+    p.w = w; p.ldw = ldw; p.x = x; p.ldx = ldx; p.in_mode = in_mode;
+    p.a_in = a_in; p.c_in = c_in; p.mean_in = mean_in; p.invstd_in = invstd_in; p.dxyz = in_mode == 1 ? dxyz : nullptr;
+    p.dx = dx; p.lddx = lddx; p.stats = stats; p.slabs = dw ? slabs : nullptr;
+    const int nslab = cmf_thin_bwd_slabs(rows, &p.tiles_per_wg);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(nslab), block(TG_THREADS);
+    // the set-conv chains always want both products of whole tiles: their switch combinations are compiled in (MODE,
+    // FULL); anything else runs the generic instantiation
+    int mode = -1;
+    const bool full = rows % 128 == 0 && cout % 32 == 0 && cin % 32 == 0;
+    if (dx && dw && full) mode = (sums ? 1 : 0) | (in_mode ? 2 : 0) | ((in_mode && dxyz) ? 4 : 0);
+#define CMF_TB_MODE(NO, NI)                                                                              \
+    switch (mode) {                                                                                     \
+        case 0: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 0, true>), grid, block, 0, st, p); break;   \
+        case 1: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 1, true>), grid, block, 0, st, p); break;   \
+        case 2: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 2, true>), grid, block, 0, st, p); break;   \
+        case 3: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 3, true>), grid, block, 0, st, p); break;   \
+        case 6: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 6, true>), grid, block, 0, st, p); break;   \
+        case 7: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 7, true>), grid, block, 0, st, p); break;   \
+        default: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, -1, false>), grid, block, 0, st, p); break; \
+    }
+    if (cout > 32) {
+        if (cin > 32) { CMF_TB_MODE(2, 2) } else { CMF_TB_MODE(2, 1) }
+    } else {
+        if (cin > 32) { CMF_TB_MODE(1, 2) } else { CMF_TB_MODE(1, 1) }
+    }
+#undef CMF_TB_MODE
+    int err = cmf_launch_status();
+    if (err) return err;
+    cmf_gemm_count_flops((dx ? 2.0 : 0.0) * rows * cout * cin + (dw ? 2.0 : 0.0) * rows * cout * cin);
+    if (dw) return cmf_splitk_reduce(cout, cin, nslab, slabs, dw, lddw, accumulate, st);
+    return 0;
+}

@@ -196,6 +196,26 @@ int cmf_act_bwd_stats(long long M, int C, const float *dY, long long ldy, const 
 int cmf_bn_bwd_apply(long long M, int C, float *dU, const float *z, long long ldz, const float *a,
                      const float *mean, const float *invstd, const float *sums, void *stream);
 
+/* One backward layer of a NARROW [1x1 conv + BatchNorm + ReLU] stack (cout, cin <= 64, cout % 8 == 0; the reference's
+ * mlp_convs / mlp2_convs of PointLocalFeature, radarflow_util.py:144-162, at its 32 / 64 channel widths) in one pass over
+ * the rows -- what bn_bwd_apply + the weight-gradient cmf_gemm + the data-gradient cmf_gemm compute as three kernels
+ * streaming eight [rows, C] matrices is done here streaming four:
+ *   dZ    = a (dU - s1/rows - (z - mean) invstd s2/rows)          (sums = {s1[cout], s2[cout]}; NULL: dZ = a dU, eval BN)
+ *   dx    = mask_in(dZ @ w),  mask_in = [a_in x + c_in > 0]       in_mode 1: x is the pre-BN output of the layer below;
+ *           stats[tile][2 or 5][cin] get the per-128-row-tile sums of dx, dx (x - mean_in) invstd_in (and dx * dxyz_k when
+ *           dxyz is given), as cmf_gemm's backward epilogue does.  in_mode 0: x is an activated input, dx = dZ @ w.
+ *   dw (+)= dZ^T @ act_in(x),  act_in = relu(a_in x + c_in) (in_mode 1) or identity; summed over cmf_thin_bwd_slabs(rows)
+ *           slabs [cout][cin] in `slabs` in fixed order (deterministic).
+ * dx == NULL skips the data gradient (and stats), dw == NULL the weight gradient.  dU and z rows must be 16-byte aligned. */
+int cmf_thin_bwd_supported(int cout, int cin);
+int cmf_thin_bwd_slabs(long long rows, int *tiles_per_workgroup);
+int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float *dU, long long lddu, const float *z, long long ldz,
+                       const float *a, const float *mean, const float *invstd, const float *sums,
+                       const float *w, long long ldw, const float *x, long long ldx, int in_mode,
+                       const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in, const float *dxyz,
+                       float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
+                       void *stream);
+
 /* Backward of the set-conv's grouping with the BatchNorm backward of the first layer fused in
  * (radarflow_util.py:148-151 backward): dZ = a*(dU - s1/M - zhat*s2/M) is formed on the fly from dU and z,
  * summed over the inverse index into grad_feat (b,n,c) with row stride ldg, and never written.  sums = {s1[C], s2[C]} or NULL

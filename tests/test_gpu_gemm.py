@@ -246,3 +246,77 @@ print("WORST", worst)
     print("max |err| / (|A||B|): fp32 MFMA %.3g, bf16x3 %.3g" % (out["f32"], out["bf16x3"]))
     assert out["f32"] < 2e-6 and out["bf16x3"] < 2e-6
     assert out["bf16x3"] < 4 * out["f32"] + 1e-7
+
+
+@pytest.mark.parametrize("rows,cout,cin", [(65536, 64, 32), (4096, 32, 32), (16384, 64, 64), (1000, 64, 64), (333, 24, 20), (128 * 1030 + 5, 32, 64)])
+@pytest.mark.parametrize("train,in_mode,dxyz", [(True, 1, False), (True, 1, True), (True, 0, False), (False, 1, False)])
+def test_thin_bwd_layer_matches_fp64_and_three_kernel_form(dev, gemm_mode, rows, cout, cin, train, in_mode, dxyz):
+    """cmf_thin_bwd_layer (BN backward + weight gradient + masked data gradient in one pass) against (a) the fp64
+    formulas of its header comment, tolerance 2e-6 * sum|terms|, and (b) the three kernels it replaces
+    (cmf_bn_bwd_apply, cmf_gemm a_t, cmf_gemm with the backward epilogue): the masks must agree exactly."""
+    if gemm_mode != "fp32":
+        pytest.skip("thin kernels have one arithmetic")
+    import ctypes
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(rows + cout * 7 + cin)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dU, z, x = rnd(rows, cout), rnd(rows, cout), rnd(rows, cin)
+    w = rnd(cout, cin) * 0.2
+    a, mean, invstd = rnd(cout), rnd(cout) * 0.3, torch.rand(cout, generator=g).to(dev) + 0.5
+    sums = rnd(2, cout) * (rows ** 0.5) if train else None
+    a_in, c_in, mean_in, invstd_in = rnd(cin), rnd(cin) * 0.3, rnd(cin) * 0.3, torch.rand(cin, generator=g).to(dev) + 0.5
+    dxy = torch.cat((rnd(rows, 3), torch.zeros(rows, 1, device=dev)), 1).contiguous() if dxyz else None
+    tpw = ctypes.c_int()
+    nslab = L.cmf_thin_bwd_slabs(rows, ctypes.addressof(tpw))
+    assert nslab * tpw.value * 128 >= rows and nslab <= max(2, min(rows // 128, 1024))
+    tiles = (rows + 127) // 128
+    nstat = 5 if dxyz else 2
+    dx = torch.full((rows, cin), float("nan"), device=dev)
+    stats = torch.full((tiles, nstat, cin), float("nan"), device=dev)
+    dw0 = rnd(cout, cin)
+    dw = dw0.clone()
+    slabs = torch.empty(nslab, cout, cin, device=dev)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(L.cmf_thin_bwd_layer(rows, cout, cin, p(dU), cout, p(z), cout, p(a), p(mean), p(invstd), p(sums), p(w), cin, p(x), cin,
+                                    in_mode, p(a_in), p(c_in), p(mean_in), p(invstd_in), p(dxy), p(dx), cin,
+                                    p(stats) if in_mode else None, p(dw), cin, 1, p(slabs), _lib.stream_ptr()), "cmf_thin_bwd_layer")
+    # (a) fp64
+    D = lambda t: t.double()
+    if train:
+        dZ = D(a) * (D(dU) - D(sums[0]) / rows - (D(z) - D(mean)) * D(invstd) * (D(sums[1]) / rows))
+    else:
+        dZ = D(a) * D(dU)
+    act = torch.relu(D(a_in) * D(x) + D(c_in)) if in_mode else D(x)
+    ref_dw = D(dw0) + dZ.t() @ act
+    abs_dw = D(dw0).abs() + dZ.abs().t() @ act.abs()
+    _check(dw, ref_dw, abs_dw, tol=4e-6)
+    raw = dZ @ D(w)
+    absraw = dZ.abs() @ D(w).abs()
+    if in_mode:
+        mask = (D(a_in) * D(x) + D(c_in)) > 0
+        ref_dx = torch.where(mask, raw, torch.zeros_like(raw))
+    else:
+        ref_dx = raw
+    edge = (D(a_in) * D(x) + D(c_in)).abs() < 1e-5 if in_mode else torch.zeros_like(raw, dtype=torch.bool)   # mask undecidable in fp64
+    err = (D(dx) - ref_dx).abs()
+    bound = 4e-6 * absraw + 1e-6
+    assert bool(((err <= bound) | edge).all())
+    if in_mode:
+        got = D(dx)
+        zh = (D(x) - D(mean_in)) * D(invstd_in)
+        want = [got, got * zh] + ([got * D(dxy[:, k:k + 1]) for k in range(3)] if dxyz else [])
+        for which, t in enumerate(want):
+            pad = torch.zeros(tiles * 128 - rows, cin, dtype=torch.float64, device=dev)
+            per_tile = torch.cat((t, pad)).view(tiles, 128, cin)
+            _check(stats[:, which], per_tile.sum(1), per_tile.abs().sum(1), tol=4e-6)
+    # (b) the three kernels
+    dZ32 = dU.clone()
+    _lib.check(L.cmf_bn_bwd_apply(rows, cout, p(dZ32), p(z), cout, p(a), p(mean), p(invstd), p(sums), _lib.stream_ptr()), "apply")
+    if in_mode:
+        dx3, part3 = gemm(dZ32, w, b_t=False, bwd=(1, x, a_in, c_in, mean_in, invstd_in) + ((dxy,) if dxyz else ()))
+        assert float(((dx3 == 0) != (dx == 0)).float().mean()) < 1e-5
+    else:
+        dx3 = gemm(dZ32, w, b_t=False)
+    assert float((dx3 - dx).abs().max()) <= 1e-4 * max(1.0, float(dx3.abs().max()))
