@@ -78,6 +78,8 @@ SIGNATURES = {
     "cmf_weightnet_ksum": [_ll, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_weightnet_ksum_grad": [_ll, _ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_global_max_cat": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _vp],
+    "cmf_stack_first_conv": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
+    "cmf_unstack_first_conv_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
     "cmf_global_max_cat_grad": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _ll, _vp],
     "cmf_radar_loss_workspace": [_ci, _ci],
     "cmf_radar_loss": [_vp, _vp],

@@ -736,3 +736,68 @@ extern "C" int cmf_global_max_cat_grad(int B, int N, int C, const float *dout, l
                        df, ldf);
     return cmf_launch_status();
 }
+
+// ---- stacked first-conv weights -----------------------------------------------------------------------------
+// The feature half of the first convs of an encoder's scales runs as ONE GEMM over the shared input (radarflow_util.py
+// :132-139 by linearity): its weight is the scales' [O1][3 + cin] conv weights without the three xyz columns, stacked by
+// rows, with the first n_tail input channels moved behind the rest and zero-padded to Kp columns.  Built every step (the
+// optimizer changes the weights) -- as torch ops that was 4 slices + 4 cats + a cat + a pad per call, and the way back
+// 2 x (add_, copy_) per scale: ~40 tiny launches per step, all of them alone on the GPU at the start of the forward /
+// the end of the backward pass.  Here one launch per direction.
+struct StackArgs { int n_w, O1, cin, n_tail, Kp; const float *w[8]; float *g[8]; };
+
+__global__ __launch_bounds__(256) void stack_first_conv_kernel(const StackArgs a, float *__restrict__ wf)
+{
+    const long long total = (long long)a.n_w * a.O1 * a.Kp;
+    const int head = a.cin - a.n_tail;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % a.Kp);
+        const long long row = i / a.Kp;
+        const int r = (int)(row % a.O1), s = (int)(row / a.O1);
+        float v = 0.f;
+        if (c < a.cin) {
+            const int src = c < head ? 3 + a.n_tail + c : 3 + (c - head);
+            v = a.w[s][(long long)r * (a.cin + 3) + src];
+        }
+        wf[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void unstack_first_conv_grad_kernel(const StackArgs a, const float *__restrict__ dwf)
+{
+    const long long total = (long long)a.n_w * a.O1 * a.cin;
+    const int head = a.cin - a.n_tail;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % a.cin);
+        const long long row = i / a.cin;
+        const int r = (int)(row % a.O1), s = (int)(row / a.O1);
+        const int dst = c < head ? 3 + a.n_tail + c : 3 + (c - head);
+        a.g[s][(long long)r * (a.cin + 3) + dst] += dwf[row * a.Kp + c];
+    }
+}
+
+extern "C" int cmf_stack_first_conv(int n_w, int O1, int cin, int n_tail, int Kp, const float *const *w, float *wf, void *stream)
+{
+    CMF_CHECK_ARG(n_w >= 1 && n_w <= 8 && O1 > 0 && cin > 0 && n_tail >= 0 && n_tail <= cin && Kp >= cin && w && wf);
+    StackArgs a;
+    a.n_w = n_w; a.O1 = O1; a.cin = cin; a.n_tail = n_tail; a.Kp = Kp;
+    for (int i = 0; i < 8; ++i) { a.w[i] = i < n_w ? w[i] : nullptr; a.g[i] = nullptr; }
+    for (int i = 0; i < n_w; ++i) CMF_CHECK_ARG(w[i] != nullptr);
+    const long long total = (long long)n_w * O1 * Kp;
+    hipLaunchKernelGGL(stack_first_conv_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, a, wf);
+    return cmf_launch_status();
+}
+
+extern "C" int cmf_unstack_first_conv_grad(int n_w, int O1, int cin, int n_tail, int Kp, const float *dwf, float *const *g, void *stream)
+{
+    CMF_CHECK_ARG(n_w >= 1 && n_w <= 8 && O1 > 0 && cin > 0 && n_tail >= 0 && n_tail <= cin && Kp >= cin && dwf && g);
+    StackArgs a;
+    a.n_w = n_w; a.O1 = O1; a.cin = cin; a.n_tail = n_tail; a.Kp = Kp;
+    for (int i = 0; i < 8; ++i) { a.w[i] = nullptr; a.g[i] = i < n_w ? g[i] : nullptr; }
+    for (int i = 0; i < n_w; ++i) CMF_CHECK_ARG(g[i] != nullptr);
+    const long long total = (long long)n_w * O1 * cin;
+    hipLaunchKernelGGL(unstack_first_conv_grad_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       (hipStream_t)stream, a, dwf);
+    return cmf_launch_status();
+}

@@ -342,6 +342,9 @@ class LinearFn(Function):
         return dx, dw, db, None, None, dib
 
 
+_STACK_KERNELS = os.environ.get("CMF_STACK_KERNELS", "1") == "1"      # 0: the torch slice / cat / add_ form (diagnostics)
+
+
 class StackedFirstConvFn(Function):
     """y_all = feats @ [W_f of every scale stacked]^T -- the feature half of the hoisted first convs of a
     MultiScaleEncoder (radarflow_util.py:132-139 by linearity) as one GEMM, with the weight bookkeeping done here
@@ -353,16 +356,29 @@ class StackedFirstConvFn(Function):
       * the weight gradient (n*O1, Kp) is added straight into the conv weights' .grad when they exist."""
 
     @staticmethod
+    def _uniform(weights):
+        w0 = weights[0]
+        return _STACK_KERNELS and len(weights) <= 8 and all(w.shape == w0.shape and w.is_contiguous() and w.dtype == _f32 for w in weights)
+
+    @staticmethod
     def forward(ctx, feats, n_tail, n_grad, *weights):
+        import ctypes
         M, Kp = feats.shape
-        with torch.no_grad():
-            parts = []
-            for w in weights:
-                w2 = w.view(w.shape[0], w.shape[1])[:, 3:]                       # feature columns (xyz columns first)
-                parts.append(torch.cat((w2[:, n_tail:], w2[:, :n_tail]), dim=1) if n_tail else w2)
-            wf = torch.cat(parts, dim=0)
-            if wf.shape[1] < Kp:
-                wf = torch.nn.functional.pad(wf, (0, Kp - wf.shape[1]))
+        if StackedFirstConvFn._uniform(weights):                                 # one launch (cmf_stack_first_conv)
+            o1, cin = weights[0].shape[0], weights[0].shape[1] - 3
+            wf = torch.empty(len(weights) * o1, Kp, dtype=_f32, device=feats.device)
+            ptrs = (ctypes.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+            _lib.check(L().cmf_stack_first_conv(len(weights), o1, cin, n_tail, Kp, ctypes.addressof(ptrs), wf.data_ptr(),
+                                                _lib.stream_ptr()), "cmf_stack_first_conv")
+        else:
+            with torch.no_grad():
+                parts = []
+                for w in weights:
+                    w2 = w.view(w.shape[0], w.shape[1])[:, 3:]                   # feature columns (xyz columns first)
+                    parts.append(torch.cat((w2[:, n_tail:], w2[:, :n_tail]), dim=1) if n_tail else w2)
+                wf = torch.cat(parts, dim=0)
+                if wf.shape[1] < Kp:
+                    wf = torch.nn.functional.pad(wf, (0, Kp - wf.shape[1]))
         y = gemm(feats, wf)
         ctx.save_for_backward(feats, wf)
         ctx.n_tail, ctx.n_grad, ctx.weights = n_tail, n_grad, weights
@@ -383,6 +399,14 @@ class StackedFirstConvFn(Function):
                 # reads them, but a caller whose tail DOES require grad must see zeros, not uninitialised memory
                 dfeats[:, ng:].zero_()
         dwf = gemm_dw(dy, feats)                                                 # (n*O1, Kp)
+        ws = ctx.weights
+        if StackedFirstConvFn._uniform(ws) and all(w.is_leaf and w.grad is not None and w.grad.is_contiguous() for w in ws):
+            import ctypes                                                        # every scale owns a gradient buffer: one launch
+            o1, cin = ws[0].shape[0], ws[0].shape[1] - 3
+            ptrs = (ctypes.c_void_p * len(ws))(*[w.grad.data_ptr() for w in ws])
+            _lib.check(L().cmf_unstack_first_conv_grad(len(ws), o1, cin, ctx.n_tail, Kp, dwf.data_ptr(), ctypes.addressof(ptrs),
+                                                       _lib.stream_ptr()), "cmf_unstack_first_conv_grad")
+            return (dfeats, None, None, *([None] * len(ws)))
         grads, r0 = [], 0
         for w in ctx.weights:
             o, cin = w.shape[0], w.shape[1] - 3

@@ -364,6 +364,15 @@ int cmf_global_max_cat(int B, int N, int C, const float *f, long long ldf, float
 int cmf_global_max_cat_grad(int B, int N, int C, const float *dout, long long ldd, const int *arg, float *df, long long ldf,
                             void *stream);
 
+/* Weight of the stacked first conv of a MultiScaleEncoder (radarflow_util.py:132-139: the feature half of every scale's
+ * first 1x1 conv applied to the SAME input, here one GEMM): wf[(s*O1 + r)][c], Kp columns, from the n_w conv weights
+ * w[s] = [O1][3 + cin] (xyz columns first): columns [0, cin - n_tail) = input channels n_tail.., then the first n_tail
+ * input channels, then zeros up to Kp.  cmf_unstack_first_conv_grad adds the GEMM's weight gradient dwf [n_w*O1][Kp] back
+ * into the conv weights' gradients g[s] (same layout as w[s]; the xyz columns are not touched).  n_w <= 8; w / g are
+ * HOST arrays of device pointers. */
+int cmf_stack_first_conv(int n_w, int O1, int cin, int n_tail, int Kp, const float *const *w, float *wf, void *stream);
+int cmf_unstack_first_conv_grad(int n_w, int O1, int cin, int n_tail, int Kp, const float *dwf, float *const *g, void *stream);
+
 /* ---- the training step's loss -------------------------------------------------------------
  * RadarFlowLoss of losses/radar_loss.py:260-292 for model 'cmflow' / 'cmflow_t': SoftChamfer (:17-58),
  * SpatialSmoothness (:60-97), RadialDisplacement (:99-122), EgoMotion (:162-183), MotionSeg (:185-205),

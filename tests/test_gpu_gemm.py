@@ -320,3 +320,39 @@ def test_thin_bwd_layer_matches_fp64_and_three_kernel_form(dev, gemm_mode, rows,
     else:
         dx3 = gemm(dZ32, w, b_t=False)
     assert float((dx3 - dx).abs().max()) <= 1e-4 * max(1.0, float(dx3.abs().max()))
+
+
+@pytest.mark.parametrize("n_tail,cin,Kp", [(0, 3, 4), (0, 64, 64), (4, 1028, 1040), (2, 10, 12)])
+def test_stacked_first_conv_weight_gather_and_gradient_scatter(dev, gemm_mode, n_tail, cin, Kp):
+    """cmf_stack_first_conv / cmf_unstack_first_conv_grad against the slice / cat / pad expressions they replace
+    (radarflow_util.py:132-139 by linearity): pure data movement, so bit-exact."""
+    if gemm_mode != "fp32":
+        pytest.skip("no GEMM involved")
+    import ctypes
+    from cmflow_amd import _lib
+    L = _lib.lib()
+    n_w, o1 = 4, 32
+    g = torch.Generator(device="cpu").manual_seed(cin)
+    ws = [torch.randn(o1, cin + 3, 1, 1, generator=g).to(dev) for _ in range(n_w)]
+    parts = []
+    for w in ws:
+        w2 = w.view(o1, cin + 3)[:, 3:]
+        parts.append(torch.cat((w2[:, n_tail:], w2[:, :n_tail]), dim=1))
+    want = torch.nn.functional.pad(torch.cat(parts, 0), (0, Kp - cin))
+    wf = torch.full((n_w * o1, Kp), float("nan"), device=dev)
+    ptrs = (ctypes.c_void_p * n_w)(*[w.data_ptr() for w in ws])
+    _lib.check(L.cmf_stack_first_conv(n_w, o1, cin, n_tail, Kp, ctypes.addressof(ptrs), wf.data_ptr(), _lib.stream_ptr()), "stack")
+    assert torch.equal(wf, want)
+    dwf = torch.randn(n_w * o1, Kp, generator=g).to(dev)
+    grads = [torch.randn(o1, cin + 3, 1, 1, generator=g).to(dev) for _ in range(n_w)]
+    ref = [t.clone() for t in grads]
+    for i, r in enumerate(ref):
+        blk = dwf[i * o1:(i + 1) * o1]
+        r2 = r.view(o1, cin + 3)
+        r2[:, 3 + n_tail:] += blk[:, :cin - n_tail]
+        if n_tail:
+            r2[:, 3:3 + n_tail] += blk[:, cin - n_tail:cin]
+    gp = (ctypes.c_void_p * n_w)(*[t.data_ptr() for t in grads])
+    _lib.check(L.cmf_unstack_first_conv_grad(n_w, o1, cin, n_tail, Kp, dwf.data_ptr(), ctypes.addressof(gp), _lib.stream_ptr()), "unstack")
+    for a, b in zip(grads, ref):
+        assert torch.equal(a, b)

@@ -1,7 +1,7 @@
 """Per-workgroup timeline of one cmf_gemm launch (cmf_gemm_trace_arm / _read): when does each workgroup start, leave its
 main loop and finish, and on which CU -- i.e. how much of a CU's time has NO workgroup in its MFMA main loop.
 
-    python tools/gemm_timeline.py [fwd|dx|dw] [M N K]
+    python tools/gemm_timeline.py [fwd|dx|dxq|dw|plain] [M N K]
 """
 import ctypes, os, sys
 import numpy as np
@@ -18,7 +18,9 @@ torch.manual_seed(0)
 A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev); dZ = torch.randn(M, N, device=dev)
 Zs = torch.randn(M, K, device=dev)
 ea, ec, em, ei = (torch.rand(K, device=dev) + 0.5 for _ in range(4))
+dxyz = torch.randn(M, 4, device=dev)
 fn = {"fwd": lambda: gemm(A, W, stats=True), "dx": lambda: gemm(dZ, W, b_t=False, bwd=(1, Zs, ea, ec, em, ei)),
+      "dxq": lambda: gemm(dZ, W, b_t=False, bwd=(1, Zs, ea, ec, em, ei, dxyz)),
       "dw": lambda: gemm_dw(dZ, A), "plain": lambda: gemm(A, W)}[which]
 for _ in range(3):
     fn()
