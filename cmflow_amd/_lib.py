@@ -67,6 +67,9 @@ SIGNATURES = {
     "cmf_affine_relu": [_ll, _ci, _vp, _ll, _vp, _vp, _vp, _ll, _vp],
     "cmf_act_bwd_stats": [_ll, _ci, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_bn_bwd_apply": [_ll, _ci, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp],
+    "cmf_maxpool_bwd_point": [_ll, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_thin_bwd_layer_pooled": [_ll, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _ci, _vp, _vp],
     "cmf_thin_bwd_supported": [_ci, _ci],
     "cmf_thin_bwd_slabs": [_ll, _vp],
     "cmf_thin_bwd_layer": [_ll, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _ci,

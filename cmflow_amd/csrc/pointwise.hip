@@ -518,6 +518,54 @@ extern "C" int cmf_maxpool_bwd(long long P, int S, int C, const float *dout, lon
     return cmf_launch_status();
 }
 
+// The same backward per POINT instead of per neighbour row: g[p,:] = dout[p,:] * [a * z[p, argmax[p,:], :] + c > 0] (the
+// only slot of a point that receives a gradient is its argmax) with the BN-backward partial sums per 128 points --
+// identical sums to maxpool_bwd's (the other rows contribute exact zeros), P rows touched instead of P * S.  The consumer
+// (cmf_thin_bwd_layer_pooled) forms dU[p,s,:] = (s == argmax[p,:]) ? g[p,:] : 0 on the fly.
+__global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_kernel(
+    long long P, int S, int C, const float *__restrict__ dout, long long ldd, const float *__restrict__ z,
+    const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const unsigned char *__restrict__ argmax, float *__restrict__ g,
+    float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const TileMap tm = tile_map(C);
+    const float4 sa = *(const float4 *)(a + tm.col), sc = *(const float4 *)(c + tm.col);
+    const float4 mu = *(const float4 *)(mean + tm.col), is = *(const float4 *)(invstd + tm.col);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    const long long p0 = (long long)blockIdx.x * PW_ROWS;
+    for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
+        const long long p = p0 + r;
+        if (p >= P) break;
+        const uchar4 am = *(const uchar4 *)(argmax + (size_t)p * C + tm.col);
+        const float4 gi = *(const float4 *)(dout + (size_t)p * ldd + tm.col);
+        const float *zp = z + (size_t)p * S * C + tm.col;
+        const float vx = zp[(size_t)am.x * C], vy = zp[(size_t)am.y * C + 1], vz = zp[(size_t)am.z * C + 2], vw = zp[(size_t)am.w * C + 3];
+        float4 d;
+        d.x = fmaf(sa.x, vx, sc.x) > 0.f ? gi.x : 0.f;
+        d.y = fmaf(sa.y, vy, sc.y) > 0.f ? gi.y : 0.f;
+        d.z = fmaf(sa.z, vz, sc.z) > 0.f ? gi.z : 0.f;
+        d.w = fmaf(sa.w, vw, sc.w) > 0.f ? gi.w : 0.f;
+        *(float4 *)(g + (size_t)p * C + tm.col) = d;
+        s1.x += d.x; s1.y += d.y; s1.z += d.z; s1.w += d.w;
+        s2.x += d.x * ((vx - mu.x) * is.x); s2.y += d.y * ((vy - mu.y) * is.y);
+        s2.z += d.z * ((vz - mu.z) * is.z); s2.w += d.w * ((vw - mu.w) * is.w);
+    }
+    tile_reduce_store(s1, s2, tm, C, partial, red);
+}
+
+extern "C" int cmf_maxpool_bwd_point(long long P, int S, int C, const float *dout, long long ldd, const float *z,
+                                     const float *a, const float *c, const float *mean, const float *invstd,
+                                     const unsigned char *argmax, float *g, float *partial, void *stream)
+{
+    CMF_CHECK_ARG(P >= 0 && S > 0 && S <= 255 && tile_ok(C) && ldd % 4 == 0);
+    if (P == 0) return 0;
+    CMF_CHECK_ARG(dout && z && a && c && mean && invstd && argmax && g && partial);
+    hipLaunchKernelGGL(maxpool_bwd_point_kernel, dim3(cmf_divup(P, PW_ROWS)), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
+                       P, S, C, dout, ldd, z, a, c, mean, invstd, argmax, g, partial);
+    return cmf_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // y = relu(a*z + c) materialised (chain ends; out may be a column slice of a concat buffer)
 // ---------------------------------------------------------------------------------------------

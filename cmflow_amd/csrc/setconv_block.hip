@@ -277,8 +277,22 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     CMF_TRY(bwd_layer(d, L, 4, P, C5, C4, L.t5, L.z5, d->w[3], L.z4, 3, L.t4, nullptr, d->dw[3], d->acc_w[3], st));
     CMF_TRY(bwd_layer(d, L, 3, P, C4, C3, L.t4, L.z4, d->w[2], L.x, -1, L.dx, nullptr, d->dw[2], d->acc_w[2], st));
     // max over the ball, layers 3 .. 1 (per neighbour slot)
-    CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
-    CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));
+    static const bool fused = !(getenv("CMF_THIN_FUSED") && getenv("CMF_THIN_FUSED")[0] == '0');
+    if (fused && cmf_thin_bwd_supported(C3, C2) && M % 128 == 0 && C3 % 32 == 0 && C2 % 32 == 0 && d->dw[1]) {
+        // narrow layers: the gradient of the pooled tensor is kept per POINT (g, in L.dx's neighbour L.dU3) and expanded
+        // by the fused layer kernel on the fly -- the [M, C3] matrix is neither written nor read
+        float *g = L.dU3;
+        CMF_TRY(cmf_maxpool_bwd_point(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, g, L.partial, st));
+        if (d->acc_bn[2]) CMF_TRY(cmf_colsum_finalize(tiles128(P), C3, L.partial, L.sums, d->dbeta[2], d->dgamma[2], st));
+        else CMF_TRY(cmf_colsum_store(tiles128(P), 2 * C3, L.partial, L.sums, C3, d->dbeta[2], d->dgamma[2], st));
+        const float *b1 = L.bn[1];
+        CMF_TRY(cmf_thin_bwd_layer_pooled(P, d->S, C3, C2, g, L.argmax, L.z3, b2 + 2 * C3, b2, b2 + C3, d->training ? L.sums : nullptr,
+                                          d->w[1], L.z2, b1 + 2 * C2, b1 + 3 * C2, b1, b1 + C2, L.dU2, L.partial, d->dw[1], d->acc_w[1],
+                                          L.splitk, st));
+    } else {
+        CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
+        CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));
+    }
     CMF_TRY(bwd_layer(d, L, 1, M, C2, O1, L.dU2, L.z2, d->w[0], L.z1, 0, L.dU1, L.dxyz, d->dw[0], d->acc_w[0], st));
     // first layer: sums {s1,s2,q0,q1,q2}; dgamma/dbeta; dW_xyz from sums; BN backward folded into the scatter
     const float *b0 = L.bn[0];

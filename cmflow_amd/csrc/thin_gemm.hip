@@ -13,6 +13,7 @@
 // Fragment maps of v_mfma_f32_32x32x2_f32 (cdna_hip_programming.md 3): A: lane l holds A[i=l&31][k=l>>5],
 // B: lane l holds B[k=l>>5][j=l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).  As in gemm.hip a lane
 // loads 4 consecutive k of its row at once (lanes 0-31: k0..k0+3, lanes 32-63: k0+4..k0+7) and feeds 4 MFMAs.
+#include <algorithm>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 #include "gemm_args.h"
@@ -343,6 +344,8 @@ struct ThinBwdArgs {
     float *stats;                                  // in_mode 1: [tiles128][2 or 5][cin]
     float *slabs;                                  // [gridDim.x][cout][cin] or null (no weight gradient)
     int tiles_per_wg;
+    // pooled form (MODE bit 3): dU is not stored -- row m = (p, s) of it is (s == pool_am[p][:]) ? pool_g[p][:] : 0
+    const float *pool_g; const unsigned char *pool_am; int pool_S;
 };
 
 // LDS of the fused layer
@@ -363,7 +366,8 @@ __device__ __forceinline__ float4 tb_ld4(const float *base, unsigned byte_off) {
 // One 128-row tile (32 rows per wave).  FULL: every row and channel of the tile exists -- no predicates around the loads.
 // Tile bases are wave-uniform (scalar registers); everything per lane is a 32-bit BYTE offset from them.
 // MODE >= 0 fixes the run-time switches at compile time (both products wanted; bit 0: train-mode BN, bit 1: in_mode,
-// bit 2: dxyz sums): the chain of a set-conv block only uses those; MODE < 0 reads them from the arguments.
+// bit 2: dxyz sums, bit 3: dU comes from the max-pool backward per point): the chain of a set-conv block only uses
+// those; MODE < 0 reads them from the arguments (and has no pooled form).
 template <int NTO, int NTI, bool FULL, int MODE>
 __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<NTO, NTI> &S, f32x16 (&accw)[NTO][NTI], long long tile,
                                               unsigned live, int parity, int lane, int wave)
@@ -406,6 +410,14 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
     const unsigned mrow = w0 + (unsigned)(lane & 31);
     const bool ok = FULL || mrow < live;
     const unsigned ou = ((ok ? mrow : 0u) * (unsigned)p.lddu + 4u * h) * 4u, oz = ((ok ? mrow : 0u) * (unsigned)p.ldz + 4u * h) * 4u;
+    // pooled form: point and slot of this lane's row; byte offset of its 4 channels in the per-point arrays
+    unsigned pool_o = 0, pool_s = 0;
+    if (MODE >= 0 && (MODE & 8)) {
+        const long long m = tile * 128 + mrow;
+        const long long pt = m / p.pool_S;
+        pool_s = (unsigned)(m - pt * p.pool_S);
+        pool_o = (unsigned)((pt * p.cout + 4 * h) * 4);
+    }
     f32x16 acc[NTI];
 #pragma unroll
     for (int j = 0; j < NTI; ++j)
@@ -419,7 +431,12 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
             const int k8 = kb + ku;
             dv[ku] = zv[ku] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k8 < ks) {
-                dv[ku] = tb_ld4(dUt, ou + 32u * k8);
+                if (MODE >= 0 && (MODE & 8)) {
+                    const float4 g4 = tb_ld4(p.pool_g, pool_o + 32u * k8);
+                    const uchar4 am = *(const uchar4 *)(p.pool_am + (pool_o >> 2) + 8u * k8);
+                    dv[ku] = make_float4(am.x == pool_s ? g4.x : 0.f, am.y == pool_s ? g4.y : 0.f, am.z == pool_s ? g4.z : 0.f,
+                                         am.w == pool_s ? g4.w : 0.f);
+                } else dv[ku] = tb_ld4(dUt, ou + 32u * k8);
                 if (train) zv[ku] = tb_ld4(zt, oz + 32u * k8);
             }
         }
@@ -617,35 +634,43 @@ extern "C" int cmf_thin_bwd_supported(int cout, int cin)
     return cout >= 8 && cout <= 64 && cout % 8 == 0 && cin >= 1 && cin <= 64;
 }
 
-extern "C" int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float *dU, long long lddu, const float *z, long long ldz,
-                                  const float *a, const float *mean, const float *invstd, const float *sums,
-                                  const float *w, long long ldw, const float *x, long long ldx, int in_mode,
-                                  const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in, const float *dxyz,
-                                  float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
-                                  void *stream)
+static int thin_bwd_layer_impl(long long rows, int cout, int cin, const float *dU, long long lddu, const float *pool_g,
+                               const unsigned char *pool_am, int pool_S, const float *z, long long ldz,
+                               const float *a, const float *mean, const float *invstd, const float *sums,
+                               const float *w, long long ldw, const float *x, long long ldx, int in_mode,
+                               const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in, const float *dxyz,
+                               float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
+                               void *stream)
 {
+    const bool pooled = pool_g != nullptr;
     CMF_CHECK_ARG(rows >= 0 && cmf_thin_bwd_supported(cout, cin) && (in_mode == 0 || in_mode == 1));
     if (rows == 0) return 0;
-    CMF_CHECK_ARG(dU && a && w && x && (!sums || (z && mean && invstd)) && (dx || dw));
-    CMF_CHECK_ARG(lddu % 4 == 0 && (uintptr_t)dU % 16 == 0 && (!sums || (ldz % 4 == 0 && (uintptr_t)z % 16 == 0)));
+    CMF_CHECK_ARG((pooled || dU) && a && w && x && (!sums || (z && mean && invstd)) && (dx || dw));
+    CMF_CHECK_ARG(pooled || (lddu % 4 == 0 && (uintptr_t)dU % 16 == 0));
+    CMF_CHECK_ARG(!sums || (ldz % 4 == 0 && (uintptr_t)z % 16 == 0));
     CMF_CHECK_ARG(((uintptr_t)a | (uintptr_t)mean | (uintptr_t)invstd | (uintptr_t)sums) % 16 == 0);
     CMF_CHECK_ARG(in_mode == 0 || !dx || (a_in && c_in && mean_in && invstd_in && stats));
-    CMF_CHECK_ARG(in_mode == 0 || a_in && c_in);
+    CMF_CHECK_ARG(in_mode == 0 || (a_in && c_in));
     CMF_CHECK_ARG(!dw || slabs);
+    // per-lane offsets inside a tile (and inside the per-point arrays of the pooled form) are 32-bit byte offsets
+    CMF_CHECK_ARG(128ll * std::max({lddu, ldz, ldx, lddx}) * 4 < (1ll << 31));
+    const bool full = rows % 128 == 0 && cout % 32 == 0 && cin % 32 == 0;
+    if (pooled) CMF_CHECK_ARG(pool_am && pool_S > 0 && rows % pool_S == 0 && (uintptr_t)pool_g % 16 == 0 && (uintptr_t)pool_am % 4 == 0 &&
+                              dx && dw && full && (rows / pool_S) * cout * 4 < (1ll << 32));
     ThinBwdArgs p;
     p.rows = rows; p.cout = cout; p.cin = cin; p.dU = dU; p.lddu = lddu; p.z = z; p.ldz = ldz;
     p.a = a; p.mean = mean; p.invstd = invstd; p.sums = sums; p.inv_count = (float)(1.0 / (double)rows);
     p.w = w; p.ldw = ldw; p.x = x; p.ldx = ldx; p.in_mode = in_mode;
     p.a_in = a_in; p.c_in = c_in; p.mean_in = mean_in; p.invstd_in = invstd_in; p.dxyz = in_mode == 1 ? dxyz : nullptr;
     p.dx = dx; p.lddx = lddx; p.stats = stats; p.slabs = dw ? slabs : nullptr;
+    p.pool_g = pool_g; p.pool_am = pool_am; p.pool_S = pool_S;
     const int nslab = cmf_thin_bwd_slabs(rows, &p.tiles_per_wg);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(nslab), block(TG_THREADS);
     // the set-conv chains always want both products of whole tiles: their switch combinations are compiled in (MODE,
     // FULL); anything else runs the generic instantiation
     int mode = -1;
-    const bool full = rows % 128 == 0 && cout % 32 == 0 && cin % 32 == 0;
-    if (dx && dw && full) mode = (sums ? 1 : 0) | (in_mode ? 2 : 0) | ((in_mode && dxyz) ? 4 : 0);
+    if (dx && dw && full) mode = (sums ? 1 : 0) | (in_mode ? 2 : 0) | ((in_mode && dxyz) ? 4 : 0) | (pooled ? 8 : 0);
 #define CMF_TB_MODE(NO, NI)                                                                              \
     switch (mode) {                                                                                     \
         case 0: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 0, true>), grid, block, 0, st, p); break;   \
@@ -654,7 +679,11 @@ extern "C" int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float
         case 3: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 3, true>), grid, block, 0, st, p); break;   \
         case 6: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 6, true>), grid, block, 0, st, p); break;   \
         case 7: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 7, true>), grid, block, 0, st, p); break;   \
-        default: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, -1, false>), grid, block, 0, st, p); break; \
+        case 10: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 10, true>), grid, block, 0, st, p); break; \
+        case 11: hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, 11, true>), grid, block, 0, st, p); break; \
+        default:                                                                                        \
+            if (pooled) return (int)hipErrorInvalidValue;     /* the pooled form feeds a BN + ReLU layer (in_mode 1, no dxyz) */ \
+            hipLaunchKernelGGL((thin_bwd_layer_kernel<NO, NI, -1, false>), grid, block, 0, st, p); break; \
     }
     if (cout > 32) {
         if (cin > 32) { CMF_TB_MODE(2, 2) } else { CMF_TB_MODE(2, 1) }
@@ -667,4 +696,27 @@ extern "C" int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float
     cmf_gemm_count_flops((dx ? 2.0 : 0.0) * rows * cout * cin + (dw ? 2.0 : 0.0) * rows * cout * cin);
     if (dw) return cmf_splitk_reduce(cout, cin, nslab, slabs, dw, lddw, accumulate, st);
     return 0;
+}
+
+extern "C" int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float *dU, long long lddu, const float *z, long long ldz,
+                                  const float *a, const float *mean, const float *invstd, const float *sums,
+                                  const float *w, long long ldw, const float *x, long long ldx, int in_mode,
+                                  const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in, const float *dxyz,
+                                  float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
+                                  void *stream)
+{
+    CMF_CHECK_ARG(dU);
+    return thin_bwd_layer_impl(rows, cout, cin, dU, lddu, nullptr, nullptr, 0, z, ldz, a, mean, invstd, sums, w, ldw, x, ldx, in_mode,
+                               a_in, c_in, mean_in, invstd_in, dxyz, dx, lddx, stats, dw, lddw, accumulate, slabs, stream);
+}
+
+extern "C" int cmf_thin_bwd_layer_pooled(long long P, int S, int cout, int cin, const float *g, const unsigned char *argmax,
+                                         const float *z, const float *a, const float *mean, const float *invstd, const float *sums,
+                                         const float *w, const float *x, const float *a_in, const float *c_in, const float *mean_in,
+                                         const float *invstd_in, float *dx, float *stats, float *dw, int accumulate, float *slabs,
+                                         void *stream)
+{
+    CMF_CHECK_ARG(P >= 0 && S > 0 && g && argmax);
+    return thin_bwd_layer_impl(P * S, cout, cin, nullptr, cout, g, argmax, S, z, cout, a, mean, invstd, sums, w, cin, x, cin, 1,
+                               a_in, c_in, mean_in, invstd_in, nullptr, dx, cin, stats, dw, cin, accumulate, slabs, stream);
 }

@@ -216,6 +216,19 @@ int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float *dU, long 
                        float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
                        void *stream);
 
+/* The same layer directly behind the max over the ball (radarflow_util.py:155-157 backward), dense: rows = P * S, row
+ * (p, s) of dU is (s == argmax[p][:]) ? g[p][:] : 0 and is formed on the fly from the per-point arrays of
+ * cmf_maxpool_bwd_point -- the [P*S, cout] gradient of the pooled tensor is never stored.  x is the pre-BN output of the
+ * layer below (in_mode 1); whole 128-row tiles and multiples of 32 channels only. */
+int cmf_maxpool_bwd_point(long long P, int S, int C, const float *dout, long long ldd, const float *z,
+                          const float *a, const float *c, const float *mean, const float *invstd,
+                          const unsigned char *argmax, float *g, float *partial, void *stream);
+int cmf_thin_bwd_layer_pooled(long long P, int S, int cout, int cin, const float *g, const unsigned char *argmax,
+                              const float *z, const float *a, const float *mean, const float *invstd, const float *sums,
+                              const float *w, const float *x, const float *a_in, const float *c_in, const float *mean_in,
+                              const float *invstd_in, float *dx, float *stats, float *dw, int accumulate, float *slabs,
+                              void *stream);
+
 /* Backward of the set-conv's grouping with the BatchNorm backward of the first layer fused in
  * (radarflow_util.py:148-151 backward): dZ = a*(dU - s1/M - zhat*s2/M) is formed on the fly from dU and z,
  * summed over the inverse index into grad_feat (b,n,c) with row stride ldg, and never written.  sums = {s1[C], s2[C]} or NULL

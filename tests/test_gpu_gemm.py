@@ -356,3 +356,56 @@ def test_stacked_first_conv_weight_gather_and_gradient_scatter(dev, gemm_mode, n
     _lib.check(L.cmf_unstack_first_conv_grad(n_w, o1, cin, n_tail, Kp, dwf.data_ptr(), ctypes.addressof(gp), _lib.stream_ptr()), "unstack")
     for a, b in zip(grads, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("P,S,cout,cin,train", [(4096, 4, 64, 32, True), (2048, 32, 64, 32, True), (1024, 8, 64, 64, True),
+                                               (2048, 16, 32, 32, False)])
+def test_pooled_thin_bwd_layer_matches_materialised_gradient(dev, gemm_mode, P, S, cout, cin, train):
+    """cmf_maxpool_bwd_point + cmf_thin_bwd_layer_pooled (the gradient of the pooled tensor kept per point) against
+    cmf_maxpool_bwd + cmf_thin_bwd_layer on the materialised [P*S, C] gradient: same masks, same non-zero entries; the
+    BN-backward sums are grouped differently (per 128 points vs per 128 rows), hence tolerances of a few fp32 ulps."""
+    if gemm_mode != "fp32":
+        pytest.skip("thin kernels have one arithmetic")
+    import ctypes
+    from cmflow_amd import _lib, fused_blocks as FB
+    L = _lib.lib()
+    M = P * S
+    g = torch.Generator(device="cpu").manual_seed(P + S)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    z3, z2, dout = rnd(M, cout), rnd(M, cin), rnd(P, cout)
+    w = rnd(cout, cin) * 0.2
+    st = FB.BNState()
+    st.a, st.c, st.mean, st.invstd = rnd(cout), rnd(cout) * 0.3, rnd(cout) * 0.3, torch.rand(cout, generator=g).to(dev) + 0.5
+    st.training, st.count = train, M
+    a_in, c_in, mean_in, invstd_in = rnd(cin), rnd(cin) * 0.3, rnd(cin) * 0.3, torch.rand(cin, generator=g).to(dev) + 0.5
+    _, am = FB.bn_relu_maxpool(z3.view(P, S, cout), st)
+    p = lambda t: None if t is None else t.data_ptr()
+    tiles = (M + 127) // 128
+    nslab = L.cmf_thin_bwd_slabs(M, None)
+    slabs = torch.empty(max(nslab, 2), cout, cin, device=dev)
+
+    def layer(pooled):
+        dx = torch.empty(M, cin, device=dev); stats = torch.empty(tiles, 2, cin, device=dev); dw = torch.zeros(cout, cin, device=dev)
+        if pooled:
+            gp = torch.empty(P, cout, device=dev); part = torch.empty((P + 127) // 128, 2, cout, device=dev)
+            _lib.check(L.cmf_maxpool_bwd_point(P, S, cout, p(dout), cout, p(z3), p(st.a), p(st.c), p(st.mean), p(st.invstd), p(am), p(gp),
+                                               p(part), _lib.stream_ptr()), "maxpool_bwd_point")
+            sums = FB.colsum_n(part)
+            _lib.check(L.cmf_thin_bwd_layer_pooled(P, S, cout, cin, p(gp), p(am), p(z3), p(st.a), p(st.mean), p(st.invstd),
+                                                   p(sums) if train else None, p(w), p(z2), p(a_in), p(c_in), p(mean_in), p(invstd_in),
+                                                   p(dx), p(stats), p(dw), 0, p(slabs), _lib.stream_ptr()), "pooled")
+        else:
+            dU, part = FB.maxpool_bwd(dout, z3.view(P, S, cout), st, am)
+            sums = FB.colsum_n(part)
+            _lib.check(L.cmf_thin_bwd_layer(M, cout, cin, p(dU), cout, p(z3), cout, p(st.a), p(st.mean), p(st.invstd),
+                                            p(sums) if train else None, p(w), cin, p(z2), cin, 1, p(a_in), p(c_in), p(mean_in),
+                                            p(invstd_in), None, p(dx), cin, p(stats), p(dw), cin, 0, p(slabs), _lib.stream_ptr()), "dense")
+        return sums, dx, stats, dw
+
+    s0, dx0, st0, dw0 = layer(False)
+    s1, dx1, st1, dw1 = layer(True)
+    scale = lambda t: max(1.0, float(t.abs().max()))
+    assert float((s0 - s1).abs().max()) <= 2e-6 * P               # sums of ~P non-zero terms of magnitude ~1, regrouped
+    assert torch.equal(dx0 == 0, dx1 == 0)
+    for a, b in ((dx0, dx1), (st0, st1), (dw0, dw1)):
+        assert float((a - b).abs().max()) <= 2e-5 * scale(a)
