@@ -5,6 +5,7 @@
 // every operation individually rounded, no FMA contraction, except the kNN dot product which
 // is the k-ordered FMA chain of a GEMM (bit-equal to torch-CPU matmul).  This file is built
 // with -ffp-contract=off and the pragma below; tests/test_build.py checks the ISA.
+#include <cstdlib>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -208,12 +209,208 @@ __global__ __launch_bounds__(BQM_NW *CMF_WAVE) void ball_query_multi_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ball query over a cell grid, for large clouds (4096 <= N <= 8192; config 5 of BASELINE: N = 4096, nsample 64).
+//
+// "The first nsample points within the radius IN INDEX ORDER" makes the scan order part of the result, which is why the
+// kernels above walk the whole cloud per centre (N^2 distance evaluations).  The order can be restored afterwards
+// instead: (1) per sample, the points are binned into cubic cells of edge >= 1.001 * radius (at most 16 per axis) --
+// a centre's hits can only lie in the 27 cells around its own; (2) one WAVE per centre evaluates the distance (same
+// canonical arithmetic) of the points of those cells, lane-parallel, in whatever order the cells hold them, and sets bit
+// `index` of an N-bit map in LDS for every hit; (3) the map is read back in index order: lane l owns words l, l + 64, ...,
+// a wave prefix sum of the population counts gives every lane the rank of its first hit, and the first nsample set
+// bits are written out -- exactly the list the scan would have produced, padded with the first hit like
+// ball_query_gpu.cu:37-41; an empty ball leaves idx untouched.  Work per centre: the points of 27 cells instead of N.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BQG_MAXC = 16;                 // cells per axis
+constexpr int BQG_CELLS = BQG_MAXC * BQG_MAXC * BQG_MAXC;
+constexpr int BQG_THREADS = 1024;
+constexpr int BQG_MAX_N = 8192;              // bitmap of 256 words per wave
+struct BqGridHeader { float mn[3], inv; int g[3], pad; };      // per sample, in scratch
+
+__device__ __forceinline__ int bqg_cell(float v, float mn, float inv, int g)     // raw cell coordinate, clamped to [-1, g]
+{
+    const float t = floorf((v - mn) * inv);
+    return t < -1.f ? -1 : (t > (float)g ? g : (int)t);
+}
+
+// one workgroup per sample: bounding box, cell of every point, counting sort (order inside a cell is arbitrary)
+__global__ __launch_bounds__(BQG_THREADS) void bq_grid_build_kernel(int n, float radius, const float *__restrict__ xyz,
+                                                                    BqGridHeader *__restrict__ hdr, int *__restrict__ cell_start,
+                                                                    float4 *__restrict__ spts)
+{
+    __shared__ float red[6][BQG_THREADS / 64];
+    __shared__ int cnt[BQG_CELLS + 1];
+    __shared__ BqGridHeader H;
+    const int bs = blockIdx.x, tid = threadIdx.x;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+    for (int i = tid; i < n; i += BQG_THREADS)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float v = pts[(size_t)i * 3 + k]; lo[k] = fminf(lo[k], v); hi[k] = fmaxf(hi[k], v); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64)); }
+        if ((tid & 63) == 0) { red[k][tid >> 6] = lo[k]; red[3 + k][tid >> 6] = hi[k]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ext[3];
+        for (int k = 0; k < 3; ++k) {
+            float a = red[k][0], b = red[3 + k][0];
+            for (int w = 1; w < BQG_THREADS / 64; ++w) { a = fminf(a, red[k][w]); b = fmaxf(b, red[3 + k][w]); }
+            H.mn[k] = a; ext[k] = b - a;
+        }
+        // edge > radius (|dq| < 1 cell whatever the rounding) and at most 16 cells per axis.  [A finer grid (8192 cells of
+        // any shape) was measured slower: the query is bound by its instruction count per (y, z) row, not by candidates.]
+        const float cs = fmaxf(radius * 1.001f, fmaxf(ext[0], fmaxf(ext[1], ext[2])) / (float)BQG_MAXC);
+        H.inv = 1.0f / cs;
+        for (int k = 0; k < 3; ++k) {
+            const int g = (int)floorf(ext[k] * H.inv) + 1;
+            H.g[k] = g < 1 ? 1 : (g > BQG_MAXC ? BQG_MAXC : g);
+        }
+        H.pad = 0;
+        hdr[bs] = H;
+    }
+    for (int i = tid; i <= BQG_CELLS; i += BQG_THREADS) cnt[i] = 0;
+    __syncthreads();
+    const int gx = H.g[0], gy = H.g[1], gz = H.g[2];
+    auto cell_of = [&](int i) {
+        const float *q = pts + (size_t)i * 3;
+        const int cx = min(gx - 1, max(0, bqg_cell(q[0], H.mn[0], H.inv, gx)));
+        const int cy = min(gy - 1, max(0, bqg_cell(q[1], H.mn[1], H.inv, gy)));
+        const int cz = min(gz - 1, max(0, bqg_cell(q[2], H.mn[2], H.inv, gz)));
+        return (cz * gy + cy) * gx + cx;
+    };
+    for (int i = tid; i < n; i += BQG_THREADS) atomicAdd(&cnt[cell_of(i) + 1], 1);
+    __syncthreads();
+    const int ncell = gx * gy * gz;
+    {   // inclusive scan of cnt[1 .. BQG_CELLS]: 4 cells per thread, wave scan, then the 16 wave totals
+        constexpr int PER = BQG_CELLS / BQG_THREADS;
+        __shared__ int wsum[BQG_THREADS / 64];
+        int v[PER], run = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { run += cnt[1 + PER * tid + k]; v[k] = run; }
+        int incl = run;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += t; }
+        if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+        __syncthreads();
+        int before = incl - run;
+        for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) cnt[1 + PER * tid + k] = before + v[k];
+    }
+    __syncthreads();
+    int *cs_out = cell_start + (size_t)bs * (BQG_CELLS + 1);
+    for (int c = tid; c <= ncell; c += BQG_THREADS) cs_out[c] = cnt[c];
+    __syncthreads();
+    float4 *sp = spts + (size_t)bs * n;
+    for (int i = tid; i < n; i += BQG_THREADS) {
+        const int slot = atomicAdd(&cnt[cell_of(i)], 1);                           // cursor of the cell (cnt[c] = its start)
+        const float *q = pts + (size_t)i * 3;
+        sp[slot] = make_float4(q[0], q[1], q[2], __int_as_float(i));
+    }
+}
+
+// one wave per centre (4 per workgroup)
+__global__ __launch_bounds__(256) void bq_grid_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
+                                                            const BqGridHeader *__restrict__ hdr, const int *__restrict__ cell_start,
+                                                            const float4 *__restrict__ spts, int *__restrict__ idx)
+{
+    __shared__ unsigned bits[4][BQG_MAX_N / 32];
+    const int bs = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pt = blockIdx.x * 4 + w;
+    if (pt >= m) return;                                                           // wave-uniform; no workgroup barrier below
+    const BqGridHeader H = hdr[bs];
+    const int *cst = cell_start + (size_t)bs * (BQG_CELLS + 1);
+    const float4 *sp = spts + (size_t)bs * n;
+    const float *c = new_xyz + ((size_t)bs * m + pt) * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    const int words = (n + 31) / 32;
+    unsigned *bm = bits[w];
+    for (int i = lane; i < words; i += 64) bm[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const int qx = bqg_cell(cx, H.mn[0], H.inv, H.g[0]), qy = bqg_cell(cy, H.mn[1], H.inv, H.g[1]), qz = bqg_cell(cz, H.mn[2], H.inv, H.g[2]);
+    const int x0 = max(0, qx - 1), x1 = min(H.g[0] - 1, qx + 1);
+    for (int z = max(0, qz - 1); z <= min(H.g[2] - 1, qz + 1); ++z)
+        for (int y = max(0, qy - 1); y <= min(H.g[1] - 1, qy + 1); ++y) {
+            if (x0 > x1) continue;
+            const int row = (z * H.g[1] + y) * H.g[0];
+            const int e0 = cst[row + x0], e1 = cst[row + x1 + 1];                  // the x-neighbours are one contiguous range
+            for (int e = e0 + lane; e < e1; e += 64) {
+                const float4 p = sp[e];
+                const float dx = cx - p.x;
+                const float dy = cy - p.y;
+                const float dz = cz - p.z;
+                const float xx = dx * dx;
+                const float yy = dy * dy;
+                const float zz = dz * dz;
+                const float s2 = xx + yy;
+                if (s2 + zz < radius2) {
+                    const int k = __float_as_int(p.w);
+                    atomicOr(&bm[k >> 5], 1u << (k & 31));
+                }
+            }
+        }
+    __builtin_amdgcn_wave_barrier();
+    // read the map back in index order
+    int *out = idx + ((size_t)bs * m + pt) * nsample;
+    int total = 0, first = -1;
+    for (int base = 0; base < words && total < nsample; base += 64) {
+        const int wi = base + lane;
+        unsigned v = wi < words ? bm[wi] : 0u;
+        const int cntl = __popc(v);
+        int incl = cntl;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        int pos = total + incl - cntl;
+        const unsigned long long any = __ballot(cntl > 0);
+        if (first < 0 && any) {
+            const int fl = __ffsll((long long)any) - 1;                            // lowest lane with a hit holds the smallest index
+            const unsigned fv = __shfl(v, fl, 64);
+            first = (base + fl) * 32 + (__ffs((int)fv) - 1);
+        }
+        while (v && pos < nsample) {
+            const int bit = __ffs((int)v) - 1;
+            out[pos++] = wi * 32 + bit;
+            v &= v - 1;
+        }
+        total += __shfl(incl, 63, 64);
+    }
+    if (total > 0 && total < nsample)
+        for (int l = total + lane; l < nsample; l += 64) out[l] = first;           // ball_query_gpu.cu:37-41
+}
+
+static int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
+                           hipStream_t st)
+{
+    const size_t ncs = (size_t)BQG_CELLS + 1;
+    const size_t off_cs = ((size_t)b * sizeof(BqGridHeader) + 255) / 256 * 256;
+    const size_t off_sp = (off_cs + (size_t)b * ncs * sizeof(int) + 255) / 256 * 256;
+    char *scratch = (char *)cmf_stream_scratch(st, 1, off_sp + (size_t)b * n * sizeof(float4));
+    if (!scratch) return (int)hipErrorOutOfMemory;
+    BqGridHeader *hdr = (BqGridHeader *)scratch;
+    int *cs = (int *)(scratch + off_cs);
+    float4 *sp = (float4 *)(scratch + off_sp);
+    hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BQG_THREADS), 0, st, n, radius, xyz, hdr, cs, sp);
+    hipLaunchKernelGGL(bq_grid_query_kernel, dim3(cmf_divup(m, 4), b), dim3(256), 0, st, n, m, radius * radius, nsample, new_xyz,
+                       hdr, cs, sp, idx);
+    return cmf_launch_status();
+}
+
 extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
                               const float *new_xyz, const float *xyz, int *idx, void *stream)
 {
     CMF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample > 0);
     if (b == 0 || m == 0 || n == 0) return 0;
     CMF_CHECK_ARG(new_xyz && xyz && idx);
+    // large clouds: cell grid + index-ordered read-back (CMF_BALL_QUERY_GRID=0 keeps the scan: diagnostics).  A radius that
+    // is not a positive finite number has no grid; the scan handles it like the reference.
+    static const bool use_grid = !(getenv("CMF_BALL_QUERY_GRID") && getenv("CMF_BALL_QUERY_GRID")[0] == '0');
+    if (use_grid && n >= 4096 && n <= BQG_MAX_N && radius > 0.f && radius < 3.0e38f)
+        return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
     dim3 grid(cmf_divup(m, CMF_WAVE), b);
     if (nsample <= BQ_MAX_NS_LDS && n <= 65535 && n >= 64) {
         const int seg = (cmf_divup(n, BQM_NW) + 3) / 4 * 4;

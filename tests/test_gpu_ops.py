@@ -37,6 +37,30 @@ def test_ball_query_bit_exact(dev, B, N, r, ns):
     assert got.dtype == torch.int32 and torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("B,N,M,r,ns,kind", [(2, 4096, 4096, 2.0, 64, "lidar"), (1, 8192, 300, 1.0, 32, "lidar"), (2, 4096, 777, 0.05, 8, "lidar"),
+                                             (1, 4096, 4096, 1.0e4, 16, "lidar"), (1, 5000, 64, 3.0, 5, "line"), (1, 4096, 100, 0.5, 4, "dup"),
+                                             (1, 6000, 50, 2.0, 7, "far")])
+def test_ball_query_cell_grid_bit_exact(dev, B, N, M, r, ns, kind):
+    """Large clouds take the cell-grid kernel (4096 <= N <= 8192: bin, lane-parallel distance tests, index-ordered read-back
+    of a hit bitmap): it must reproduce the scan's "first nsample in index order" exactly -- dense and empty balls, a
+    radius larger than the cloud, degenerate clouds (all points on a line / identical), centres far outside the cloud,
+    m != n (ball_query_gpu.cu:9-45)."""
+    from cmflow_amd.pointnet2_utils import ball_query
+    xyz, other = clouds(B, N, seed=N + ns, lidar=True)
+    if kind == "line":
+        xyz = xyz.clone(); xyz[:, :, 1:] = 0.25
+    if kind == "dup":
+        xyz = xyz[:, :1].expand(B, N, 3).contiguous()
+    ctr = xyz[:, :M].contiguous() if M <= N else xyz
+    if kind == "far":
+        ctr = ctr.clone(); ctr[:, ::2] += 500.0; ctr[:, 1::4] -= 300.0
+    elif M != N:
+        ctr = (other[:, :M] * 1.0).contiguous()
+    ref = orc.ball_query(r, ns, xyz, ctr)
+    got = ball_query(r, ns, xyz.to(dev), ctr.to(dev)).cpu()
+    assert torch.equal(got, ref)
+
+
 def test_ball_query_edge_cases(dev):
     """strict '<', first-hit padding, empty ball leaves the pre-zeroed idx, duplicates, m != n."""
     from cmflow_amd.pointnet2_utils import ball_query
