@@ -302,6 +302,7 @@ class LinearFn(Function):
         # multiply and a reduction as separate torch kernels in the producer's backward
         ctx.preact_grad = preact_grad
         ctx.in_bias = in_bias
+        ctx.w_in = w
         ok = x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[1] % 4 == 0
         x2 = x if ok else _pad_cols(x)
         w2 = _pad_cols(w)
@@ -336,7 +337,10 @@ class LinearFn(Function):
             else:
                 dx = gemm(dyp, wp, b_t=False)[:, :K]
         if ctx.needs_input_grad[1]:
-            dw = gemm_dw(dyp, x2)[:N, :K]
+            if dyp.shape[1] == N and x2.shape[1] == K and grad_sink(ctx.w_in) is not None and grad_sink(ctx.w_in).shape == (N, K):
+                gemm_dw(dyp, x2, w=ctx.w_in)                                    # accumulated in place: no AccumulateGrad add_
+            else:
+                dw = gemm_dw(dyp, x2)[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum(0)
         return dx, dw, db, None, None, dib
