@@ -100,14 +100,15 @@ def join_side_streams(main=None):
 
 def scale_streams(n_scales, cloud=0):
     """The side stream of each scale of a MultiScaleEncoder call (scales ordered by growing neighbourhood).  With four
-    scales on three streams the largest scale (half of the rows) shares its stream with the smallest; the second
-    cloud's call is rotated by one stream.  Measured against other deals of the same pool and against one stream per
-    chain (8 + 4 streams aliased onto the hardware queues by creation order): 26.3 vs 26.4-27.3 ms per step.
+    scales on three streams the two middle scales share a stream, the smallest and the largest (half of the rows) have
+    one each; the second cloud's call is rotated by one stream.  Re-measured after the narrow layers were fused
+    (tools/r02_session33.sh, three runs per deal): 23.1 ms per step against 23.5 for "largest shares with smallest"
+    (the round-1 choice), 23.2-23.6 for five other deals, 24.0 with three scales on one stream.
     CMF_SCALE_SLOTS="a,b,c,d|e,f,g,h" overrides the deal (diagnostics)."""
     if n_scales == 4 and os.environ.get("CMF_SCALE_SLOTS"):
         slots = [int(v) for v in os.environ["CMF_SCALE_SLOTS"].split("|")[cloud % 2].split(",")]
     elif n_scales == 4:
-        slots = ([0, 1, 2, 0], [1, 2, 0, 1])[cloud % 2]
+        slots = ([0, 1, 1, 2], [1, 2, 2, 0])[cloud % 2]
     else:
         slots = [(i + cloud) % N_SIDE for i in range(n_scales)]
     return [side_stream(s) for s in slots]
