@@ -70,6 +70,10 @@ SIGNATURES = {
     "cmf_maxpool_bwd_point": [_ll, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_thin_bwd_layer_pooled": [_ll, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _ci, _vp, _vp],
+    "cmf_thin_bwd_wide_supported": [_ci, _ci],
+    "cmf_thin_bwd_wide_slabs": [_ll, _ci, _vp],
+    "cmf_thin_bwd_wide_layer": [_ll, _ci, _vp, _ll, _vp, _vp, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll,
+                                _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _ll, _ci, _vp, _vp],
     "cmf_thin_bwd_supported": [_ci, _ci],
     "cmf_thin_bwd_slabs": [_ll, _vp],
     "cmf_thin_bwd_layer": [_ll, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _ci,

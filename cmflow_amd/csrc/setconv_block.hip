@@ -278,6 +278,10 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     CMF_TRY(bwd_layer(d, L, 3, P, C4, C3, L.t4, L.z4, d->w[2], L.x, -1, L.dx, nullptr, d->dw[2], d->acc_w[2], st));
     // max over the ball, layers 3 .. 1 (per neighbour slot)
     static const bool fused = !(getenv("CMF_THIN_FUSED") && getenv("CMF_THIN_FUSED")[0] == '0');
+    // the wide-input form of the fused layer (64 <- 256 channels, second encoder) is opt-in: measured equal to the four
+    // kernels it replaces (620 vs 623 us at 524288 rows, 24.0 vs 24.0 ms per step) -- with 128 weight-gradient accumulators
+    // per lane it runs two waves per SIMD without room to prefetch and sits at 35 % MFMA / 2.2 TB/s
+    static const bool wide = getenv("CMF_THIN_WIDE") && getenv("CMF_THIN_WIDE")[0] == '1';
     if (fused && cmf_thin_bwd_supported(C3, C2) && M % 128 == 0 && C3 % 32 == 0 && C2 % 32 == 0 && d->dw[1]) {
         // narrow layers: the gradient of the pooled tensor is kept per POINT (g, in L.dx's neighbour L.dU3) and expanded
         // by the fused layer kernel on the fly -- the [M, C3] matrix is neither written nor read
@@ -289,6 +293,16 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
         CMF_TRY(cmf_thin_bwd_layer_pooled(P, d->S, C3, C2, g, L.argmax, L.z3, b2 + 2 * C3, b2, b2 + C3, d->training ? L.sums : nullptr,
                                           d->w[1], L.z2, b1 + 2 * C2, b1 + 3 * C2, b1, b1 + C2, L.dU2, L.partial, d->dw[1], d->acc_w[1],
                                           L.splitk, st));
+    } else if (fused && wide && cmf_thin_bwd_wide_supported(C3, C2) && M % 128 == 0 && d->dw[1]) {
+        // 64 <- 256 channels (second encoder): the same single pass, a workgroup per (row range, 128 input channels)
+        float *g = L.dU3;
+        CMF_TRY(cmf_maxpool_bwd_point(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, g, L.partial, st));
+        if (d->acc_bn[2]) CMF_TRY(cmf_colsum_finalize(tiles128(P), C3, L.partial, L.sums, d->dbeta[2], d->dgamma[2], st));
+        else CMF_TRY(cmf_colsum_store(tiles128(P), 2 * C3, L.partial, L.sums, C3, d->dbeta[2], d->dgamma[2], st));
+        const float *b1 = L.bn[1];
+        CMF_TRY(cmf_thin_bwd_wide_layer(M, C2, nullptr, C3, g, L.argmax, d->S, L.z3, C3, b2 + 2 * C3, b2, b2 + C3,
+                                        d->training ? L.sums : nullptr, d->w[1], C2, L.z2, C2, b1 + 2 * C2, b1 + 3 * C2, b1, b1 + C2,
+                                        L.dU2, C2, L.partial, d->dw[1], C2, d->acc_w[1], L.splitk, st));
     } else {
         CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
         CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));

@@ -615,6 +615,295 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_layer_kernel(const Thi
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same fused backward layer for a WIDE input: cout = 64, cin a multiple of 128 (the third conv of a second-encoder
+// block, 256 -> 64 channels per neighbour row).  As tiled GEMMs its two products are the worst shapes of the step -- a
+// data gradient with K = 64 (four K-chunks per 128 x 128 tile: all prologue and epilogue) and a weight gradient with 64
+// output rows: 39 TF each, 0.87 ms for the largest scale, plus the max-pool backward and the BN backward as passes of
+// their own.  Here a workgroup owns a range of rows and a HALF of 128 input channels (grid.y): dZ of a 128-row tile is
+// formed once into the per-wave LDS tiles (from the per-point pooled gradient or a stored dU), then for each of its two
+// 64-channel chunks the wave runs the masked data gradient (A from the LDS tile, B = W^T chunk resident in LDS) and the
+// weight gradient (register r = row pair, as above).  The weight-gradient accumulators of both chunks (128 registers)
+// stay live across the workgroup's tiles; dZ is recomputed by the two channel halves (its inputs are 1/5 of the traffic).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TBW_LDO = 68;
+struct ThinBwdWideLds {
+    float tile[4 * 32 * TBW_LDO];           // per-wave dZ tile [32 rows][64]
+    float wt[128 * TBW_LDO];                // W^T of this workgroup's 128 input channels: [n][k]
+    float sred[4][2][128];                  // per-wave column sums of the current tile
+    float ko[4][64], ki[4][128];
+};
+
+template <int MODE>                          // bit 0: train-mode BN, bit 3: pooled dU (in_mode 1, both products, whole tiles)
+__global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const ThinBwdArgs p)
+{
+    constexpr int LDO = TBW_LDO;
+    constexpr bool train = (MODE & 1) != 0, pooled = (MODE & 8) != 0;
+    __shared__ ThinBwdWideLds S;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases stay scalar
+    const int h = lane >> 5, cl = lane & 31;
+    const int col0 = blockIdx.y * 128;                     // first input channel of this workgroup
+    if (threadIdx.x < 64) {
+        const int n = threadIdx.x;
+        S.ko[0][n] = p.a[n];
+        S.ko[1][n] = train ? p.mean[n] : 0.f;
+        S.ko[2][n] = train ? p.invstd[n] * (p.sums[64 + n] * p.inv_count) : 0.f;
+        S.ko[3][n] = train ? p.sums[n] * p.inv_count : 0.f;
+    } else if (threadIdx.x < 192) {
+        const int n = threadIdx.x - 64;
+        S.ki[0][n] = p.a_in[col0 + n]; S.ki[1][n] = p.c_in[col0 + n];
+        S.ki[2][n] = p.mean_in[col0 + n]; S.ki[3][n] = p.invstd_in[col0 + n];
+    }
+    for (int i = threadIdx.x; i < 64 * 128; i += TG_THREADS) {
+        const int k = i >> 7, n = i & 127;
+        S.wt[n * LDO + k] = p.w[(long long)k * p.ldw + col0 + n];
+    }
+    __syncthreads();
+    float *dzt = S.tile + wave * 32 * LDO;
+    f32x16 accw[2][2][2];                                   // [chunk][cout block][cin block]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[c][i][j][r] = 0.f;
+    const unsigned w0 = (unsigned)wave * 32u;
+    const unsigned lane_x = (4u * h * (unsigned)p.ldx + (unsigned)cl) * 4u, lane_dx = (4u * h * (unsigned)p.lddx + (unsigned)cl) * 4u;
+
+    for (int t = 0; t < p.tiles_per_wg; ++t) {
+        const long long tile = (long long)blockIdx.x * p.tiles_per_wg + t;
+        if (tile * 128 >= p.rows) break;
+        // Per-lane LDS offsets, made opaque once per tile: as loop invariants the compiler materialises EVERY (offset +
+        // constant) address of the tile body as a live register of its own (130-190 spilled registers); behind the empty
+        // asm they are values of this iteration and the constants fold into the DS instructions' offset fields.
+        int oA = (lane & 31) * LDO + 4 * h, oC = 4 * h * LDO + cl, oW = cl * LDO + 4 * h, oK = 4 * h, oN = cl;
+        unsigned lx = lane_x, ldx_ = lane_dx;                  // same for the per-lane part of the global addresses
+        int ldx_s = (int)p.ldx, lddx_s = (int)p.lddx;           // ... and for the row strides (else 128 hoisted row bases)
+        asm volatile("" : "+v"(oA), "+v"(oC), "+v"(oW), "+v"(oK), "+v"(oN), "+v"(lx), "+v"(ldx_), "+s"(ldx_s), "+s"(lddx_s));
+        const float *zt = train ? p.z + tile * 128 * p.ldz : nullptr;
+        const float *xt = p.x + tile * 128 * p.ldx + col0;
+        float *dxt = p.dx + tile * 128 * p.lddx + col0;
+        // ---- dZ of the wave's 32 rows (rows on the lanes) into its LDS tile ----
+        {
+            const unsigned mrow = w0 + (unsigned)(lane & 31);
+            const unsigned oz = (mrow * (unsigned)p.ldz + 4u * h) * 4u;
+            unsigned ou = 0, pool_s = 0;
+            const float *src = nullptr;
+            if (pooled) {
+                const long long m = tile * 128 + mrow;
+                const long long pt = m / p.pool_S;
+                pool_s = (unsigned)(m - pt * p.pool_S);
+                ou = (unsigned)((pt * 64 + 4 * h) * 4);
+                src = p.pool_g;
+            } else {
+                ou = (mrow * (unsigned)p.lddu + 4u * h) * 4u;
+                src = p.dU + tile * 128 * p.lddu;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 8; kb += 4) {                    // two halves: 32 load registers in flight next to 128 accumulators
+            float4 dv[4], zv[4];
+#pragma unroll
+            for (int ku = 0; ku < 4; ++ku) {
+                const int k8 = kb + ku;
+                if (pooled) {
+                    const float4 g4 = tb_ld4(src, ou + 32u * k8);
+                    const uchar4 am = *(const uchar4 *)(p.pool_am + (ou >> 2) + 8u * k8);
+                    dv[ku] = make_float4(am.x == pool_s ? g4.x : 0.f, am.y == pool_s ? g4.y : 0.f, am.z == pool_s ? g4.z : 0.f,
+                                         am.w == pool_s ? g4.w : 0.f);
+                } else dv[ku] = tb_ld4(src, ou + 32u * k8);
+                zv[ku] = train ? tb_ld4(zt, oz + 32u * k8) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int ku = 0; ku < 4; ++ku) {
+                const int k8 = kb + ku;
+                float4 d = dv[ku];
+                const float4 sa = *(const float4 *)&S.ko[0][oK + 8 * k8];
+                if (train) {
+                    const float4 v = zv[ku];
+                    const float4 mu = *(const float4 *)&S.ko[1][oK + 8 * k8], u = *(const float4 *)&S.ko[2][oK + 8 * k8],
+                                 t1 = *(const float4 *)&S.ko[3][oK + 8 * k8];
+                    d.x = sa.x * (d.x - t1.x - (v.x - mu.x) * u.x);
+                    d.y = sa.y * (d.y - t1.y - (v.y - mu.y) * u.y);
+                    d.z = sa.z * (d.z - t1.z - (v.z - mu.z) * u.z);
+                    d.w = sa.w * (d.w - t1.w - (v.w - mu.w) * u.w);
+                } else { d.x *= sa.x; d.y *= sa.y; d.z *= sa.z; d.w *= sa.w; }
+                *(float4 *)(dzt + oA + 8 * k8) = d;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float (*sr)[2][128] = S.sred;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            // layer input of this chunk in the accumulator layout
+            // (row base pointers are wave-uniform -> scalar registers; the only per-lane address register is lane_x)
+            float xc[2][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *xr = xt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * ldx_s) + ch * 64;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xc[j][r] = tb_ld(xr + j * 32, lx);
+            }
+            // data gradient of the chunk: A from the LDS tile, B = W^T chunk
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const float4 d = *(const float4 *)(dzt + oA + 8 * k8);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 b = *(const float4 *)&S.wt[oW + (ch * 64 + j * 32) * LDO + 8 * k8];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, b.x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.y, b.y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.z, b.z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.w, b.w, acc[j], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = oN + ch * 64 + j * 32;
+                const float ia = S.ki[0][n], ic = S.ki[1][n], im = S.ki[2][n], ii = S.ki[3][n];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float zz = xc[j][r];
+                    const float v = (fmaf(ia, zz, ic) > 0.f) ? acc[j][r] : 0.f;
+                    s1 += v; s2 += v * ((zz - im) * ii);
+                    float *dr = dxt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * lddx_s) + ch * 64 + j * 32;
+                    *(float *)((char *)dr + ldx_) = v;
+                    xc[j][r] = fmaxf(fmaf(ia, zz, ic), 0.f);           // activated: B operand of the weight gradient
+                }
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32) { sr[wave][0][n] = s1; sr[wave][1][n] = s2; }
+            }
+            // weight gradient of the chunk
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *src = dzt + oC + ((r & 3) + 8 * (r >> 2)) * LDO;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const float dz = src[i * 32];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        accw[ch][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, xc[j][r], accw[ch][i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int i = threadIdx.x;      // 2 * 128 outputs, one per thread
+            const int which = i >> 7, n = i & 127;
+            p.stats[(tile * 2 + which) * p.cin + col0 + n] = sr[0][which][n] + sr[1][which][n] + sr[2][which][n] + sr[3][which][n];
+        }
+        __syncthreads();                    // the sums are rewritten by the next tile
+    }
+    __syncthreads();                        // tiles and W^T are dead: their LDS becomes the reduction buffer (2 x 8 blocks x 4 KB)
+    float (*red)[8 * 16 * CMF_WAVE] = (float (*)[8 * 16 * CMF_WAVE])S.tile;
+    static_assert(sizeof(S.tile) + sizeof(S.wt) >= 2 * 8 * 16 * CMF_WAVE * sizeof(float), "reduction buffer");
+    auto put = [&](float *dst) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((((c * 2 + i) * 2 + j) * 16) + r) * CMF_WAVE + lane] = accw[c][i][j][r];
+    };
+    auto add = [&](const float *src) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accw[c][i][j][r] += src[((((c * 2 + i) * 2 + j) * 16) + r) * CMF_WAVE + lane];
+    };
+    if (wave >= 2) put(red[wave - 2]);
+    __syncthreads();
+    if (wave < 2) add(red[wave]);
+    __syncthreads();
+    if (wave == 1) put(red[0]);
+    __syncthreads();
+    if (wave != 0) return;
+    add(red[0]);
+    float *slab = p.slabs + (long long)blockIdx.x * 64 * p.cin + col0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = c * 64 + j * 32 + cl;
+                    slab[(long long)n * p.cin + k] = accw[c][i][j][r];
+                }
+}
+
+extern "C" int cmf_thin_bwd_wide_supported(int cout, int cin) { return cout == 64 && cin >= 128 && cin % 128 == 0 && cin <= 1024; }
+
+// row slabs of the wide form: one round of 512 resident workgroups over (row slabs) x (cin / 128 channel halves)
+extern "C" int cmf_thin_bwd_wide_slabs(long long rows, int cin, int *tiles_per_wg)
+{
+    const long long tiles = (rows + 127) / 128;
+    long long split = 512 / (cin / 128 > 0 ? cin / 128 : 1);
+    if (split < 1) split = 1;
+    if (split > tiles) split = tiles;
+    if (split < 1) split = 1;
+    const long long tpw = (tiles + split - 1) / split;
+    if (tiles_per_wg) *tiles_per_wg = (int)tpw;
+    return (int)((tiles + tpw - 1) / tpw);
+}
+
+// dU given ([rows][64], row stride lddu) or pooled (pool_g != NULL: rows = P * pool_S, see cmf_thin_bwd_layer_pooled)
+extern "C" int cmf_thin_bwd_wide_layer(long long rows, int cin, const float *dU, long long lddu, const float *pool_g,
+                                       const unsigned char *pool_am, int pool_S, const float *z, long long ldz,
+                                       const float *a, const float *mean, const float *invstd, const float *sums,
+                                       const float *w, long long ldw, const float *x, long long ldx,
+                                       const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in,
+                                       float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
+                                       void *stream)
+{
+    const bool pooled = pool_g != nullptr;
+    CMF_CHECK_ARG(rows >= 0 && rows % 128 == 0 && cmf_thin_bwd_wide_supported(64, cin));
+    if (rows == 0) return 0;
+    CMF_CHECK_ARG((pooled || dU) && a && w && x && (!sums || (z && mean && invstd)) && dx && dw && stats && slabs);
+    CMF_CHECK_ARG(a_in && c_in && mean_in && invstd_in);
+    CMF_CHECK_ARG(pooled || (lddu % 4 == 0 && (uintptr_t)dU % 16 == 0));
+    CMF_CHECK_ARG(!sums || (ldz % 4 == 0 && (uintptr_t)z % 16 == 0));
+    CMF_CHECK_ARG(128ll * std::max({lddu, ldz, ldx, lddx}) * 4 < (1ll << 31));
+    if (pooled) CMF_CHECK_ARG(pool_am && pool_S > 0 && rows % pool_S == 0 && (uintptr_t)pool_g % 16 == 0 && (uintptr_t)pool_am % 4 == 0 &&
+                              (rows / pool_S) * 64 * 4 < (1ll << 32));
+    ThinBwdArgs p;
+    p.rows = rows; p.cout = 64; p.cin = cin; p.dU = dU; p.lddu = lddu; p.z = z; p.ldz = ldz;
+    p.a = a; p.mean = mean; p.invstd = invstd; p.sums = sums; p.inv_count = (float)(1.0 / (double)rows);
+    p.w = w; p.ldw = ldw; p.x = x; p.ldx = ldx; p.in_mode = 1;
+    p.a_in = a_in; p.c_in = c_in; p.mean_in = mean_in; p.invstd_in = invstd_in; p.dxyz = nullptr;
+    p.dx = dx; p.lddx = lddx; p.stats = stats; p.slabs = slabs;
+    p.pool_g = pool_g; p.pool_am = pool_am; p.pool_S = pool_S;
+    const int nslab = cmf_thin_bwd_wide_slabs(rows, cin, &p.tiles_per_wg);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(nslab, cin / 128), block(TG_THREADS);
+    const int mode = (sums ? 1 : 0) | (pooled ? 8 : 0);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL((thin_bwd_wide_kernel<0>), grid, block, 0, st, p); break;
+        case 1: hipLaunchKernelGGL((thin_bwd_wide_kernel<1>), grid, block, 0, st, p); break;
+        case 8: hipLaunchKernelGGL((thin_bwd_wide_kernel<8>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((thin_bwd_wide_kernel<9>), grid, block, 0, st, p); break;
+    }
+    int err = cmf_launch_status();
+    if (err) return err;
+    cmf_gemm_count_flops(4.0 * rows * 64 * cin);
+    return cmf_splitk_reduce(64, cin, nslab, slabs, dw, lddw, accumulate, st);
+}
+
 // slabs of the fused layer for `rows` rows: workgroups take whole 128-row tiles, at most 1024 of them (the rule of
 // dw_split's thin branch, rounded to tiles -- never more slabs than dw_split sizes the workspace for)
 extern "C" int cmf_thin_bwd_slabs(long long rows, int *tiles_per_wg)

@@ -229,6 +229,21 @@ int cmf_thin_bwd_layer_pooled(long long P, int S, int cout, int cin, const float
                               const float *invstd_in, float *dx, float *stats, float *dw, int accumulate, float *slabs,
                               void *stream);
 
+/* The fused backward layer for a WIDE input: cout = 64, cin a multiple of 128 (<= 1024), whole 128-row tiles, input
+ * through BN + ReLU (in_mode 1), both products -- the 256 -> 64 conv of a second-encoder block (radarflow_util.py:144-162),
+ * whose two gradients are the worst GEMM shapes of the step (K = 64 / 64 output rows).  dU is either given
+ * ([rows][64], row stride lddu) or pooled (pool_g != NULL: rows = P * pool_S, per-point arrays of cmf_maxpool_bwd_point).
+ * slabs: cmf_thin_bwd_wide_slabs(rows, cin, NULL) x 64 x cin floats of workspace. */
+int cmf_thin_bwd_wide_supported(int cout, int cin);
+int cmf_thin_bwd_wide_slabs(long long rows, int cin, int *tiles_per_workgroup);
+int cmf_thin_bwd_wide_layer(long long rows, int cin, const float *dU, long long lddu, const float *pool_g,
+                            const unsigned char *pool_am, int pool_S, const float *z, long long ldz,
+                            const float *a, const float *mean, const float *invstd, const float *sums,
+                            const float *w, long long ldw, const float *x, long long ldx,
+                            const float *a_in, const float *c_in, const float *mean_in, const float *invstd_in,
+                            float *dx, long long lddx, float *stats, float *dw, long long lddw, int accumulate, float *slabs,
+                            void *stream);
+
 /* Backward of the set-conv's grouping with the BatchNorm backward of the first layer fused in
  * (radarflow_util.py:148-151 backward): dZ = a*(dU - s1/M - zhat*s2/M) is formed on the fly from dU and z,
  * summed over the inverse index into grad_feat (b,n,c) with row stride ldg, and never written.  sums = {s1[C], s2[C]} or NULL

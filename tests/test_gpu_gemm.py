@@ -409,3 +409,59 @@ def test_pooled_thin_bwd_layer_matches_materialised_gradient(dev, gemm_mode, P, 
     assert torch.equal(dx0 == 0, dx1 == 0)
     for a, b in ((dx0, dx1), (st0, st1), (dw0, dw1)):
         assert float((a - b).abs().max()) <= 2e-5 * scale(a)
+
+
+@pytest.mark.parametrize("P,S,cin,train,pooled", [(2048, 8, 256, True, True), (1024, 32, 128, True, True), (4096, 4, 256, False, True),
+                                                  (2048, 16, 256, True, False), (512, 4, 384, True, False)])
+def test_wide_thin_bwd_layer_matches_three_kernel_form(dev, gemm_mode, P, S, cin, train, pooled):
+    """cmf_thin_bwd_wide_layer (64 <- cin in {128, 256, ...}: the 256 -> 64 conv of a second-encoder block, backward in one
+    pass, optionally straight from the per-point max-pool gradient) against max-pool backward + BN backward in place + the
+    two tiled GEMMs it replaces.  Same masks; sums regrouped: tolerance of a few fp32 ulps of the accumulated magnitudes."""
+    if gemm_mode != "fp32":
+        pytest.skip("thin kernels have one arithmetic")
+    import ctypes
+    from cmflow_amd import _lib, fused_blocks as FB
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    M, cout = P * S, 64
+    g = torch.Generator(device="cpu").manual_seed(P + S + cin)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    z3, z2, dout = rnd(M, cout), rnd(M, cin), rnd(P, cout)
+    w = rnd(cout, cin) * 0.1
+    st = FB.BNState()
+    st.a, st.c, st.mean, st.invstd = rnd(cout), rnd(cout) * 0.3, rnd(cout) * 0.3, torch.rand(cout, generator=g).to(dev) + 0.5
+    st.training, st.count = train, M
+    a_in, c_in, mean_in, invstd_in = rnd(cin), rnd(cin) * 0.3, rnd(cin) * 0.3, torch.rand(cin, generator=g).to(dev) + 0.5
+    _, am = FB.bn_relu_maxpool(z3.view(P, S, cout), st)
+    p = lambda t: None if t is None else t.data_ptr()
+    # reference: the three-kernel form on the materialised gradient
+    dU, part = FB.maxpool_bwd(dout, z3.view(P, S, cout), st, am)
+    sums0 = FB.colsum_n(part)
+    dZ = dU.clone()
+    _lib.check(L.cmf_bn_bwd_apply(M, cout, p(dZ), p(z3), cout, p(st.a), p(st.mean), p(st.invstd), p(sums0) if train else None,
+                                  _lib.stream_ptr()), "apply")
+    dw0 = FB.gemm_dw(dZ, z2, prob=(a_in, c_in))
+    dx0, st0 = gemm(dZ, w, b_t=False, bwd=(1, z2, a_in, c_in, mean_in, invstd_in))
+    # fused
+    tiles = M // 128
+    nslab = L.cmf_thin_bwd_wide_slabs(M, cin, None)
+    slabs = torch.empty(nslab, cout, cin, device=dev)
+    dx1 = torch.full((M, cin), float("nan"), device=dev); st1 = torch.full((tiles, 2, cin), float("nan"), device=dev)
+    dw1 = torch.zeros(cout, cin, device=dev)
+    if pooled:
+        gp = torch.empty(P, cout, device=dev); part1 = torch.empty((P + 127) // 128, 2, cout, device=dev)
+        _lib.check(L.cmf_maxpool_bwd_point(P, S, cout, p(dout), cout, p(z3), p(st.a), p(st.c), p(st.mean), p(st.invstd), p(am), p(gp),
+                                           p(part1), _lib.stream_ptr()), "maxpool_bwd_point")
+        sums1 = FB.colsum_n(part1)
+        src = (None, cout, p(gp), p(am), S)
+    else:
+        sums1 = sums0
+        src = (p(dU), cout, None, None, 0)
+    _lib.check(L.cmf_thin_bwd_wide_layer(M, cin, *src, p(z3), cout, p(st.a), p(st.mean), p(st.invstd), p(sums1) if train else None,
+                                         p(w), cin, p(z2), cin, p(a_in), p(c_in), p(mean_in), p(invstd_in), p(dx1), cin, p(st1), p(dw1), cin, 0,
+                                         p(slabs), _lib.stream_ptr()), "wide")
+    scale = lambda t: max(1.0, float(t.abs().max()))
+    assert torch.equal(dx0 == 0, dx1 == 0)
+    assert float((dx0 - dx1).abs().max()) <= 2e-5 * scale(dx0)
+    assert float((st0 - st1).abs().max()) <= 2e-5 * scale(st0)
+    assert float((dw0 - dw1).abs().max()) <= 3e-5 * scale(dw0)

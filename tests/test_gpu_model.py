@@ -495,7 +495,7 @@ def test_side_streams_do_not_change_results(dev, manifest, golden_dir, args):
     from cmflow_amd.radarflow_util import FeatureCorrelator
     from cmflow_amd.train import TrainStep
     assert FB.side_stream(0) is FB.side_stream(FB.N_SIDE) and len({FB.side_stream(i) for i in range(FB.N_SIDE)}) == FB.N_SIDE
-    assert [s is FB.side_stream(i) for s, i in zip(FB.scale_streams(4, 0), (0, 1, 2, 0))] == [True] * 4
+    assert [s is FB.side_stream(i) for s, i in zip(FB.scale_streams(4, 0), (0, 1, 1, 2))] == [True] * 4
     b = {k: v.to(dev) for k, v in synth.make_batch(8, seed=77, train_extras=True).items()}
     results = []
     for side in (True, False, True):
