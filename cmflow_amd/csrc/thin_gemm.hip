@@ -386,22 +386,30 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
     float *dxt = has_dx ? p.dx + tile * 128 * p.lddx : nullptr;
     float *dzt = S.tile + wave * 32 * LDO;
     const unsigned w0 = (unsigned)wave * 32u;
-    const unsigned ldxb = (unsigned)p.ldx * 4u, lddxb = (unsigned)p.lddx * 4u;
+    // Per-lane offsets (LDS and global) and the row strides are made opaque once per tile: as loop invariants the compiler
+    // materialises every (offset + constant) address of the tile body as a live register of its own and spills them;
+    // behind the empty asm they belong to this iteration, the constants fold into the instructions' offset fields and the
+    // row bases stay in scalar registers.
+    int oA = (lane & 31) * LDO + 4 * h, oC = 4 * h * LDO + cl, oW = cl * LDO + 4 * h, oK = 4 * h, oN = cl;
+    int ldx_s = (int)p.ldx, lddx_s = (int)p.lddx;
+    unsigned lx = (4u * h * (unsigned)p.ldx + (unsigned)cl) * 4u, ldx_ = (4u * h * (unsigned)p.lddx + (unsigned)cl) * 4u;
+    asm volatile("" : "+v"(oA), "+v"(oC), "+v"(oW), "+v"(oK), "+v"(oN), "+v"(lx), "+v"(ldx_), "+s"(ldx_s), "+s"(lddx_s));
     // ---- layer input in the accumulator layout (lane = channel, register r = rows rho(r) + 4h): mask of the data
     //      gradient, B operand of the weight gradient.  Issued first: it is consumed last. ----
     float xc[NTI][16];
-    const unsigned xo = (w0 + 4u * h) * ldxb + (unsigned)cl * 4u;
 #pragma unroll
-    for (int j = 0; j < NTI; ++j)
+    for (int r = 0; r < 16; ++r) {
+        const unsigned rho = (unsigned)((r & 3) + 8 * (r >> 2));
+        const float *xr = xt + (long long)((int)(w0 + rho) * ldx_s);          // wave-uniform row base
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned rho = (unsigned)((r & 3) + 8 * (r >> 2));
-            if (FULL) xc[j][r] = tb_ld(xt, xo + rho * ldxb + j * 128u);
+        for (int j = 0; j < NTI; ++j) {
+            if (FULL) xc[j][r] = tb_ld(xr + j * 32, lx);
             else {
                 const unsigned m = w0 + rho + 4u * h, n = (unsigned)(j * 32 + cl);
-                xc[j][r] = (m < live && n < cin) ? tb_ld(xt, xo + rho * ldxb + j * 128u) : 0.f;
+                xc[j][r] = (m < live && n < cin) ? tb_ld(xr + j * 32, lx) : 0.f;
             }
         }
+    }
     if (want_q && lane < 32) {
         const unsigned m = w0 + (unsigned)lane;
         S.dq[wave][lane] = (FULL || m < live) ? *(const float4 *)(p.dxyz + (tile * 128 + m) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -444,23 +452,23 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
         for (int ku = 0; ku < CH; ++ku) {
             const int k8 = kb + ku;
             if (k8 >= ks) break;
-            const int k = 8 * k8 + 4 * h;
             float4 d = dv[ku];
-            const float4 sa = *(const float4 *)&S.ko[0][k];
+            const float4 sa = *(const float4 *)&S.ko[0][oK + 8 * k8];
             if (train) {
                 const float4 v = zv[ku];
-                const float4 mu = *(const float4 *)&S.ko[1][k], u = *(const float4 *)&S.ko[2][k], t1 = *(const float4 *)&S.ko[3][k];
+                const float4 mu = *(const float4 *)&S.ko[1][oK + 8 * k8], u = *(const float4 *)&S.ko[2][oK + 8 * k8],
+                             t1 = *(const float4 *)&S.ko[3][oK + 8 * k8];
                 d.x = sa.x * (d.x - t1.x - (v.x - mu.x) * u.x);
                 d.y = sa.y * (d.y - t1.y - (v.y - mu.y) * u.y);
                 d.z = sa.z * (d.z - t1.z - (v.z - mu.z) * u.z);
                 d.w = sa.w * (d.w - t1.w - (v.w - mu.w) * u.w);
             } else { d.x *= sa.x; d.y *= sa.y; d.z *= sa.z; d.w *= sa.w; }
             if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (has_dw) *(float4 *)(dzt + (lane & 31) * LDO + k) = d;
+            if (has_dw) *(float4 *)(dzt + oA + 8 * k8) = d;
             if (has_dx) {
 #pragma unroll
                 for (int j = 0; j < NTI; ++j) {
-                    const float4 b = *(const float4 *)&S.wt[(j * 32 + cl) * LDO + k];
+                    const float4 b = *(const float4 *)&S.wt[oW + j * 32 * LDO + 8 * k8];
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, b.x, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.y, b.y, acc[j], 0, 0, 0);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.z, b.z, acc[j], 0, 0, 0);
@@ -472,12 +480,11 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
     if (has_dx) {
         // epilogue of the data gradient: ReLU mask of the layer below, its BN-backward partial sums, store
         float (*sr)[5][NTI * 32] = S.sred[parity];
-        const unsigned so = (w0 + 4u * h) * lddxb + (unsigned)cl * 4u;
 #pragma unroll
         for (int j = 0; j < NTI; ++j) {
             const unsigned n = (unsigned)(j * 32 + cl);
             const bool nok = FULL || n < cin;
-            const float ia = S.ki[0][j * 32 + cl], ic = S.ki[1][j * 32 + cl], im = S.ki[2][j * 32 + cl], ii = S.ki[3][j * 32 + cl];
+            const float ia = S.ki[0][oN + j * 32], ic = S.ki[1][oN + j * 32], im = S.ki[2][oN + j * 32], ii = S.ki[3][oN + j * 32];
             float s1 = 0.f, s2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -490,7 +497,8 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
                         s1 += v; s2 += v * ((zz - im) * ii);
                         if (want_q) { const float4 dd = S.dq[wave][mr]; q0 += v * dd.x; q1 += v * dd.y; q2 += v * dd.z; }
                     }
-                    *(float *)((char *)dxt + (so + rho * lddxb + j * 128u)) = v;
+                    float *dr = dxt + (long long)((int)(w0 + rho) * lddx_s) + j * 32;
+                    *(float *)((char *)dr + ldx_) = v;
                 }
             }
             if (in_mode == 1) {
@@ -515,14 +523,14 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
         if (in_mode == 1) {
 #pragma unroll
             for (int j = 0; j < NTI; ++j) {
-                const float ia = S.ki[0][j * 32 + cl], ic = S.ki[1][j * 32 + cl];
+                const float ia = S.ki[0][oN + j * 32], ic = S.ki[1][oN + j * 32];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) xc[j][r] = fmaxf(fmaf(ia, xc[j][r], ic), 0.f);
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float *src = dzt + ((r & 3) + 8 * (r >> 2) + 4 * h) * LDO + cl;
+            const float *src = dzt + oC + ((r & 3) + 8 * (r >> 2)) * LDO;
 #pragma unroll
             for (int i = 0; i < NTO; ++i) {
                 const float dz = src[i * 32];
@@ -536,11 +544,11 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
 
 // FULL (decided by the host): rows % 128 == 0, cout == NTO * 32, cin == NTI * 32 -- the kernel then contains no ragged-edge code
 template <int NTO, int NTI, int MODE, bool FULL>
-__global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_layer_kernel(const ThinBwdArgs p)
+__global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_kernel(const ThinBwdArgs p)
 {
     constexpr int LDO = ThinBwdLds<NTO, NTI>::LDO;
     __shared__ ThinBwdLds<NTO, NTI> S;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases stay scalar
     const int h = lane >> 5, cl = lane & 31;
     const bool train = p.sums != nullptr;
     if (threadIdx.x < NTO * 32) {
@@ -904,19 +912,21 @@ extern "C" int cmf_thin_bwd_wide_layer(long long rows, int cin, const float *dU,
     return cmf_splitk_reduce(64, cin, nslab, slabs, dw, lddw, accumulate, st);
 }
 
-// slabs of the fused layer for `rows` rows: workgroups take whole 128-row tiles, at most 1024 of them (the rule of
-// dw_split's thin branch, rounded to tiles -- never more slabs than dw_split sizes the workspace for)
-extern "C" int cmf_thin_bwd_slabs(long long rows, int *tiles_per_wg)
+// slabs of the fused layer for `rows` rows: workgroups take whole 128-row tiles.  One round of resident workgroups: three
+// per CU for <= 32 input channels (<= 168 registers), two otherwise -- 1024 slabs of 4 tiles ran 1.33 rounds, a third of
+// the chip idle in the second.  Never more than dw_split's thin rule max(2, min(rows / 128, 1024)) sizes the workspace for.
+static int thin_bwd_slabs_for(long long rows, int cap, int *tiles_per_wg)
 {
     const long long tiles = (rows + 127) / 128;
-    // two workgroups are resident per CU (register budget of 2 waves per SIMD): at most one round of 512 workgroups, each
-    // walking its share of the tiles -- 1024 slabs of 4 tiles ran 1.33 rounds, a third of the chip idle in the second
-    long long split = rows / 128 < 512 ? rows / 128 : 512;                       // <= dw_split's thin rule max(2, min(rows / 128, 1024))
+    long long split = rows / 128 < cap ? rows / 128 : cap;
     if (split < 2) split = 2;
     const long long tpw = (tiles + split - 1) / split;
     if (tiles_per_wg) *tiles_per_wg = (int)tpw;
     return (int)((tiles + tpw - 1) / tpw);
 }
+
+// upper bound of the slab count (what a caller sizes `slabs` with)
+extern "C" int cmf_thin_bwd_slabs(long long rows, int *tiles_per_wg) { return thin_bwd_slabs_for(rows, 768, tiles_per_wg); }
 
 extern "C" int cmf_thin_bwd_supported(int cout, int cin)
 {
@@ -953,7 +963,7 @@ static int thin_bwd_layer_impl(long long rows, int cout, int cin, const float *d
     p.a_in = a_in; p.c_in = c_in; p.mean_in = mean_in; p.invstd_in = invstd_in; p.dxyz = in_mode == 1 ? dxyz : nullptr;
     p.dx = dx; p.lddx = lddx; p.stats = stats; p.slabs = dw ? slabs : nullptr;
     p.pool_g = pool_g; p.pool_am = pool_am; p.pool_S = pool_S;
-    const int nslab = cmf_thin_bwd_slabs(rows, &p.tiles_per_wg);
+    const int nslab = thin_bwd_slabs_for(rows, cin > 32 ? 512 : 768, &p.tiles_per_wg);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(nslab), block(TG_THREADS);
     // the set-conv chains always want both products of whole tiles: their switch combinations are compiled in (MODE,
