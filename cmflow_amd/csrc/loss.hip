@@ -22,6 +22,7 @@ constexpr int LS_THREADS = 256;
 constexpr int LS_NB = 8;                    // smoothness neighbours (radar_loss.py:66 num_nb)
 constexpr int LS_MAX_N = 704;               // 48 words of LDS per point
 constexpr int LS_WORDS_PER_POINT = 48;
+constexpr int LS_INV_MAX_N = 512;           // + 10 words per point (inverse list of pass 3) while that fits next to the rest
 constexpr int LS_PARTIALS = 8;              // sc, ss, rd, em, ms0, ms1, of, dyn  (per-sample un-normalised sums)
 
 __device__ __forceinline__ float ls_sqnorm3(float x, float y, float z)
@@ -107,6 +108,7 @@ struct LossArgs {
     const float *pre_trans, *gt_trans, *cam_inv, *t_cr;
     float w_self, w_em, w_ms, w_opt, w_dyn, zeta, alpha, lower_bound;
     int self_only;
+    int use_inv;                // pass 3 through an inverse list of the pushed gradients (N <= LS_INV_MAX_N)
     const float *counts;
     float *partials, *d_pred_f, *d_pre_trans, *d_mseg_pre;
 };
@@ -329,19 +331,76 @@ __global__ __launch_bounds__(LS_THREADS) void loss_sample_kernel(const LossArgs 
     }
     __syncthreads();
     // ---------------- pass 3: gather the gradients other points push onto this one ----------------
+    // Every point scanning all N + 8 N pushes for its own (2304 LDS reads per thread at N = 256) was half of the kernel's
+    // 280 us.  Instead the pushes are binned by target -- id j < N: chamfer pair of pc2_j, id N + e: smoothness pair e --
+    // with a counting sort whose bins are then sorted by id, so a point adds its ~9 pushes in exactly the order the scan
+    // visited them (chamfer j ascending, then pairs e ascending): bit-identical sums.
+    int *inv_lst = reinterpret_cast<int *>(gv + 3 * LS_NB * N);       // [9 N] ids binned by target
+    int *inv_end = inv_lst + (LS_NB + 1) * N;                           // [N + 1] bin ends (cursor during the fill)
+    if (a.use_inv) {
+        for (int i = tid; i <= N; i += LS_THREADS) inv_end[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < N; j += LS_THREADS) if (arg2[j] >= 0) atomicAdd(&inv_end[arg2[j] + 1], 1);
+        for (int e = tid; e < N * LS_NB; e += LS_THREADS) atomicAdd(&inv_end[nbr[e] + 1], 1);
+        __syncthreads();
+        {   // inclusive scan of inv_end[1 .. N] (N <= 512: two entries per thread), wave scan + wave totals
+            __shared__ int wsum[LS_THREADS / 64];
+            const int i0 = 1 + 2 * tid;
+            const int v0 = i0 <= N ? inv_end[i0] : 0, v1 = i0 + 1 <= N ? inv_end[i0 + 1] : 0;
+            int incl = v0 + v1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += t; }
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+            __syncthreads();
+            int before = incl - (v0 + v1);
+            for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+            // inv_end[i] becomes the START of bin i - 1 ... shifted: after this, inv_end[t + 1] = start of bin t's successor;
+            // stored as cursor: inv_end[i0 - 1 + 1] -- keep it simple: write exclusive starts into place i (bin i - 1 starts at inv_end[i - 1])
+            if (i0 <= N) inv_end[i0] = before + v0;
+            if (i0 + 1 <= N) inv_end[i0 + 1] = before + v0 + v1;
+        }
+        __syncthreads();
+        // now inv_end[t + 1] = end of bin t and inv_end[t] = its start; fill with a cursor per bin kept in the bin's START slot:
+        // the cursor of bin t is inv_end[t] and finishes at inv_end[t + 1]'s value, so afterwards inv_end[t] == end of bin t
+        for (int j = tid; j < N; j += LS_THREADS)
+            if (arg2[j] >= 0) inv_lst[atomicAdd(&inv_end[arg2[j]], 1)] = j;
+        for (int e = tid; e < N * LS_NB; e += LS_THREADS) inv_lst[atomicAdd(&inv_end[nbr[e]], 1)] = N + e;
+        __syncthreads();
+    }
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int i = tid + q * LS_THREADS;
         if (i >= N) continue;
         const float wx = pw[i], wy = pw[N + i], wz = pw[2 * N + i];
-        for (int j = 0; j < N; ++j)                       // chamfer term 2: pc2_j whose nearest warped point is i
-            if (arg2[j] == i) {
-                gx[q] += k_self * 2.0f * (wx - p2[j]);
-                gy[q] += k_self * 2.0f * (wy - p2[N + j]);
-                gz[q] += k_self * 2.0f * (wz - p2[2 * N + j]);
+        if (a.use_inv) {
+            const int s0 = i > 0 ? inv_end[i - 1] : 0, s1 = inv_end[i];       // bin i (ends double as the next bin's start)
+            for (int u = s0 + 1; u < s1; ++u) {                               // insertion sort by id (bins hold ~9 entries)
+                const int v = inv_lst[u];
+                int w = u - 1;
+                while (w >= s0 && inv_lst[w] > v) { inv_lst[w + 1] = inv_lst[w]; --w; }
+                inv_lst[w + 1] = v;
             }
-        for (int e = 0; e < N * LS_NB; ++e)               // smoothness pairs (i', k) whose neighbour is i
-            if (nbr[e] == i) { gx[q] += gv[e * 3]; gy[q] += gv[e * 3 + 1]; gz[q] += gv[e * 3 + 2]; }
+            for (int u = s0; u < s1; ++u) {
+                const int id = inv_lst[u];
+                if (id < N) {
+                    gx[q] += k_self * 2.0f * (wx - p2[id]);
+                    gy[q] += k_self * 2.0f * (wy - p2[N + id]);
+                    gz[q] += k_self * 2.0f * (wz - p2[2 * N + id]);
+                } else {
+                    const int e = id - N;
+                    gx[q] += gv[e * 3]; gy[q] += gv[e * 3 + 1]; gz[q] += gv[e * 3 + 2];
+                }
+            }
+        } else {
+            for (int j = 0; j < N; ++j)                       // chamfer term 2: pc2_j whose nearest warped point is i
+                if (arg2[j] == i) {
+                    gx[q] += k_self * 2.0f * (wx - p2[j]);
+                    gy[q] += k_self * 2.0f * (wy - p2[N + j]);
+                    gz[q] += k_self * 2.0f * (wz - p2[2 * N + j]);
+                }
+            for (int e = 0; e < N * LS_NB; ++e)               // smoothness pairs (i', k) whose neighbour is i
+                if (nbr[e] == i) { gx[q] += gv[e * 3]; gy[q] += gv[e * 3 + 1]; gz[q] += gv[e * 3 + 2]; }
+        }
         if (a.d_pred_f) { a.d_pred_f[o3 + i] = gx[q]; a.d_pred_f[o3 + N + i] = gy[q]; a.d_pred_f[o3 + 2 * N + i] = gz[q]; }
     }
     // ---------------- per-sample partial sums ----------------
@@ -416,7 +475,8 @@ extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
     if (!d->self_only)
         hipLaunchKernelGGL(loss_count_kernel, dim3(1), dim3(1024), 0, st, (long long)d->B * d->N, d->mseg_gt, d->dyn_mask,
                            d->workspace);
-    const size_t lds = (size_t)LS_WORDS_PER_POINT * d->N * sizeof(float);
+    a.use_inv = d->N <= LS_INV_MAX_N ? 1 : 0;
+    const size_t lds = ((size_t)(LS_WORDS_PER_POINT + (a.use_inv ? LS_NB + 2 : 0)) * d->N + 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)loss_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
