@@ -233,7 +233,7 @@ def dw_split(M, N, K):
     if chunks < 64:
         return 1
     best, best_cost = 8, 1e30
-    for s in (8, 16, 24, 32, 48, 64, 96, 128):             # multiples of 8: slabs are dealt to the 8 XCDs
+    for s in (8, 16, 24, 32, 48, 64, 96, 128, 256, 384):   # multiples of 8: slabs are dealt to the 8 XCDs
         if chunks // s < 8:
             break
         cost = ((tiles * s + 767) // 768) * (chunks / s + 12.0)
