@@ -34,6 +34,12 @@ constexpr int G_THREADS = 256;
 #ifndef CMF_EMUL_DIAG
 #define CMF_EMUL_DIAG 0                   // diagnostics of the bf16x3 loop (tools/diag builds)
 #endif
+#ifndef CMF_EPI_DIRECT
+#define CMF_EPI_DIRECT 1                  // 1: kinds 0 / 1 (plain store, forward) store straight from the accumulator layout, no LDS
+                                          //    transposition: epilogue 6.7 vs 10.4 us (plain) / 13.7 vs 14.6 us (forward + statistics) per tile.
+                                          //    The backward kinds keep the transposed form: their Z tile wants 16-byte loads issued a band
+                                          //    ahead (direct: 36 vs 17 us per tile).
+#endif
 #ifndef CMF_GEMM_W3
 #define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
 #endif
@@ -739,8 +745,114 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
         if (p.trace) t_e[2] = wall_clock64();
         if (want_stats) lds_barrier();                   // all tile reads done: the LDS is reused for the column reduction
     };
+    // ---- direct form of the fast path (CMF_EPI_DIRECT): no transposition.  In the accumulator layout a store instruction
+    // of register r already writes two full 128-byte row segments (lanes 0-31: row rho(r), lanes 32-63: row rho(r) + 4), a
+    // lane owns ONE column per accumulator block (its statistics are plain per-lane sums), and the producer's Z tile is read
+    // with the same map -- every load of the epilogue is issued before its first store, there is no band loop, no LDS round
+    // trip and no barrier until the column sums of the wave rows are combined.
+    bool stats_done = false;
+    auto direct_epilogue = [&](auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool USE_Z = KIND >= 2, WQ = KIND >= 4, BNR = KIND == 2 || KIND == 4;
+        const int h = lane >> 5, cl = lane & 31;
+        // wave-uniform tile coordinates in scalar registers: row bases are scalar, a lane adds ONE offset (its half-wave's
+        // 4 rows down, its column) -- per-lane 64-bit addresses for the 2 x 32 rows would take 128 registers
+        const int wms = __builtin_amdgcn_readfirstlane(wm), wns = __builtin_amdgcn_readfirstlane(wn);
+        const int rbase = m0 + wms * WM;                              // + i * 32 + rho(r)   (+ 4 h per lane)
+        const int cbase = n0 + wns * WN;                              // + j * 32            (+ cl per lane)
+        const unsigned lane_c = (unsigned)((4 * h * (int)p.ldc + cl) * 4), lane_z = (unsigned)((4 * h * (int)p.ldz + cl) * 4);
+        float *dq = smem;                                             // [BM][4] dxyz rows of the tile
+        if (WQ) {
+            if (tid < BM) *(f32x4 *)(dq + tid * 4) = *(const f32x4 *)(p.dxyz + (long long)(m0 + tid) * 4);
+        }
+        // the producer's Z rows of one block row (32 rows of the wave tile); block row i + 1 is requested before block row i
+        // is stored, so no load is ever waited on behind a store (one in-order counter for both on gfx950)
+        float zv[2][USE_Z ? TN : 1][16];
+        auto load_z = [&](int i, float (&dst)[USE_Z ? TN : 1][16]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *zr = p.Z + (long long)(rbase + i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldz + cbase;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dst[j][r] = *(const float *)((const char *)(zr + j * 32) + lane_z);
+            }
+        };
+        if (USE_Z) load_z(0, zv[0]);
+        float k0[TN], k1[TN], k2[TN], k3[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            k0[j] = k1[j] = k2[j] = k3[j] = 0.f;
+            const int c = cbase + j * 32 + cl;
+            if (KIND == 1) k0[j] = p.bias ? p.bias[c] : 0.f;
+            if (BNR) { k0[j] = p.ea[c]; k1[j] = p.ec[c]; k2[j] = p.emean[c]; k3[j] = p.einvstd[c]; }
+        }
+        const float slope = KIND == 1 ? (p.act == 1 ? 0.f : (p.act == 2 ? 0.1f : 1.f)) : (p.bwd_mode == 2 ? 0.1f : 0.f);
+        if (WQ) lds_barrier();
+        float t1[TN], t2[TN], q0[TN], q1[TN], q2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) t1[j] = t2[j] = q0[j] = q1[j] = q2[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float xs[TN][16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ru = wms * WM + i * 32 + (r & 3) + 8 * (r >> 2);            // row inside the tile, before the lane's + 4 h
+                f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                if (WQ) d4 = *(const f32x4 *)(dq + (ru + 4 * h) * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float x = acc[i][j][r];
+                    if (KIND == 1) {
+                        x += k0[j];
+                        x = x > 0.f ? x : slope * x;
+                        t1[j] += x; t2[j] += x * x;
+                    } else if (BNR) {
+                        const float z = zv[i & 1][USE_Z ? j : 0][r];
+                        x = (fmaf(k0[j], z, k1[j]) > 0.f) ? x : 0.f;
+                        t1[j] += x; t2[j] += x * ((z - k2[j]) * k3[j]);
+                    } else if (KIND >= 2) {
+                        x = zv[i & 1][USE_Z ? j : 0][r] > 0.f ? x : slope * x;
+                        t1[j] += x;
+                    }
+                    if (WQ) { q0[j] += x * d4[0]; q1[j] += x * d4[1]; q2[j] += x * d4[2]; }
+                    xs[j][r] = x;
+                }
+            }
+            if (USE_Z && i + 1 < TM) load_z(i + 1, zv[(i + 1) & 1]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float *cr = Cout + (long long)(m0 + wms * WM + i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc + cbase;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *(float *)((char *)(cr + j * 32) + lane_c) = xs[j][r];
+            }
+        }
+        if (want_stats) {
+            // per-lane column sums -> the two half-waves -> the WARPS_M wave rows (LDS, fixed order)
+            float *red = smem + BM * 4;                               // [WARPS_M][nstat][BN]
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v1 = t1[j] + __shfl_xor(t1[j], 32, 64), v2 = t2[j] + __shfl_xor(t2[j], 32, 64);
+                const int c = wns * WN + j * 32 + cl;
+                if (h == 0) { red[(wms * nstat + 0) * BN + c] = v1; red[(wms * nstat + 1) * BN + c] = v2; }
+                if (WQ) {
+                    const float w0 = q0[j] + __shfl_xor(q0[j], 32, 64), w1 = q1[j] + __shfl_xor(q1[j], 32, 64),
+                                w2 = q2[j] + __shfl_xor(q2[j], 32, 64);
+                    if (h == 0) { red[(wms * nstat + 2) * BN + c] = w0; red[(wms * nstat + 3) * BN + c] = w1; red[(wms * nstat + 4) * BN + c] = w2; }
+                }
+            }
+            lds_barrier();
+            for (int c = tid; c < nstat * BN; c += G_THREADS) {
+                const int which = c / BN, cc = c % BN;
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < WARPS_M; ++g) sum += red[(g * nstat + which) * BN + cc];
+                p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
+            }
+        }
+        stats_done = true;
+    };
     if (fast_epi && epilogue_kind(p) == EPI && CMF_EMUL_DIAG != 8) {
-        fast_epilogue(std::integral_constant<int, EPI>{});
+        if constexpr (CMF_EPI_DIRECT && BM == 128 && EPI <= 1) direct_epilogue(std::integral_constant<int, EPI>{});
+        else fast_epilogue(std::integral_constant<int, EPI>{});
     } else {
     if (p.split_k == 1)
         for (int q = 0; q < 4; ++q)
@@ -793,7 +905,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
     }
     if (want_stats) __syncthreads();                     // all tile reads done: reuse LDS for the column reduction
     }
-    if (want_stats) {
+    if (want_stats && !stats_done) {
         float *red = smem;                               // [RPP][nstat][BN]
         const int rg = tid / TPR;
         *(float4 *)(red + (rg * nstat + 0) * BN + col) = make_float4(s1[0], s1[1], s1[2], s1[3]);

@@ -6,6 +6,7 @@
 // is the k-ordered FMA chain of a GEMM (bit-equal to torch-CPU matmul).  This file is built
 // with -ffp-contract=off and the pragma below; tests/test_build.py checks the ISA.
 #include <cstdlib>
+#include <mutex>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -389,6 +390,11 @@ static int ball_query_grid(int b, int n, int m, float radius, int nsample, const
     const size_t ncs = (size_t)BQG_CELLS + 1;
     const size_t off_cs = ((size_t)b * sizeof(BqGridHeader) + 255) / 256 * 256;
     const size_t off_sp = (off_cs + (size_t)b * ncs * sizeof(int) + 255) / 256 * 256;
+    // The grid lives in the per-stream library scratch between the two launches.  The scales of an encoder call are enqueued
+    // from several host threads, two of them onto the SAME stream: the pair of launches must be adjacent in the stream, or
+    // another chain's build overwrites the grid before this query has read it.
+    static std::mutex pair_mutex;
+    std::lock_guard<std::mutex> pair_lock(pair_mutex);
     char *scratch = (char *)cmf_stream_scratch(st, 1, off_sp + (size_t)b * n * sizeof(float4));
     if (!scratch) return (int)hipErrorOutOfMemory;
     BqGridHeader *hdr = (BqGridHeader *)scratch;

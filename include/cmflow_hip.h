@@ -12,8 +12,10 @@
  *     need working memory their reference signature has no argument for and take it from a library-owned scratch, one
  *     buffer per (device, stream), allocated with hipMalloc on first use, grown on demand and kept for the life of the
  *     process: cmf_ball_query (spilled hit lists when nsample > 32 and more than 768 workgroups: 32 KB per workgroup,
- *     64 MB at b = 32, m = 4096) and cmf_group_points_grad (inverse index: 4 * b * (n + 1 + npoints * nsample) bytes).
- *     Nothing else is retained between calls.
+ *     64 MB at b = 32, m = 4096; the cell grid of clouds with 4096-8192 points: 16 * b * n + 16 KB * b bytes, used by two
+ *     launches that the library enqueues back to back under a lock, so calls from several host threads onto one stream
+ *     are safe) and cmf_group_points_grad (inverse index: 4 * b * (n + 1 + npoints * nsample) bytes; one host thread per
+ *     stream).  Nothing else is retained between calls.
  *   - return value: hipError_t as int (0 = hipSuccess).  The reference launchers print and
  *     exit(-1) on a launch failure (lib/src/ball_query_gpu.cu:62-66); this library reports the
  *     error to the caller instead.  Invalid arguments return hipErrorInvalidValue (1).
