@@ -210,7 +210,17 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_kernel(
         if (VEC == 4) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int t = beg;
-            for (; t + 4 <= end; t += 4) {          // 4 index loads, then 4 row loads in flight; sum order unchanged
+            for (; t + 8 <= end; t += 8) {          // 8 index loads, then 8 row loads in flight; sum order unchanged
+                int e[8];
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e[q] = lst[t + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4 *>(g + (size_t)e[q] * c + col);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+            }
+            for (; t + 4 <= end; t += 4) {          // 4 index loads, then 4 row loads in flight
                 const int e0 = lst[t], e1 = lst[t + 1], e2 = lst[t + 2], e3 = lst[t + 3];
                 const float4 v0 = *reinterpret_cast<const float4 *>(g + (size_t)e0 * c + col);
                 const float4 v1 = *reinterpret_cast<const float4 *>(g + (size_t)e1 * c + col);
