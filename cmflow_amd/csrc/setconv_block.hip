@@ -278,10 +278,9 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     CMF_TRY(bwd_layer(d, L, 3, P, C4, C3, L.t4, L.z4, d->w[2], L.x, -1, L.dx, nullptr, d->dw[2], d->acc_w[2], st));
     // max over the ball, layers 3 .. 1 (per neighbour slot)
     static const bool fused = !(getenv("CMF_THIN_FUSED") && getenv("CMF_THIN_FUSED")[0] == '0');
-    // the wide-input form of the fused layer (64 <- 256 channels, second encoder) is opt-in: measured equal to the four
-    // kernels it replaces (620 vs 623 us at 524288 rows, 24.0 vs 24.0 ms per step) -- with 128 weight-gradient accumulators
-    // per lane it runs two waves per SIMD without room to prefetch and sits at 35 % MFMA / 2.2 TB/s
-    static const bool wide = getenv("CMF_THIN_WIDE") && getenv("CMF_THIN_WIDE")[0] == '1';
+    // the wide-input form of the fused layer (64 <- 256 channels, second encoder): CMF_THIN_WIDE=0 keeps max-pool backward, BN
+    // backward and the two tiled GEMMs (A/B: 22.6 vs 22.9 ms per step)
+    static const bool wide = !(getenv("CMF_THIN_WIDE") && getenv("CMF_THIN_WIDE")[0] == '0');
     if (fused && cmf_thin_bwd_supported(C3, C2) && M % 128 == 0 && C3 % 32 == 0 && C2 % 32 == 0 && d->dw[1]) {
         // narrow layers: the gradient of the pooled tensor is kept per POINT (g, in L.dx's neighbour L.dU3) and expanded
         // by the fused layer kernel on the fly -- the [M, C3] matrix is neither written nor read

@@ -637,61 +637,80 @@ __global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_k
 constexpr int TBW_LDO = 68;
 struct ThinBwdWideLds {
     float tile[4 * 32 * TBW_LDO];           // per-wave dZ tile [32 rows][64]
-    float wt[128 * TBW_LDO];                // W^T of this workgroup's 128 input channels: [n][k]
-    float sred[4][2][128];                  // per-wave column sums of the current tile
-    float ko[4][64], ki[4][128];
+    float wt[64 * TBW_LDO];                 // W^T of this workgroup's 64 input channels: [n][k]
+    float sred[4][2][64];                   // per-wave column sums of the current tile
+    float ko[4][64], ki[4][64];
 };
 
+// One workgroup = (a range of 128-row tiles) x (ONE chunk of 64 input channels): 64 weight-gradient accumulators per lane
+// leave room to request the next tile's layer input while the current tile computes.  The cin / 64 workgroups of a row range
+// get consecutive slots on the SAME XCD (id % 8), so the dZ inputs they all read come from that XCD's L2 after the first.
 template <int MODE>                          // bit 0: train-mode BN, bit 3: pooled dU (in_mode 1, both products, whole tiles)
-__global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const ThinBwdArgs p)
+__global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const ThinBwdArgs p, const int nchunk, const int nslab)
 {
     constexpr int LDO = TBW_LDO;
     constexpr bool train = (MODE & 1) != 0, pooled = (MODE & 8) != 0;
     __shared__ ThinBwdWideLds S;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: row bases stay scalar
     const int h = lane >> 5, cl = lane & 31;
-    const int col0 = blockIdx.y * 128;                     // first input channel of this workgroup
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int chunk = q % nchunk, slab = (q / nchunk) * 8 + xcd;
+    if (slab >= nslab) return;
+    const int col0 = chunk * 64;                           // first input channel of this workgroup
     if (threadIdx.x < 64) {
         const int n = threadIdx.x;
         S.ko[0][n] = p.a[n];
         S.ko[1][n] = train ? p.mean[n] : 0.f;
         S.ko[2][n] = train ? p.invstd[n] * (p.sums[64 + n] * p.inv_count) : 0.f;
         S.ko[3][n] = train ? p.sums[n] * p.inv_count : 0.f;
-    } else if (threadIdx.x < 192) {
+    } else if (threadIdx.x < 128) {
         const int n = threadIdx.x - 64;
         S.ki[0][n] = p.a_in[col0 + n]; S.ki[1][n] = p.c_in[col0 + n];
         S.ki[2][n] = p.mean_in[col0 + n]; S.ki[3][n] = p.invstd_in[col0 + n];
     }
-    for (int i = threadIdx.x; i < 64 * 128; i += TG_THREADS) {
-        const int k = i >> 7, n = i & 127;
+    for (int i = threadIdx.x; i < 64 * 64; i += TG_THREADS) {
+        const int k = i >> 6, n = i & 63;
         S.wt[n * LDO + k] = p.w[(long long)k * p.ldw + col0 + n];
     }
     __syncthreads();
     float *dzt = S.tile + wave * 32 * LDO;
-    f32x16 accw[2][2][2];                                   // [chunk][cout block][cin block]
+    f32x16 accw[2][2];                                      // [cout block][cin block]
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accw[c][i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) accw[i][j][r] = 0.f;
     const unsigned w0 = (unsigned)wave * 32u;
     const unsigned lane_x = (4u * h * (unsigned)p.ldx + (unsigned)cl) * 4u, lane_dx = (4u * h * (unsigned)p.lddx + (unsigned)cl) * 4u;
+    const long long tile0 = (long long)slab * p.tiles_per_wg;
+    const long long ntile = (p.rows + 127) / 128;
+
+    // layer input of a tile in the accumulator layout (row bases are wave-uniform -> scalar registers)
+    auto load_x = [&](long long tile, float (&dst)[2][16]) {
+        unsigned lx = lane_x;
+        int ldx_s = (int)p.ldx;
+        asm volatile("" : "+v"(lx), "+s"(ldx_s));
+        const float *xt = p.x + tile * 128 * p.ldx + col0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *xr = xt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * ldx_s);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[j][r] = tb_ld(xr + j * 32, lx);
+        }
+    };
+    float xc[2][16];
+    if (tile0 < ntile) load_x(tile0, xc);
 
     for (int t = 0; t < p.tiles_per_wg; ++t) {
-        const long long tile = (long long)blockIdx.x * p.tiles_per_wg + t;
-        if (tile * 128 >= p.rows) break;
-        // Per-lane LDS offsets, made opaque once per tile: as loop invariants the compiler materialises EVERY (offset +
-        // constant) address of the tile body as a live register of its own (130-190 spilled registers); behind the empty
-        // asm they are values of this iteration and the constants fold into the DS instructions' offset fields.
+        const long long tile = tile0 + t;
+        if (tile >= ntile) break;
+        // per-lane offsets made opaque once per tile (see thin_bwd_tile)
         int oA = (lane & 31) * LDO + 4 * h, oC = 4 * h * LDO + cl, oW = cl * LDO + 4 * h, oK = 4 * h, oN = cl;
-        unsigned lx = lane_x, ldx_ = lane_dx;                  // same for the per-lane part of the global addresses
-        int ldx_s = (int)p.ldx, lddx_s = (int)p.lddx;           // ... and for the row strides (else 128 hoisted row bases)
-        asm volatile("" : "+v"(oA), "+v"(oC), "+v"(oW), "+v"(oK), "+v"(oN), "+v"(lx), "+v"(ldx_), "+s"(ldx_s), "+s"(lddx_s));
+        unsigned ldx_ = lane_dx;
+        int lddx_s = (int)p.lddx;
+        asm volatile("" : "+v"(oA), "+v"(oC), "+v"(oW), "+v"(oK), "+v"(oN), "+v"(ldx_), "+s"(lddx_s));
         const float *zt = train ? p.z + tile * 128 * p.ldz : nullptr;
-        const float *xt = p.x + tile * 128 * p.ldx + col0;
         float *dxt = p.dx + tile * 128 * p.lddx + col0;
         // ---- dZ of the wave's 32 rows (rows on the lanes) into its LDS tile ----
         {
@@ -709,27 +728,23 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
                 ou = (mrow * (unsigned)p.lddu + 4u * h) * 4u;
                 src = p.dU + tile * 128 * p.lddu;
             }
+            float4 dv[8], zv[8];
 #pragma unroll
-            for (int kb = 0; kb < 8; kb += 4) {                    // two halves: 32 load registers in flight next to 128 accumulators
-            float4 dv[4], zv[4];
-#pragma unroll
-            for (int ku = 0; ku < 4; ++ku) {
-                const int k8 = kb + ku;
+            for (int k8 = 0; k8 < 8; ++k8) {
                 if (pooled) {
                     const float4 g4 = tb_ld4(src, ou + 32u * k8);
                     const uchar4 am = *(const uchar4 *)(p.pool_am + (ou >> 2) + 8u * k8);
-                    dv[ku] = make_float4(am.x == pool_s ? g4.x : 0.f, am.y == pool_s ? g4.y : 0.f, am.z == pool_s ? g4.z : 0.f,
+                    dv[k8] = make_float4(am.x == pool_s ? g4.x : 0.f, am.y == pool_s ? g4.y : 0.f, am.z == pool_s ? g4.z : 0.f,
                                          am.w == pool_s ? g4.w : 0.f);
-                } else dv[ku] = tb_ld4(src, ou + 32u * k8);
-                zv[ku] = train ? tb_ld4(zt, oz + 32u * k8) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else dv[k8] = tb_ld4(src, ou + 32u * k8);
+                zv[k8] = train ? tb_ld4(zt, oz + 32u * k8) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int ku = 0; ku < 4; ++ku) {
-                const int k8 = kb + ku;
-                float4 d = dv[ku];
+            for (int k8 = 0; k8 < 8; ++k8) {
+                float4 d = dv[k8];
                 const float4 sa = *(const float4 *)&S.ko[0][oK + 8 * k8];
                 if (train) {
-                    const float4 v = zv[ku];
+                    const float4 v = zv[k8];
                     const float4 mu = *(const float4 *)&S.ko[1][oK + 8 * k8], u = *(const float4 *)&S.ko[2][oK + 8 * k8],
                                  t1 = *(const float4 *)&S.ko[3][oK + 8 * k8];
                     d.x = sa.x * (d.x - t1.x - (v.x - mu.x) * u.x);
@@ -739,99 +754,89 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
                 } else { d.x *= sa.x; d.y *= sa.y; d.z *= sa.z; d.w *= sa.w; }
                 *(float4 *)(dzt + oA + 8 * k8) = d;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            }
         }
-        float (*sr)[2][128] = S.sred;
+        // the next tile's layer input is requested now and lands while this tile computes
+        float xn[2][16];
+        const bool more = t + 1 < p.tiles_per_wg && tile + 1 < ntile;
+        if (more) load_x(tile + 1, xn);
+        // data gradient: A from the LDS tile, B = W^T chunk
+        f32x16 acc[2];
 #pragma unroll
-        for (int ch = 0; ch < 2; ++ch) {
-            // layer input of this chunk in the accumulator layout
-            // (row base pointers are wave-uniform -> scalar registers; the only per-lane address register is lane_x)
-            float xc[2][16];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float *xr = xt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * ldx_s) + ch * 64;
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xc[j][r] = tb_ld(xr + j * 32, lx);
-            }
-            // data gradient of the chunk: A from the LDS tile, B = W^T chunk
-            f32x16 acc[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) {
-                const float4 d = *(const float4 *)(dzt + oA + 8 * k8);
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float4 b = *(const float4 *)&S.wt[oW + (ch * 64 + j * 32) * LDO + 8 * k8];
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, b.x, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.y, b.y, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.z, b.z, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.w, b.w, acc[j], 0, 0, 0);
-                }
-            }
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const float4 d = *(const float4 *)(dzt + oA + 8 * k8);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int n = oN + ch * 64 + j * 32;
-                const float ia = S.ki[0][n], ic = S.ki[1][n], im = S.ki[2][n], ii = S.ki[3][n];
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float zz = xc[j][r];
-                    const float v = (fmaf(ia, zz, ic) > 0.f) ? acc[j][r] : 0.f;
-                    s1 += v; s2 += v * ((zz - im) * ii);
-                    float *dr = dxt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * lddx_s) + ch * 64 + j * 32;
-                    *(float *)((char *)dr + ldx_) = v;
-                    xc[j][r] = fmaxf(fmaf(ia, zz, ic), 0.f);           // activated: B operand of the weight gradient
-                }
-                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32) { sr[wave][0][n] = s1; sr[wave][1][n] = s2; }
+                const float4 b = *(const float4 *)&S.wt[oW + j * 32 * LDO + 8 * k8];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, b.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.y, b.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.z, b.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.w, b.w, acc[j], 0, 0, 0);
             }
-            // weight gradient of the chunk
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = oN + j * 32;
+            const float ia = S.ki[0][n], ic = S.ki[1][n], im = S.ki[2][n], ii = S.ki[3][n];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float *src = dzt + oC + ((r & 3) + 8 * (r >> 2)) * LDO;
+                const float zz = xc[j][r];
+                const float v = (fmaf(ia, zz, ic) > 0.f) ? acc[j][r] : 0.f;
+                s1 += v; s2 += v * ((zz - im) * ii);
+                float *dr = dxt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * lddx_s) + j * 32;
+                *(float *)((char *)dr + ldx_) = v;
+                xc[j][r] = fmaxf(fmaf(ia, zz, ic), 0.f);           // activated: B operand of the weight gradient
+            }
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) { S.sred[wave][0][n] = s1; S.sred[wave][1][n] = s2; }
+        }
+        // weight gradient
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float dz = src[i * 32];
+        for (int r = 0; r < 16; ++r) {
+            const float *src = dzt + oC + ((r & 3) + 8 * (r >> 2)) * LDO;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        accw[ch][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, xc[j][r], accw[ch][i][j], 0, 0, 0);
-                }
+            for (int i = 0; i < 2; ++i) {
+                const float dz = src[i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, xc[j][r], accw[i][j], 0, 0, 0);
             }
         }
         __syncthreads();
-        {
-            const int i = threadIdx.x;      // 2 * 128 outputs, one per thread
-            const int which = i >> 7, n = i & 127;
-            p.stats[(tile * 2 + which) * p.cin + col0 + n] = sr[0][which][n] + sr[1][which][n] + sr[2][which][n] + sr[3][which][n];
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6, n = threadIdx.x & 63;
+            p.stats[(tile * 2 + which) * p.cin + col0 + n] = S.sred[0][which][n] + S.sred[1][which][n] + S.sred[2][which][n] + S.sred[3][which][n];
         }
         __syncthreads();                    // the sums are rewritten by the next tile
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xc[j][r] = xn[j][r];
+        }
     }
-    __syncthreads();                        // tiles and W^T are dead: their LDS becomes the reduction buffer (2 x 8 blocks x 4 KB)
-    float (*red)[8 * 16 * CMF_WAVE] = (float (*)[8 * 16 * CMF_WAVE])S.tile;
-    static_assert(sizeof(S.tile) + sizeof(S.wt) >= 2 * 8 * 16 * CMF_WAVE * sizeof(float), "reduction buffer");
+    __syncthreads();                        // tiles are dead: their LDS becomes the reduction buffer (2 x 4 blocks x 4 KB)
+    float (*red)[4 * 16 * CMF_WAVE] = (float (*)[4 * 16 * CMF_WAVE])S.tile;
+    static_assert(sizeof(S.tile) >= 2 * 4 * 16 * CMF_WAVE * sizeof(float), "reduction buffer");
     auto put = [&](float *dst) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[((((c * 2 + i) * 2 + j) * 16) + r) * CMF_WAVE + lane] = accw[c][i][j][r];
+                for (int r = 0; r < 16; ++r) dst[(((i * 2 + j) * 16) + r) * CMF_WAVE + lane] = accw[i][j][r];
     };
     auto add = [&](const float *src) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accw[c][i][j][r] += src[((((c * 2 + i) * 2 + j) * 16) + r) * CMF_WAVE + lane];
+                for (int r = 0; r < 16; ++r) accw[i][j][r] += src[(((i * 2 + j) * 16) + r) * CMF_WAVE + lane];
     };
     if (wave >= 2) put(red[wave - 2]);
     __syncthreads();
@@ -841,27 +846,25 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
     __syncthreads();
     if (wave != 0) return;
     add(red[0]);
-    float *slab = p.slabs + (long long)blockIdx.x * 64 * p.cin + col0;
+    float *slabp = p.slabs + (long long)slab * 64 * p.cin + col0;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = c * 64 + j * 32 + cl;
-                    slab[(long long)n * p.cin + k] = accw[c][i][j][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = j * 32 + cl;
+                slabp[(long long)n * p.cin + k] = accw[i][j][r];
+            }
 }
 
-extern "C" int cmf_thin_bwd_wide_supported(int cout, int cin) { return cout == 64 && cin >= 128 && cin % 128 == 0 && cin <= 1024; }
+extern "C" int cmf_thin_bwd_wide_supported(int cout, int cin) { return cout == 64 && cin >= 128 && cin % 64 == 0 && cin <= 1024; }
 
-// row slabs of the wide form: one round of 512 resident workgroups over (row slabs) x (cin / 128 channel halves)
+// row slabs of the wide form: one round of 512 resident workgroups over (row slabs) x (cin / 64 channel chunks)
 extern "C" int cmf_thin_bwd_wide_slabs(long long rows, int cin, int *tiles_per_wg)
 {
     const long long tiles = (rows + 127) / 128;
-    long long split = 512 / (cin / 128 > 0 ? cin / 128 : 1);
+    long long split = 512 / (cin / 64 > 0 ? cin / 64 : 1);
     if (split < 1) split = 1;
     if (split > tiles) split = tiles;
     if (split < 1) split = 1;
@@ -898,13 +901,14 @@ extern "C" int cmf_thin_bwd_wide_layer(long long rows, int cin, const float *dU,
     p.pool_g = pool_g; p.pool_am = pool_am; p.pool_S = pool_S;
     const int nslab = cmf_thin_bwd_wide_slabs(rows, cin, &p.tiles_per_wg);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(nslab, cin / 128), block(TG_THREADS);
+    const int nchunk = cin / 64;
+    const dim3 grid(8 * ((nslab + 7) / 8) * nchunk), block(TG_THREADS);
     const int mode = (sums ? 1 : 0) | (pooled ? 8 : 0);
     switch (mode) {
-        case 0: hipLaunchKernelGGL((thin_bwd_wide_kernel<0>), grid, block, 0, st, p); break;
-        case 1: hipLaunchKernelGGL((thin_bwd_wide_kernel<1>), grid, block, 0, st, p); break;
-        case 8: hipLaunchKernelGGL((thin_bwd_wide_kernel<8>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((thin_bwd_wide_kernel<9>), grid, block, 0, st, p); break;
+        case 0: hipLaunchKernelGGL((thin_bwd_wide_kernel<0>), grid, block, 0, st, p, nchunk, nslab); break;
+        case 1: hipLaunchKernelGGL((thin_bwd_wide_kernel<1>), grid, block, 0, st, p, nchunk, nslab); break;
+        case 8: hipLaunchKernelGGL((thin_bwd_wide_kernel<8>), grid, block, 0, st, p, nchunk, nslab); break;
+        default: hipLaunchKernelGGL((thin_bwd_wide_kernel<9>), grid, block, 0, st, p, nchunk, nslab); break;
     }
     int err = cmf_launch_status();
     if (err) return err;
