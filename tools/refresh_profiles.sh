@@ -18,6 +18,8 @@ cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $R/fwd_kernel_stats.csv
 cp $(find /tmp/p3 -name "*kernel_stats.csv" | head -1) $R/train_serial_kernel_stats.csv
 python tools/enc1_profile.py 2>&1 | grep -v "Warning\|_warn_once\|amdgpu.ids" > $R/enc1_profile.txt
 python tools/thin_bwd_probe.py 2>&1 | grep -v amdgpu.ids > $R/thin_bwd_probe.txt
+python tools/thin_wide_probe.py 2>&1 | grep -v amdgpu.ids > $R/thin_wide_probe.txt
+python tools/ball_query_probe.py 2>&1 | grep -v amdgpu.ids > $R/ball_query_probe.txt
 python tools/gemm_vendor_compare.py 2>&1 | grep -v amdgpu.ids > $R/gemm_vendor_compare.txt
 python tools/host_time_probe.py 20 2>&1 | grep -v amdgpu.ids > $R/host_time_probe.txt
 python tools/phase_probe.py 2>&1 | grep -v amdgpu.ids > $R/phase_probe.txt
