@@ -67,7 +67,8 @@ def _oracle(batch, pred_f, pre_trans, mseg_pre, dtype, monkeypatch=None):
 
 
 @pytest.mark.parametrize("B,N,seed,real_like", [(4, 256, 1, False), (2, 256, 2, True), (3, 100, 3, False),
-                                                (1, 300, 4, False), (2, 640, 5, False), (64, 256, 6, False)])
+                                                (1, 300, 4, False), (2, 640, 5, False), (64, 256, 6, False),
+                                                (1, 512, 7, True), (1, 520, 8, False)])     # 512 / 520: last size with / first without the inverse list of pass 3
 def test_fused_loss_matches_oracle(dev, monkeypatch, B, N, seed, real_like):
     batch, pred_f, pre_trans, mseg_pre = _case(B, N, seed, real_like)
     ref_total, ref_items, ref_g32 = _oracle(batch, pred_f, pre_trans, mseg_pre, torch.float32, monkeypatch)
