@@ -25,11 +25,6 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this stack (already exported on the pool)
-# stdout carries exactly ONE line (the JSON record): libraries that print to the C-level stdout (RCCL's version banner at
-# communicator creation) are sent to stderr, and the record is written to the saved descriptor at the end
-_RESULT_FD = os.dup(1)
-os.dup2(2, 1)
-
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -208,6 +203,12 @@ def main():
     ap.add_argument("--clip", type=int, default=5, help="cmflow_t: frames per mini-clip (clip_util.py:34-62)")
     ap.add_argument("--gemm-table", default=None, help="write a markdown table of the bracketed cmf_gemm launches by shape to this file")
     a = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON record): libraries that print to the C-level stdout (RCCL's version banner
+    # at communicator creation) are sent to stderr, and the record is written to the saved descriptor at the end.  Done
+    # here, not at import: tools and tests import this module for Args / load_weights and keep their own stdout.
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -401,7 +402,7 @@ def main():
                 if iso_prof:
                     f.write("\n" + gemm_shape_table(iso_prof, "3 extra steps with every chain on one stream (the kernel's own rate)"))
         sys.stdout.flush()
-        os.write(_RESULT_FD, (json.dumps(line) + "\n").encode())
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         fence()                                             # leave together
     if dist.is_initialized():

@@ -91,6 +91,7 @@ SIGNATURES = {
     "cmf_radar_loss_workspace": [_ci, _ci],
     "cmf_radar_loss": [_vp, _vp],
     "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
+    "cmf_debug_spin": [_cf, _vp],
     "cmf_eval_metrics": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _cf, _cf, _vp, _vp, _vp],
 }
 RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_gemm_trace_read": _ll, "cmf_gemm_profile_records": _ll}

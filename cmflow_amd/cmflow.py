@@ -149,9 +149,10 @@ class CMFlow(nn.Module):
                 self._head_stream = FB.side_stream(0)
             side = self._head_stream
             side.wait_stream(main)
+            FB.stress_point([side, main])
             with torch.cuda.stream(side):
-                stat_cls = self.mp.forward_pm(ff).transpose(1, 2)
-            output = self.fp.forward_pm(ff).transpose(1, 2)
+                stat_cls = FB.stress_mark(self.mp.forward_pm(ff)).transpose(1, 2)
+            output = FB.stress_mark(self.fp.forward_pm(ff)).transpose(1, 2)
             main.wait_stream(side)
             ff.record_stream(side)
             stat_cls.record_stream(main)

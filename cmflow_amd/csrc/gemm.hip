@@ -716,14 +716,14 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
                         float x = t4[it][q];
                         if (KIND == 1) {
                             x += k0[q];
-                            x = x > 0.f ? x : slope * x;
+                            x = x > 0.f ? x : (slope == 0.f ? 0.f : slope * x);      // select, not 0 * x: -inf must give 0 like torch.relu
                             s1[q] += x; s2[q] += x * x;
                         } else if (BNR) {
                             const float z = zp[it][q];
                             x = (fmaf(k0[q], z, k1[q]) > 0.f) ? x : 0.f;
                             s1[q] += x; s2[q] += x * ((z - k2[q]) * k3[q]);
                         } else {
-                            x = zp[it][q] > 0.f ? x : slope * x;
+                            x = zp[it][q] > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
                             s1[q] += x;
                         }
                         if (WQ) { qs[0][q] += x * d4.x; qs[1][q] += x * d4.y; qs[2][q] += x * d4.z; }
@@ -803,14 +803,14 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
                     float x = acc[i][j][r];
                     if (KIND == 1) {
                         x += k0[j];
-                        x = x > 0.f ? x : slope * x;
+                        x = x > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
                         t1[j] += x; t2[j] += x * x;
                     } else if (BNR) {
                         const float z = zv[i & 1][USE_Z ? j : 0][r];
                         x = (fmaf(k0[j], z, k1[j]) > 0.f) ? x : 0.f;
                         t1[j] += x; t2[j] += x * ((z - k2[j]) * k3[j]);
                     } else if (KIND >= 2) {
-                        x = zv[i & 1][USE_Z ? j : 0][r] > 0.f ? x : slope * x;
+                        x = zv[i & 1][USE_Z ? j : 0][r] > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
                         t1[j] += x;
                     }
                     if (WQ) { q0[j] += x * d4[0]; q1[j] += x * d4[1]; q2[j] += x * d4[2]; }

@@ -252,4 +252,19 @@ extern "C" int cmf_weighted_kabsch_grad(int b, int n, const float *A, const floa
     return cmf_launch_status();
 }
 
+// test-only stream delay (cmflow_hip.h): one wave polling the constant-frequency clock
+__global__ __launch_bounds__(64) void debug_spin_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+extern "C" int cmf_debug_spin(float microseconds, void *stream)
+{
+    CMF_CHECK_ARG(microseconds >= 0.f && microseconds <= 1.0e6f);
+    if (microseconds == 0.f) return 0;
+    hipLaunchKernelGGL(debug_spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)(microseconds * 100.0f));
+    return cmf_launch_status();
+}
+
 extern "C" const char *cmf_version(void) { return "cmflow_hip 0.1 (gfx950)"; }

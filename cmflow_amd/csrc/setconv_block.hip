@@ -107,6 +107,12 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         sk = std::max(sk, (size_t)dw_split(P, C4, C3) * C4 * C3);
         sk = std::max(sk, (size_t)dw_split(M, C3, C2) * C3 * C2);
         sk = std::max(sk, (size_t)dw_split(M, C2, O1) * C2 * O1);
+        // the fused single-pass layers write their own slab counts (one slab per workgroup): size for those as well --
+        // the wide form's tiles128(M) slabs of 64 x C2 exceed the dw_split-based sizes for 128 <= M < 1024 rows
+        const struct { long long rows; int cout, cin; } lay[5] = {{P, C6, C5}, {P, C5, C4}, {P, C4, C3}, {M, C3, C2}, {M, C2, O1}};
+        for (const auto &l : lay)
+            if (cmf_thin_bwd_supported(l.cout, l.cin)) sk = std::max(sk, (size_t)cmf_thin_bwd_slabs(l.rows, nullptr) * l.cout * l.cin);
+        if (cmf_thin_bwd_wide_supported(C3, C2)) sk = std::max(sk, (size_t)cmf_thin_bwd_wide_slabs(M, C2, nullptr) * 64 * C2);
         L.splitk = t.take(sk);
     } else {
         L.t6 = L.t5 = L.t4 = L.dx = L.dU3 = L.dU2 = L.dU1 = L.splitk = nullptr;

@@ -93,9 +93,57 @@ def join_side_streams(main=None):
     without passing through autograd's AccumulateGrad, so autograd does not know those streams wrote the leaves: whoever
     reads the bucket next (all-reduce, optimizer) on `main` must be ordered behind the pool explicitly."""
     main = main or torch.cuda.current_stream()
+    stress_point([st for pool in _side_pool.values() for st in pool])
     for pool in _side_pool.values():
         for st in pool:
             main.wait_stream(st)
+
+
+# ---- timing perturbation at the fork points (tests/test_gpu_stress.py; CMF_STRESS=seed) -------------------------
+# Every place where independent chains leave the caller's stream (the block calls of an encoder, the two heads, the
+# cost-volume branches, the final join) can enqueue a random 0-300 us delay (cmf_debug_spin: one sleeping wave) ahead of
+# the chain's first kernel.  Results must not depend on it: a missing stream dependency, an arena shared by two chains
+# or a buffer handed back to the allocator too early shows up as a difference against the single-stream run.
+_stress_rng = None
+
+
+def stress_seed(seed):
+    """seed: int to switch the perturbation on (deterministic sequence of delays), None to switch it off."""
+    global _stress_rng
+    import random
+    _stress_rng = random.Random(seed) if seed is not None else None
+
+
+if os.environ.get("CMF_STRESS"):
+    stress_seed(int(os.environ["CMF_STRESS"]))
+
+
+def stress_point(streams=()):
+    """Fork point: maybe delay each of `streams` (the chains about to start) and one random stream of the pool."""
+    r = _stress_rng
+    if r is None or not torch.cuda.is_available():
+        return
+    for st in list(streams) + [side_stream(r.randrange(N_SIDE))]:
+        if r.random() < 0.6:
+            _lib.check(L().cmf_debug_spin(r.uniform(0.0, 300.0), st.cuda_stream), "cmf_debug_spin")
+
+
+class _StressMarkFn(Function):
+    """Identity whose backward is a fork point on the stream autograd replays it on (= the forward's stream): delays the
+    backward of a side-stream branch.  Only inserted while the perturbation is on."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        stress_point([torch.cuda.current_stream()])
+        return g
+
+
+def stress_mark(t):
+    return _StressMarkFn.apply(t) if (_stress_rng is not None and t.requires_grad) else t
 
 
 def scale_streams(n_scales, cloud=0):
@@ -859,6 +907,7 @@ def _multi_call(backward, n, plan, sp, streams, main):
         return
     for st in streams:
         st.wait_stream(main)
+    stress_point(streams)
     fn = L().cmf_setconv_backward_multi if backward else L().cmf_setconv_forward_multi
     _lib.check(fn(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_*_multi")
     for st in streams:

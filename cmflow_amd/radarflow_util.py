@@ -395,13 +395,14 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
     if side:
         for st in side:
             st.wait_stream(main)
+        FB.stress_point(list(side) + [main])
     with torch.cuda.stream(side[0]) if side else contextlib.nullcontext():
         nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])     # needed after p1: off the main stream too
-        p2 = FB.linear(f2, w0[:, D1:D1 + D2])
+        p2 = FB.stress_mark(FB.linear(f2, w0[:, D1:D1 + D2]))
     with torch.cuda.stream(side[1]) if side else contextlib.nullcontext():
         nbr2 = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
         dxyz2 = F.pad(group_rows(xyz1_t, nbr2) - xyz1_t.unsqueeze(2), (0, 1))
-        h2 = self.weightnet2.hidden_pm(dxyz2)
+        h2 = FB.stress_mark(self.weightnet2.hidden_pm(dxyz2))
     p1 = FB.linear(f1, w0[:, :D1], c0.bias)
     if side:
         main.wait_stream(side[0])

@@ -449,6 +449,11 @@ int cmf_pseudo_labels(int b, int n, const float *pc1, const float *gt_trans, con
                       const float *fg_mask, const float *flow_label, float vr_thres,
                       float *dyn_mask, float *mseg_gt, float *residual, void *stream);
 
+/* Test-only: occupies `stream` for about `microseconds` with a one-wave kernel that polls the constant 100 MHz clock
+ * (s_sleep between polls: no measurable load on the chip).  tests/test_gpu_stress.py uses it to shift the relative timing of
+ * the side-stream chains at every fork point (fused_blocks.stress_*): results must not depend on it. */
+int cmf_debug_spin(float microseconds, void *stream);
+
 /* Library / device identification: returns a static NUL-terminated string. */
 const char *cmf_version(void);
 

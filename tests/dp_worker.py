@@ -22,47 +22,56 @@ sys.path.insert(0, REPO)
 def main():
     out_dir = sys.argv[1]
     global_b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    model = sys.argv[3] if len(sys.argv) > 3 else "cmflow"
+    n_frames = int(sys.argv[4]) if len(sys.argv) > 4 else 1
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     import bench
     from cmflow_amd import synth
-    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.cmflow import CMFlow, CMFlow_T
     from cmflow_amd.dp import broadcast_module, shard_batch
+    from cmflow_amd.fused_blocks import join_side_streams
     from cmflow_amd.train import TrainStep
 
-    net = CMFlow(bench.Args())
-    net.load_state_dict(bench.load_weights("cmflow"))
+    net = {"cmflow": CMFlow, "cmflow_t": CMFlow_T}[model](bench.Args())
+    net.load_state_dict(bench.load_weights(model))
     net = net.to(dev).train()
     if rank != 0:                                   # replicas must come out of the broadcast identical, whatever they held
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(0.01)
     broadcast_module(net)
-    gb = synth.make_batch(global_b, seed=777, train_extras=True)
-    b = {k: v.to(dev) for k, v in shard_batch(gb, rank, world).items()}
     step = TrainStep(net, vr_thres=bench.Args.vr_thres)
-    loss, items, outs, _ = step.forward_loss(b)
-    step.bucket.zero()
-    loss.backward()
-    from cmflow_amd.fused_blocks import join_side_streams
-    join_side_streams()
-    local = step.bucket.flat.detach().clone()
-    step.bucket.all_reduce_mean()
-    averaged = step.bucket.flat.detach().clone()
-    step.opt.step()
-    torch.cuda.synchronize()
+    frames = []
+    # CMFlow-T: the frames of one mini-clip (clip_util.py:34-62) -- the GRU state is carried per rank, detached, and the
+    # optimizer steps after every frame on the all-reduced gradient
+    for f in range(n_frames):
+        gb = synth.make_batch(global_b, seed=777 + f, train_extras=True)
+        b = {k: v.to(dev) for k, v in shard_batch(gb, rank, world).items()}
+        loss, items, outs, _ = step.forward_loss(b)
+        step.bucket.zero()
+        loss.backward()
+        join_side_streams()
+        local = step.bucket.flat.detach().clone()
+        step.bucket.all_reduce_mean()
+        averaged = step.bucket.flat.detach().clone()
+        step.opt.step()
+        torch.cuda.synchronize()
+        frames.append({"local": local.cpu(), "averaged": averaged.cpu(), "loss": loss.detach().cpu(),
+                       "outs": [o.detach().cpu() for o in outs[:3]],
+                       "gfeat": step.gfeat.detach().cpu() if step.gfeat is not None else None})
     sd = net.state_dict()
-    torch.save({"local": local.cpu(), "averaged": averaged.cpu(), "loss": loss.detach().cpu(),
-                "outs": [o.detach().cpu() for o in outs[:3]],
+    rec = dict(frames[0])
+    rec.update({"frames": frames,
                 "params": {k: v.detach().cpu() for k, v in net.named_parameters()},
-                "buffers": {k: v.detach().cpu() for k, v in sd.items() if "running_" in k or "num_batches" in k}},
-               os.path.join(out_dir, "rank%d.pt" % rank))
+                "buffers": {k: v.detach().cpu() for k, v in sd.items() if "running_" in k or "num_batches" in k}})
+    torch.save(rec, os.path.join(out_dir, "rank%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        json.dump({"world": world, "global_b": global_b}, open(os.path.join(out_dir, "done.json"), "w"))
+        json.dump({"world": world, "global_b": global_b, "model": model, "frames": n_frames}, open(os.path.join(out_dir, "done.json"), "w"))
 
 
 if __name__ == "__main__":

@@ -465,3 +465,83 @@ def test_wide_thin_bwd_layer_matches_three_kernel_form(dev, gemm_mode, P, S, cin
     assert float((dx0 - dx1).abs().max()) <= 2e-5 * scale(dx0)
     assert float((st0 - st1).abs().max()) <= 2e-5 * scale(st0)
     assert float((dw0 - dw1).abs().max()) <= 3e-5 * scale(dw0)
+
+
+@pytest.mark.parametrize("N,S", [(40, 16), (48, 16), (56, 16), (24, 32), (250, 4)])
+def test_setconv_block_small_m_matches_python_sequence_and_stays_inside_its_arena(dev, gemm_mode, N, S, monkeypatch):
+    """A second-encoder set-conv block (512 -> 256 -> 64 | 64 -> 64 -> 64) whose neighbourhood matrix has 640 ... 1000
+    rows: the fused wide backward layer writes tiles128(M) weight-gradient slabs of 64 x 256 floats, more than the split-K
+    rule of the tiled kernels asks for at that size -- the arena of cmf_setconv_backward must be sized for them (round-2
+    advisor finding).  The block call (one C-ABI call per direction) against the same kernels sequenced from Python
+    (SetConvFn, separately allocated buffers), and a guard band behind the block's scratch arena that must stay untouched."""
+    if gemm_mode != "fp32":
+        pytest.skip("one arithmetic is enough")
+    from cmflow_amd import fused_blocks as FB
+    from cmflow_amd.radarflow_util import PointLocalFeature
+    torch.manual_seed(N * 100 + S)
+    B = 1
+    mod = PointLocalFeature(4.0, S, in_channel=13, mlp=[512, 256, 64], mlp2=[64, 64, 64]).to(dev).train()
+    xyz = (torch.rand(B, N, 3, device=dev) * torch.tensor([12.0, 12.0, 2.0], device=dev)).contiguous()
+    y0 = torch.randn(B, N, 512, device=dev)
+    dout = torch.randn(B, N, 64, device=dev)
+    res = {}
+    guard = {}
+    real_empty = torch.empty
+    for block in (False, True):
+        monkeypatch.setattr(FB, "USE_BLOCK_CALLS", block)
+        mod.zero_grad(set_to_none=True)
+        y = y0.clone().requires_grad_(True)
+        out = FB.set_conv(mod, xyz, y)
+        if block:
+            n_bwd = out.grad_fn.state["n_bwd"]
+            big = torch.full((n_bwd + (1 << 18),), 12345.0, device=dev)
+
+            def fake_empty(*a, **k):
+                if len(a) == 1 and a[0] == n_bwd and k.get("dtype") == torch.float32:
+                    return big[:n_bwd]
+                return real_empty(*a, **k)
+            monkeypatch.setattr(torch, "empty", fake_empty)
+            guard["big"], guard["n"] = big, n_bwd
+        out.backward(dout)
+        monkeypatch.setattr(torch, "empty", real_empty)
+        torch.cuda.synchronize()
+        res[block] = (out.detach().clone(), y.grad.clone(), {k: p.grad.clone() for k, p in mod.named_parameters() if p.grad is not None})
+    assert bool((guard["big"][guard["n"]:] == 12345.0).all()), "cmf_setconv_backward wrote past its scratch arena"
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0])
+    scale = lambda t: max(1e-6, float(t.abs().max()))
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * scale(a[1])
+    assert set(a[2]) == set(b[2]) and len(a[2]) >= 17
+    for k in a[2]:
+        assert float((a[2][k] - b[2][k]).abs().max()) <= 2e-5 * scale(a[2][k]), k
+
+
+def test_gemm_relu_epilogues_select_on_non_finite_values(dev, gemm_mode):
+    """ReLU / masks in the fast epilogues are selects, not multiplications by a zero slope: a pre-activation of -inf gives 0
+    (0 * -inf would be NaN) and an infinite gradient at a masked position gives 0, in interior tiles (fast path) and edge
+    tiles (generic loop) alike -- the same values torch.relu and a boolean mask produce (round-2 advisor finding)."""
+    if gemm_mode != "fp32":
+        pytest.skip("the experimental bf16 split has no defined result for infinite operands (inf - inf in the split)")
+    from cmflow_amd.fused import gemm
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 300, 256, 64                                           # two interior row tiles + one edge tile
+    A = torch.randn(M, K, generator=g)
+    A[5] = float("-inf"); A[200] = float("-inf"); A[290] = float("-inf")
+    W = torch.rand(N, K, generator=g) + 0.1                          # positive: the row sums are -inf, not inf - inf
+    got = gemm(A.to(dev), W.to(dev), act=1).cpu()
+    want = torch.relu(A @ W.t())
+    assert torch.isfinite(got).all() and float(got[5].abs().max()) == 0.0 and float(got[290].abs().max()) == 0.0
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    got2, _ = gemm(A.to(dev), W.to(dev), act=1, stats=True)          # the direct forward epilogue with statistics
+    assert torch.equal(got2.cpu(), got)
+    # backward through ReLU (mode 3): an infinite upstream gradient where the stored activation is 0 is masked to 0
+    dY = torch.randn(M, N, generator=g)
+    Wb = torch.rand(N, K, generator=g) + 0.1
+    X = torch.randn(M, K, generator=g)
+    X[7] = -1.0; X[295] = -1.0
+    dY[7] = float("inf"); dY[295] = float("inf")
+    dx = gemm(dY.to(dev), Wb.to(dev), b_t=False, bwd=(3, X.to(dev))).cpu()
+    assert torch.isfinite(dx[7]).all() and float(dx[7].abs().max()) == 0.0 and float(dx[295].abs().max()) == 0.0
+    keep = torch.ones(M, dtype=torch.bool); keep[7] = keep[295] = False
+    want = torch.where(X > 0, dY @ Wb, torch.zeros(()))
+    np.testing.assert_allclose(dx[keep].numpy(), want[keep].numpy(), rtol=1e-4, atol=1e-3)

@@ -267,6 +267,30 @@ def _check_transform(got, want, pc1, weight):
     return float(ang.max()), float(dt.max())
 
 
+def _check_gradients(net, gref, what):
+    """Every parameter gradient against the oracle's, three ways: the norm (1e-2 relative: the fp32 gradient noise floor
+    of this net is ~1e-3), the DIRECTION (cosine >= 1 - 1e-5, i.e. a relative error vector below
+    4.5e-3: a permutation, a swapped column block or a missing term inside a tensor keeps the norm and fails this) and the
+    largest single element (<= 1e-2 of the tensor's largest entry).  -> (count, worst norm error, worst 1 - cos, worst
+    element error), each with the parameter's name."""
+    wn, wc, we, n = ("", 0.0), ("", 0.0), ("", 0.0), 0
+    for k, p in net.named_parameters():
+        if gref[k] is None:
+            assert p.grad is None, k
+            continue
+        a, r = p.grad.detach().double().cpu().reshape(-1), gref[k].double().reshape(-1)
+        na, nr = float(a.norm()), float(r.norm())
+        wn = max(wn, (k, abs(na - nr) / max(nr, 1e-3)), key=lambda t: t[1])
+        if nr > 1e-6:                                  # direction of a numerically-zero gradient is undefined
+            wc = max(wc, (k, 1.0 - float(a @ r) / (na * nr)), key=lambda t: t[1])
+        we = max(we, (k, float((a - r).abs().max()) / max(float(r.abs().max()), 1e-6)), key=lambda t: t[1])
+        n += 1
+    assert wn[1] <= 1e-2, (what, "norm", wn)
+    assert wc[1] <= 1e-5, (what, "direction", wc)
+    assert we[1] <= 1e-2, (what, "element", we)
+    return n, wn, wc, we
+
+
 def test_full_size_forward_matches_oracle(dev):
     """BASELINE config 2 at its own size -- bench.py's batch (B=64, N=256, seed 1234) and weights, eval mode -- HIP
     path vs the CPU oracle, with the bound of every quantity of SURVEY 8d written out:
@@ -331,23 +355,82 @@ def test_full_size_train_step_matches_oracle(dev):
     ang, dt = _check_transform(outs[2].detach(), out_ref[2].detach(), b["pc1"], score / score.sum(dim=1, keepdim=True))
     epe = (outs[0].detach().cpu() - out_ref[0].detach()).norm(dim=1)
     assert float(epe.mean()) <= 1e-4 and float(epe.max()) <= 1e-4 + 2e-6 * 100.0 + dt
+    from cmflow_amd.fused_blocks import join_side_streams
+    join_side_streams()
     gref = {k: p.grad for k, p in ref.named_parameters()}
-    worst, n = ("", 0.0), 0
-    for k, p in net.named_parameters():
-        if gref[k] is None:
-            assert p.grad is None, k
-            continue
-        a, r = float(p.grad.norm()), float(gref[k].norm())
-        rel = abs(a - r) / max(r, 1e-3)
-        worst = max(worst, (k, rel), key=lambda t: t[1])
-        n += 1
-    assert n >= 180 and worst[1] <= 1e-2, worst        # 182 parameter tensors receive a gradient
+    n, worst, wcos, welem = _check_gradients(net, gref, "B=64 CMFlow")
+    assert n >= 180                                     # 182 parameter tensors receive a gradient
     want, have = ref.state_dict(), net.state_dict()
     for k, v in want.items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             np.testing.assert_allclose(have[k].cpu().numpy(), v.numpy(), rtol=2e-4, atol=2e-5 * float(v.abs().max()) + 1e-7, err_msg=k)
-    print("full-size train: loss %.6f vs %.6f, worst grad-norm rel err %.3g (%s), rot %.3g rad, dt %.3g m"
-          % (loss.item(), loss_ref.item(), worst[1], worst[0], ang, dt))
+    print("full-size train: loss %.6f vs %.6f, worst grad-norm rel err %.3g (%s), worst 1-cos %.3g (%s), worst element %.3g (%s), "
+          "rot %.3g rad, dt %.3g m" % (loss.item(), loss_ref.item(), worst[1], worst[0], wcos[1], wcos[0], welem[1], welem[0], ang, dt))
+
+
+def test_full_size_cmflow_t_clip_matches_oracle(dev):
+    """BASELINE config 4's per-rank workload at its own size: bench.py --model cmflow_t's clip -- B=64, five frames
+    (seeds 1234 + 1000 f), weights of load_weights('cmflow_t') -- trained the way clip_util.py:34-62 does: gfeat = None at
+    the first frame, gfeat.detach() handed to the next one, one optimizer step per frame.  HIP path vs the CPU oracle,
+    per frame: labels bit-equal, loss and every loss item within 2e-4, flow EPE / stat_cls / transform as in the CMFlow
+    test, the new GRU state within 1e-4, every parameter gradient by norm, direction and largest element
+    (_check_gradients), BN running statistics.  Adam's first steps move a weight by ~lr*sign(g), so elements whose
+    gradient is at rounding level go different ways in two correct implementations: the weights (and the carried state)
+    are re-synchronised from the oracle before each frame, as in the B=4 test."""
+    import bench
+    from cmflow_amd.cmflow import CMFlow_T
+    from cmflow_amd.fused_blocks import join_side_streams
+    from cmflow_amd.train import TrainStep
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    sd = bench.load_weights("cmflow_t")
+    ref = O.CMFlow_T(bench.Args())
+    ref.load_state_dict(sd)
+    ref.train()
+    net = CMFlow_T(bench.Args())
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    step = TrainStep(net, vr_thres=bench.Args.vr_thres)
+    opt = torch.optim.Adam(ref.parameters(), lr=0.001, weight_decay=1e-4)
+    P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
+    g_prev = None
+    for f in range(5):
+        net.load_state_dict(ref.state_dict())
+        b = synth.make_batch(64, seed=1234 + 1000 * f, train_extras=True)
+        dyn_ref, mseg_ref = TO.make_labels(b)
+        out = ref(b["pc1"], b["pc2"], b["ft1"], b["ft2"], mseg_ref, "train", g_prev)
+        loss_ref, items_ref = TO.radar_flow_loss(b, out[0], out[2], out[1], mseg_ref, dyn_ref, P, Tcr)
+        opt.zero_grad()
+        loss_ref.backward()
+        if f == 0:
+            step.reset_clip()
+        else:
+            step.gfeat = g_prev.to(dev)                               # the same carried state on both sides
+        loss, items, outs, (dyn, mseg) = step.forward_loss({k: v.to(dev) for k, v in b.items()})
+        step.bucket.zero()
+        loss.backward()
+        join_side_streams()
+        assert torch.equal(dyn.cpu(), dyn_ref) and torch.equal(mseg.cpu(), mseg_ref), f
+        assert abs(loss.item() - loss_ref.item()) <= 2e-4 * max(1.0, abs(loss_ref.item())), (f, loss.item(), loss_ref.item())
+        for k, v in items.items():
+            assert abs(v.item() - items_ref[k]) <= 2e-4 * max(1.0, abs(items_ref[k])), (f, k, v.item(), items_ref[k])
+        assert torch.equal(outs[3].cpu(), out[3])
+        assert float((outs[1].detach().cpu() - out[1].detach()).abs().max()) <= 1e-4
+        score = mseg_ref                                              # cmflow_t.py:119: no 1e-4 on the scores
+        ang, dt = _check_transform(outs[2].detach(), out[2].detach(), b["pc1"], score / score.sum(dim=1, keepdim=True))
+        epe = (outs[0].detach().cpu() - out[0].detach()).norm(dim=1)
+        assert float(epe.mean()) <= 1e-4 and float(epe.max()) <= 1e-4 + 2e-6 * 100.0 + dt, (f, float(epe.mean()), float(epe.max()))
+        np.testing.assert_allclose(step.gfeat.detach().cpu().numpy(), out[4].detach().numpy(), rtol=0, atol=1e-4)
+        gref = {k: p.grad for k, p in ref.named_parameters()}
+        n, worst, wcos, welem = _check_gradients(net, gref, "CMFlow-T frame %d" % f)
+        assert n >= 184                                               # 182 + the four GRU tensors
+        want, have = ref.state_dict(), net.state_dict()
+        for k, v in want.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                np.testing.assert_allclose(have[k].cpu().numpy(), v.numpy(), rtol=2e-4, atol=2e-5 * float(v.abs().max()) + 1e-7, err_msg=k)
+        print("CMFlow-T B=64 frame %d: loss %.6f vs %.6f, grads: norm %.3g (%s) 1-cos %.3g (%s) element %.3g (%s), rot %.3g rad, dt %.3g m"
+              % (f, loss.item(), loss_ref.item(), worst[1], worst[0], wcos[1], wcos[0], welem[1], welem[0], ang, dt))
+        g_prev = out[4].detach().clone()
+        opt.step()
 
 
 def test_cmflow_t_clip_training_matches_oracle(dev, manifest_t, golden_dir, args):
@@ -702,3 +785,68 @@ def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path, gemm_mod
     assert float((ranks[0]["averaged"].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
     assert float(ranks[0]["local"].abs().sum()) > 0 and not torch.equal(ranks[0]["local"], ranks[1]["local"])
     print("2-rank CMFlow step vs single-rank shards: bit-identical" if exact else "2-rank CMFlow step vs single-rank shards: within 1e-6")
+
+
+def test_two_rank_cmflow_t_clip_matches_single_rank_shards(dev, tmp_path):
+    """BASELINE config 4's semantics on the real model: a 2-rank data-parallel CMFlow-T mini-clip (two frames; both ranks on
+    cuda:0 over gloo, tests/dp_worker.py) against single-process runs on each shard.  The GRU state is carried PER RANK
+    (gfeat.detach(), clip_util.py:54) and the optimizer steps after every frame on the all-reduced gradient (:60-62), so
+    the single-process twin of rank r steps with the 2-rank run's averaged bucket and must then reproduce rank r's second
+    frame -- loss, outputs, the new state and the local gradient bucket -- which only works if state hand-off, bucket
+    layout (incl. the four GRU tensors) and parameter update agree."""
+    import socket
+    import subprocess
+    import sys
+    import bench
+    from cmflow_amd.cmflow import CMFlow_T
+    from cmflow_amd.dp import shard_batch
+    from cmflow_amd.fused_blocks import join_side_streams
+    from cmflow_amd.train import TrainStep
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dp_worker.py"), str(tmp_path), "8", "cmflow_t", "2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(2)]
+    for f in range(2):
+        assert torch.equal(ranks[0]["frames"][f]["averaged"], ranks[1]["frames"][f]["averaged"]), f
+        assert not torch.equal(ranks[0]["frames"][f]["gfeat"], ranks[1]["frames"][f]["gfeat"])     # per-rank state
+    for k, v in ranks[0]["params"].items():
+        assert torch.equal(v, ranks[1]["params"][k]), k
+
+    def close(a, b, what):
+        a, b = a.double(), b.double()
+        assert float((a - b).abs().max()) <= 1e-6 * max(1e-30, float(b.abs().max())), what
+
+    for r in range(2):
+        net = CMFlow_T(bench.Args())
+        net.load_state_dict(bench.load_weights("cmflow_t"))
+        net = net.to(dev).train()
+        step = TrainStep(net, vr_thres=bench.Args.vr_thres)
+        locals_ = []
+        for f in range(2):
+            gb = synth.make_batch(8, seed=777 + f, train_extras=True)
+            loss, _, outs, _ = step.forward_loss({k: v.to(dev) for k, v in shard_batch(gb, r, 2).items()})
+            step.bucket.zero()
+            loss.backward()
+            join_side_streams()
+            torch.cuda.synchronize()
+            fr = ranks[r]["frames"][f]
+            close(fr["loss"], loss.detach().cpu(), "loss, rank %d frame %d" % (r, f))
+            for a, b in zip(fr["outs"], outs[:3]):
+                close(a, b.detach().cpu(), "outputs, rank %d frame %d" % (r, f))
+            close(fr["gfeat"], step.gfeat.detach().cpu(), "GRU state, rank %d frame %d" % (r, f))
+            close(fr["local"], step.bucket.flat.cpu(), "local gradient bucket, rank %d frame %d" % (r, f))
+            locals_.append(step.bucket.flat.detach().cpu().double())
+            step.bucket.flat.copy_(fr["averaged"].to(dev))            # step on what the all-reduce delivered
+            step.opt.step()
+        have = dict(net.named_parameters())
+        for k, v in ranks[r]["params"].items():
+            close(v, have[k].detach().cpu(), k)
+        ranks[r]["_locals"] = locals_
+    for f in range(2):
+        mean = (ranks[0]["_locals"][f] + ranks[1]["_locals"][f]) / 2
+        assert float((ranks[0]["frames"][f]["averaged"].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max())

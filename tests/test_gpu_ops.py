@@ -106,6 +106,35 @@ def test_group_points_and_grad(dev, B, C, N, P, S):
     np.testing.assert_allclose(gp.cpu().numpy(), 2 * ref.numpy(), rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("C", [64, 128])
+def test_config5_shapes_match_oracle(dev, C):
+    """BASELINE config 5 at its own op shape -- N = 4096 LiDAR-like points, K = 64, r = 2.0, C in {64, 128} -- the first
+    two samples of the very tensors bench.py's `roofline_hbm` times (same generator, seed 1234, B = 32): cell-grid ball
+    query bit-exact, group_points a bit-exact copy, group_points_grad within fp32 rounding of the oracle's scan-order sum
+    (its order is the LDS-atomic kernel's: undefined, like the reference's atomicAdd, group_points_gpu.cu:8-25)."""
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    B, N, K, r = 2, 4096, 64, 2.0
+    xyz = synth.make_batch(32, N=N, seed=1234, lidar=True)["pc1"][:B].contiguous()       # (B,3,N) as bench.py builds it
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    idx = torch.zeros(B, N, K, dtype=torch.int32, device=dev)
+    ext.ball_query_wrapper(B, N, N, r, K, xyz_t.to(dev), xyz_t.to(dev), idx)
+    want_idx = orc.ball_query(r, K, xyz_t, xyz_t)
+    assert torch.equal(idx.cpu(), want_idx)
+    gx = torch.empty(B, 3, N, K, device=dev)
+    ext.group_points_wrapper(B, 3, N, N, K, xyz.to(dev), idx, gx)
+    assert torch.equal(gx.cpu(), orc.group_points(xyz, want_idx))
+    g = torch.Generator().manual_seed(C)
+    feats = torch.randn(B, C, N, generator=g)
+    out = torch.empty(B, C, N, K, device=dev)
+    ext.group_points_wrapper(B, C, N, N, K, feats.to(dev), idx, out)
+    assert torch.equal(out.cpu(), orc.group_points(feats, want_idx))
+    go = torch.randn(B, C, N, K, generator=g)
+    gp = torch.zeros(B, C, N, device=dev)
+    ext.group_points_grad_wrapper(B, C, N, N, K, go.to(dev), idx, gp)
+    ref = orc.group_points_grad(go, want_idx, N)
+    np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("r,S", [(2.0, 32), (16.0, 32), (4.0, 8), (0.01, 4)])
 def test_group_points_grad_skewed_index(dev, r, S):
     """Real ball-query indices: first-hit padding makes the inverse lists of low-numbered points ~10x the

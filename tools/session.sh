@@ -1,0 +1,25 @@
+#!/bin/bash
+# One gpurun session: tools/session.sh <outdir> <step> [<step> ...] runs the named steps below in order, output under
+# gpurun_out/<outdir>/.
+# (replaces the one-off tools/r02_session*.sh scripts of round 2)
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+NAME=$1; shift
+R=$GRAFT_REPO_ROOT/gpurun_out/$NAME; mkdir -p $R
+filter() { grep -v "amdgpu.ids\|_warn_once\|Warning:" ; }
+
+tests_new() {          # the round-3 tests, one by one so that a failure does not hide the others
+    python -m pytest tests/test_gpu_stress.py -x -q -m gpu -s 2>&1 | tail -25 > $R/stress.txt
+    python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size or two_rank_cmflow_t" 2>&1 | tail -40 > $R/model.txt
+    python -m pytest tests/test_gpu_ops.py tests/test_gpu_gemm.py -q -m gpu -k "config5 or small_m or non_finite" 2>&1 | tail -25 > $R/ops.txt
+}
+gemm_diag() {
+    for d in 0 8 9 12 1; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
+    CMF_GEMM_DIAG_RT=8 python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq_noepi.txt
+    python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq.txt
+}
+suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
+bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
+
+for step in "$@"; do echo "== $step"; $step; done
+ls -la $R
