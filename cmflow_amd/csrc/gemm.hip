@@ -40,6 +40,10 @@ constexpr int G_THREADS = 256;
                                           //    The backward kinds keep the transposed form: their Z tile wants 16-byte loads issued a band
                                           //    ahead (direct: 36 vs 17 us per tile).
 #endif
+#ifndef CMF_EPI_WAVE
+#define CMF_EPI_WAVE 1                    // bit 0: the backward kinds (2-5) of the 128 x 128 kernels finish their tiles per wave (wave_epilogue);
+                                          // bit 1: kinds 0 / 1 as well (instead of the direct form) -- experiment
+#endif
 #ifndef CMF_GEMM_W3
 #define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
 #endif
@@ -140,7 +144,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
-__global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 3)) ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 3 || CMF_GEMM_W3) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 3)) ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 3 || CMF_GEMM_W3 || (CMF_EPI_WAVE & 1)) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -850,8 +854,143 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
         }
         stats_done = true;
     };
+    // ---- wave-private form of the fast path (backward kinds; CMF_EPI_WAVE): every wave transposes ITS OWN 32 x 64 block
+    // rows through a private LDS tile and finishes them alone -- LDS operations of one wave execute in order, so between
+    // the accumulator stores and the row reads there is no barrier and no wait, the four waves never meet until the column
+    // sums are combined, and nobody idles while two of them spill a band (the banded form above: 2.5 us until the first
+    // band is visible + 2.4 us per band behind workgroup barriers, 13.7 us per K = 256 data-gradient tile against a 15.6 us
+    // main loop).  Rows are still read and written as 16-byte pieces of 256-byte segments (16 lanes per row, 4 rows per
+    // instruction); the producer's Z rows of block row i + 1 are requested before block row i is stored.
+    auto wave_epilogue = [&](auto kind_c) {
+        constexpr int KIND = decltype(kind_c)::value;
+        constexpr bool USE_Z = KIND >= 2, WQ = KIND >= 4, BNR = KIND == 2 || KIND == 4;
+        static_assert(WN == 64 && TN == 2, "wave tile 64 columns wide");
+        constexpr int W_LD = WN + 4;                                  // 68 floats: 16-byte rows, bank shift 4 per row
+        constexpr int W_TILE = 32 * W_LD, W_SZ = W_TILE + WM * 4 + 4 * WN;     // per wave: transposition tile | dxyz rows | column constants
+        float *wt = smem + wid * W_SZ, *wdq = wt + W_TILE;
+        const int rl = lane >> 4, c4 = (lane & 15) * 4;               // row inside a group of 4, first of the lane's 4 columns
+        const int cb = wn * WN + c4;                                  // tile-local column; global: n0 + cb
+        // wave-uniform row bases in scalar registers, ONE 32-bit per-lane byte offset per matrix (the lane's row of the group
+        // of 4 and its columns): per-lane 64-bit addresses for 16 rows x 2 matrices would take 64 registers
+        const int wms = __builtin_amdgcn_readfirstlane(wm), wns = __builtin_amdgcn_readfirstlane(wn);
+        const int rbase = m0 + wms * WM;
+        const float *zbase = p.Z + (long long)rbase * p.ldz + n0 + wns * WN;
+        float *cbase = Cout + (long long)rbase * p.ldc + n0 + wns * WN;
+        const unsigned lane_z = (unsigned)((rl * (int)p.ldz + c4) * 4), lane_c = (unsigned)((rl * (int)p.ldc + c4) * 4);
+        // Z rows of ONE half block row (16 rows: 4 per lane) at a time, requested one half ahead: the next half's loads are
+        // issued after this half's arithmetic and BEFORE its stores, so no load is ever waited on behind a store
+        f32x4 zp[4];
+        auto load_z = [&](int g) {                                    // g = 2 * block row + half
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                zp[u] = *(const f32x4 *)((const char *)(zbase + (long long)(g * 16 + u * 4) * p.ldz) + lane_z);
+        };
+        if (USE_Z) load_z(0);
+        // per-column constants and the wave's dxyz rows: wave-private LDS (re-read per half: 16 registers less)
+        float *wk = wdq + WM * 4;                                     // [4][WN]
+        if (WQ) {
+#pragma unroll
+            for (int q = lane; q < WM; q += 64) *(f32x4 *)(wdq + q * 4) = *(const f32x4 *)(p.dxyz + (long long)(rbase + q) * 4);
+        }
+        if (KIND == 1) wk[lane] = p.bias ? p.bias[n0 + wns * WN + lane] : 0.f;
+        if (BNR) {
+            const int c = n0 + wns * WN + lane;
+            wk[lane] = p.ea[c]; wk[WN + lane] = p.ec[c]; wk[2 * WN + lane] = p.emean[c]; wk[3 * WN + lane] = p.einvstd[c];
+        }
+        const float slope = KIND == 1 ? (p.act == 1 ? 0.f : (p.act == 2 ? 0.1f : 1.f)) : (p.bwd_mode == 2 ? 0.1f : 0.f);
+        // compiler fences (no instructions): without them the scheduler hoists the LDS reads and Z loads of later halves above
+        // the arithmetic of earlier ones -- 256 registers and spills instead of ~150
+        auto fence = [&]() { asm volatile("" ::: "memory"); };
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * W_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            if (p.trace && i == 0) t_e[0] = wall_clock64();
+            fence();
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {                           // two halves of 16 rows
+                f32x4 t4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t4[u] = *(const f32x4 *)(wt + (rl + (hf * 4 + u) * 4) * W_LD + c4);
+                if (KIND != 0) {
+                    f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, k2 = k0, k3 = k0;
+                    if (KIND == 1 || BNR) k0 = *(const f32x4 *)(wk + c4);
+                    if (BNR) { k1 = *(const f32x4 *)(wk + WN + c4); k2 = *(const f32x4 *)(wk + 2 * WN + c4); k3 = *(const f32x4 *)(wk + 3 * WN + c4); }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+                        if (WQ) d4 = *(const f32x4 *)(wdq + (i * 32 + rl + (hf * 4 + u) * 4) * 4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float x = t4[u][q];
+                            if (KIND == 1) {
+                                x += k0[q];
+                                x = x > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
+                                s1[q] += x; s2[q] += x * x;
+                            } else if (BNR) {
+                                const float z = zp[u][q];
+                                x = (fmaf(k0[q], z, k1[q]) > 0.f) ? x : 0.f;
+                                s1[q] += x; s2[q] += x * ((z - k2[q]) * k3[q]);
+                            } else {
+                                x = zp[u][q] > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
+                                s1[q] += x;
+                            }
+                            if (WQ) { qs[0][q] += x * d4.x; qs[1][q] += x * d4.y; qs[2][q] += x * d4.z; }
+                            t4[u][q] = x;
+                        }
+                    }
+                }
+                // pin the running sums here: otherwise the scheduler sinks the statistics below the stores and spills this
+                // half's values and Z rows to scratch for them (121 spilled registers)
+                if (KIND != 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile("" : "+v"(s1[q]));
+                        if (KIND == 1 || BNR) asm volatile("" : "+v"(s2[q]));
+                        if (WQ) asm volatile("" : "+v"(qs[0][q]), "+v"(qs[1][q]), "+v"(qs[2][q]));
+                    }
+                }
+                fence();
+                if (USE_Z && 2 * i + hf + 1 < 2 * TM) load_z(2 * i + hf + 1);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *(f32x4 *)((char *)(cbase + (long long)(i * 32 + (hf * 4 + u) * 4) * p.ldc) + lane_c) = t4[u];
+                fence();
+            }
+            if (p.trace && i == 0) t_e[1] = wall_clock64();
+        }
+        if (p.trace) t_e[2] = wall_clock64();
+        if (want_stats) {
+            // the lane's 16 rows -> the 4 row groups of the wave (lanes l, l^16, l^32, l^48) -> the WARPS_M wave rows (LDS)
+            lds_barrier();                                            // every wave is done with its tile: the LDS is reused
+            float *red = smem;                                        // [WARPS_M][nstat][BN]
+            auto fold = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v1 = fold(s1[q]), v2 = fold(s2[q]);
+                if (rl == 0) { red[(wm * nstat + 0) * BN + cb + q] = v1; red[(wm * nstat + 1) * BN + cb + q] = v2; }
+                if (WQ) {
+                    const float w0 = fold(qs[0][q]), w1 = fold(qs[1][q]), w2 = fold(qs[2][q]);
+                    if (rl == 0) { red[(wm * nstat + 2) * BN + cb + q] = w0; red[(wm * nstat + 3) * BN + cb + q] = w1; red[(wm * nstat + 4) * BN + cb + q] = w2; }
+                }
+            }
+            lds_barrier();
+            for (int c = tid; c < nstat * BN; c += G_THREADS) {
+                const int which = c / BN, cc = c % BN;
+                float sum = 0.f;
+#pragma unroll
+                for (int g = 0; g < WARPS_M; ++g) sum += red[(g * nstat + which) * BN + cc];
+                p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
+            }
+        }
+        stats_done = true;
+    };
     if (fast_epi && epilogue_kind(p) == EPI && CMF_EMUL_DIAG != 8) {
-        if constexpr (CMF_EPI_DIRECT && BM == 128 && EPI <= 1) direct_epilogue(std::integral_constant<int, EPI>{});
+        if constexpr (CMF_EPI_DIRECT && BM == 128 && EPI <= 1 && !(CMF_EPI_WAVE & 2)) direct_epilogue(std::integral_constant<int, EPI>{});
+        else if constexpr ((CMF_EPI_WAVE & 1) && BM == 128 && BN == 128) wave_epilogue(std::integral_constant<int, EPI>{});
         else fast_epilogue(std::integral_constant<int, EPI>{});
     } else {
     if (p.split_k == 1)
