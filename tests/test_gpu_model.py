@@ -271,8 +271,10 @@ def _check_gradients(net, gref, what):
     """Every parameter gradient against the oracle's, three ways: the norm (1e-2 relative: the fp32 gradient noise floor
     of this net is ~1e-3), the DIRECTION (cosine >= 1 - 1e-5, i.e. a relative error vector below
     4.5e-3: a permutation, a swapped column block or a missing term inside a tensor keeps the norm and fails this) and the
-    largest single element (<= 1e-2 of the tensor's largest entry).  -> (count, worst norm error, worst 1 - cos, worst
-    element error), each with the parameter's name."""
+    largest single element (<= 3e-2 of the tensor's largest entry).  The bounds sit 2-3x above what the ORACLE's own fp32
+    evaluation differs from its fp64 evaluation at this size (tests/grad_noise_floor.py, B = 64: norm 5.9e-4, 1 - cos
+    3.6e-6, element 1.31e-2 -- a 1e-2 element bound is below the fp32 noise of the oracle itself).
+    -> (count, worst norm error, worst 1 - cos, worst element error), each with the parameter's name."""
     wn, wc, we, n = ("", 0.0), ("", 0.0), ("", 0.0), 0
     for k, p in net.named_parameters():
         if gref[k] is None:
@@ -287,7 +289,7 @@ def _check_gradients(net, gref, what):
         n += 1
     assert wn[1] <= 1e-2, (what, "norm", wn)
     assert wc[1] <= 1e-5, (what, "direction", wc)
-    assert we[1] <= 1e-2, (what, "element", we)
+    assert we[1] <= 3e-2, (what, "element", we)
     return n, wn, wc, we
 
 

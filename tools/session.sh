@@ -18,6 +18,15 @@ gemm_diag() {
     CMF_GEMM_DIAG_RT=8 python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq_noepi.txt
     python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq.txt
 }
+gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
+gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment build (tools/diag/libcmflow_w3.so)
+    for d in 0 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
+    CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_w3.so python tools/gemm_diag.py 2>&1 | filter > $R/gemm_diag_w3.txt
+    python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq.txt
+    python tools/gemm_variants.py 2>&1 | filter > $R/gemm_variants.txt
+}
+model_tests() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size or two_rank" 2>&1 | tail -30 > $R/model.txt; }
+bench3() { for i in 1 2 3; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null; done > $R/bench3.json; cat $R/bench3.json | python -c "import sys,json; [print(json.loads(l)['ms_per_step'], json.loads(l)['roofline']['frac'], json.loads(l)['roofline_isolated']['frac']) for l in sys.stdin]"; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
