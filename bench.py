@@ -133,7 +133,8 @@ def hbm_op_rooflines(dev, iters=20):
     launches between one HIP event pair on the launch stream (kernel duration incl. the ~1.5 us launch gap).
     Algorithmic bytes (every tensor touched once):
       ball_query+group = 2*B*N*12 (xyz, centres) + B*C*N*4 (features) + B*M*K*4 (idx) + B*(3+C)*M*K*4 (grouped out)
-                         over t(ball_query) + t(group xyz) + t(group features)
+                         over t(ball_query) + t(group xyz) + t(group features); `query_and_group`: the same bytes over ONE
+                         cmf_query_and_group call (QueryAndGroup.forward as the reference's module issues it)
       group_grad       = B*C*M*K*4 (grad_out) + B*M*K*4 (idx) + B*C*N*4 (grad_points)"""
     from cmflow_amd import _lib, synth
     L = _lib.lib()
@@ -151,6 +152,29 @@ def hbm_op_rooflines(dev, iters=20):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e-3
 
+    def check_sample0(xyz, xyz_t, r, K, idx, feats, out, fused):
+        """One batch row of the timed outputs against the definition of the ops written in plain torch on the device (no
+        oracle here: that is tests/test_gpu_ops.py::test_config5_shapes_match_oracle's job): ball query = first K points in
+        index order with ((dx*dx)+(dy*dy))+(dz*dz) < r*r, every operation individually rounded, padded with the first hit;
+        grouping = a gather; the fused call = cat(xyz[idx] - centre, feats[idx])."""
+        p = xyz_t[0]                                                                     # (N,3)
+        d = p[:, None, :] - p[None, :, :]                                                # centre - point
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        hit = d2 < (torch.tensor(r, device=dev) * torch.tensor(r, device=dev))
+        rank = torch.cumsum(hit.int(), dim=1) - 1
+        want = torch.zeros(p.shape[0], K, dtype=torch.int32, device=dev)
+        sel = hit & (rank < K)
+        ci, pi = sel.nonzero(as_tuple=True)
+        want[ci, rank[ci, pi].long()] = pi.int()
+        cnt = hit.sum(dim=1).clamp(max=K)
+        pad = torch.arange(K, device=dev)[None, :] >= cnt[:, None]
+        want = torch.where(pad & (cnt[:, None] > 0), want[:, :1].expand(-1, K), want)
+        assert torch.equal(idx[0], want), "ball query: timed output differs from its definition"
+        g = feats[0][:, want.long()]                                                     # (C,N,K)
+        assert torch.equal(out[0], g), "group_points: timed output differs from its definition"
+        rel = xyz[0][:, want.long()] - xyz[0][:, :, None]
+        assert torch.equal(fused[0], torch.cat((rel, g), dim=0)), "query_and_group: timed output differs from its definition"
+
     rows = []
     for (B, N, K, r, lidar), Cs in (((64, 256, 32, 2.0, False), (3, 64, 1027)), ((32, 4096, 64, 2.0, True), (64, 128))):
         xyz = synth.make_batch(B, N=N, seed=1234, lidar=lidar)["pc1"].to(dev)          # (B,3,N) channel-major
@@ -164,6 +188,14 @@ def hbm_op_rooflines(dev, iters=20):
             feats = torch.randn(B, C, N, device=dev)
             out = torch.empty(B, C, N, K, device=dev)
             t_gf = timed(lambda: _lib.check(L.cmf_group_points(B, C, N, N, K, feats.data_ptr(), idx.data_ptr(), out.data_ptr(), st), "gf"))
+            # the same as ONE call (QueryAndGroup.forward, lib/pointnet2_utils.py:269-292)
+            fused = torch.empty(B, 3 + C, N, K, device=dev)
+            idx2 = torch.empty(B, N, K, dtype=torch.int32, device=dev)
+            t_qg = timed(lambda: _lib.check(L.cmf_query_and_group(B, N, N, r, K, C, 1, xyz_t.data_ptr(), xyz_t.data_ptr(), feats.data_ptr(),
+                                                                  idx2.data_ptr(), fused.data_ptr(), st), "qg"))
+            if C == Cs[-1]:
+                check_sample0(xyz, xyz_t, r, K, idx, feats, out, fused)
+            del fused, idx2
             out.normal_()
             gp = torch.zeros(B, C, N, device=dev)
             t_gg = timed(lambda: _lib.check(L.cmf_group_points_grad(B, C, N, N, K, out.data_ptr(), idx.data_ptr(), gp.data_ptr(), st), "gg"))
@@ -174,12 +206,14 @@ def hbm_op_rooflines(dev, iters=20):
                          "ball_query+group": {"bytes": nb, "us": round(t_f * 1e6, 1), "achieved": round(nb / t_f / 1e9, 1),
                                               "frac": round(nb / t_f / 1e9 / HBM_PEAK_GBS, 4),
                                               "us_parts": [round(t * 1e6, 1) for t in (t_bq, t_gx, t_gf)]},
+                         "query_and_group": {"bytes": nb, "us": round(t_qg * 1e6, 1), "achieved": round(nb / t_qg / 1e9, 1),
+                                             "frac": round(nb / t_qg / 1e9 / HBM_PEAK_GBS, 4)},
                          "group_grad": {"bytes": ng, "us": round(t_gg * 1e6, 1), "achieved": round(ng / t_gg / 1e9, 1),
                                         "frac": round(ng / t_gg / 1e9 / HBM_PEAK_GBS, 4)}})
             del feats, out, gp
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "traffic_profile": "profiles/r02_op_hbm_pmc.md",
-            "kernels": ["ball_query_kernel", "group_points_kernel", "group_points_grad_*_kernel"],
+            "kernels": ["ball_query_ballot_kernel / bq_grid_*", "group_points_kernel", "query_and_group_kernel", "group_points_grad_*_kernel"],
             "method": "%d back-to-back launches per op between one HIP event pair; bytes = SURVEY 8d algorithmic bytes" % iters,
             "rows": rows}
 

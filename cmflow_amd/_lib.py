@@ -20,6 +20,7 @@ SIGNATURES = {
     "cmf_ball_query": [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp],
     "cmf_group_points": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_group_points_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
+    "cmf_query_and_group": [_ci, _ci, _ci, _cf, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_knn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch_grad": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

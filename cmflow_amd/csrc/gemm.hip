@@ -882,8 +882,10 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
         f32x4 zp[4];
         auto load_z = [&](int g) {                                    // g = 2 * block row + half
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u) {
+                if (p.diag & 32) { zp[u] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }            // timing diagnostic: no Z loads
                 zp[u] = *(const f32x4 *)((const char *)(zbase + (long long)(g * 16 + u * 4) * p.ldz) + lane_z);
+            }
         };
         if (USE_Z) load_z(0);
         // per-column constants and the wave's dxyz rows: wave-private LDS (re-read per half: 16 registers less)
@@ -956,8 +958,10 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
                 fence();
                 if (USE_Z && 2 * i + hf + 1 < 2 * TM) load_z(2 * i + hf + 1);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u) {
+                    if (p.diag & 16) { asm volatile("" :: "v"(t4[u])); continue; }                // timing diagnostic: no C stores
                     *(f32x4 *)((char *)(cbase + (long long)(i * 32 + (hf * 4 + u) * 4) * p.ldc) + lane_c) = t4[u];
+                }
                 fence();
             }
             if (p.trace && i == 0) t_e[1] = wall_clock64();

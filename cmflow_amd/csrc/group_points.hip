@@ -11,6 +11,9 @@
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
+int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                             long long out_bstride, void *stream);
+
 constexpr int GP_THREADS = 256;
 // channels per workgroup: 8 when the rows are short (8 rows of n floats in LDS), 2 for long rows so that
 // several workgroups still fit on a CU (occupancy hides the LDS gather latency)
@@ -22,7 +25,7 @@ constexpr int GP_MAX_N_LDS = 8192;    // rows staged in LDS up to this n
 template <bool ROWS_IN_LDS, int GP_CH, int TPB>
 __global__ __launch_bounds__(TPB) void group_points_kernel(
     int c, int n, int total /* npoints*nsample */, int tiles_per_sample, int tiles_per_wg,
-    const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out)
+    const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out, long long out_bstride)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];   // [GP_CH][n] when ROWS_IN_LDS
     // a workgroup stages its feature rows once and walks tiles_per_wg consecutive idx tiles with them: with long rows
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
     const int nch = min(GP_CH, c - c0);
     const int *ix = idx + (size_t)bs * total;
     const float *src = points + ((size_t)bs * c + c0) * n;
-    float *dst = out + ((size_t)bs * c + c0) * total;
+    float *dst = out + (size_t)bs * out_bstride + (size_t)c0 * total;
 
     if (ROWS_IN_LDS) {
         for (int i = threadIdx.x; i < nch * n; i += TPB) rows[i] = src[i];
@@ -83,9 +86,18 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
                                 const float *points, const int *idx, float *out, void *stream)
 {
     CMF_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
+    return cmf_group_points_strided(b, c, n, npoints, nsample, points, idx, out, (long long)c * npoints * nsample, stream);
+}
+
+// out_bstride: floats between consecutive samples of `out` (c * npoints * nsample for a dense output; larger when the
+// feature planes are part of a wider tensor: cmf_query_and_group)
+int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                             long long out_bstride, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
     const long long total = (long long)npoints * nsample;
     if (b == 0 || c == 0 || total == 0) return 0;
-    CMF_CHECK_ARG(points && idx && out && n > 0 && total < (1LL << 31));
+    CMF_CHECK_ARG(points && idx && out && n > 0 && total < (1LL << 31) && out_bstride >= (long long)c * total);
     int tiles = cmf_divup(total, GP_TILE);
     hipStream_t st = (hipStream_t)stream;
     // tiles per workgroup: as many as possible while the launch still has >= ~1024 workgroups
@@ -98,7 +110,7 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
         const int t = tiles_per_wg(cmf_divup(c, 8));
         dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 8));
         hipLaunchKernelGGL((group_points_kernel<true, 8, GP_THREADS>), grid, dim3(GP_THREADS), (size_t)8 * n * sizeof(float), st,
-                           c, n, (int)total, tiles, t, points, idx, out);
+                           c, n, (int)total, tiles, t, points, idx, out, out_bstride);
     } else if (n <= GP_MAX_N_LDS) {
         // 4 rows when they fit in 64 KB (two workgroups per CU), else 2
         const bool four = (size_t)4 * n * sizeof(float) <= 64 * 1024;
@@ -115,17 +127,17 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
             const int t = tiles_per_wg(cmf_divup(c, 4));
             dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 4));
             hipLaunchKernelGGL((group_points_kernel<true, 4, 512>), grid, dim3(512), (size_t)4 * n * sizeof(float), st,
-                               c, n, (int)total, tiles, t, points, idx, out);
+                               c, n, (int)total, tiles, t, points, idx, out, out_bstride);
         } else {
             const int t = tiles_per_wg(cmf_divup(c, 2));
             dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 2));
             hipLaunchKernelGGL((group_points_kernel<true, 2, 512>), grid, dim3(512), (size_t)2 * n * sizeof(float), st,
-                               c, n, (int)total, tiles, t, points, idx, out);
+                               c, n, (int)total, tiles, t, points, idx, out, out_bstride);
         }
     } else {
         dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 8));
         hipLaunchKernelGGL((group_points_kernel<false, 8, GP_THREADS>), grid, dim3(GP_THREADS), 0, st,
-                           c, n, (int)total, tiles, 1, points, idx, out);
+                           c, n, (int)total, tiles, 1, points, idx, out, out_bstride);
     }
     return cmf_launch_status();
 }

@@ -384,6 +384,170 @@ __global__ __launch_bounds__(256) void bq_grid_query_kernel(int n, int m, float 
         for (int l = total + lane; l < nsample; l += 64) out[l] = first;           // ball_query_gpu.cu:37-41
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Ball query for small clouds (n <= 1024: every shape of the model), ballot form.  The scan kernels above give a lane
+// one centre and walk the cloud in a dependent loop (n = 256: 64 + points per wave, ~10 us per launch whatever the
+// batch).  Here a WAVE owns a centre and the cloud lives in its registers: lane l holds points 4l .. 4l+3 of every
+// 256-point chunk, evaluates their distances (same canonical arithmetic), and four ballots per chunk ARE the hit list in
+// index order -- a hit's slot is (hits of earlier chunks) + (hits in lower lanes) + (own earlier hits): two mbcnt
+// pairs and a few adds, no loop over points, no atomics.  A wave serves G consecutive centres from the same registers
+// and collects their lists in a wave-private LDS block; the write-out of the G x nsample block is coalesced.
+//   first nsample hits in index order, padded with the first hit, strict d2 < r^2 (ball_query_gpu.cu:29-41)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int BQB_WAVES = 4;                 // waves per workgroup (independent of each other)
+constexpr int BQB_CHUNK = 256;               // points per register chunk (4 per lane)
+constexpr int BQB_MAX_N = 1024;
+
+template <int NCH>
+struct BqbCloud { float x[NCH][4], y[NCH][4], z[NCH][4]; };
+
+template <int NCH>
+__device__ __forceinline__ void bqb_load_cloud(const float *__restrict__ pts, int n, int lane, BqbCloud<NCH> &c)
+{
+    const float far = __builtin_inff();                       // out-of-range slots: never inside a ball (inf < r2 is false)
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = k * BQB_CHUNK + 4 * lane + j;
+            const bool ok = p < n;
+            const float *q = pts + (size_t)(ok ? p : 0) * 3;
+            c.x[k][j] = ok ? q[0] : far; c.y[k][j] = ok ? q[1] : far; c.z[k][j] = ok ? q[2] : far;
+        }
+}
+
+// One centre: fills lst[0 .. nsample) (wave-private LDS) and returns the number of hits found before the list was full
+// (0: empty ball, lst untouched).
+template <int NCH>
+__device__ __forceinline__ int bqb_centre(const BqbCloud<NCH> &c, float cx, float cy, float cz, float radius2, int nsample, int lane,
+                                          int *lst)
+{
+    int cnt = 0;                                               // wave-uniform
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if (cnt >= nsample) break;
+        bool h[4];
+        unsigned long long B[4];
+        int lower = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dx = cx - c.x[k][j];
+            const float dy = cy - c.y[k][j];
+            const float dz = cz - c.z[k][j];
+            const float xx = dx * dx;
+            const float yy = dy * dy;
+            const float zz = dz * dz;
+            const float sxy = xx + yy;
+            const float d2 = sxy + zz;
+            h[j] = d2 < radius2;
+            B[j] = __ballot(h[j]);
+            lower += (int)__builtin_amdgcn_mbcnt_hi((unsigned)(B[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)B[j], 0u));
+            tot += __popcll(B[j]);
+        }
+        if (tot) {                                             // wave-uniform
+            int pos = cnt + lower;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (h[j]) { if (pos < nsample) lst[pos] = k * BQB_CHUNK + 4 * lane + j; ++pos; }
+            cnt += tot;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > 0 && cnt < nsample) {
+        const int first = lst[0];
+        for (int sl = cnt + lane; sl < nsample; sl += CMF_WAVE) lst[sl] = first;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return cnt;
+}
+
+// idx-only form (cmf_ball_query): G centres per wave; empty balls leave idx untouched (ball_query_gpu.cu:29-41 with the
+// caller's pre-zeroed idx, lib/pointnet2_utils.py:246)
+template <int NCH>
+__global__ __launch_bounds__(BQB_WAVES *CMF_WAVE) void ball_query_ballot_kernel(
+    int n, int m, float radius2, int nsample, int G, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    int *__restrict__ idx)
+{
+    extern __shared__ int bqb_lds[];                          // [BQB_WAVES][G * nsample]
+    const int bs = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pt0 = (blockIdx.x * BQB_WAVES + w) * G;
+    if (pt0 >= m) return;                                     // wave-uniform; no workgroup barrier anywhere
+    BqbCloud<NCH> cloud;
+    bqb_load_cloud<NCH>(xyz + (size_t)bs * n * 3, n, lane, cloud);
+    int *lst = bqb_lds + w * G * nsample;
+    const int gv = min(G, m - pt0);
+    unsigned empty = 0u;
+    for (int g = 0; g < gv; ++g) {
+        const float *cc = new_xyz + ((size_t)bs * m + pt0 + g) * 3;
+        if (bqb_centre<NCH>(cloud, cc[0], cc[1], cc[2], radius2, nsample, lane, lst + g * nsample) == 0) empty |= 1u << g;
+    }
+    __builtin_amdgcn_wave_barrier();
+    int *out = idx + ((size_t)bs * m + pt0) * nsample;
+    for (int e = lane; e < gv * nsample; e += CMF_WAVE)
+        if (!((empty >> (e / nsample)) & 1u)) out[e] = lst[e];
+}
+
+// QueryAndGroup.forward (lib/pointnet2_utils.py:269-292) in ONE launch: ball query + grouped xyz relative to the centre
+// + grouped features, written in the reference's (B, 3 + C, M, nsample) layout.  The wave that found the G lists
+// gathers them: entry e of its G x nsample block is contiguous in every channel plane, so each channel is one (or a
+// few) coalesced 256-byte stores per wave; the feature rows (n floats per channel) are read through the caches.
+// An empty ball groups point 0 (the reference's pre-zeroed idx).
+template <int NCH>
+__global__ __launch_bounds__(BQB_WAVES *CMF_WAVE) void query_and_group_kernel(
+    int n, int m, float radius2, int nsample, int G, int c, int use_xyz, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, const float *__restrict__ features, int *__restrict__ idx, float *__restrict__ out)
+{
+    extern __shared__ int bqb_lds[];
+    const int bs = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pt0 = (blockIdx.x * BQB_WAVES + w) * G;
+    if (pt0 >= m) return;
+    const float *pts = xyz + (size_t)bs * n * 3;
+    BqbCloud<NCH> cloud;
+    bqb_load_cloud<NCH>(pts, n, lane, cloud);
+    int *lst = bqb_lds + w * G * nsample;
+    const int gv = min(G, m - pt0);
+    for (int g = 0; g < gv; ++g) {
+        const float *cc = new_xyz + ((size_t)bs * m + pt0 + g) * 3;
+        if (bqb_centre<NCH>(cloud, cc[0], cc[1], cc[2], radius2, nsample, lane, lst + g * nsample) == 0)
+            for (int sl = lane; sl < nsample; sl += CMF_WAVE) lst[g * nsample + sl] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int ctot = (use_xyz ? 3 : 0) + c;
+    const size_t plane = (size_t)m * nsample;                  // one channel of one sample
+    const size_t e0 = (size_t)pt0 * nsample;
+    float *ob = out + (size_t)bs * ctot * plane + e0;
+    const float *fb = features ? features + (size_t)bs * c * n : nullptr;
+    for (int e = lane; e < gv * nsample; e += CMF_WAVE) {
+        const int id = lst[e];
+        if (idx) idx[(size_t)bs * plane + e0 + e] = id;
+        float *o = ob + e;
+        if (use_xyz) {
+            const float *cc = new_xyz + ((size_t)bs * m + pt0 + e / nsample) * 3;
+            const float *q = pts + (size_t)id * 3;
+            o[0] = q[0] - cc[0]; o[plane] = q[1] - cc[1]; o[2 * plane] = q[2] - cc[2];
+            o += 3 * plane;
+        }
+        int ch = 0;
+        for (; ch + 4 <= c; ch += 4) {                          // 4 gathers in flight
+            const float v0 = fb[(size_t)ch * n + id], v1 = fb[(size_t)(ch + 1) * n + id];
+            const float v2 = fb[(size_t)(ch + 2) * n + id], v3 = fb[(size_t)(ch + 3) * n + id];
+            o[(size_t)ch * plane] = v0; o[(size_t)(ch + 1) * plane] = v1; o[(size_t)(ch + 2) * plane] = v2; o[(size_t)(ch + 3) * plane] = v3;
+        }
+        for (; ch < c; ++ch) o[(size_t)ch * plane] = fb[(size_t)ch * n + id];
+    }
+}
+
+// centres per wave: enough waves to fill the chip (>= ~4096), rows of at least 64 entries for the write-out
+static int bqb_group(int b, int m, int nsample)
+{
+    long long g = (long long)b * m / 4096;
+    const int g_min = nsample >= 64 ? 1 : (64 + nsample - 1) / nsample;
+    if (g < g_min) g = g_min;
+    if (g > 16) g = 16;
+    if (g > m) g = m;
+    return (int)(g < 1 ? 1 : g);
+}
+
 static int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
                            hipStream_t st)
 {
@@ -417,6 +581,17 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     static const bool use_grid = !(getenv("CMF_BALL_QUERY_GRID") && getenv("CMF_BALL_QUERY_GRID")[0] == '0');
     if (use_grid && n >= 4096 && n <= BQG_MAX_N && radius > 0.f && radius < 3.0e38f)
         return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
+    // small clouds: the ballot kernel (CMF_BALL_QUERY_BALLOT=0 keeps the scan kernels: diagnostics)
+    static const bool use_ballot = !(getenv("CMF_BALL_QUERY_BALLOT") && getenv("CMF_BALL_QUERY_BALLOT")[0] == '0');
+    if (use_ballot && n <= BQB_MAX_N && nsample <= 256) {
+        const int G = bqb_group(b, m, nsample);
+        const dim3 bgrid(cmf_divup(m, G * BQB_WAVES), b), block(BQB_WAVES * CMF_WAVE);
+        const size_t lds = (size_t)BQB_WAVES * G * nsample * sizeof(int);
+        if (n <= 256) hipLaunchKernelGGL(ball_query_ballot_kernel<1>, bgrid, block, lds, (hipStream_t)stream, n, m, radius * radius, nsample, G, new_xyz, xyz, idx);
+        else if (n <= 512) hipLaunchKernelGGL(ball_query_ballot_kernel<2>, bgrid, block, lds, (hipStream_t)stream, n, m, radius * radius, nsample, G, new_xyz, xyz, idx);
+        else hipLaunchKernelGGL(ball_query_ballot_kernel<4>, bgrid, block, lds, (hipStream_t)stream, n, m, radius * radius, nsample, G, new_xyz, xyz, idx);
+        return cmf_launch_status();
+    }
     dim3 grid(cmf_divup(m, CMF_WAVE), b);
     if (nsample <= BQ_MAX_NS_LDS && n <= 65535 && n >= 64) {
         const int seg = (cmf_divup(n, BQM_NW) + 3) / 4 * 4;
@@ -440,6 +615,65 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
         hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
                            n, m, radius * radius, nsample, new_xyz, xyz, idx);
     return cmf_launch_status();
+}
+
+// internal (group_points.hip): cmf_group_points with a batch stride for `out` (floats) -- the feature planes of the fused
+// op's (B, 3 + C, M, nsample) output start 3 planes into every sample
+int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                             long long out_batch_stride, void *stream);
+
+// grouped xyz relative to the centre (lib/pointnet2_utils.py:279-280), 3 planes of a (B, ctot, M, nsample) tensor
+__global__ __launch_bounds__(256) void group_xyz_rel_kernel(int n, int m, int nsample, int ctot, const float *__restrict__ new_xyz,
+                                                            const float *__restrict__ xyz, const int *__restrict__ idx,
+                                                            float *__restrict__ out)
+{
+    const int bs = blockIdx.y;
+    const size_t plane = (size_t)m * nsample;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= plane) return;
+    const int id = idx[(size_t)bs * plane + e];
+    const float *q = xyz + ((size_t)bs * n + id) * 3, *cc = new_xyz + ((size_t)bs * m + e / nsample) * 3;
+    float *o = out + (size_t)bs * ctot * plane + e;
+    o[0] = q[0] - cc[0]; o[plane] = q[1] - cc[1]; o[2 * plane] = q[2] - cc[2];
+}
+
+extern "C" int cmf_query_and_group(int b, int n, int m, float radius, int nsample, int c, int use_xyz,
+                                   const float *new_xyz, const float *xyz, const float *features, int *idx, float *out, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample > 0 && c >= 0 && (use_xyz || c > 0));
+    if (b == 0 || m == 0) return 0;
+    CMF_CHECK_ARG(n > 0 && new_xyz && xyz && out && (c == 0 || features));
+    hipStream_t st = (hipStream_t)stream;
+    const int ctot = (use_xyz ? 3 : 0) + c;
+    const long long plane = (long long)m * nsample;
+    // one launch when the cloud fits the ballot kernel's registers and the gather is short enough to be done by the waves
+    // that ran the query; wide features (the 1027-channel embeddings) go through the LDS-staged gather instead
+    if (n <= BQB_MAX_N && nsample <= 256 && ctot <= 160) {
+        const int G = bqb_group(b, m, nsample);
+        const dim3 grid(cmf_divup(m, G * BQB_WAVES), b), block(BQB_WAVES * CMF_WAVE);
+        const size_t lds = (size_t)BQB_WAVES * G * nsample * sizeof(int);
+        const float r2 = radius * radius;
+        if (n <= 256) hipLaunchKernelGGL(query_and_group_kernel<1>, grid, block, lds, st, n, m, r2, nsample, G, c, use_xyz, new_xyz, xyz, features, idx, out);
+        else if (n <= 512) hipLaunchKernelGGL(query_and_group_kernel<2>, grid, block, lds, st, n, m, r2, nsample, G, c, use_xyz, new_xyz, xyz, features, idx, out);
+        else hipLaunchKernelGGL(query_and_group_kernel<4>, grid, block, lds, st, n, m, r2, nsample, G, c, use_xyz, new_xyz, xyz, features, idx, out);
+        return cmf_launch_status();
+    }
+    // query (+ zero fill for empty balls: the reference pre-zeroes idx), relative xyz, LDS-staged feature gather
+    int *ix = idx;
+    if (!ix) {
+        ix = (int *)cmf_stream_scratch(st, 2, (size_t)b * plane * sizeof(int));
+        if (!ix) return (int)hipErrorOutOfMemory;
+    }
+    if (hipMemsetAsync(ix, 0, (size_t)b * plane * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
+    int err = cmf_ball_query(b, n, m, radius, nsample, new_xyz, xyz, ix, stream);
+    if (err) return err;
+    if (use_xyz) {
+        hipLaunchKernelGGL(group_xyz_rel_kernel, dim3((unsigned)cmf_divup(plane, 256), b), dim3(256), 0, st, n, m, nsample, ctot, new_xyz, xyz, ix, out);
+        err = cmf_launch_status();
+        if (err) return err;
+    }
+    if (c > 0) err = cmf_group_points_strided(b, c, n, m, nsample, features, ix, out + (use_xyz ? 3 : 0) * plane, (long long)ctot * plane, stream);
+    return err;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -148,6 +148,43 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+class QueryAndGroupFn(Function):
+    """QueryAndGroup.forward (lib/pointnet2_utils.py:269-292) as ONE kernel launch -- cmf_query_and_group: ball query,
+    grouped xyz relative to the centre, grouped features, concatenated in the reference's (B, 3 + C, npoint, nsample)
+    layout.  Gradient w.r.t. the features only (GroupingOperation.backward, :208-222, over the feature planes of the
+    incoming gradient); coordinates that require a gradient take the unfused path in QueryAndGroup.forward."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, radius, nsample, use_xyz):
+        assert xyz.is_contiguous() and new_xyz.is_contiguous()                     # :241-242
+        B, N, _ = xyz.size()
+        M = new_xyz.size(1)
+        C = 0
+        if features is not None:
+            assert features.is_contiguous()                                        # :195
+            C = features.size(1)
+        ctot = (3 if (use_xyz or features is None) else 0) + C
+        out = torch.empty(B, ctot, M, nsample, dtype=_f32, device=xyz.device)
+        idx = torch.empty(B, M, nsample, dtype=_i32, device=xyz.device)
+        _lib.check(_lib.lib().cmf_query_and_group(B, N, M, radius, nsample, C, int(ctot > C), _lib.dev_ptr(new_xyz, _f32),
+                                                  _lib.dev_ptr(xyz, _f32), _lib.dev_ptr(features, _f32), _lib.dev_ptr(idx, _i32),
+                                                  _lib.dev_ptr(out, _f32), _lib.stream_ptr()), "cmf_query_and_group")
+        ctx.for_backwards = (idx, N, C, ctot)
+        ctx.mark_non_differentiable(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, N, C, ctot = ctx.for_backwards
+        if C == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None, None, None
+        B, M, nsample = idx.size()
+        g = grad_out[:, ctot - C:].contiguous()                                    # the feature planes
+        grad_features = torch.zeros(B, C, N, dtype=_f32, device=grad_out.device)
+        group_points_grad_wrapper(B, C, N, M, nsample, g, idx, grad_features)
+        return None, None, grad_features, None, None, None
+
+
 class QueryAndGroup(nn.Module):
     """lib/pointnet2_utils.py:259-292: -> (B, 3 + C, npoint, nsample), relative xyz first."""
 
@@ -155,7 +192,13 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
+    fused = True            # one launch through cmf_query_and_group (False: the reference's op sequence over the three kernels)
+
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+        if self.fused and not (xyz.requires_grad or new_xyz.requires_grad):
+            return QueryAndGroupFn.apply(xyz, new_xyz, features, self.radius, self.nsample, self.use_xyz)
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         xyz_trans = xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)

@@ -48,6 +48,15 @@ int cmf_group_points(int b, int c, int n, int npoints, int nsample,
 int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx, float *grad_points, void *stream);
 
+/* QueryAndGroup.forward (lib/pointnet2_utils.py:269-292) as one call: ball query (cmf_ball_query semantics; an empty ball
+ * groups point 0, the reference's pre-zeroed idx) + grouped xyz minus the centre (:279-280) + grouped features (:283),
+ * concatenated as the reference does (:285): out (b, 3*use_xyz + c, m, nsample), relative xyz planes first.
+ * new_xyz (b,m,3) centres, xyz (b,n,3), features (b,c,n) or NULL with c == 0 (then use_xyz must be set), idx (b,m,nsample)
+ * optional output (what GroupingOperation.backward needs, :204).  n <= 1024 and 3*use_xyz + c <= 160: ONE launch (the
+ * waves that find the neighbour lists gather them); otherwise query + relative-xyz + LDS-staged feature gather. */
+int cmf_query_and_group(int b, int n, int m, float radius, int nsample, int c, int use_xyz,
+                        const float *new_xyz, const float *xyz, const float *features, int *idx, float *out, void *stream);
+
 /* ---- torch-level hot loops of the reference, as kernels ------------------------------------ */
 
 /* knn_point (utils/model_utils/radarflow_util.py:88-99 = square_distance :8-30 + topk).

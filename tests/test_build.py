@@ -59,7 +59,9 @@ def test_ball_query_isa_has_no_fma_contraction():
                           "--cuda-device-only", "-o", "-", src], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     asm = out.stdout
-    for sym in ("_Z17ball_query_kernel", "_Z23ball_query_multi_kernelILb0", "_Z23ball_query_multi_kernelILb1"):
+    for sym in ("_Z17ball_query_kernel", "_Z23ball_query_multi_kernelILb0", "_Z23ball_query_multi_kernelILb1",
+                "_Z24ball_query_ballot_kernelILi1E", "_Z24ball_query_ballot_kernelILi4E", "_Z22query_and_group_kernelILi1E",
+                "_Z22query_and_group_kernelILi2E", "_Z20bq_grid_query_kernel"):
         start = asm.index(sym)
         body = asm[start:asm.index("s_endpgm", start)]
         assert not re.search(r"v_(fma|fmac|mad|pk_fma)_f32", body), sym

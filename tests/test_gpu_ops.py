@@ -106,6 +106,53 @@ def test_group_points_and_grad(dev, B, C, N, P, S):
     np.testing.assert_allclose(gp.cpu().numpy(), 2 * ref.numpy(), rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("B,N,M,r,ns", [(3, 512, 512, 4.0, 16), (2, 1024, 300, 2.0, 64), (2, 700, 701 - 1, 8.0, 100), (5, 257, 33, 3.0, 7),
+                                        (64, 256, 256, 2.0, 32), (1, 64, 64, 100.0, 200), (2, 1000, 5, 0.01, 4)])
+def test_ball_query_ballot_kernel_bit_exact(dev, B, N, M, r, ns):
+    """Small clouds (n <= 1024) take the ballot kernel: a wave per centre, the cloud in registers, four ballots per
+    256-point chunk are the hit list in index order.  Chunk boundaries (n = 257, 512, 700, 1000, 1024), nsample larger
+    than a wave, lists longer than the cloud, centres that are not the points, empty balls, m not a multiple of the
+    centres-per-wave group."""
+    from cmflow_amd.pointnet2_utils import ball_query
+    xyz, other = clouds(B, N, seed=N + ns)
+    ctr = xyz[:, :M].contiguous() if (M <= N and (M % 2 == 0)) else other[:, :M].contiguous()
+    ref = orc.ball_query(r, ns, xyz, ctr)
+    got = ball_query(r, ns, xyz.to(dev), ctr.to(dev)).cpu()
+    assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("B,N,M,r,ns,C,use_xyz", [(64, 256, 256, 2.0, 32, 3, True), (4, 256, 256, 2.0, 4, 6, True), (2, 100, 37, 4.0, 8, 5, True),
+                                                  (2, 700, 700, 8.0, 16, 64, True), (1, 1500, 300, 3.0, 16, 4, True),
+                                                  (2, 256, 256, 16.0, 32, 200, True), (3, 256, 256, 4.0, 8, 0, True),
+                                                  (3, 256, 200, 0.05, 8, 12, False), (2, 512, 512, 2.0, 64, 64, True)])
+def test_query_and_group_fused_matches_the_three_op_sequence(dev, B, N, M, r, ns, C, use_xyz):
+    """cmf_query_and_group (QueryAndGroup.forward, lib/pointnet2_utils.py:269-292, in one call) against the oracle's ball
+    query + two grouping operations + subtraction + cat: indices and every output float bit-equal (gathers and ONE
+    subtraction), empty balls group point 0, gradient w.r.t. the features equal to GroupingOperation.backward of the
+    feature planes.  Covers the single-launch form, the wide-feature form (3 + C > 160) and large clouds (n > 1024)."""
+    from cmflow_amd.pointnet2_utils import QueryAndGroup
+    xyz, other = clouds(B, N, seed=N + ns + C)
+    ctr = xyz[:, :M].contiguous() if M == N else other[:, :M].contiguous()
+    g = torch.Generator().manual_seed(C + 1)
+    feats = torch.randn(B, C, N, generator=g) if C else None
+    idx = orc.ball_query(r, ns, xyz, ctr)
+    gx = orc.group_points(xyz.transpose(1, 2).contiguous(), idx) - ctr.transpose(1, 2).unsqueeze(-1)
+    want = gx if C == 0 else (torch.cat([gx, orc.group_points(feats, idx)], dim=1) if use_xyz else orc.group_points(feats, idx))
+    mod = QueryAndGroup(r, ns, use_xyz=use_xyz)
+    fd = feats.to(dev).requires_grad_(True) if C else None
+    got = mod(xyz.to(dev), ctr.to(dev), fd)
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    assert torch.equal(got.grad_fn.for_backwards[0].cpu(), idx)
+    if C:
+        go = torch.randn(want.shape, generator=g)
+        got.backward(go.to(dev))
+        ref = orc.group_points_grad(go[:, want.shape[1] - C:].contiguous(), idx, N)
+        np.testing.assert_allclose(fd.grad.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()) + 1e-6)
+    # the unfused module path gives the same tensor
+    mod.fused = False
+    assert torch.equal(mod(xyz.to(dev), ctr.to(dev), feats.to(dev) if C else None).cpu(), want)
+
+
 @pytest.mark.parametrize("C", [64, 128])
 def test_config5_shapes_match_oracle(dev, C):
     """BASELINE config 5 at its own op shape -- N = 4096 LiDAR-like points, K = 64, r = 2.0, C in {64, 128} -- the first

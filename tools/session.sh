@@ -27,6 +27,12 @@ gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment
 }
 model_tests() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size or two_rank" 2>&1 | tail -30 > $R/model.txt; }
 bench3() { for i in 1 2 3; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null; done > $R/bench3.json; cat $R/bench3.json | python -c "import sys,json; [print(json.loads(l)['ms_per_step'], json.loads(l)['roofline']['frac'], json.loads(l)['roofline_isolated']['frac']) for l in sys.stdin]"; }
+ops_tests() { python -m pytest tests/test_gpu_ops.py tests/test_gpu_extension_surface.py tests/test_gpu_modules.py -q -m gpu 2>&1 | tail -15 > $R/ops_tests.txt; }
+epi_diag() {           # which part of the backward epilogue costs: 16 no C stores, 32 no Z loads, 48 neither, 8 no epilogue
+    for d in 0 16 32 48 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter | grep "dX BN"; done > $R/epi_diag.txt
+}
+model_full() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train or full_size_cmflow_t" 2>&1 | grep -v "^  \|^$" | tail -60 > $R/model_full.txt; }
+opbench() { python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>$R/opbench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); [print(r) for r in d['roofline_hbm']['rows']]" > $R/opbench.txt; tail -3 $R/opbench.err; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
