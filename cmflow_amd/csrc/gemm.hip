@@ -44,6 +44,12 @@ constexpr int G_THREADS = 256;
 #define CMF_EPI_WAVE 1                    // bit 0: the backward kinds (2-5) of the 128 x 128 kernels finish their tiles per wave (wave_epilogue);
                                           // bit 1: kinds 0 / 1 as well (instead of the direct form) -- experiment
 #endif
+#ifndef CMF_GEMM_PIPE
+#define CMF_GEMM_PIPE 0                   // 1: barrier in the middle of a chunk, first fragment reads of the next chunk under the second half
+#endif
+#ifndef CMF_GEMM_PRIO
+#define CMF_GEMM_PRIO 0                   // n > 0: s_setprio n for the main loop (experiment)
+#endif
 #ifndef CMF_GEMM_W3
 #define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
 #endif
@@ -461,6 +467,42 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
                 }
         };
         int st = 0;
+#if CMF_GEMM_PRIO
+        __builtin_amdgcn_s_setprio(CMF_GEMM_PRIO);
+#endif
+#if CMF_GEMM_PIPE
+        // Software-pipelined form: the barrier sits in the MIDDLE of a chunk's MFMAs.  When a wave arrives there it has read
+        // all of chunk c (its second fragment set was awaited just before), so the barrier still means "stage c is free and
+        // chunk c + 1 is visible" -- but the first fragment reads of chunk c + 1 are issued right behind it and land under
+        // the 16 MFMAs of the second half of chunk c, instead of being waited for with nothing to issue.
+        if (!EMUL) {
+            {
+                const float *sa = smem, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
+                read_frags(sa, sb, sp, 0, 0);
+                g_lds_wait(); pin_frags(0);
+                read_frags(sa, sb, sp, 8, 1);
+            }
+            for (int c = 0; c < nch; ++c) {
+                mfma_step(0);
+                g_lds_wait(); pin_frags(1);                                         // every LDS read of chunk c by this wave is complete
+                if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);   // (st + 2) % 3: the stage of chunk c - 1
+                const int sn = st == 2 ? 0 : st + 1;
+                const float *sa = smem + sn * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
+                if (c + 1 < nch) {
+                    if (!(p.diag & 3)) wait_prev(c + 2 < nch);
+                    if (!(p.diag & 4)) __builtin_amdgcn_s_barrier();
+                    read_frags(sa, sb, sp, 0, 0);                                   // in flight under the second half of chunk c
+                }
+                mfma_step(1);
+                if (c + 1 < nch) {
+                    g_lds_wait(); pin_frags(0);
+                    read_frags(sa, sb, sp, 8, 1);
+                }
+                st = sn;
+            }
+            __builtin_amdgcn_s_barrier();                                            // the epilogue reuses the staging buffers
+        } else
+#endif
         for (int c = 0; c < nch; ++c) {
             if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);       // (st + 2) % 3
             const float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
@@ -526,6 +568,9 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
             if (!(p.diag & 4)) __builtin_amdgcn_s_barrier();                    // ... and everybody else's; stage st is free again
             st = st == 2 ? 0 : st + 1;
         }
+#if CMF_GEMM_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
     } else
     if (kc_begin < kc_end) {
         load_tiles(kc_begin);
@@ -865,7 +910,8 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
         constexpr int KIND = decltype(kind_c)::value;
         constexpr bool USE_Z = KIND >= 2, WQ = KIND >= 4, BNR = KIND == 2 || KIND == 4;
         static_assert(WN == 64 && TN == 2, "wave tile 64 columns wide");
-        constexpr int W_LD = WN + 4;                                  // 68 floats: 16-byte rows, bank shift 4 per row
+        constexpr int W_LD = WN;                                      // 64 floats = one pass over the 64 banks: the 32 lanes of a ds_write_b32 group
+                                                                      // write one row, the 16 lanes of a ds_read_b128 group read whole rows -- no padding needed
         constexpr int W_TILE = 32 * W_LD, W_SZ = W_TILE + WM * 4 + 4 * WN;     // per wave: transposition tile | dxyz rows | column constants
         float *wt = smem + wid * W_SZ, *wdq = wt + W_TILE;
         const int rl = lane >> 4, c4 = (lane & 15) * 4;               // row inside a group of 4, first of the lane's 4 columns

@@ -13,6 +13,8 @@
 
 int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
                              long long out_bstride, void *stream);
+int cmf_group_points_xyz(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                         long long out_bstride, const float *xyz, const float *new_xyz, void *stream);
 
 constexpr int GP_THREADS = 256;
 // channels per workgroup: 8 when the rows are short (8 rows of n floats in LDS), 2 for long rows so that
@@ -22,10 +24,15 @@ constexpr int GP_STEPS = 4;           // steps per thread -> GP_TILE = 256*4*4 =
 constexpr int GP_TILE = GP_THREADS * GP_VEC * GP_STEPS;
 constexpr int GP_MAX_N_LDS = 8192;    // rows staged in LDS up to this n
 
+// XYZ planes (cmf_query_and_group): the last ceil(3 / GP_CH) channel chunks of the grid write the grouped coordinates relative
+// to the centre, xyz[idx] - new_xyz (lib/pointnet2_utils.py:279-280), into planes 0..2 of `out`, and the feature planes start at
+// plane 3 -- one gather launch for the whole (B, 3 + C, M, nsample) tensor.  xyz / ctr are point-major (b,n,3) / (b,m,3).
+struct GpXyz { const float *xyz, *ctr; int nsample, m, chunks; };
+
 template <bool ROWS_IN_LDS, int GP_CH, int TPB>
 __global__ __launch_bounds__(TPB) void group_points_kernel(
     int c, int n, int total /* npoints*nsample */, int tiles_per_sample, int tiles_per_wg,
-    const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out, long long out_bstride)
+    const float *__restrict__ points, const int *__restrict__ idx, float *__restrict__ out, long long out_bstride, const GpXyz X)
 {
     extern __shared__ __attribute__((aligned(16))) float rows[];   // [GP_CH][n] when ROWS_IN_LDS
     // a workgroup stages its feature rows once and walks tiles_per_wg consecutive idx tiles with them: with long rows
@@ -35,14 +42,20 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
     const int tile0 = (blockIdx.x % groups_per_sample) * tiles_per_wg;
     const int tile1 = min(tile0 + tiles_per_wg, tiles_per_sample);
     const int bs = blockIdx.x / groups_per_sample;
-    const int c0 = blockIdx.y * GP_CH;
-    const int nch = min(GP_CH, c - c0);
+    const int fchunks = (int)gridDim.y - X.chunks;                 // feature chunks come first in the grid
+    const bool is_xyz = (int)blockIdx.y >= fchunks;
+    const int c0 = is_xyz ? ((int)blockIdx.y - fchunks) * GP_CH : blockIdx.y * GP_CH;
+    const int nch = min(GP_CH, (is_xyz ? 3 : c) - c0);
     const int *ix = idx + (size_t)bs * total;
-    const float *src = points + ((size_t)bs * c + c0) * n;
-    float *dst = out + (size_t)bs * out_bstride + (size_t)c0 * total;
+    // a "row" = the n values of one plane: features[bs][c0 + ch][:] (unit stride) or coordinate c0 + ch of xyz[bs] (stride 3)
+    const float *src = is_xyz ? X.xyz + (size_t)bs * n * 3 + c0 : points + ((size_t)bs * c + c0) * n;
+    const int estr = is_xyz ? 3 : 1;
+    const size_t rstr = is_xyz ? 1 : (size_t)n;
+    float *dst = out + (size_t)bs * out_bstride + (size_t)((is_xyz ? 0 : (X.chunks ? 3 : 0)) + c0) * total;
+    const float *ctr = is_xyz ? X.ctr + (size_t)bs * X.m * 3 + c0 : nullptr;
 
     if (ROWS_IN_LDS) {
-        for (int i = threadIdx.x; i < nch * n; i += TPB) rows[i] = src[i];
+        for (int i = threadIdx.x; i < nch * n; i += TPB) { const int ch = i / n, k = i - ch * n; rows[i] = src[ch * rstr + (size_t)k * estr]; }
     }
     const bool vec_ok = (total % GP_VEC) == 0;
     for (int tile = tile0; tile < tile1; ++tile) {
@@ -63,19 +76,24 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
     if (ROWS_IN_LDS && tile == tile0) __syncthreads();
 
     for (int ch = 0; ch < nch; ++ch) {
-        const float *row = ROWS_IN_LDS ? rows + (size_t)ch * n : src + (size_t)ch * n;
+        const float *row = ROWS_IN_LDS ? rows + (size_t)ch * n : src + ch * rstr;
+        const int es = ROWS_IN_LDS ? 1 : estr;
         float *o = dst + (size_t)ch * total;
 #pragma unroll
         for (int s = 0; s < GP_STEPS; ++s) {
             const int e = e0 + (s * TPB + threadIdx.x) * GP_VEC;
             if (vec_ok && e + GP_VEC <= total) {
                 float4 v;
-                v.x = row[my[s][0]]; v.y = row[my[s][1]]; v.z = row[my[s][2]]; v.w = row[my[s][3]];
+                v.x = row[(size_t)my[s][0] * es]; v.y = row[(size_t)my[s][1] * es]; v.z = row[(size_t)my[s][2] * es]; v.w = row[(size_t)my[s][3] * es];
+                if (is_xyz) {                           // minus the centre of each entry (one subtraction: bit-equal to the reference's)
+                    v.x -= ctr[(size_t)(e / X.nsample) * 3 + ch]; v.y -= ctr[(size_t)((e + 1) / X.nsample) * 3 + ch];
+                    v.z -= ctr[(size_t)((e + 2) / X.nsample) * 3 + ch]; v.w -= ctr[(size_t)((e + 3) / X.nsample) * 3 + ch];
+                }
                 *reinterpret_cast<float4 *>(o + e) = v;
             } else {
 #pragma unroll
                 for (int j = 0; j < GP_VEC; ++j)
-                    if (e + j < total) o[e + j] = row[my[s][j]];
+                    if (e + j < total) o[e + j] = row[(size_t)my[s][j] * es] - (is_xyz ? ctr[(size_t)((e + j) / X.nsample) * 3 + ch] : 0.f);
             }
         }
     }
@@ -94,10 +112,21 @@ extern "C" int cmf_group_points(int b, int c, int n, int npoints, int nsample,
 int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
                              long long out_bstride, void *stream)
 {
+    return cmf_group_points_xyz(b, c, n, npoints, nsample, points, idx, out, out_bstride, nullptr, nullptr, stream);
+}
+
+// + the relative-coordinate planes when xyz / new_xyz are given: out is then (b, 3 + c, npoints, nsample)
+int cmf_group_points_xyz(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                         long long out_bstride, const float *xyz, const float *new_xyz, void *stream)
+{
     CMF_CHECK_ARG(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0);
     const long long total = (long long)npoints * nsample;
-    if (b == 0 || c == 0 || total == 0) return 0;
-    CMF_CHECK_ARG(points && idx && out && n > 0 && total < (1LL << 31) && out_bstride >= (long long)c * total);
+    const bool with_xyz = xyz != nullptr;
+    if (b == 0 || (c == 0 && !with_xyz) || total == 0) return 0;
+    CMF_CHECK_ARG((points || c == 0) && idx && out && n > 0 && total < (1LL << 31) && out_bstride >= (long long)(c + (with_xyz ? 3 : 0)) * total);
+    CMF_CHECK_ARG(!with_xyz || new_xyz);
+    GpXyz X{xyz, new_xyz, nsample, npoints, 0};
+#define CMF_GP_CHUNKS(CH) (X.chunks = with_xyz ? (3 + (CH) - 1) / (CH) : 0, (unsigned)(cmf_divup(c, (CH)) + X.chunks))
     int tiles = cmf_divup(total, GP_TILE);
     hipStream_t st = (hipStream_t)stream;
     // tiles per workgroup: as many as possible while the launch still has >= ~1024 workgroups
@@ -108,9 +137,9 @@ int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, cons
     };
     if (n <= 1024) {
         const int t = tiles_per_wg(cmf_divup(c, 8));
-        dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 8));
+        dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), CMF_GP_CHUNKS(8));
         hipLaunchKernelGGL((group_points_kernel<true, 8, GP_THREADS>), grid, dim3(GP_THREADS), (size_t)8 * n * sizeof(float), st,
-                           c, n, (int)total, tiles, t, points, idx, out, out_bstride);
+                           c, n, (int)total, tiles, t, points, idx, out, out_bstride, X);
     } else if (n <= GP_MAX_N_LDS) {
         // 4 rows when they fit in 64 KB (two workgroups per CU), else 2
         const bool four = (size_t)4 * n * sizeof(float) <= 64 * 1024;
@@ -125,20 +154,21 @@ int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, cons
         tiles = cmf_divup(total, 512 * GP_VEC * GP_STEPS);                 // 512 threads: twice the waves per CU for the LDS gather
         if (four) {
             const int t = tiles_per_wg(cmf_divup(c, 4));
-            dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 4));
+            dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), CMF_GP_CHUNKS(4));
             hipLaunchKernelGGL((group_points_kernel<true, 4, 512>), grid, dim3(512), (size_t)4 * n * sizeof(float), st,
-                               c, n, (int)total, tiles, t, points, idx, out, out_bstride);
+                               c, n, (int)total, tiles, t, points, idx, out, out_bstride, X);
         } else {
             const int t = tiles_per_wg(cmf_divup(c, 2));
-            dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), cmf_divup(c, 2));
+            dim3 grid((unsigned)(cmf_divup(tiles, t) * (long long)b), CMF_GP_CHUNKS(2));
             hipLaunchKernelGGL((group_points_kernel<true, 2, 512>), grid, dim3(512), (size_t)2 * n * sizeof(float), st,
-                               c, n, (int)total, tiles, t, points, idx, out, out_bstride);
+                               c, n, (int)total, tiles, t, points, idx, out, out_bstride, X);
         }
     } else {
-        dim3 grid((unsigned)(tiles * (long long)b), cmf_divup(c, 8));
+        dim3 grid((unsigned)(tiles * (long long)b), CMF_GP_CHUNKS(8));
         hipLaunchKernelGGL((group_points_kernel<false, 8, GP_THREADS>), grid, dim3(GP_THREADS), 0, st,
-                           c, n, (int)total, tiles, 1, points, idx, out, out_bstride);
+                           c, n, (int)total, tiles, 1, points, idx, out, out_bstride, X);
     }
+#undef CMF_GP_CHUNKS
     return cmf_launch_status();
 }
 

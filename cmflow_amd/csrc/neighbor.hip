@@ -465,7 +465,7 @@ __device__ __forceinline__ int bqb_centre(const BqbCloud<NCH> &c, float cx, floa
 // caller's pre-zeroed idx, lib/pointnet2_utils.py:246)
 template <int NCH>
 __global__ __launch_bounds__(BQB_WAVES *CMF_WAVE) void ball_query_ballot_kernel(
-    int n, int m, float radius2, int nsample, int G, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
+    int n, int m, float radius2, int nsample, int G, int zero_empty, const float *__restrict__ new_xyz, const float *__restrict__ xyz,
     int *__restrict__ idx)
 {
     extern __shared__ int bqb_lds[];                          // [BQB_WAVES][G * nsample]
@@ -483,8 +483,10 @@ __global__ __launch_bounds__(BQB_WAVES *CMF_WAVE) void ball_query_ballot_kernel(
     }
     __builtin_amdgcn_wave_barrier();
     int *out = idx + ((size_t)bs * m + pt0) * nsample;
-    for (int e = lane; e < gv * nsample; e += CMF_WAVE)
+    for (int e = lane; e < gv * nsample; e += CMF_WAVE) {
         if (!((empty >> (e / nsample)) & 1u)) out[e] = lst[e];
+        else if (zero_empty) out[e] = 0;                        // idx not pre-zeroed by the caller (cmf_query_and_group)
+    }
 }
 
 // QueryAndGroup.forward (lib/pointnet2_utils.py:269-292) in ONE launch: ball query + grouped xyz relative to the centre
@@ -570,6 +572,19 @@ static int ball_query_grid(int b, int n, int m, float radius, int nsample, const
     return cmf_launch_status();
 }
 
+static int ball_query_ballot(int b, int n, int m, float radius, int nsample, int zero_empty, const float *new_xyz, const float *xyz,
+                             int *idx, hipStream_t st)
+{
+    const int G = bqb_group(b, m, nsample);
+    const dim3 grid(cmf_divup(m, G * BQB_WAVES), b), block(BQB_WAVES * CMF_WAVE);
+    const size_t lds = (size_t)BQB_WAVES * G * nsample * sizeof(int);
+    const float r2 = radius * radius;
+    if (n <= 256) hipLaunchKernelGGL(ball_query_ballot_kernel<1>, grid, block, lds, st, n, m, r2, nsample, G, zero_empty, new_xyz, xyz, idx);
+    else if (n <= 512) hipLaunchKernelGGL(ball_query_ballot_kernel<2>, grid, block, lds, st, n, m, r2, nsample, G, zero_empty, new_xyz, xyz, idx);
+    else hipLaunchKernelGGL(ball_query_ballot_kernel<4>, grid, block, lds, st, n, m, r2, nsample, G, zero_empty, new_xyz, xyz, idx);
+    return cmf_launch_status();
+}
+
 extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
                               const float *new_xyz, const float *xyz, int *idx, void *stream)
 {
@@ -583,15 +598,8 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
         return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
     // small clouds: the ballot kernel (CMF_BALL_QUERY_BALLOT=0 keeps the scan kernels: diagnostics)
     static const bool use_ballot = !(getenv("CMF_BALL_QUERY_BALLOT") && getenv("CMF_BALL_QUERY_BALLOT")[0] == '0');
-    if (use_ballot && n <= BQB_MAX_N && nsample <= 256) {
-        const int G = bqb_group(b, m, nsample);
-        const dim3 bgrid(cmf_divup(m, G * BQB_WAVES), b), block(BQB_WAVES * CMF_WAVE);
-        const size_t lds = (size_t)BQB_WAVES * G * nsample * sizeof(int);
-        if (n <= 256) hipLaunchKernelGGL(ball_query_ballot_kernel<1>, bgrid, block, lds, (hipStream_t)stream, n, m, radius * radius, nsample, G, new_xyz, xyz, idx);
-        else if (n <= 512) hipLaunchKernelGGL(ball_query_ballot_kernel<2>, bgrid, block, lds, (hipStream_t)stream, n, m, radius * radius, nsample, G, new_xyz, xyz, idx);
-        else hipLaunchKernelGGL(ball_query_ballot_kernel<4>, bgrid, block, lds, (hipStream_t)stream, n, m, radius * radius, nsample, G, new_xyz, xyz, idx);
-        return cmf_launch_status();
-    }
+    if (use_ballot && n <= BQB_MAX_N && nsample <= 256)
+        return ball_query_ballot(b, n, m, radius, nsample, 0, new_xyz, xyz, idx, (hipStream_t)stream);
     dim3 grid(cmf_divup(m, CMF_WAVE), b);
     if (nsample <= BQ_MAX_NS_LDS && n <= 65535 && n >= 64) {
         const int seg = (cmf_divup(n, BQM_NW) + 3) / 4 * 4;
@@ -617,25 +625,10 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     return cmf_launch_status();
 }
 
-// internal (group_points.hip): cmf_group_points with a batch stride for `out` (floats) -- the feature planes of the fused
-// op's (B, 3 + C, M, nsample) output start 3 planes into every sample
-int cmf_group_points_strided(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
-                             long long out_batch_stride, void *stream);
-
-// grouped xyz relative to the centre (lib/pointnet2_utils.py:279-280), 3 planes of a (B, ctot, M, nsample) tensor
-__global__ __launch_bounds__(256) void group_xyz_rel_kernel(int n, int m, int nsample, int ctot, const float *__restrict__ new_xyz,
-                                                            const float *__restrict__ xyz, const int *__restrict__ idx,
-                                                            float *__restrict__ out)
-{
-    const int bs = blockIdx.y;
-    const size_t plane = (size_t)m * nsample;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= plane) return;
-    const int id = idx[(size_t)bs * plane + e];
-    const float *q = xyz + ((size_t)bs * n + id) * 3, *cc = new_xyz + ((size_t)bs * m + e / nsample) * 3;
-    float *o = out + (size_t)bs * ctot * plane + e;
-    o[0] = q[0] - cc[0]; o[plane] = q[1] - cc[1]; o[2 * plane] = q[2] - cc[2];
-}
+// internal (group_points.hip): the LDS-staged gather writing the feature planes AND the relative-coordinate planes of the
+// fused op's (B, 3 + C, M, nsample) output in one launch
+int cmf_group_points_xyz(int b, int c, int n, int npoints, int nsample, const float *points, const int *idx, float *out,
+                         long long out_bstride, const float *xyz, const float *new_xyz, void *stream);
 
 extern "C" int cmf_query_and_group(int b, int n, int m, float radius, int nsample, int c, int use_xyz,
                                    const float *new_xyz, const float *xyz, const float *features, int *idx, float *out, void *stream)
@@ -646,9 +639,11 @@ extern "C" int cmf_query_and_group(int b, int n, int m, float radius, int nsampl
     hipStream_t st = (hipStream_t)stream;
     const int ctot = (use_xyz ? 3 : 0) + c;
     const long long plane = (long long)m * nsample;
-    // one launch when the cloud fits the ballot kernel's registers and the gather is short enough to be done by the waves
-    // that ran the query; wide features (the 1027-channel embeddings) go through the LDS-staged gather instead
-    if (n <= BQB_MAX_N && nsample <= 256 && ctot <= 160) {
+    // ONE launch when the cloud fits the ballot kernel's registers and the gather is a few planes (the waves that ran the
+    // query write them: 8.6 us against 14.5 us for three launches at (64,256,32) with C = 3); wider features go through the
+    // LDS-staged gather, which also writes the relative-coordinate planes: two launches (measured: the single launch with
+    // cache-served feature gathers is slower from C ~ 32 on -- 36.6 against 33.0 us at C = 64)
+    if (n <= BQB_MAX_N && nsample <= 256 && ctot <= 24) {
         const int G = bqb_group(b, m, nsample);
         const dim3 grid(cmf_divup(m, G * BQB_WAVES), b), block(BQB_WAVES * CMF_WAVE);
         const size_t lds = (size_t)BQB_WAVES * G * nsample * sizeof(int);
@@ -658,22 +653,21 @@ extern "C" int cmf_query_and_group(int b, int n, int m, float radius, int nsampl
         else hipLaunchKernelGGL(query_and_group_kernel<4>, grid, block, lds, st, n, m, r2, nsample, G, c, use_xyz, new_xyz, xyz, features, idx, out);
         return cmf_launch_status();
     }
-    // query (+ zero fill for empty balls: the reference pre-zeroes idx), relative xyz, LDS-staged feature gather
+    // query (+ zero fill for empty balls: the reference pre-zeroes idx), then one gather launch for all planes
     int *ix = idx;
     if (!ix) {
         ix = (int *)cmf_stream_scratch(st, 2, (size_t)b * plane * sizeof(int));
         if (!ix) return (int)hipErrorOutOfMemory;
     }
-    if (hipMemsetAsync(ix, 0, (size_t)b * plane * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
-    int err = cmf_ball_query(b, n, m, radius, nsample, new_xyz, xyz, ix, stream);
-    if (err) return err;
-    if (use_xyz) {
-        hipLaunchKernelGGL(group_xyz_rel_kernel, dim3((unsigned)cmf_divup(plane, 256), b), dim3(256), 0, st, n, m, nsample, ctot, new_xyz, xyz, ix, out);
-        err = cmf_launch_status();
-        if (err) return err;
+    int err;
+    if (n <= BQB_MAX_N && nsample <= 256) err = ball_query_ballot(b, n, m, radius, nsample, 1, new_xyz, xyz, ix, st);
+    else {
+        if (hipMemsetAsync(ix, 0, (size_t)b * plane * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
+        err = cmf_ball_query(b, n, m, radius, nsample, new_xyz, xyz, ix, stream);
     }
-    if (c > 0) err = cmf_group_points_strided(b, c, n, m, nsample, features, ix, out + (use_xyz ? 3 : 0) * plane, (long long)ctot * plane, stream);
-    return err;
+    if (err) return err;
+    return cmf_group_points_xyz(b, c, n, m, nsample, features, ix, out, (long long)ctot * plane, use_xyz ? xyz : nullptr,
+                                use_xyz ? new_xyz : nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,6 +33,21 @@ epi_diag() {           # which part of the backward epilogue costs: 16 no C stor
 }
 model_full() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train or full_size_cmflow_t" 2>&1 | grep -v "^  \|^$" | tail -60 > $R/model_full.txt; }
 opbench() { python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>$R/opbench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); [print(r) for r in d['roofline_hbm']['rows']]" > $R/opbench.txt; tail -3 $R/opbench.err; }
+variants() {           # kernel experiment builds (tools/diag/libcmflow_<name>.so) against the product: correctness, then rates, then the step
+    for v in $VARIANTS; do
+        L=$GRAFT_REPO_ROOT/tools/diag/libcmflow_$v.so
+        CMF_LIB=$L python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -3 > $R/var_${v}_tests.txt
+        CMF_LIB=$L python tools/gemm_diag.py 2>&1 | filter > $R/var_${v}_diag.txt
+        CMF_LIB=$L python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null > $R/var_${v}_bench.json
+    done
+    python tools/gemm_diag.py 2>&1 | filter > $R/var_product_diag.txt
+    python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null > $R/var_product_bench.json
+    for f in $R/var_*_bench.json; do echo $f; python -c "import sys,json; d=json.loads(open('$f').read()); print(d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
+}
+grad_ab() {            # the directional gradient check with the round-2 epilogue (libcmflow_w0) and with the product, same box
+    CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_w0.so python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train" 2>&1 | grep -E "full-size train|AssertionError|passed|failed" > $R/grad_w0.txt
+    python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train" 2>&1 | grep -E "full-size train|AssertionError|passed|failed" > $R/grad_product.txt
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
