@@ -354,6 +354,206 @@ __global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_bal_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Plan form of the balanced kernel (idx of shape (P <= 256 rows) x (S <= 64), the model's ball-query / kNN lists).
+// What made narrow features slow was everything AROUND the rows: the inverse index was a separate launch of one
+// workgroup per sample with 256-step dependent LDS chains (21-59 us), and every scatter workgroup then rebuilt its
+// tables from that index (flags, two block scans per 256 targets, 32 list entries per thread) -- ~67 us of fixed cost
+// against 0.45 us per channel row, i.e. (64,256,32) with C = 3 / 64 ran at 0.016 / 0.18 of HBM.  Here ONE kernel per call
+// (gpg_plan_kernel, a workgroup per sample) turns idx straight into the register image of the scatter workgroups: per
+// thread the row positions of its E sorted entries (two 16-bit positions per word), the run-end mask, the rank of its
+// first run end; per target (rank among non-empty targets | first chunk | last chunk).  A scatter workgroup loads that
+// image (E / 2 + 2 words per thread, n words through LDS) and starts streaming rows.  Same order of additions as
+// group_points_grad_bal_kernel: deterministic, bit-reproducible.
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t gpg_plan_words(int E, int n) { return (size_t)GG_THREADS * (E / 2) + 2 * GG_THREADS + (size_t)n; }
+
+template <int E>
+__global__ __launch_bounds__(GG_THREADS) void gpg_plan_kernel(int n, int P, int S, const int *__restrict__ idx, unsigned *__restrict__ plan_all)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    __shared__ int scan[GG_THREADS / 64];
+    const int ld = n | 1;                                             // odd row stride: column walks spread over the banks
+    const int total = P * S;
+    unsigned short *cnt = reinterpret_cast<unsigned short *>(psm);    // [P][ld] multiplicities, then exclusive prefixes over p
+    size_t o = ((size_t)P * ld * 2 + 15) / 16 * 16;
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += ((size_t)total * 2 + 15) / 16 * 16;   // [total] positions by target
+    int *offs = reinterpret_cast<int *>(psm + o); o += ((size_t)(n + 1) * 4 + 15) / 16 * 16;                         // [n + 1]
+    unsigned char *rk = psm + o;                                      // [total] rank of an entry among its row's entries of the same target;
+    unsigned char *flags = rk;                                        //         later: 1 at the last sorted entry of every target
+    const int t = threadIdx.x, bs = blockIdx.x;
+    const int *ix = idx + (size_t)bs * total;
+    unsigned *plan = plan_all + (size_t)bs * gpg_plan_words(E, n);
+    for (int i = t; i < (int)(((size_t)P * ld * 2 + 15) / 16); i += GG_THREADS) reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // A: row p counts its targets; the running count is the entry's rank inside (row, target) -- one owner per row: no atomics
+    if (t < P)
+        for (int sl = 0; sl < S; ++sl) {
+            const int j = ix[t * S + sl];
+            const unsigned short c = cnt[t * ld + j];
+            rk[t * S + sl] = (unsigned char)c;
+            cnt[t * ld + j] = (unsigned short)(c + 1);
+        }
+    __syncthreads();
+    // B: column j -> exclusive prefix over the rows (8 loads in flight, then 8 stores: the loads of a serial read-modify-write
+    // loop cannot be overlapped by the compiler, it must assume the store aliases the next load); column totals -> offsets
+    int base = 0;
+    for (int j0 = 0; j0 < n; j0 += GG_THREADS) {
+        const int j = j0 + t;
+        int run = 0;
+        if (j < n) {
+            int p0 = 0;
+            for (; p0 + 8 <= P; p0 += 8) {
+                unsigned short v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cnt[(p0 + u) * ld + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { cnt[(p0 + u) * ld + j] = (unsigned short)run; run += v[u]; }
+            }
+            for (; p0 < P; ++p0) { const int c = cnt[p0 * ld + j]; cnt[p0 * ld + j] = (unsigned short)run; run += c; }
+        }
+        int tot;
+        const int incl = gg_block_scan(run, scan, tot);
+        if (j < n) offs[j] = base + incl - run;
+        base += tot;
+    }
+    if (t == 0) offs[n] = base;
+    __syncthreads();
+    // C: every entry to its slot: ascending (row, slot) order inside a target's list
+    if (t < P)
+        for (int sl = 0; sl < S; ++sl) {
+            const int j = ix[t * S + sl];
+            sorted[offs[j] + cnt[t * ld + j] + rk[t * S + sl]] = (unsigned short)(t * S + sl);
+        }
+    __syncthreads();
+    // D: the scatter workgroup's register image
+    for (int i = t; i < (total + 3) / 4; i += GG_THREADS) reinterpret_cast<unsigned *>(flags)[i] = 0u;
+    __syncthreads();
+    for (int j = t; j < n; j += GG_THREADS)
+        if (offs[j + 1] > offs[j]) flags[offs[j + 1] - 1] = 1;
+    __syncthreads();
+    unsigned mask = 0;
+#pragma unroll
+    for (int k = 0; k < E; k += 2) {
+        const int e = t * E + k;
+        const unsigned p0 = e < total ? sorted[e] : (unsigned)(GG_THREADS * E);       // padding reads the zero slot behind the row
+        const unsigned p1 = e + 1 < total ? sorted[e + 1] : (unsigned)(GG_THREADS * E);
+        plan[(size_t)t * (E / 2) + k / 2] = p0 | (p1 << 16);
+        if (e < total && flags[e]) mask |= 1u << k;
+        if (e + 1 < total && flags[e + 1]) mask |= 1u << (k + 1);
+    }
+    unsigned *pm = plan + (size_t)GG_THREADS * (E / 2);
+    int tot;
+    const int rank0 = gg_block_scan(__popc(mask), scan, tot) - __popc(mask);
+    pm[t] = mask; pm[GG_THREADS + t] = (unsigned)rank0;
+    unsigned *pt = pm + 2 * GG_THREADS;                               // per target: rank (16) | first chunk (8) | last chunk (8); 0xFFFF....: empty
+    base = 0;
+    for (int j0 = 0; j0 < n; j0 += GG_THREADS) {
+        const int j = j0 + t;
+        const int ne = (j < n && offs[j + 1] > offs[j]) ? 1 : 0;
+        const int inc = gg_block_scan(ne, scan, tot);
+        if (j < n) pt[j] = ne ? ((unsigned)(base + inc - 1) | ((unsigned)(offs[j] / E) << 16) | ((unsigned)((offs[j + 1] - 1) / E) << 24)) : 0xFFFFFFFFu;
+        base += tot;
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_plan_kernel(
+    int c, int n, int total, int ch_per_wg, const float *__restrict__ grad_out, const unsigned *__restrict__ plan_all,
+    float *__restrict__ grad_points)
+{
+    constexpr int RS = GG_THREADS * E + 4;                          // row buffer: entries + one zero slot (padding reads)
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *row = sm;
+    float *ranked = row + RS;                                       // [n]   sum up to each run end inside its chunk
+    float *tails = ranked + n;                                      // [256] chunk sum after its last run end
+    unsigned *tgt = reinterpret_cast<unsigned *>(tails + GG_THREADS);   // [n]
+    const int tid = threadIdx.x, bs = blockIdx.x;
+    const int c0 = blockIdx.y * ch_per_wg;
+    const int nch = min(ch_per_wg, c - c0);
+    const unsigned *plan = plan_all + (size_t)bs * gpg_plan_words(E, n);
+    const float *g = grad_out + ((size_t)bs * c + c0) * total;
+    float *gp = grad_points + ((size_t)bs * c + c0) * n;
+    constexpr int V = E / 4;
+    const bool vec = (total & 3) == 0 && ((uintptr_t)grad_out & 15) == 0;
+    auto fetch = [&](const float *src, float4 (&r)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int i = (v * GG_THREADS + tid) * 4;
+            if (vec) r[v] = i < total ? *(const float4 *)(src + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            else {
+                r[v].x = i < total ? src[i] : 0.f;         r[v].y = i + 1 < total ? src[i + 1] : 0.f;
+                r[v].z = i + 2 < total ? src[i + 2] : 0.f; r[v].w = i + 3 < total ? src[i + 3] : 0.f;
+            }
+        }
+    };
+    auto stash = [&](const float4 (&r)[V]) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) *(float4 *)(row + (v * GG_THREADS + tid) * 4) = r[v];
+        if (tid == 0) row[GG_THREADS * E] = 0.f;
+    };
+    float4 nxt[V];
+    fetch(g, nxt);                                                  // the first row is requested before the tables
+    unsigned pos2[E / 2];
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) pos2[k] = plan[(size_t)tid * (E / 2) + k];
+    const unsigned *pm = plan + (size_t)GG_THREADS * (E / 2);
+    const unsigned mask = pm[tid];
+    const int rank0 = (int)pm[GG_THREADS + tid];
+    for (int j = tid; j < n; j += GG_THREADS) tgt[j] = pm[2 * GG_THREADS + j];
+    stash(nxt);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) fetch(g + (size_t)(ch + 1) * total, nxt);  // in flight during the reduction below
+        float run = 0.f;
+        int rk = rank0;
+#pragma unroll
+        for (int k0 = 0; k0 < E; k0 += 8) {
+            float val[8];
+#pragma unroll
+            for (int k = 0; k < 8 && k0 + k < E; ++k) {
+                const unsigned pp = pos2[(k0 + k) / 2];
+                val[k] = row[((k0 + k) & 1) ? (pp >> 16) : (pp & 0xffffu)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8 && k0 + k < E; ++k) {
+                run += val[k];
+                if ((mask >> (k0 + k)) & 1u) { ranked[rk++] = run; run = 0.f; }
+            }
+        }
+        tails[tid] = run;
+        __syncthreads();
+        if (ch + 1 < nch) stash(nxt);                               // every read of the current row is done
+        for (int j = tid; j < n; j += GG_THREADS) {
+            const unsigned w = tgt[j];
+            if (w == 0xFFFFFFFFu) continue;
+            float s = 0.f;
+            for (int k = (int)((w >> 16) & 0xFFu); k < (int)(w >> 24); ++k) s += tails[k];
+            s += ranked[w & 0xFFFFu];
+            gp[(size_t)ch * n + j] += s;
+        }
+        __syncthreads();
+    }
+}
+
+template <int E>
+static int launch_plan(int b, int c, int n, int P, int S, int ch_per_wg, size_t lds_plan, const float *grad_out, const int *idx,
+                       unsigned *plan, float *grad_points, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gpg_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        (void)hipFuncSetAttribute((const void *)group_points_grad_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  ((GG_THREADS * E + 4) + 2 * GG_MAX_N_BAL + GG_THREADS) * 4);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gpg_plan_kernel<E>, dim3(b), dim3(GG_THREADS), lds_plan, st, n, P, S, idx, plan);
+    const size_t lds = (size_t)((GG_THREADS * E + 4) + 2 * n + GG_THREADS) * 4;
+    hipLaunchKernelGGL(group_points_grad_plan_kernel<E>, dim3(b, cmf_divup(c, ch_per_wg)), dim3(GG_THREADS), lds, st, c, n, P * S, ch_per_wg,
+                       grad_out, plan, grad_points);
+    return cmf_launch_status();
+}
+
 constexpr int GA_CH = 4;                    // channels per workgroup (streamed kernel)
 constexpr int GA_THREADS = 512;
 constexpr int GA_RUN = 8;                   // consecutive entries per thread
@@ -735,6 +935,23 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         hipLaunchKernelGGL(group_points_grad_stream_kernel, dim3(b, cmf_divup(c, GA_CH)), dim3(GA_THREADS),
                            (size_t)GA_CH * n * sizeof(float), st, c, n, (int)total, grad_out, idx, grad_points);
         return cmf_launch_status();
+    }
+    // rows x slots lists of the model's sizes: one plan kernel + the plan form of the balanced kernel (CMF_GROUP_GRAD_PLAN=0:
+    // the inverse index + balanced kernel below, diagnostics)
+    static const bool use_plan = !(getenv("CMF_GROUP_GRAD_PLAN") && getenv("CMF_GROUP_GRAD_PLAN")[0] == '0');
+    const size_t lds_plan = ((size_t)npoints * (n | 1) * 2 + 15) / 16 * 16 + ((size_t)total * 2 + 15) / 16 * 16 +
+                            ((size_t)(n + 1) * 4 + 15) / 16 * 16 + ((size_t)total + 15) / 16 * 16;
+    if (use_plan && balanced && npoints <= GG_THREADS && nsample <= 64 && n <= 65535 && lds_plan <= 160 * 1024 - 64) {
+        int ch_per_wg = GG_CH;
+        while (ch_per_wg > 2 && (long long)b * cmf_divup(c, ch_per_wg) < 1024) ch_per_wg /= 2;
+        const int e_need = (int)cmf_divup(total, GG_THREADS);
+        const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
+        unsigned *plan = (unsigned *)cmf_stream_scratch(st, 0, (size_t)b * gpg_plan_words(E, n) * sizeof(unsigned));
+        if (!plan) return (int)hipErrorOutOfMemory;
+        if (E == 4) return launch_plan<4>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
+        if (E == 8) return launch_plan<8>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
+        if (E == 16) return launch_plan<16>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
+        return launch_plan<32>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
     }
     // per-stream library scratch for the inverse index (cmf_common.h)
     const size_t n_off = (size_t)b * (n + 1), n_inv = (size_t)b * total;

@@ -183,6 +183,33 @@ def test_config5_shapes_match_oracle(dev, C):
     np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,C,N,P,S", [(64, 3, 256, 256, 32), (8, 64, 256, 256, 32), (2, 70, 256, 128, 64), (3, 5, 100, 256, 8), (2, 9, 290, 256, 4),
+                                       (1, 130, 256, 256, 17), (2, 4, 600, 100, 50), (5, 1, 16, 3, 1)])
+def test_group_points_grad_plan_form(dev, B, C, N, P, S):
+    """Lists of <= 256 rows x <= 64 slots (the model's ball-query / kNN shapes) take the plan form: one kernel turns idx into
+    the register image of the scatter workgroups, no separate inverse index.  Real ball-query lists (first-hit padding: heavy
+    low-numbered targets, empty targets) and uniform random ones; result within fp32 rounding of the oracle's scan-order sum,
+    bit-reproducible run to run, accumulating into grad_points."""
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    g = torch.Generator().manual_seed(B * 7 + C + N + S)
+    if N >= 100 and P <= N:
+        xyz, _ = clouds(B, N, seed=N + S)
+        idx = orc.ball_query(4.0, S, xyz, xyz[:, :P].contiguous())
+    else:
+        idx = torch.randint(0, N, (B, P, S), generator=g, dtype=torch.int32)
+    go = torch.randn(B, C, P, S, generator=g)
+    ref = orc.group_points_grad(go, idx, N)
+    outs = []
+    for _ in range(2):
+        gp = torch.zeros(B, C, N, device=dev)
+        ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp)
+        outs.append(gp)
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()) + 1e-6)
+    ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), outs[0])
+    np.testing.assert_allclose(outs[0].cpu().numpy(), 2 * ref.numpy(), rtol=1e-5, atol=2e-5 * float(ref.abs().max()) + 1e-6)
+
+
 @pytest.mark.parametrize("r,S", [(2.0, 32), (16.0, 32), (4.0, 8), (0.01, 4)])
 def test_group_points_grad_skewed_index(dev, r, S):
     """Real ball-query indices: first-hit padding makes the inverse lists of low-numbered points ~10x the
