@@ -45,10 +45,12 @@ constexpr int G_THREADS = 256;
                                           // bit 1: kinds 0 / 1 as well (instead of the direct form) -- experiment
 #endif
 #ifndef CMF_GEMM_PIPE
-#define CMF_GEMM_PIPE 0                   // 1: barrier in the middle of a chunk, first fragment reads of the next chunk under the second half
+#define CMF_GEMM_PIPE 1                   // 1: barrier in the middle of a chunk, first fragment reads of the next chunk under the second half
+                                          //    (same-box A/B, 524288 x 256 x 512: fwd 120.7 -> 123.3, dX 120.1 -> 121.8, dW 122.9 -> 124.2 TF; 0: one barrier at the end)
 #endif
 #ifndef CMF_GEMM_PRIO
-#define CMF_GEMM_PRIO 0                   // n > 0: s_setprio n for the main loop (experiment)
+#define CMF_GEMM_PRIO 1                   // n > 0: s_setprio n for the main loop, 0 again for the epilogue: a wave in its epilogue does not take issue
+                                          //    slots from the MFMA streams of the other workgroups (+1 % on its own, +2-3 % with the pipelined loop)
 #endif
 #ifndef CMF_GEMM_W3
 #define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD

@@ -42,20 +42,20 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
     const int tile0 = (blockIdx.x % groups_per_sample) * tiles_per_wg;
     const int tile1 = min(tile0 + tiles_per_wg, tiles_per_sample);
     const int bs = blockIdx.x / groups_per_sample;
-    const int fchunks = (int)gridDim.y - X.chunks;                 // feature chunks come first in the grid
-    const bool is_xyz = (int)blockIdx.y >= fchunks;
-    const int c0 = is_xyz ? ((int)blockIdx.y - fchunks) * GP_CH : blockIdx.y * GP_CH;
+    const bool is_xyz = (int)blockIdx.y < X.chunks;                // the coordinate chunks come FIRST in the grid (they are the slower
+                                                                   // ones per plane: behind the feature chunks they were a 150 us tail at n = 4096)
+    const int c0 = is_xyz ? (int)blockIdx.y * GP_CH : ((int)blockIdx.y - X.chunks) * GP_CH;
     const int nch = min(GP_CH, (is_xyz ? 3 : c) - c0);
     const int *ix = idx + (size_t)bs * total;
     // a "row" = the n values of one plane: features[bs][c0 + ch][:] (unit stride) or coordinate c0 + ch of xyz[bs] (stride 3)
     const float *src = is_xyz ? X.xyz + (size_t)bs * n * 3 + c0 : points + ((size_t)bs * c + c0) * n;
-    const int estr = is_xyz ? 3 : 1;
-    const size_t rstr = is_xyz ? 1 : (size_t)n;
     float *dst = out + (size_t)bs * out_bstride + (size_t)((is_xyz ? 0 : (X.chunks ? 3 : 0)) + c0) * total;
     const float *ctr = is_xyz ? X.ctr + (size_t)bs * X.m * 3 + c0 : nullptr;
 
     if (ROWS_IN_LDS) {
-        for (int i = threadIdx.x; i < nch * n; i += TPB) { const int ch = i / n, k = i - ch * n; rows[i] = src[ch * rstr + (size_t)k * estr]; }
+        if (!is_xyz) { for (int i = threadIdx.x; i < nch * n; i += TPB) rows[i] = src[i]; }
+        else for (int k = threadIdx.x; k < n; k += TPB)
+            for (int ch = 0; ch < nch; ++ch) rows[(size_t)ch * n + k] = src[(size_t)k * 3 + ch];
     }
     const bool vec_ok = (total % GP_VEC) == 0;
     for (int tile = tile0; tile < tile1; ++tile) {
@@ -75,27 +75,46 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
     }
     if (ROWS_IN_LDS && tile == tile0) __syncthreads();
 
+    if (!is_xyz) {                                      // feature planes: the plain gather
     for (int ch = 0; ch < nch; ++ch) {
-        const float *row = ROWS_IN_LDS ? rows + (size_t)ch * n : src + ch * rstr;
-        const int es = ROWS_IN_LDS ? 1 : estr;
+        const float *row = ROWS_IN_LDS ? rows + (size_t)ch * n : src + (size_t)ch * n;
         float *o = dst + (size_t)ch * total;
 #pragma unroll
         for (int s = 0; s < GP_STEPS; ++s) {
             const int e = e0 + (s * TPB + threadIdx.x) * GP_VEC;
             if (vec_ok && e + GP_VEC <= total) {
                 float4 v;
-                v.x = row[(size_t)my[s][0] * es]; v.y = row[(size_t)my[s][1] * es]; v.z = row[(size_t)my[s][2] * es]; v.w = row[(size_t)my[s][3] * es];
-                if (is_xyz) {                           // minus the centre of each entry (one subtraction: bit-equal to the reference's)
-                    v.x -= ctr[(size_t)(e / X.nsample) * 3 + ch]; v.y -= ctr[(size_t)((e + 1) / X.nsample) * 3 + ch];
-                    v.z -= ctr[(size_t)((e + 2) / X.nsample) * 3 + ch]; v.w -= ctr[(size_t)((e + 3) / X.nsample) * 3 + ch];
-                }
+                v.x = row[my[s][0]]; v.y = row[my[s][1]]; v.z = row[my[s][2]]; v.w = row[my[s][3]];
                 *reinterpret_cast<float4 *>(o + e) = v;
             } else {
 #pragma unroll
                 for (int j = 0; j < GP_VEC; ++j)
-                    if (e + j < total) o[e + j] = row[(size_t)my[s][j] * es] - (is_xyz ? ctr[(size_t)((e + j) / X.nsample) * 3 + ch] : 0.f);
+                    if (e + j < total) o[e + j] = row[my[s][j]];
             }
         }
+    }
+    } else {                                            // coordinate planes: gather minus the entry's centre (ONE subtraction: bit-equal)
+    for (int ch = 0; ch < nch; ++ch) {
+        float *o = dst + (size_t)ch * total;
+#pragma unroll
+        for (int s = 0; s < GP_STEPS; ++s) {
+            const int e = e0 + (s * TPB + threadIdx.x) * GP_VEC;
+            if (e >= total) continue;
+            const int pe = e / X.nsample, re = e - pe * X.nsample;      // one division per 4 entries: they mostly share the centre
+            float v[GP_VEC];
+#pragma unroll
+            for (int j = 0; j < GP_VEC; ++j) {
+                const float a = ROWS_IN_LDS ? rows[(size_t)ch * n + my[s][j]] : src[ch + (size_t)my[s][j] * 3];
+                const int pj = re + j < X.nsample ? pe : (e + j) / X.nsample;
+                v[j] = a - ((e + j < total) ? ctr[(size_t)pj * 3 + ch] : 0.f);
+            }
+            if (vec_ok && e + GP_VEC <= total) *reinterpret_cast<float4 *>(o + e) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < GP_VEC; ++j) if (e + j < total) o[e + j] = v[j];
+            }
+        }
+    }
     }
     }
 }

@@ -267,13 +267,17 @@ def _check_transform(got, want, pc1, weight):
     return float(ang.max()), float(dt.max())
 
 
-def _check_gradients(net, gref, what):
-    """Every parameter gradient against the oracle's, three ways: the norm (1e-2 relative: the fp32 gradient noise floor
-    of this net is ~1e-3), the DIRECTION (cosine >= 1 - 1e-5, i.e. a relative error vector below
-    4.5e-3: a permutation, a swapped column block or a missing term inside a tensor keeps the norm and fails this) and the
-    largest single element (<= 3e-2 of the tensor's largest entry).  The bounds sit 2-3x above what the ORACLE's own fp32
-    evaluation differs from its fp64 evaluation at this size (tests/grad_noise_floor.py, B = 64: norm 5.9e-4, 1 - cos
-    3.6e-6, element 1.31e-2 -- a 1e-2 element bound is below the fp32 noise of the oracle itself).
+def _check_gradients(net, gref, what, bounds=(1e-2, 2e-4, 6e-2)):
+    """Every parameter gradient against the oracle's, three ways: the norm, the DIRECTION (1 - cosine: a permutation, a
+    swapped column block or a missing term inside a tensor keeps the norm and moves this to 1e-2 ... 1) and the largest
+    single element relative to the tensor's largest entry.  bounds = (norm, 1 - cos, element).  They are set from
+    measurements, not wishes (tests/grad_noise_floor.py: the ORACLE's own fp32 evaluation against its fp64 evaluation at
+    B = 64, 8 threads): CMFlow norm 5.9e-4 / 1 - cos 3.6e-6 / element 1.3e-2; CMFlow-T first frame 2.6e-3 / 2.5e-5 / 2.2e-2,
+    second frame (weights after one Adam step: the motion head's BCE saturates) 1.2e-2 / 9.5e-4 / 0.115.  The worst
+    tensors are column sums over 524288 rows with heavy cancellation (BN shifts of the widest scale), whose fp32 value
+    depends on the summation order -- i.e. on the oracle's thread count: on the 32-thread GPU hosts the same GPU gradient
+    (bit-identical statistics from two different epilogue implementations) sits 4.0e-5 from the oracle in direction where
+    the 8-thread run had < 1e-5.  Defaults: 2-3x above those floors, still 100x below what a structural error produces.
     -> (count, worst norm error, worst 1 - cos, worst element error), each with the parameter's name."""
     wn, wc, we, n = ("", 0.0), ("", 0.0), ("", 0.0), 0
     for k, p in net.named_parameters():
@@ -287,9 +291,9 @@ def _check_gradients(net, gref, what):
             wc = max(wc, (k, 1.0 - float(a @ r) / (na * nr)), key=lambda t: t[1])
         we = max(we, (k, float((a - r).abs().max()) / max(float(r.abs().max()), 1e-6)), key=lambda t: t[1])
         n += 1
-    assert wn[1] <= 1e-2, (what, "norm", wn)
-    assert wc[1] <= 1e-5, (what, "direction", wc)
-    assert we[1] <= 3e-2, (what, "element", we)
+    assert wn[1] <= bounds[0], (what, "norm", wn)
+    assert wc[1] <= bounds[1], (what, "direction", wc)
+    assert we[1] <= bounds[2], (what, "element", we)
     return n, wn, wc, we
 
 
@@ -423,7 +427,8 @@ def test_full_size_cmflow_t_clip_matches_oracle(dev):
         assert float(epe.mean()) <= 1e-4 and float(epe.max()) <= 1e-4 + 2e-6 * 100.0 + dt, (f, float(epe.mean()), float(epe.max()))
         np.testing.assert_allclose(step.gfeat.detach().cpu().numpy(), out[4].detach().numpy(), rtol=0, atol=1e-4)
         gref = {k: p.grad for k, p in ref.named_parameters()}
-        n, worst, wcos, welem = _check_gradients(net, gref, "CMFlow-T frame %d" % f)
+        # later frames: weights after Adam steps, saturating motion-head BCE -- the oracle's own fp32 floor is 10-40x the first frame's
+        n, worst, wcos, welem = _check_gradients(net, gref, "CMFlow-T frame %d" % f, (1e-2, 2e-4, 6e-2) if f == 0 else (4e-2, 5e-3, 0.4))
         assert n >= 184                                               # 182 + the four GRU tensors
         want, have = ref.state_dict(), net.state_dict()
         for k, v in want.items():
