@@ -48,6 +48,15 @@ grad_ab() {            # the directional gradient check with the round-2 epilogu
     CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_w0.so python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train" 2>&1 | grep -E "full-size train|AssertionError|passed|failed" > $R/grad_w0.txt
     python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train" 2>&1 | grep -E "full-size train|AssertionError|passed|failed" > $R/grad_product.txt
 }
+trace() {              # kernel trace of 10 timed steps (csv copied back for tools/trace_overlap.py / offline analysis) + aten attribution
+    rm -rf /tmp/p1
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines > /dev/null 2>&1)
+    cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $R/train_kernel_stats.csv
+    cp $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) $R/train_kernel_trace.csv
+    python tools/trace_overlap.py $R/train_kernel_trace.csv loss_sample_kernel 5 11 > $R/train_overlap.txt 2>&1
+    python tools/aten_sources.py 2>&1 | filter > $R/aten_sources.txt
+    python tools/phase_probe.py 2>&1 | filter > $R/phase_probe.txt
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
