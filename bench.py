@@ -257,6 +257,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1 and not one_gpu:
+        from cmflow_amd.dp import pin_rank_to_cores
+        pin_rank_to_cores(local_rank, world)          # before the library creates its chain-worker threads (they inherit the mask)
     if world == 1 and a.force_allreduce:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -96,6 +96,16 @@ class CMFlow(nn.Module):
         else:
             f1 = self.mse_layer.forward_pm(x1, a1)
             f2 = self.mse_layer.forward_pm(x2, a2)
+        # train.TrainStep reduces the gradient bucket in segments as backward completes them.  Every autograd node of the cost
+        # volume, the second encoder and the heads is created AFTER the first encoder's node and depends only on gradients that
+        # exist before that node becomes ready, so the engine (highest sequence number first among ready nodes, AccumulateGrad
+        # ahead of everything) has run all of them when the first encoder's output gradient is handed over: segment 1 (cost
+        # volume) is complete there, segment 0 (heads, GRU, second encoder) when the embedding's gradient is.
+        ready = getattr(self, "_grad_ready", None)
+        if ready is not None:
+            for t in (f1, f2):
+                if t.requires_grad:
+                    t.register_hook(lambda g: ready(1))
         if self.path == "pm":
             f1, f2 = FB.global_max_cat(f1), FB.global_max_cat(f2)                          # (B,N,512): features + global max
         else:
@@ -109,6 +119,8 @@ class CMFlow(nn.Module):
             n_grad, n_tail = f1.shape[2] + cor.shape[2], a1.shape[2]
             pad = -(n_grad + n_tail) % 16
             emb = torch.cat((f1, cor, a1, a1.new_zeros(a1.shape[0], a1.shape[1], pad)), dim=2)
+            if ready is not None and emb.requires_grad:
+                emb.register_hook(lambda g: ready(0))      # heads + second encoder have run their backward
             prop = self._second_encoder().forward_pm(x1, emb, n_tail=n_tail, n_grad=n_grad)       # (B,N,256)
         else:
             prop = self._second_encoder().forward_pm(x1, torch.cat((a1, f1, cor), dim=2))

@@ -6,10 +6,12 @@
 gradient bucket and the loss module; ``__call__(batch)`` runs one optimizer step and returns
 (loss, items) as device tensors.
 """
+import os
+
 import torch
 
 from . import synth
-from .dp import FlatGradBucket
+from .dp import FlatGradBucket, SegmentedReducer
 from .fused_blocks import join_side_streams
 from .losses import RadarFlowLoss, make_labels
 
@@ -31,6 +33,20 @@ class TrainStep:
         self.gfeat = None
         # diagnostics (bench.py --force-allreduce): run the gradient all-reduce even with a single rank
         self.force_allreduce = False
+        # The all-reduce is cut into three segments in the order backward completes them -- heads + second encoder (+ GRU),
+        # cost volume, first encoder -- and each is launched from a tensor hook as soon as its chains have been enqueued
+        # (models/model.py:40-42: nn.DataParallel reduces inside backward too).  overlap_allreduce = False: one all-reduce
+        # of the whole bucket after backward (round 2's form).
+        self.overlap_allreduce = os.environ.get("CMF_NO_OVERLAP_ALLREDUCE") != "1"
+        self.reducer = None
+        enc2 = net._second_encoder() if hasattr(net, "_second_encoder") else None
+        if enc2 is not None and hasattr(net, "fc_layer") and hasattr(net, "mse_layer") and not self.self_supervised:
+            try:
+                late = [m for m in (enc2, getattr(net, "gru", None), net.fp, net.mp) if m is not None]
+                segs = [self.bucket.segment_of(late), self.bucket.segment_of([net.fc_layer]), self.bucket.segment_of([net.mse_layer])]
+                self.reducer = SegmentedReducer(self.bucket, segs)
+            except ValueError:                                   # a model whose parameter order does not follow the data flow
+                self.reducer = None
 
     def reset_clip(self):
         """clip_util.py:51-52: the first frame of a mini-clip starts from gfeat=None."""
@@ -53,12 +69,28 @@ class TrainStep:
                                     batch["radar_v"], batch["opt_flow"])
         return loss, items, (pred_f, mseg_pre, pre_trans, mask), (dyn_mask, mseg_gt)
 
+    def _segment_ready(self, i):
+        """Tensor hook (autograd thread): everything that writes segment i has been enqueued.  Parameter gradients are
+        accumulated in place by kernels on the side streams (fused_blocks.grad_sink), so the pool is joined into this
+        stream first; the collective then waits for this stream."""
+        if self.reducer is not None and self.reducer.active:
+            join_side_streams()
+            self.reducer.launch(i)
+
     def __call__(self, batch):
-        loss, items, outs, labels = self.forward_loss(batch)
+        overlap = self.overlap_allreduce and self.reducer is not None and self.reducer.begin(self.force_allreduce)
+        self.net._grad_ready = self._segment_ready if overlap else None
+        try:
+            loss, items, outs, labels = self.forward_loss(batch)
+        finally:
+            self.net._grad_ready = None
         self.bucket.zero()
         loss.backward()
         if loss.is_cuda:
             join_side_streams()                     # gradient sinks written on side streams (fused_blocks.grad_sink)
-        self.bucket.all_reduce_mean(force=self.force_allreduce)
+        if overlap:
+            self.reducer.finish()
+        else:
+            self.bucket.all_reduce_mean(force=self.force_allreduce)
         self.opt.step()
         return loss.detach(), items, outs, labels

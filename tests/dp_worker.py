@@ -50,16 +50,27 @@ def main():
     for f in range(n_frames):
         gb = synth.make_batch(global_b, seed=777 + f, train_extras=True)
         b = {k: v.to(dev) for k, v in shard_batch(gb, rank, world).items()}
-        loss, items, outs, _ = step.forward_loss(b)
-        step.bucket.zero()
-        loss.backward()
-        join_side_streams()
-        local = step.bucket.flat.detach().clone()
-        step.bucket.all_reduce_mean()
-        averaged = step.bucket.flat.detach().clone()
-        step.opt.step()
+        # the product's own step: the gradient all-reduce is cut into segments launched from tensor hooks during backward
+        # (train.TrainStep / dp.SegmentedReducer).  The LOCAL gradient of a segment is copied right before its collective.
+        local = torch.empty_like(step.bucket.flat)
+        red = step.reducer
+        real_launch = red.launch
+
+        def launch(i, red=red, real=real_launch, local=local):
+            if red.active and red.work[i] is None:
+                off, n = red.segments[i]
+                local[off:off + n].copy_(step.bucket.flat[off:off + n])
+            real(i)
+        red.launch = launch
+        opt_step = step.opt.step
+        averaged = []
+        step.opt.step = lambda: (averaged.append(step.bucket.flat.detach().clone()), opt_step())[1]
+        loss, items, outs, _ = step(b)
+        step.opt.step = opt_step
+        red.launch = real_launch
+        averaged = averaged[0]
         torch.cuda.synchronize()
-        frames.append({"local": local.cpu(), "averaged": averaged.cpu(), "loss": loss.detach().cpu(),
+        frames.append({"local": local.cpu(), "averaged": averaged.cpu(), "loss": loss.detach().cpu(), "early": red.early,
                        "outs": [o.detach().cpu() for o in outs[:3]],
                        "gfeat": step.gfeat.detach().cpu() if step.gfeat is not None else None})
     sd = net.state_dict()

@@ -59,3 +59,78 @@ def test_flat_bucket_allreduce_world2():
         assert p.exitcode == 0
     assert ok and same and slice_ok
     assert diff > 0           # the two ranks really had different local gradients before the reduce
+
+
+def _seg_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cmflow_amd.dp import FlatGradBucket, SegmentedReducer
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    bucket = FlatGradBucket(net)
+    segs = [bucket.segment_of([net[2]]), bucket.segment_of([net[1]]), bucket.segment_of([net[0]])]      # backward order
+    red = SegmentedReducer(bucket, segs)
+    g = torch.Generator().manual_seed(20 + rank)
+    x, y = torch.randn(4, 6, generator=g), torch.randn(4, 2, generator=g)
+    # reference: whole-bucket all-reduce after backward
+    bucket.zero()
+    ((net(x) - y) ** 2).mean().backward()
+    local = bucket.flat.clone()
+    bucket.all_reduce_mean()
+    want = bucket.flat.clone()
+    # segments launched from tensor hooks while backward is still running (the last one is left to finish())
+    bucket.zero()
+    assert red.begin()
+    h1 = net[0](x)
+    h2 = net[1](h1)
+    h2.register_hook(lambda gr: red.launch(0))          # gradient of the last layer's input: its parameters are done
+    h1.register_hook(lambda gr: red.launch(1))
+    ((net[2](h2) - y) ** 2).mean().backward()
+    launched = [w is not None for w in red.work]
+    red.finish()
+    ok = torch.equal(bucket.flat, want) and launched == [True, True, False]
+    bad_cover = False
+    try:
+        SegmentedReducer(bucket, segs[:2])
+    except ValueError:
+        bad_cover = True
+    if rank == 0:
+        out.put((ok, bad_cover, float((local - want).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_segmented_reducer_matches_whole_bucket_allreduce_world2():
+    """The overlapped form of the gradient all-reduce (segments launched from tensor hooks during backward, the rest in
+    finish()) leaves the bucket bit-identical to one all-reduce after backward; segments must tile the bucket."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, bad_cover, diff = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert ok and bad_cover and diff > 0
+
+
+def test_pin_rank_to_cores_deals_disjoint_blocks():
+    from cmflow_amd.dp import pin_rank_to_cores
+    if not hasattr(os, "sched_getaffinity"):
+        return
+    before = os.sched_getaffinity(0)
+    try:
+        if len(before) < 4:
+            assert pin_rank_to_cores(0, 2) is None
+            return
+        a = pin_rank_to_cores(0, 2)
+        os.sched_setaffinity(0, before)
+        b = pin_rank_to_cores(1, 2)
+        assert a and b and not (set(a) & set(b)) and len(a) == len(b) == len(before) // 2
+        os.environ["CMF_NO_AFFINITY"] = "1"
+        os.sched_setaffinity(0, before)
+        assert pin_rank_to_cores(1, 2) is None
+    finally:
+        os.environ.pop("CMF_NO_AFFINITY", None)
+        os.sched_setaffinity(0, before)

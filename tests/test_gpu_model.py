@@ -761,6 +761,7 @@ def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path, gemm_mod
     assert out.returncode == 0, out.stderr[-3000:]
     ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(2)]
     assert torch.equal(ranks[0]["averaged"], ranks[1]["averaged"])
+    assert ranks[0]["early"] == 2 and ranks[1]["early"] == 2      # heads + second encoder and the cost volume were reduced DURING backward
     for k, v in ranks[0]["params"].items():
         assert torch.equal(v, ranks[1]["params"][k]), k
 
@@ -819,6 +820,7 @@ def test_two_rank_cmflow_t_clip_matches_single_rank_shards(dev, tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(2)]
     for f in range(2):
+        assert ranks[0]["frames"][f]["early"] == 2 and ranks[1]["frames"][f]["early"] == 2
         assert torch.equal(ranks[0]["frames"][f]["averaged"], ranks[1]["frames"][f]["averaged"]), f
         assert not torch.equal(ranks[0]["frames"][f]["gfeat"], ranks[1]["frames"][f]["gfeat"])     # per-rank state
     for k, v in ranks[0]["params"].items():
