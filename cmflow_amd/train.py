@@ -33,11 +33,16 @@ class TrainStep:
         self.gfeat = None
         # diagnostics (bench.py --force-allreduce): run the gradient all-reduce even with a single rank
         self.force_allreduce = False
-        # The all-reduce is cut into three segments in the order backward completes them -- heads + second encoder (+ GRU),
-        # cost volume, first encoder -- and each is launched from a tensor hook as soon as its chains have been enqueued
-        # (models/model.py:40-42: nn.DataParallel reduces inside backward too).  overlap_allreduce = False: one all-reduce
-        # of the whole bucket after backward (round 2's form).
-        self.overlap_allreduce = os.environ.get("CMF_NO_OVERLAP_ALLREDUCE") != "1"
+        # The all-reduce can be cut into three segments in the order backward completes them -- heads + second encoder
+        # (+ GRU), cost volume, first encoder -- each launched from a tensor hook as soon as its chains have been enqueued
+        # (models/model.py:40-42: nn.DataParallel reduces inside backward too).  Opt-in (CMF_OVERLAP_ALLREDUCE=1 or
+        # overlap_allreduce = True): measured on one MI355X with a world-1 RCCL group inside every step (bench.py
+        # --force-allreduce, same box) the step is 22.22 ms without a collective, 22.79 ms with ONE all-reduce after backward
+        # and 23.00 ms with the three overlapped segments -- RCCL's stream is a fifth busy hardware queue next to the four
+        # the step uses (more queues are slower on this part), so running it DURING backward costs more
+        # than the 0.2-0.3 ms of ring time it could hide at 8 GPUs.  Both forms leave bit-identical buckets (tests/test_dp.py,
+        # the two-rank GPU tests run the overlapped one).
+        self.overlap_allreduce = os.environ.get("CMF_OVERLAP_ALLREDUCE") == "1"
         self.reducer = None
         enc2 = net._second_encoder() if hasattr(net, "_second_encoder") else None
         if enc2 is not None and hasattr(net, "fc_layer") and hasattr(net, "mse_layer") and not self.self_supervised:

@@ -44,6 +44,7 @@ def main():
                 p.add_(0.01)
     broadcast_module(net)
     step = TrainStep(net, vr_thres=bench.Args.vr_thres)
+    step.overlap_allreduce = True                   # the segmented form (opt-in in the product): launched from hooks during backward
     frames = []
     # CMFlow-T: the frames of one mini-clip (clip_util.py:34-62) -- the GRU state is carried per rank, detached, and the
     # optimizer steps after every frame on the all-reduced gradient

@@ -60,8 +60,8 @@ trace() {              # kernel trace of 10 timed steps (csv copied back for too
 dp_tests() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "two_rank or rccl or bench_two" 2>&1 | tail -12 > $R/dp_tests.txt; }
 allreduce_ab() {       # world-1 RCCL all-reduce inside every step: none / overlapped segments / one bucket after backward
     python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null > $R/ar_none.json
-    python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_overlap.json
-    CMF_NO_OVERLAP_ALLREDUCE=1 python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_single.json
+    CMF_OVERLAP_ALLREDUCE=1 python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_overlap.json
+    python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_single.json
     for f in none overlap single; do python -c "import json; print('$f', json.loads(open('$R/ar_$f.json').read())['ms_per_step'])"; done
 }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
