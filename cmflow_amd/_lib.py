@@ -45,6 +45,10 @@ SIGNATURES = {
     "cmf_bn_running_update": [_ci, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_forward_multi": [_ci, _vp, _vp],
     "cmf_setconv_backward_multi": [_ci, _vp, _vp],
+    "cmf_setconv_forward_heads_multi": [_ci, _vp, _vp],
+    "cmf_setconv_tail_forward": [_ci, _vp, _vp],
+    "cmf_setconv_tail_backward": [_ci, _vp, _vp],
+    "cmf_setconv_backward_bodies_multi": [_ci, _vp, _vp],
     "cmf_setconv_forward_on": [_ci, _vp, _vp, _vp],
     "cmf_setconv_backward_on": [_ci, _vp, _vp, _vp],
     "cmf_graph_stats": [_vp, _vp],

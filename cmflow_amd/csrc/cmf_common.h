@@ -19,3 +19,36 @@ static inline int cmf_divup(long long a, long long b) { return (int)((a + b - 1)
 // used hipMallocAsync / hipFreeAsync per call: normally a pool hit, but measured at 4.6 ms for one 64 MB request after
 // the pool had been trimmed -- 25x the kernel it served.]  Returns nullptr on allocation failure.  group_points.hip.
 void *cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes);
+
+// ---- batched launches (round 3) -------------------------------------------------------------------------------------
+// The narrow layers of the set-conv chains are latency, not work: the per-point tail of a block is three 64-channel
+// layers over B*N rows (128 workgroups per kernel), and the eight chains of an encoder call each issued their own ~10
+// tiny kernels per direction -- 1.5 ms of the 22 ms training step (measured by leaving the tails out).  A batch kernel
+// takes up to CMF_MAX_BATCH argument blocks BY VALUE; blockIdx.y selects the problem and blocks past a problem's last tile
+// leave at once.  Same device code, same arithmetic, same results as the single launches -- one launch per layer for all
+// chains instead of one per chain.
+constexpr int CMF_MAX_BATCH = 8;
+template <typename A> struct CmfBatch { A a[CMF_MAX_BATCH]; };
+
+struct GemmArgs;
+// BatchNorm finalize (cmf_bn_finalize), column sums (cmf_colsum_finalize / cmf_colsum_store), dU = dY * mask with the BN
+// sums (cmf_act_bwd_stats), y = relu(a z + c) (cmf_affine_relu), split-K slab sums (cmf_splitk_reduce)
+struct CmfBnFinArgs { int tiles, C; double count; const float *partial, *gamma, *beta; float eps, momentum;
+                      float *rmean, *rvar, *mean_out, *invstd_out, *a_out, *c_out; long long *nbt; };
+struct CmfColsumArgs { int tiles, ncols; const float *partial; float *out; int C; float *acc0, *acc1; int store; };
+struct CmfActBwdArgs { long long rows; int C; const float *dY; long long ldy; const float *z; long long ldz;
+                       const float *a, *c, *mean, *invstd; float *dU, *partial; };
+struct CmfAffineArgs { long long M; int C; const float *z; long long ldz; const float *a, *c; float *out; long long ldo; };
+struct CmfSplitkArgs { int M, N, split_k; const float *workspace; float *C; long long ldc; int accumulate; };
+// one fused backward layer (cmf_thin_bwd_layer); nslab is filled in by the batch call
+struct CmfThinBwdCall { long long rows; int cout, cin; const float *dU; long long lddu; const float *z; long long ldz;
+                        const float *a, *mean, *invstd, *sums; const float *w; long long ldw; const float *x; long long ldx; int in_mode;
+                        const float *a_in, *c_in, *mean_in, *invstd_in; float *dx; long long lddx; float *stats;
+                        float *dw; long long lddw; int accumulate; float *slabs; int nslab; };
+int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st);                 // pointwise.hip
+int cmf_colsum_batch(int n, const CmfColsumArgs *a, hipStream_t st);                     // pointwise.hip
+int cmf_act_bwd_stats_batch(int n, const CmfActBwdArgs *a, hipStream_t st);              // pointwise.hip
+int cmf_affine_relu_batch(int n, const CmfAffineArgs *a, hipStream_t st);                // pointwise.hip
+int cmf_splitk_reduce_batch(int n, const CmfSplitkArgs *a, hipStream_t st);              // gemm.hip
+int cmf_thin_fwd_batch(int n, const GemmArgs *g, hipStream_t st);                        // thin_gemm.hip: A[M,K] W[N,K]^T, K, N <= 64, same (N, K) for all
+int cmf_thin_bwd_layer_batch(int n, CmfThinBwdCall *c, hipStream_t st);                  // thin_gemm.hip: kernels only (no slab sum), same widths / mode

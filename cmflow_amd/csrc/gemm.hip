@@ -1129,8 +1129,8 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 
 }
 
 // Sum split-K slabs: C[m,n] (+)= sum_s P[s][m][n]   (fixed order -> deterministic weight gradients)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(long long total, int splits, int N, long long ldc, int accumulate,
-                                                            const float *__restrict__ P, float *__restrict__ C)
+__device__ __forceinline__ void splitk_reduce_body(long long total, int splits, int N, long long ldc, int accumulate,
+                                                   const float *__restrict__ P, float *__restrict__ C)
 {
     const bool v4 = (N % 4 == 0) && (ldc % 4 == 0);
     if (v4) {
@@ -1168,13 +1168,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(long long total, int
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(long long total, int splits, int N, long long ldc, int accumulate,
+                                                            const float *__restrict__ P, float *__restrict__ C)
+{
+    splitk_reduce_body(total, splits, N, ldc, accumulate, P, C);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(const CmfBatch<CmfSplitkArgs> b)
+{
+    const CmfSplitkArgs &p = b.a[blockIdx.y];
+    splitk_reduce_body((long long)p.M * p.N, p.split_k, p.N, p.ldc, p.accumulate, p.workspace, p.C);      // grid-stride
+}
+
 // The same sum for a SMALL output with MANY slabs (the thin layers' weight gradients: 32 x 32 ... 64 x 64 outputs, up to
 // 1024 slabs).  One thread per output element walks all slabs serially -- 128 dependent rounds of loads for 512 threads,
 // 38 us for 8 MB; here 16 lanes share an output float4, each sums every 16th slab (8 loads in flight), and the 16 partial
 // sums are folded in lane order through LDS: a fixed order again, so the result stays deterministic.
 constexpr int SKW_LANES = 16, SKW_OUT = 256 / SKW_LANES;
-__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(long long total, int splits, int N, long long ldc, int accumulate,
-                                                                 const float *__restrict__ P, float *__restrict__ C)
+__device__ __forceinline__ void splitk_reduce_wide_body(long long total, int splits, int N, long long ldc, int accumulate,
+                                                        const float *__restrict__ P, float *__restrict__ C)
 {
     __shared__ float4 part[SKW_OUT][SKW_LANES + 1];
     const int o = threadIdx.x / SKW_LANES, l = threadIdx.x % SKW_LANES;
@@ -1208,11 +1220,48 @@ __global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(long long total
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(long long total, int splits, int N, long long ldc, int accumulate,
+                                                                 const float *__restrict__ P, float *__restrict__ C)
+{
+    splitk_reduce_wide_body(total, splits, N, ldc, accumulate, P, C);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_wide_batch_kernel(const CmfBatch<CmfSplitkArgs> b)
+{
+    const CmfSplitkArgs &p = b.a[blockIdx.y];
+    if ((long long)blockIdx.x * SKW_OUT * 4 >= (long long)p.M * p.N) return;      // whole workgroup: before the barrier inside
+    splitk_reduce_wide_body((long long)p.M * p.N, p.split_k, p.N, p.ldc, p.accumulate, p.workspace, p.C);
+}
+
+static bool splitk_wide_ok(long long total, int N, long long ldc, int split_k, const float *workspace, const float *C)
+{
+    return N % 4 == 0 && ldc % 4 == 0 && total <= 16384 && split_k >= 4 * SKW_LANES && (((uintptr_t)C | (uintptr_t)workspace) & 15) == 0;
+}
+
+// n <= CMF_MAX_BATCH slab sums in one launch (cmf_common.h "batched launches"); every problem must take the same kernel
+int cmf_splitk_reduce_batch(int n, const CmfSplitkArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfSplitkArgs> b;
+    const bool wide = splitk_wide_ok((long long)a[0].M * a[0].N, a[0].N, a[0].ldc, a[0].split_k, a[0].workspace, a[0].C);
+    long long tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long total = (long long)a[i].M * a[i].N;
+        CMF_CHECK_ARG(a[i].workspace && a[i].C && a[i].split_k >= 1 && total > 0);
+        CMF_CHECK_ARG(splitk_wide_ok(total, a[i].N, a[i].ldc, a[i].split_k, a[i].workspace, a[i].C) == wide);
+        b.a[i] = a[i];
+        tmax = std::max(tmax, total);
+    }
+    if (wide) hipLaunchKernelGGL(splitk_reduce_wide_batch_kernel, dim3((unsigned)((tmax / 4 + SKW_OUT - 1) / SKW_OUT), n), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)std::min<long long>((tmax + 255) / 256, 4096), n), dim3(256), 0, st, b);
+    return cmf_launch_status();
+}
+
 // C[M][N] (+)= the sum of `split_k` slabs [M][N] in slab order (internal; also used by thin_gemm.hip)
 int cmf_splitk_reduce(int M, int N, int split_k, const float *workspace, float *C, long long ldc, int accumulate, hipStream_t st)
 {
     const long long total = (long long)M * N;
-    if (N % 4 == 0 && ldc % 4 == 0 && total <= 16384 && split_k >= 4 * SKW_LANES && (((uintptr_t)C | (uintptr_t)workspace) & 15) == 0) {
+    if (splitk_wide_ok(total, N, ldc, split_k, workspace, C)) {
         hipLaunchKernelGGL(splitk_reduce_wide_kernel, dim3((unsigned)((total / 4 + SKW_OUT - 1) / SKW_OUT)), dim3(256), 0, st,
                            total, split_k, N, ldc, accumulate, workspace, C);
         return cmf_launch_status();

@@ -97,17 +97,17 @@ __device__ __forceinline__ void fin_reduce4(int tiles, int ncols, const int (&co
 }
 
 // bn_finalize for C % 4 == 0: one workgroup per 4 channels, sums and sums of squares reduced together
-__global__ __launch_bounds__(256) void bn_finalize4_kernel(
+__device__ __forceinline__ void bn_finalize4_body(
     int tiles, int C, double count, const float *__restrict__ partial,
     const float *__restrict__ gamma, const float *__restrict__ beta,
     float eps, float momentum, float *__restrict__ running_mean,
     float *__restrict__ running_var, float *__restrict__ mean_out,
     float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out,
-    long long *__restrict__ num_batches_tracked)
+    long long *__restrict__ num_batches_tracked, const int bx)
 {
     __shared__ double sh[4][2][4];
-    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    const int c0 = blockIdx.x * 4;
+    if (num_batches_tracked && bx == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    const int c0 = bx * 4;
     const int col4[2] = {c0, C + c0};
     double r[2][4];
     fin_reduce4<2>(tiles, 2 * C, col4, partial, sh, r);
@@ -130,6 +130,37 @@ __global__ __launch_bounds__(256) void bn_finalize4_kernel(
     if (invstd_out) invstd_out[ch] = (float)invstd;
     a_out[ch] = (float)a;
     c_out[ch] = (float)((beta ? (double)beta[ch] : 0.0) - mean * a);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize4_kernel(
+    int tiles, int C, double count, const float *__restrict__ partial, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
+    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out, long long *__restrict__ num_batches_tracked)
+{
+    bn_finalize4_body(tiles, C, count, partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
+                      num_batches_tracked, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize4_batch_kernel(const CmfBatch<CmfBnFinArgs> b)
+{
+    const CmfBnFinArgs &p = b.a[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= p.C) return;
+    bn_finalize4_body(p.tiles, p.C, p.count, p.partial, p.gamma, p.beta, p.eps, p.momentum, p.rmean, p.rvar, p.mean_out, p.invstd_out,
+                      p.a_out, p.c_out, p.nbt, blockIdx.x);
+}
+
+int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfBnFinArgs> b;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        CMF_CHECK_ARG(a[i].tiles > 0 && a[i].C > 0 && a[i].C % 4 == 0 && a[i].partial && (uintptr_t)a[i].partial % 16 == 0 && a[i].a_out && a[i].c_out);
+        b.a[i] = a[i];
+        cmax = std::max(cmax, a[i].C);
+    }
+    hipLaunchKernelGGL(bn_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
+    return cmf_launch_status();
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
@@ -201,11 +232,11 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(int tiles, int C2,
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize4_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
-                                                               int C, float *__restrict__ acc0, float *__restrict__ acc1, int store)
+__device__ __forceinline__ void colsum_finalize4_body(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
+                                                      int C, float *__restrict__ acc0, float *__restrict__ acc1, int store, const int bx)
 {
     __shared__ double sh[4][1][4];
-    const int col4[1] = {(int)blockIdx.x * 4};
+    const int col4[1] = {bx * 4};
     double r[1][4];
     fin_reduce4<1>(tiles, C2, col4, partial, sh, r);
     if (threadIdx.x >= 4) return;
@@ -214,6 +245,33 @@ __global__ __launch_bounds__(256) void colsum_finalize4_kernel(int tiles, int C2
     out[col] = (float)s;
     if (acc0 && col < C) acc0[col] = store ? (float)s : acc0[col] + (float)s;
     if (acc1 && col >= C && col < 2 * C) acc1[col - C] = store ? (float)s : acc1[col - C] + (float)s;
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize4_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
+                                                               int C, float *__restrict__ acc0, float *__restrict__ acc1, int store)
+{
+    colsum_finalize4_body(tiles, C2, partial, out, C, acc0, acc1, store, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize4_batch_kernel(const CmfBatch<CmfColsumArgs> b)
+{
+    const CmfColsumArgs &p = b.a[blockIdx.y];
+    if ((int)blockIdx.x * 4 >= p.ncols) return;
+    colsum_finalize4_body(p.tiles, p.ncols, p.partial, p.out, p.C, p.acc0, p.acc1, p.store, blockIdx.x);
+}
+
+int cmf_colsum_batch(int n, const CmfColsumArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfColsumArgs> b;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        CMF_CHECK_ARG(a[i].tiles > 0 && a[i].ncols > 0 && a[i].ncols % 4 == 0 && a[i].partial && (uintptr_t)a[i].partial % 16 == 0 && a[i].out);
+        b.a[i] = a[i];
+        cmax = std::max(cmax, a[i].ncols);
+    }
+    hipLaunchKernelGGL(colsum_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
+    return cmf_launch_status();
 }
 
 static int launch_colsum(int tiles, int ncols, const float *partial, float *out, int C, float *a0, float *a1, int store, void *stream)
@@ -569,9 +627,9 @@ extern "C" int cmf_maxpool_bwd_point(long long P, int S, int C, const float *dou
 // ---------------------------------------------------------------------------------------------
 // y = relu(a*z + c) materialised (chain ends; out may be a column slice of a concat buffer)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PW_THREADS) void affine_relu_kernel(long long M, int C, const float *__restrict__ z, long long ldz,
-                                                                 const float *__restrict__ a, const float *__restrict__ c,
-                                                                 float *__restrict__ out, long long ldo)
+__device__ __forceinline__ void affine_relu_body(long long M, int C, const float *__restrict__ z, long long ldz,
+                                                 const float *__restrict__ a, const float *__restrict__ c,
+                                                 float *__restrict__ out, long long ldo)
 {
     const int cg = C / 4;
     for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < M * cg; i += (long long)gridDim.x * PW_THREADS) {
@@ -583,6 +641,34 @@ __global__ __launch_bounds__(PW_THREADS) void affine_relu_kernel(long long M, in
         v.z = fmaxf(fmaf(sa.z, v.z, sc.z), 0.f); v.w = fmaxf(fmaf(sa.w, v.w, sc.w), 0.f);
         *(float4 *)(out + (size_t)m * ldo + col) = v;
     }
+}
+
+__global__ __launch_bounds__(PW_THREADS) void affine_relu_kernel(long long M, int C, const float *__restrict__ z, long long ldz,
+                                                                 const float *__restrict__ a, const float *__restrict__ c,
+                                                                 float *__restrict__ out, long long ldo)
+{
+    affine_relu_body(M, C, z, ldz, a, c, out, ldo);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void affine_relu_batch_kernel(const CmfBatch<CmfAffineArgs> b)
+{
+    const CmfAffineArgs &p = b.a[blockIdx.y];
+    affine_relu_body(p.M, p.C, p.z, p.ldz, p.a, p.c, p.out, p.ldo);          // grid-stride over the problem's elements
+}
+
+int cmf_affine_relu_batch(int n, const CmfAffineArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfAffineArgs> b;
+    long long work = 0;
+    for (int i = 0; i < n; ++i) {
+        CMF_CHECK_ARG(a[i].M > 0 && a[i].C % 4 == 0 && a[i].ldz % 4 == 0 && a[i].ldo % 4 == 0 && a[i].z && a[i].a && a[i].c && a[i].out);
+        b.a[i] = a[i];
+        work = std::max(work, a[i].M * (a[i].C / 4));
+    }
+    const int grid = (int)std::min<long long>((work + PW_THREADS - 1) / PW_THREADS, 8192);
+    hipLaunchKernelGGL(affine_relu_batch_kernel, dim3(grid, n), dim3(PW_THREADS), 0, st, b);
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_affine_relu(long long M, int C, const float *z, long long ldz, const float *a, const float *c,
@@ -598,7 +684,7 @@ extern "C" int cmf_affine_relu(long long M, int C, const float *z, long long ldz
 
 // dU = dY * [a*z + c > 0] with the BN-backward partial sums (stand-alone form of cmf_gemm's bwd_mode 1,
 // for gradients that do not come out of a GEMM: concat slices, global max, ...).
-__global__ __launch_bounds__(PW_THREADS) void act_bwd_stats_kernel(
+__device__ __forceinline__ void act_bwd_stats_body(
     long long rows, int C, const float *__restrict__ dY, long long ldy, const float *__restrict__ z, long long ldz,
     const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
     const float *__restrict__ invstd, float *__restrict__ dU, float *__restrict__ partial)
@@ -623,6 +709,36 @@ __global__ __launch_bounds__(PW_THREADS) void act_bwd_stats_kernel(
         s2.z += d.z * ((v.z - mu.z) * is.z); s2.w += d.w * ((v.w - mu.w) * is.w);
     }
     tile_reduce_store(s1, s2, tm, C, partial, red);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void act_bwd_stats_kernel(
+    long long rows, int C, const float *__restrict__ dY, long long ldy, const float *__restrict__ z, long long ldz,
+    const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
+    const float *__restrict__ invstd, float *__restrict__ dU, float *__restrict__ partial)
+{
+    act_bwd_stats_body(rows, C, dY, ldy, z, ldz, a, c, mean, invstd, dU, partial);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void act_bwd_stats_batch_kernel(const CmfBatch<CmfActBwdArgs> b)
+{
+    const CmfActBwdArgs &p = b.a[blockIdx.y];
+    if ((long long)blockIdx.x * PW_ROWS >= p.rows) return;
+    act_bwd_stats_body(p.rows, p.C, p.dY, p.ldy, p.z, p.ldz, p.a, p.c, p.mean, p.invstd, p.dU, p.partial);
+}
+
+int cmf_act_bwd_stats_batch(int n, const CmfActBwdArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfActBwdArgs> b;
+    long long rmax = 0;
+    for (int i = 0; i < n; ++i) {
+        CMF_CHECK_ARG(a[i].rows > 0 && a[i].C == a[0].C && tile_ok(a[i].C) && a[i].ldy % 4 == 0 && a[i].ldz % 4 == 0 && a[i].dY && a[i].z && a[i].a &&
+                      a[i].c && a[i].mean && a[i].invstd && a[i].dU && a[i].partial);
+        b.a[i] = a[i];
+        rmax = std::max(rmax, a[i].rows);
+    }
+    hipLaunchKernelGGL(act_bwd_stats_batch_kernel, dim3(cmf_divup(rmax, PW_ROWS), n), dim3(PW_THREADS), tile_lds(a[0].C), st, b);
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_act_bwd_stats(long long M, int C, const float *dY, long long ldy, const float *z, long long ldz,

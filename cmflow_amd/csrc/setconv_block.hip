@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include "cmf_common.h"
+#include "gemm_args.h"
 #include "../../include/cmflow_hip.h"
 
 namespace {
@@ -237,7 +238,8 @@ extern "C" int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_flo
     return 0;
 }
 
-extern "C" int cmf_setconv_forward(const cmf_setconv_desc *d, void *st)
+// part: 0 whole block, 1 up to the max over the ball (the per-point tail is left to cmf_setconv_tail_forward)
+static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
 {
     CMF_CHECK_ARG(d && d->xyz && d->y && d->wx && d->saved && d->scratch && d->out);
     const Layout L = make_layout(d, d->saved, d->scratch, false);
@@ -256,6 +258,10 @@ extern "C" int cmf_setconv_forward(const cmf_setconv_desc *d, void *st)
     CMF_TRY(fwd_gemm(d, L, M, C2, C3, L.z2, 1, d->w[1], L.z3, st));
     CMF_TRY(fold(d, L, 2, M, st));
     CMF_TRY(cmf_bn_relu_maxpool(P, d->S, C3, L.z3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, L.x, C3, L.argmax, st));
+    if (part == 1) return 0;
+    // timing diagnostic (results are garbage): the per-point tail left out -- an upper bound for what fusing it can save
+    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
+    if (skip_tail) return cmf_affine_relu(P, C6, L.x, C3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, d->out, d->ldo, st);
     CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, st));
     CMF_TRY(fold(d, L, 3, P, st));
     CMF_TRY(fwd_gemm(d, L, P, C4, C5, L.z4, 3, d->w[3], L.z5, st));
@@ -265,7 +271,153 @@ extern "C" int cmf_setconv_forward(const cmf_setconv_desc *d, void *st)
     return cmf_affine_relu(P, C6, L.z6, C6, L.bn[5] + 2 * C6, L.bn[5] + 3 * C6, d->out, d->ldo, st);
 }
 
-extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
+extern "C" int cmf_setconv_forward(const cmf_setconv_desc *d, void *st) { return setconv_forward_part(d, st, 0); }
+
+// ---- the per-point tails of n blocks in batched launches (cmf_common.h "batched launches") ---------------------------
+// Layers 4-6 of a block work on B*N rows of <= 64 channels: 128 workgroups of latency per kernel.  The blocks of an
+// encoder call (4 scales, or 2 x 4 for the two clouds of the first encoder) run them as ONE launch per kernel of the
+// sequence below -- the same kernels in the same order as cmf_setconv_forward / _backward, so results are bit-identical.
+static bool tail_batchable(int n, const cmf_setconv_desc *descs)
+{
+    static const bool on = !(getenv("CMF_TAIL_BATCH") && getenv("CMF_TAIL_BATCH")[0] == '0');
+    if (!on || n < 1 || n > CMF_MAX_BATCH) return false;
+    for (int i = 0; i < n; ++i) {
+        const cmf_setconv_desc &d = descs[i];
+        for (int k = 1; k < 5; ++k)
+            if (d.C[k] > 64 || d.C[k] % 32 || d.C[k] != descs[0].C[k]) return false;
+        if (d.training != descs[0].training || ((long long)d.B * d.N) % 128) return false;
+        for (int k = 2; k < 5; ++k) if (!d.dw[k] && descs[0].dw[k]) return false;
+    }
+    return true;
+}
+
+extern "C" int cmf_setconv_tail_forward(int n, const cmf_setconv_desc *descs, void *stream)
+{
+    CMF_CHECK_ARG(n >= 0 && (n == 0 || descs));
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
+    if (!tail_batchable(n, descs) || skip_tail) {                    // one block after the other, unbatched kernels
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc *d = &descs[i];
+            const Layout L = make_layout(d, d->saved, d->scratch, false);
+            const long long P = (long long)d->B * d->N;
+            const int C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
+            if (skip_tail) { CMF_TRY(cmf_affine_relu(P, C6, L.x, C3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, d->out, d->ldo, stream)); continue; }
+            CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, stream));
+            CMF_TRY(fold(d, L, 3, P, stream));
+            CMF_TRY(fwd_gemm(d, L, P, C4, C5, L.z4, 3, d->w[3], L.z5, stream));
+            CMF_TRY(fold(d, L, 4, P, stream));
+            CMF_TRY(fwd_gemm(d, L, P, C5, C6, L.z5, 4, d->w[4], L.z6, stream));
+            CMF_TRY(fold(d, L, 5, P, stream));
+            CMF_TRY(cmf_affine_relu(P, C6, L.z6, C6, L.bn[5] + 2 * C6, L.bn[5] + 3 * C6, d->out, d->ldo, stream));
+        }
+        return 0;
+    }
+    Layout L[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) L[i] = make_layout(&descs[i], descs[i].saved, descs[i].scratch, false);
+    const bool training = descs[0].training != 0;
+    for (int layer = 0; layer < 3; ++layer) {                        // BN layer 3 + layer: (x | z4 | z5) -> (z4 | z5 | z6)
+        GemmArgs g[CMF_MAX_BATCH];
+        CmfBnFinArgs f[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long P = (long long)d.B * d.N;
+            const int cin = d.C[1 + layer], cout = d.C[2 + layer], lb = 3 + layer;
+            const float *zin = layer == 0 ? L[i].x : (layer == 1 ? L[i].z4 : L[i].z5);
+            float *zout = layer == 0 ? L[i].z4 : (layer == 1 ? L[i].z5 : L[i].z6);
+            GemmArgs &q = g[i];
+            q = GemmArgs{};
+            q.M = (int)P; q.N = cout; q.K = cin; q.A = zin; q.lda = cin; q.B = d.w[2 + layer]; q.ldb = cin; q.C = zout; q.ldc = cout;
+            if (layer > 0) { q.pro_a = L[i].bn[lb - 1] + 2 * cin; q.pro_c = L[i].bn[lb - 1] + 3 * cin; }
+            q.stats = training ? L[i].partial : nullptr;
+            q.split_k = 1;
+            float *b = L[i].bn[lb];
+            f[i] = CmfBnFinArgs{tiles128(P), cout, (double)P, L[i].partial, d.gamma[lb], d.beta[lb], d.eps[lb], d.momentum[lb], d.rmean[lb],
+                                d.rvar[lb], b, b + cout, b + 2 * cout, b + 3 * cout, d.nbt[lb]};
+        }
+        CMF_TRY(cmf_thin_fwd_batch(n, g, st));
+        if (training) CMF_TRY(cmf_bn_finalize_batch(n, f, st));
+    }
+    CmfAffineArgs a[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        const cmf_setconv_desc &d = descs[i];
+        const int C6 = d.C[4];
+        a[i] = CmfAffineArgs{(long long)d.B * d.N, C6, L[i].z6, C6, L[i].bn[5] + 2 * C6, L[i].bn[5] + 3 * C6, d.out, d.ldo};
+    }
+    return cmf_affine_relu_batch(n, a, st);
+}
+
+// gradient of the tails: from dout to the gradient of the pooled features (Layout::dx), with the weight / BN gradients of
+// layers 4-6; the rest of each block's backward is cmf_setconv_backward with part 2
+extern "C" int cmf_setconv_tail_backward(int n, const cmf_setconv_desc *descs, void *stream)
+{
+    CMF_CHECK_ARG(n >= 0 && (n == 0 || descs));
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
+    if (skip_tail) return 0;
+    if (!tail_batchable(n, descs)) {
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc *d = &descs[i];
+            const Layout L = make_layout(d, d->saved, d->scratch, true);
+            const long long P = (long long)d->B * d->N;
+            const int C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
+            const float *b5 = L.bn[5];
+            CMF_TRY(cmf_act_bwd_stats(P, C6, d->dout, d->lddout, L.z6, C6, b5 + 2 * C6, b5 + 3 * C6, b5, b5 + C6, L.t6, L.partial, stream));
+            CMF_TRY(bwd_layer(d, L, 5, P, C6, C5, L.t6, L.z6, d->w[4], L.z5, 4, L.t5, nullptr, d->dw[4], d->acc_w[4], stream));
+            CMF_TRY(bwd_layer(d, L, 4, P, C5, C4, L.t5, L.z5, d->w[3], L.z4, 3, L.t4, nullptr, d->dw[3], d->acc_w[3], stream));
+            CMF_TRY(bwd_layer(d, L, 3, P, C4, C3, L.t4, L.z4, d->w[2], L.x, -1, L.dx, nullptr, d->dw[2], d->acc_w[2], stream));
+        }
+        return 0;
+    }
+    Layout L[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) L[i] = make_layout(&descs[i], descs[i].saved, descs[i].scratch, true);
+    const bool training = descs[0].training != 0;
+    {
+        CmfActBwdArgs a[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const int C6 = d.C[4];
+            const float *b5 = L[i].bn[5];
+            a[i] = CmfActBwdArgs{(long long)d.B * d.N, C6, d.dout, d.lddout, L[i].z6, C6, b5 + 2 * C6, b5 + 3 * C6, b5, b5 + C6, L[i].t6, L[i].partial};
+        }
+        CMF_TRY(cmf_act_bwd_stats_batch(n, a, st));
+    }
+    for (int layer = 2; layer >= 0; --layer) {                       // BN layer 3 + layer, weights w[2 + layer]: cout <- cin
+        CmfColsumArgs cs[CMF_MAX_BATCH];
+        CmfThinBwdCall tb[CMF_MAX_BATCH];
+        CmfSplitkArgs sk[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long P = (long long)d.B * d.N;
+            const int cin = d.C[1 + layer], cout = d.C[2 + layer], lb = 3 + layer;
+            float *dU = layer == 2 ? L[i].t6 : (layer == 1 ? L[i].t5 : L[i].t4);
+            const float *zout = layer == 2 ? L[i].z6 : (layer == 1 ? L[i].z5 : L[i].z4);
+            const float *x = layer == 2 ? L[i].z5 : (layer == 1 ? L[i].z4 : L[i].x);
+            float *dUin = layer == 2 ? L[i].t5 : (layer == 1 ? L[i].t4 : L[i].dx);
+            const float *b = L[i].bn[lb], *bi = layer > 0 ? L[i].bn[lb - 1] : nullptr;
+            cs[i] = CmfColsumArgs{tiles128(P), 2 * cout, L[i].partial, L[i].sums, cout, d.dbeta[lb], d.dgamma[lb], d.acc_bn[lb] ? 0 : 1};
+            CmfThinBwdCall &q = tb[i];
+            q = CmfThinBwdCall{};
+            q.rows = P; q.cout = cout; q.cin = cin; q.dU = dU; q.lddu = cout; q.z = zout; q.ldz = cout;
+            q.a = b + 2 * cout; q.mean = b; q.invstd = b + cout; q.sums = training ? L[i].sums : nullptr;
+            q.w = d.w[2 + layer]; q.ldw = cin; q.x = x; q.ldx = cin; q.in_mode = layer > 0 ? 1 : 0;
+            if (bi) { q.a_in = bi + 2 * cin; q.c_in = bi + 3 * cin; q.mean_in = bi; q.invstd_in = bi + cin; }
+            q.dx = dUin; q.lddx = cin; q.stats = layer > 0 ? L[i].partial : nullptr;
+            q.dw = d.dw[2 + layer]; q.lddw = cin; q.accumulate = d.acc_w[2 + layer]; q.slabs = L[i].splitk;
+        }
+        CMF_TRY(cmf_colsum_batch(n, cs, st));
+        CMF_TRY(cmf_thin_bwd_layer_batch(n, tb, st));
+        for (int i = 0; i < n; ++i)
+            sk[i] = CmfSplitkArgs{tb[i].cout, tb[i].cin, tb[i].nslab, tb[i].slabs, tb[i].dw, tb[i].lddw, tb[i].accumulate};
+        CMF_TRY(cmf_splitk_reduce_batch(n, sk, st));
+    }
+    return 0;
+}
+
+// part: 0 whole block, 2 everything behind the per-point tail (cmf_setconv_tail_backward has produced Layout::dx)
+static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
 {
     CMF_CHECK_ARG(d && d->xyz && d->saved && d->scratch && d->dout);
     const Layout L = make_layout(d, d->saved, d->scratch, true);
@@ -278,10 +430,13 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     // it runs next to the small per-point kernels and is long done when the scatter needs it.
     if (d->dy) CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
     // layer 6 .. 4 (per point)
+    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
+    if (!skip_tail && part != 2) {
     CMF_TRY(cmf_act_bwd_stats(P, C6, d->dout, d->lddout, L.z6, C6, b5 + 2 * C6, b5 + 3 * C6, b5, b5 + C6, L.t6, L.partial, st));
     CMF_TRY(bwd_layer(d, L, 5, P, C6, C5, L.t6, L.z6, d->w[4], L.z5, 4, L.t5, nullptr, d->dw[4], d->acc_w[4], st));
     CMF_TRY(bwd_layer(d, L, 4, P, C5, C4, L.t5, L.z5, d->w[3], L.z4, 3, L.t4, nullptr, d->dw[3], d->acc_w[3], st));
     CMF_TRY(bwd_layer(d, L, 3, P, C4, C3, L.t4, L.z4, d->w[2], L.x, -1, L.dx, nullptr, d->dw[2], d->acc_w[2], st));
+    }
     // max over the ball, layers 3 .. 1 (per neighbour slot)
     static const bool fused = !(getenv("CMF_THIN_FUSED") && getenv("CMF_THIN_FUSED")[0] == '0');
     // the wide-input form of the fused layer (64 <- 256 channels, second encoder): CMF_THIN_WIDE=0 keeps max-pool backward, BN
@@ -329,6 +484,8 @@ extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st)
     }
     return 0;
 }
+
+extern "C" int cmf_setconv_backward(const cmf_setconv_desc *d, void *st) { return setconv_backward_part(d, st, 0); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // The independent scales of a MultiScaleEncoder (radarflow_util.py:101-118) in ONE call: descs[i] is issued on
@@ -402,7 +559,7 @@ ChainWorker *chain_worker(size_t i)
 }
 }  // namespace
 
-static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *streams, bool backward)
+static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *streams, bool backward, int part = 0)
 {
     CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
     int dev = 0;
@@ -410,7 +567,7 @@ static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *stre
     int err[16] = {0};
     auto run = [&](int i) {
         if (i > 0 && hipSetDevice(dev) != hipSuccess) { err[i] = (int)hipGetLastError(); return; }
-        err[i] = backward ? cmf_setconv_backward(&descs[i], streams[i]) : cmf_setconv_forward(&descs[i], streams[i]);
+        err[i] = backward ? setconv_backward_part(&descs[i], streams[i], part) : setconv_forward_part(&descs[i], streams[i], part);
     };
     {
         std::lock_guard<std::mutex> pool_lock(g_pool_mutex);
@@ -430,6 +587,19 @@ extern "C" int cmf_setconv_forward_multi(int n, const cmf_setconv_desc *descs, v
 extern "C" int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
     return setconv_multi(n, descs, streams, true);
+}
+
+// The same with the per-point tails taken out: forward stops behind the max over the ball, backward starts there.  The
+// caller runs cmf_setconv_tail_forward behind the forward heads (after joining the streams) and cmf_setconv_tail_backward in
+// front of the backward bodies (before forking): the tails of all blocks as batched launches on one stream.
+extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
+{
+    return setconv_multi(n, descs, streams, false, 1);
+}
+
+extern "C" int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
+{
+    return setconv_multi(n, descs, streams, true, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

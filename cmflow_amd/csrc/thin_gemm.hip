@@ -32,7 +32,7 @@ __device__ __forceinline__ float thin_act(float v, int act)
 
 // epilogue shared by thin_fwd / thin_dx: bias, activation, backward masks, column statistics, store
 template <int NT>
-__device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[NT], int m0, int lane, int wave, float *red)
+__device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[NT], int m0, int lane, int wave, float *red, int bx)
 {
     const int h = lane >> 5, cl = lane & 31;
     const bool want_stats = p.stats != nullptr;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[N
             const int which = i / p.N, n = i - which * p.N;
             const float s = red[(0 * 5 + which) * 64 + n] + red[(1 * 5 + which) * 64 + n] +
                             red[(2 * 5 + which) * 64 + n] + red[(3 * 5 + which) * 64 + n];
-            p.stats[((long long)blockIdx.x * nstat + which) * p.N + n] = s;
+            p.stats[((long long)bx * nstat + which) * p.N + n] = s;
         }
     }
 }
@@ -112,12 +112,13 @@ __device__ __forceinline__ void thin_load_a(const GemmArgs &p, int m0, int lane,
 }
 
 // C = epi(pro(A) @ W^T): K = 8*KS <= 64, N <= 32*NT
+// (body + single / batch entry: cmf_common.h "batched launches")
 template <int KS, int NT>
-__global__ __launch_bounds__(TG_THREADS) void thin_fwd_kernel(const GemmArgs p)
+__device__ __forceinline__ void thin_fwd_body(const GemmArgs &p, const int bx)
 {
     __shared__ float red[4 * 5 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = bx * 128 + wave * 32;
     const int h = lane >> 5, cl = lane & 31;
     float4 a[KS];
     thin_load_a<KS>(p, m0, lane, a);
@@ -138,7 +139,18 @@ __global__ __launch_bounds__(TG_THREADS) void thin_fwd_kernel(const GemmArgs p)
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b.w, acc[nt], 0, 0, 0);
         }
     }
-    thin_epilogue<NT>(p, acc, m0, lane, wave, red);
+    thin_epilogue<NT>(p, acc, m0, lane, wave, red, bx);
+}
+
+template <int KS, int NT>
+__global__ __launch_bounds__(TG_THREADS) void thin_fwd_kernel(const GemmArgs p) { thin_fwd_body<KS, NT>(p, blockIdx.x); }
+
+template <int KS, int NT>
+__global__ __launch_bounds__(TG_THREADS) void thin_fwd_batch_kernel(const CmfBatch<GemmArgs> b)
+{
+    const GemmArgs &p = b.a[blockIdx.y];
+    if ((long long)blockIdx.x * 128 >= p.M) return;
+    thin_fwd_body<KS, NT>(p, blockIdx.x);
 }
 
 // C = epi(A @ B), B stored [K][N] (row stride ldb): the data-gradient form dZ @ W
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(TG_THREADS) void thin_dx_kernel(const GemmArgs p)
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, bw, acc[nt], 0, 0, 0);
         }
     }
-    thin_epilogue<NT>(p, acc, m0, lane, wave, red);
+    thin_epilogue<NT>(p, acc, m0, lane, wave, red, blockIdx.x);
 }
 
 // Weight gradient: slab[wave][n][k] = sum over the wave's row range of A[m][n] * B'[m][k], A = dZ (rows of MT*32
@@ -283,6 +295,36 @@ static int launch_fwd_dx(const GemmArgs &g, bool dx, hipStream_t st)
         if (dx) hipLaunchKernelGGL((thin_dx_kernel<KS, 2>), grid, block, 0, st, g);
         else hipLaunchKernelGGL((thin_fwd_kernel<KS, 2>), grid, block, 0, st, g);
     }
+    return cmf_launch_status();
+}
+
+// n <= CMF_MAX_BATCH forward GEMMs C = epi(pro(A) W^T) with the SAME (N, K) in one launch (rows may differ)
+int cmf_thin_fwd_batch(int n, const GemmArgs *g, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && g);
+    CmfBatch<GemmArgs> b;
+    int max_m = 0;
+    for (int i = 0; i < n; ++i) {
+        const GemmArgs &q = g[i];
+        CMF_CHECK_ARG(q.N == g[0].N && q.K == g[0].K && q.split_k == 1 && q.K % 8 == 0 && q.K >= 8 && q.K <= 64 && q.N <= 64 && q.M >= 1 &&
+                      !q.prob_a && q.lda % 4 == 0 && ((uintptr_t)q.A % 16 == 0) && q.ldb % 4 == 0 && ((uintptr_t)q.B % 16 == 0) &&
+                      (!q.pro_a || (((uintptr_t)q.pro_a | (uintptr_t)q.pro_c) % 16 == 0)));
+        b.a[i] = q;
+        max_m = std::max(max_m, q.M);
+    }
+    const dim3 grid((max_m + 127) / 128, n), block(TG_THREADS);
+    const int ks = g[0].K / 8, nt = g[0].N <= 32 ? 1 : 2;
+#define CMF_TF(KS_) do { if (nt == 1) hipLaunchKernelGGL((thin_fwd_batch_kernel<KS_, 1>), grid, block, 0, st, b); \
+                         else hipLaunchKernelGGL((thin_fwd_batch_kernel<KS_, 2>), grid, block, 0, st, b); } while (0)
+    switch (ks) {
+        case 1: CMF_TF(1); break;
+        case 2: CMF_TF(2); break;
+        case 4: CMF_TF(4); break;
+        case 8: CMF_TF(8); break;
+        default: return (int)hipErrorInvalidValue;
+    }
+#undef CMF_TF
+    for (int i = 0; i < n; ++i) cmf_gemm_count_flops(2.0 * g[i].M * g[i].N * g[i].K);
     return cmf_launch_status();
 }
 
@@ -544,7 +586,7 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
 
 // FULL (decided by the host): rows % 128 == 0, cout == NTO * 32, cin == NTI * 32 -- the kernel then contains no ragged-edge code
 template <int NTO, int NTI, int MODE, bool FULL>
-__global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_kernel(const ThinBwdArgs p)
+__device__ __forceinline__ void thin_bwd_layer_body(const ThinBwdArgs &p, const int bx)
 {
     constexpr int LDO = ThinBwdLds<NTO, NTI>::LDO;
     __shared__ ThinBwdLds<NTO, NTI> S;
@@ -578,7 +620,7 @@ __global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) accw[i][j][r] = 0.f;
     for (int t = 0; t < p.tiles_per_wg; ++t) {
-        const long long tile = (long long)blockIdx.x * p.tiles_per_wg + t;
+        const long long tile = (long long)bx * p.tiles_per_wg + t;
         if (tile * 128 >= p.rows) break;                                         // uniform over the workgroup
         const long long left = p.rows - tile * 128;
         thin_bwd_tile<NTO, NTI, FULL, MODE>(p, S, accw, tile, (FULL || left >= 128) ? 128u : (unsigned)left, t & 1, lane, wave);
@@ -611,7 +653,7 @@ __global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_k
     __syncthreads();
     if (wave != 0) return;
     add(red[0]);
-    float *slab = p.slabs + (long long)blockIdx.x * p.cout * p.cin;
+    float *slab = p.slabs + (long long)bx * p.cout * p.cin;
 #pragma unroll
     for (int i = 0; i < NTO; ++i)
 #pragma unroll
@@ -621,6 +663,21 @@ __global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_k
                 const int n = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = j * 32 + cl;
                 if (n < p.cout && k < p.cin) slab[(long long)n * p.cin + k] = accw[i][j][r];
             }
+}
+
+template <int NTO, int NTI, int MODE, bool FULL>
+__global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_kernel(const ThinBwdArgs p)
+{
+    thin_bwd_layer_body<NTO, NTI, MODE, FULL>(p, blockIdx.x);
+}
+
+// batch form: every problem has the same slab count (gridDim.x), see thin_bwd_layer_batch
+template <int NTO, int NTI, int MODE, bool FULL>
+__global__ __launch_bounds__(TG_THREADS, NTI == 1 ? 3 : 2) void thin_bwd_layer_batch_kernel(const CmfBatch<ThinBwdArgs> b)
+{
+    const ThinBwdArgs &p = b.a[blockIdx.y];
+    if ((long long)blockIdx.x * p.tiles_per_wg * 128 >= p.rows) return;        // past this problem's last slab
+    thin_bwd_layer_body<NTO, NTI, MODE, FULL>(p, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -999,6 +1056,55 @@ static int thin_bwd_layer_impl(long long rows, int cout, int cin, const float *d
     cmf_gemm_count_flops((dx ? 2.0 : 0.0) * rows * cout * cin + (dw ? 2.0 : 0.0) * rows * cout * cin);
     if (dw) return cmf_splitk_reduce(cout, cin, nslab, slabs, dw, lddw, accumulate, st);
     return 0;
+}
+
+// n <= CMF_MAX_BATCH fused backward layers in ONE launch: dense dU, both products, whole 128-row tiles, the same channel
+// widths and the same mode (train / eval BN, BN + ReLU or activated input) for all -- the per-point tails of the scales of
+// an encoder call.  Launches the layer kernel only; c[i].nslab = the slab count of problem i, to be summed by the caller
+// (cmf_splitk_reduce_batch).
+int cmf_thin_bwd_layer_batch(int n, CmfThinBwdCall *c, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && c);
+    CmfBatch<ThinBwdArgs> b;
+    int max_slab = 0, mode0 = -1;
+    for (int i = 0; i < n; ++i) {
+        const CmfThinBwdCall &q = c[i];
+        CMF_CHECK_ARG(q.rows > 0 && q.rows % 128 == 0 && q.cout == c[0].cout && q.cin == c[0].cin && q.cout % 32 == 0 && q.cin % 32 == 0 &&
+                      q.cout <= 64 && q.cin <= 64 && (q.in_mode == 0 || q.in_mode == 1));
+        CMF_CHECK_ARG(q.dU && q.a && q.w && q.x && q.dx && q.dw && q.slabs && (!q.sums || (q.z && q.mean && q.invstd)));
+        CMF_CHECK_ARG(q.lddu % 4 == 0 && (uintptr_t)q.dU % 16 == 0 && (!q.sums || (q.ldz % 4 == 0 && (uintptr_t)q.z % 16 == 0)));
+        CMF_CHECK_ARG(((uintptr_t)q.a | (uintptr_t)q.mean | (uintptr_t)q.invstd | (uintptr_t)q.sums) % 16 == 0);
+        CMF_CHECK_ARG(q.in_mode == 0 || (q.a_in && q.c_in && q.mean_in && q.invstd_in && q.stats));
+        CMF_CHECK_ARG(128ll * std::max({q.lddu, q.ldz, q.ldx, q.lddx}) * 4 < (1ll << 31));
+        const int mode = (q.sums ? 1 : 0) | (q.in_mode ? 2 : 0);
+        if (i == 0) mode0 = mode;
+        CMF_CHECK_ARG(mode == mode0);
+        ThinBwdArgs &p = b.a[i];
+        p.rows = q.rows; p.cout = q.cout; p.cin = q.cin; p.dU = q.dU; p.lddu = q.lddu; p.z = q.z; p.ldz = q.ldz;
+        p.a = q.a; p.mean = q.mean; p.invstd = q.invstd; p.sums = q.sums; p.inv_count = (float)(1.0 / (double)q.rows);
+        p.w = q.w; p.ldw = q.ldw; p.x = q.x; p.ldx = q.ldx; p.in_mode = q.in_mode;
+        p.a_in = q.a_in; p.c_in = q.c_in; p.mean_in = q.mean_in; p.invstd_in = q.invstd_in; p.dxyz = nullptr;
+        p.dx = q.dx; p.lddx = q.lddx; p.stats = q.stats; p.slabs = q.slabs;
+        p.pool_g = nullptr; p.pool_am = nullptr; p.pool_S = 0;
+        c[i].nslab = thin_bwd_slabs_for(q.rows, q.cin > 32 ? 512 : 768, &p.tiles_per_wg);
+        max_slab = std::max(max_slab, c[i].nslab);
+        cmf_gemm_count_flops(4.0 * q.rows * q.cout * q.cin);
+    }
+    const dim3 grid(max_slab, n), block(TG_THREADS);
+#define CMF_TBB(NO, NI)                                                                                              \
+    switch (mode0) {                                                                                                \
+        case 0: hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<NO, NI, 0, true>), grid, block, 0, st, b); break;   \
+        case 1: hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<NO, NI, 1, true>), grid, block, 0, st, b); break;   \
+        case 2: hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<NO, NI, 2, true>), grid, block, 0, st, b); break;   \
+        default: hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<NO, NI, 3, true>), grid, block, 0, st, b); break;  \
+    }
+    if (c[0].cout > 32) {
+        if (c[0].cin > 32) { CMF_TBB(2, 2) } else { CMF_TBB(2, 1) }
+    } else {
+        if (c[0].cin > 32) { CMF_TBB(1, 2) } else { CMF_TBB(1, 1) }
+    }
+#undef CMF_TBB
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_thin_bwd_layer(long long rows, int cout, int cin, const float *dU, long long lddu, const float *z, long long ldz,

@@ -905,13 +905,21 @@ def _multi_call(backward, n, plan, sp, streams, main):
         fn = L().cmf_setconv_backward_on if backward else L().cmf_setconv_forward_on
         _lib.check(fn(n, ctypes.addressof(plan.descs), ctypes.addressof(sp), main.cuda_stream), "cmf_setconv_*_on")
         return
+    # The per-point tails of the n blocks (three <= 64-channel layers over the B*N points: latency, not work) run as batched
+    # launches on the caller's stream -- behind the joined chains in forward, in front of the fork in backward; the chains on
+    # the side streams carry the neighbourhood layers only (cmflow_hip.h, cmf_setconv_tail_*).
+    descs = ctypes.addressof(plan.descs)
+    if backward:
+        _lib.check(L().cmf_setconv_tail_backward(n, descs, main.cuda_stream), "cmf_setconv_tail_backward")
     for st in streams:
         st.wait_stream(main)
     stress_point(streams)
-    fn = L().cmf_setconv_backward_multi if backward else L().cmf_setconv_forward_multi
-    _lib.check(fn(n, ctypes.addressof(plan.descs), ctypes.addressof(sp)), "cmf_setconv_*_multi")
+    fn = L().cmf_setconv_backward_bodies_multi if backward else L().cmf_setconv_forward_heads_multi
+    _lib.check(fn(n, descs, ctypes.addressof(sp)), "cmf_setconv_*_multi")
     for st in streams:
         main.wait_stream(st)
+    if not backward:
+        _lib.check(L().cmf_setconv_tail_forward(n, descs, main.cuda_stream), "cmf_setconv_tail_forward")
 
 
 class MultiScaleBlockFn(Function):

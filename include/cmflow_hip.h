@@ -355,6 +355,18 @@ int cmf_bn_running_update(int n_entries, const cmf_bn_update_entry *table, int n
  * (events before and after); nothing is synchronised. */
 int cmf_setconv_forward_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
 int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
+/* The same with the per-point tails (layers 4-6: three <= 64-channel layers over the B*N points) taken out of the chains and
+ * run for ALL blocks of the call as batched launches on one stream -- one launch per kernel of the tail instead of one per
+ * block (at N = 256 these kernels are 128 workgroups of latency each; the eight chains of an encoder call spent 1.5 ms of
+ * the 22 ms training step in them).  Forward: cmf_setconv_forward_heads_multi (up to the max over the ball, per stream),
+ * join the streams, cmf_setconv_tail_forward(n, descs, stream).  Backward: cmf_setconv_tail_backward(n, descs, stream) (from
+ * dout to the gradient of the pooled features + the gradients of layers 4-6), fork, cmf_setconv_backward_bodies_multi.
+ * Same kernels, same order per block: results are bit-identical to cmf_setconv_forward / _backward.  CMF_TAIL_BATCH=0 (or
+ * blocks whose tails differ in width / mode) runs the tails block by block. */
+int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
+int cmf_setconv_tail_forward(int n, const cmf_setconv_desc *descs, void *stream);
+int cmf_setconv_tail_backward(int n, const cmf_setconv_desc *descs, void *stream);
+int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
 /* The same, ordered against main_stream by the library (as if everything had been enqueued on main_stream): the whole
  * fork/join events around the threaded direct launch.  With CMF_GRAPHS=1 (opt-in, experimental) the call is recorded
  * into a hipGraph and launched as one (CMF_GRAPH_CACHE=1 additionally replays a cached exec when the descriptor

@@ -64,6 +64,13 @@ allreduce_ab() {       # world-1 RCCL all-reduce inside every step: none / overl
     python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_single.json
     for f in none overlap single; do python -c "import json; print('$f', json.loads(open('$R/ar_$f.json').read())['ms_per_step'])"; done
 }
+skiptail() {           # upper bound for fusing the per-point tails: the step without them (garbage results, timing only)
+    for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; print('full', json.loads(sys.stdin.read())['ms_per_step'])"; 
+    CMF_DIAG_SKIP_TAIL=1 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; print('no tail', json.loads(sys.stdin.read())['ms_per_step'])"; done > $R/skiptail.txt; cat $R/skiptail.txt
+}
+tail_ab() { for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batched tails', d['ms_per_step'], d['roofline_isolated']['frac'])";
+    CMF_TAIL_BATCH=0 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('per-block tails', d['ms_per_step'])"; done > $R/tail_ab.txt; cat $R/tail_ab.txt; }
+model_quick() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "not full_size and not two_rank and not bench_two and not dense" 2>&1 | tail -5 > $R/model_quick.txt; cat $R/model_quick.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
