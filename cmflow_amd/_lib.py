@@ -42,6 +42,9 @@ SIGNATURES = {
     "cmf_setconv_forward": [_vp, _vp],
     "cmf_setconv_backward": [_vp, _vp],
     "cmf_setconv_bn_offsets": [_vp, _vp],
+    "cmf_mlp_sizes": [_vp, _vp, _vp, _vp],
+    "cmf_mlp_forward": [_vp, _vp],
+    "cmf_mlp_backward": [_vp, _vp],
     "cmf_bn_running_update": [_ci, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_forward_multi": [_ci, _vp, _vp],
     "cmf_setconv_backward_multi": [_ci, _vp, _vp],
@@ -117,6 +120,15 @@ class SetConvDesc(ctypes.Structure):
                 ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
                 ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("lddy", _ll), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
                 ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6)]
+
+
+class MlpDesc(ctypes.Structure):
+    """cmf_mlp_desc of include/cmflow_hip.h"""
+    _fields_ = [("M", _ll), ("L", _ci), ("C", _ci * 5), ("training", _ci), ("eps", _cf * 4), ("momentum", _cf * 4),
+                ("x", _vp), ("ldx", _ll), ("w", _vp * 4), ("gamma", _vp * 4), ("beta", _vp * 4),
+                ("rmean", _vp * 4), ("rvar", _vp * 4), ("nbt", _vp * 4), ("saved", _vp), ("scratch", _vp),
+                ("out", _vp), ("ldo", _ll), ("dout", _vp), ("lddout", _ll), ("dx", _vp), ("lddx", _ll),
+                ("dw", _vp * 4), ("acc_w", _ci * 4), ("dgamma", _vp * 4), ("dbeta", _vp * 4), ("acc_bn", _ci * 4)]
 
 
 class BnUpdateEntry(ctypes.Structure):

@@ -755,6 +755,116 @@ extern "C" int cmf_setconv_backward_on(int n, const cmf_setconv_desc *descs, voi
     return multi_on_main(n, descs, streams, main_stream, true);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// [conv + BN + ReLU] x L on a materialised input (the heads' stacks): cmf_mlp_forward / _backward.  The kernel sequence
+// of fused_blocks.MLPChainFn, issued from here.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct MlpLayout {
+    float *z[4], *bn[4];
+    float *partial, *sums, *dU[4], *splitk;
+    size_t saved_floats, scratch_floats;
+};
+MlpLayout mlp_layout(const cmf_mlp_desc *d, float *saved, float *scratch, bool backward)
+{
+    MlpLayout L;
+    Bump s(saved);
+    for (int l = 0; l < d->L; ++l) L.z[l] = s.take((size_t)d->M * d->C[l + 1]);
+    for (int l = 0; l < d->L; ++l) L.bn[l] = s.take(4 * (size_t)d->C[l + 1]);
+    L.saved_floats = s.off;
+    Bump t(scratch);
+    int cmax = 0;
+    for (int l = 0; l <= d->L; ++l) cmax = std::max(cmax, d->C[l]);
+    L.partial = t.take((size_t)tiles128(d->M) * 2 * cmax);
+    L.sums = t.take(2 * (size_t)cmax);
+    size_t sk = 0;
+    if (backward) {
+        for (int l = 0; l < d->L; ++l) L.dU[l] = t.take((size_t)d->M * d->C[l + 1]);
+        for (int l = 0; l < d->L; ++l) sk = std::max(sk, (size_t)dw_split(d->M, d->C[l + 1], d->C[l]) * d->C[l + 1] * d->C[l]);
+        L.splitk = t.take(sk);
+    } else {
+        for (int l = 0; l < 4; ++l) L.dU[l] = nullptr;
+        L.splitk = nullptr;
+    }
+    L.scratch_floats = t.off;
+    return L;
+}
+bool mlp_ok(const cmf_mlp_desc *d)
+{
+    if (!d || d->M <= 0 || d->M >= (1ll << 31) || d->L < 1 || d->L > 4) return false;
+    for (int l = 0; l <= d->L; ++l) if (d->C[l] <= 0 || d->C[l] % 4) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" int cmf_mlp_sizes(const cmf_mlp_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd)
+{
+    CMF_CHECK_ARG(mlp_ok(d));
+    const MlpLayout f = mlp_layout(d, nullptr, nullptr, false), b = mlp_layout(d, nullptr, nullptr, true);
+    if (saved_floats) *saved_floats = (long long)f.saved_floats;
+    if (scratch_fwd) *scratch_fwd = (long long)f.scratch_floats;
+    if (scratch_bwd) *scratch_bwd = (long long)b.scratch_floats;
+    return 0;
+}
+
+extern "C" int cmf_mlp_forward(const cmf_mlp_desc *d, void *st)
+{
+    CMF_CHECK_ARG(mlp_ok(d) && d->x && d->saved && d->scratch && d->out && d->ldx % 4 == 0 && d->ldo % 4 == 0);
+    const MlpLayout L = mlp_layout(d, d->saved, d->scratch, false);
+    for (int l = 0; l < d->L; ++l) {
+        const int cin = d->C[l], cout = d->C[l + 1];
+        const float *zin = l == 0 ? d->x : L.z[l - 1];
+        const long long ldin = l == 0 ? d->ldx : cin;
+        const float *pa = l > 0 ? L.bn[l - 1] + 2 * cin : nullptr, *pc = l > 0 ? L.bn[l - 1] + 3 * cin : nullptr;
+        CMF_TRY(cmf_gemm((int)d->M, cout, cin, 0, 1, zin, ldin, d->w[l], cin, L.z[l], cout, pa, pc, nullptr, nullptr, nullptr, 0,
+                         d->training ? L.partial : nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0, st));
+        float *b = L.bn[l];
+        if (d->training)
+            CMF_TRY(cmf_bn_finalize(tiles128(d->M), cout, (double)d->M, L.partial, d->gamma[l], d->beta[l], d->eps[l], d->momentum[l],
+                                    d->rmean[l], d->rvar[l], b, b + cout, b + 2 * cout, b + 3 * cout, d->nbt[l], st));
+        else
+            CMF_TRY(cmf_bn_finalize(0, cout, 1.0, nullptr, d->gamma[l], d->beta[l], d->eps[l], 0.f, d->rmean[l], d->rvar[l], b, b + cout,
+                                    b + 2 * cout, b + 3 * cout, nullptr, st));
+    }
+    const int cl = d->C[d->L];
+    return cmf_affine_relu(d->M, cl, L.z[d->L - 1], cl, L.bn[d->L - 1] + 2 * cl, L.bn[d->L - 1] + 3 * cl, d->out, d->ldo, st);
+}
+
+extern "C" int cmf_mlp_backward(const cmf_mlp_desc *d, void *st)
+{
+    CMF_CHECK_ARG(mlp_ok(d) && d->x && d->saved && d->scratch && d->dout && d->lddout % 4 == 0 && (!d->dx || d->lddx % 4 == 0));
+    const MlpLayout L = mlp_layout(d, d->saved, d->scratch, true);
+    const long long M = d->M;
+    {
+        const int c = d->C[d->L];
+        const float *b = L.bn[d->L - 1];
+        CMF_TRY(cmf_act_bwd_stats(M, c, d->dout, d->lddout, L.z[d->L - 1], c, b + 2 * c, b + 3 * c, b, b + c, L.dU[d->L - 1], L.partial, st));
+    }
+    for (int l = d->L - 1; l >= 0; --l) {
+        const int cin = d->C[l], cout = d->C[l + 1];
+        const float *b = L.bn[l];
+        CMF_CHECK_ARG(d->dw[l] && d->dgamma[l] && d->dbeta[l]);
+        if (d->acc_bn[l]) CMF_TRY(cmf_colsum_finalize(tiles128(M), cout, L.partial, L.sums, d->dbeta[l], d->dgamma[l], st));
+        else CMF_TRY(cmf_colsum_store(tiles128(M), 2 * cout, L.partial, L.sums, cout, d->dbeta[l], d->dgamma[l], st));
+        CMF_TRY(cmf_bn_bwd_apply(M, cout, L.dU[l], L.z[l], cout, b + 2 * cout, b, b + cout, d->training ? L.sums : nullptr, st));
+        // weight gradient: dZ^T act(x_in), deterministic split-K
+        const float *xin = l == 0 ? d->x : L.z[l - 1];
+        const long long ldin = l == 0 ? d->ldx : cin;
+        const float *bi = l > 0 ? L.bn[l - 1] : nullptr;
+        const int split = dw_split(M, cout, cin);
+        CMF_TRY(cmf_gemm(cout, cin, (int)M, 1, 0, L.dU[l], cout, xin, ldin, d->dw[l], cin, nullptr, nullptr, bi ? bi + 2 * cin : nullptr,
+                         bi ? bi + 3 * cin : nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, split,
+                         split > 1 ? L.splitk : nullptr, d->acc_w[l], st));
+        if (l > 0)                      // gradient w.r.t. the pre-activation of the layer below, masked, with its BN-backward sums
+            CMF_TRY(cmf_gemm((int)M, cin, cout, 0, 0, L.dU[l], cout, d->w[l], cin, L.dU[l - 1], cin, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                             L.partial, 1, L.z[l - 1], cin, bi + 2 * cin, bi + 3 * cin, bi, bi + cin, nullptr, 1, nullptr, 0, st));
+        else if (d->dx)
+            CMF_TRY(cmf_gemm((int)M, cin, cout, 0, 0, L.dU[0], cout, d->w[0], cin, d->dx, d->lddx, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                             nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, 0, st));
+    }
+    return 0;
+}
+
 // Float offsets of the per-layer BatchNorm blocks (mean | invstd | a | c, 4*C_l floats each) inside `saved`.
 extern "C" int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6)
 {

@@ -548,13 +548,84 @@ class MLPChainFn(Function):
         return (dx, None, None, *grads)
 
 
+class MLPChainBlockFn(Function):
+    """MLPChainFn with the kernel sequence issued by ONE C-ABI call per direction (cmf_mlp_forward / _backward,
+    csrc/setconv_block.hip): same kernels, same order, same numerics.  Sequenced from Python the heads' chains were host
+    bound -- ~25 launches of 5-45 us with 15-30 us of interpreter time between them, and the autograd thread enqueues the
+    two heads one after the other: 1.0 ms at the start of every backward pass with the GPU idle."""
+
+    @staticmethod
+    def forward(ctx, x, bns, training, *params):
+        import ctypes
+        x = x if (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else x.contiguous()
+        M, dev, nl = x.shape[0], x.device, len(bns)
+        d = _lib.MlpDesc()
+        d.M, d.L, d.training = M, nl, int(training)
+        d.C[0] = x.shape[1]
+        ws = []
+        for l, bn in enumerate(bns):
+            w = params[3 * l].contiguous()
+            ws.append(w)
+            assert bn.momentum is not None, "cumulative moving average BN is not supported by the block call"
+            d.C[l + 1] = w.shape[0]
+            d.eps[l], d.momentum[l] = bn.eps, bn.momentum
+            d.w[l], d.gamma[l], d.beta[l] = w.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
+            d.rmean[l], d.rvar[l] = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats) else None
+        n_s, n_f, n_b = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+        _lib.check(L().cmf_mlp_sizes(ctypes.addressof(d), ctypes.addressof(n_s), ctypes.addressof(n_f), ctypes.addressof(n_b)), "cmf_mlp_sizes")
+        saved = torch.empty(n_s.value, dtype=_f32, device=dev)
+        scratch = torch.empty(n_f.value, dtype=_f32, device=dev)
+        out = torch.empty(M, ws[-1].shape[0], dtype=_f32, device=dev)
+        d.x, d.ldx, d.saved, d.scratch, d.out, d.ldo = x.data_ptr(), x.stride(0), saved.data_ptr(), scratch.data_ptr(), out.data_ptr(), out.stride(0)
+        _lib.check(L().cmf_mlp_forward(ctypes.addressof(d), _lib.stream_ptr()), "cmf_mlp_forward")
+        ctx.state = (d, x, ws, saved, n_b.value)
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        import ctypes
+        d, x, ws, saved, n_bwd = ctx.state
+        P = ctx.params
+        dev = dy.device
+        if dy.stride(1) != 1 or dy.stride(0) % 4 or dy.data_ptr() % 16:
+            dy = dy.contiguous()
+        scratch = torch.empty(n_bwd, dtype=_f32, device=dev)
+        d.scratch, d.dout, d.lddout = scratch.data_ptr(), dy.data_ptr(), dy.stride(0)
+        grads = [None] * len(P)
+        for l in range(d.L):
+            sink = grad_sink(P[3 * l])
+            if sink is not None:
+                d.dw[l], d.acc_w[l] = sink.data_ptr(), 1
+            else:
+                grads[3 * l] = torch.empty_like(ws[l])
+                d.dw[l], d.acc_w[l] = grads[3 * l].data_ptr(), 0
+            sg, sb = grad_sink(P[3 * l + 1]), grad_sink(P[3 * l + 2])
+            if sg is not None and sb is not None:
+                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = sg.data_ptr(), sb.data_ptr(), 1
+            else:
+                grads[3 * l + 1], grads[3 * l + 2] = torch.empty_like(P[3 * l + 1]), torch.empty_like(P[3 * l + 2])
+                d.dgamma[l], d.dbeta[l], d.acc_bn[l] = grads[3 * l + 1].data_ptr(), grads[3 * l + 2].data_ptr(), 0
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x.shape[0], x.shape[1], dtype=_f32, device=dev)
+            d.dx, d.lddx = dx.data_ptr(), dx.stride(0)
+        else:
+            d.dx, d.lddx = None, 0
+        _lib.check(L().cmf_mlp_backward(ctypes.addressof(d), _lib.stream_ptr()), "cmf_mlp_backward")
+        return (dx, None, None, *grads)
+
+
 def mlp_chain(x, layers, training):
     """layers: list of (conv, bn) modules.  x (..., K) -> (..., C_L)."""
     shp = x.shape
     params = []
     for conv, bn in layers:
         params += [conv.weight.view(conv.weight.shape[0], conv.weight.shape[1]), bn.weight, bn.bias]
-    y = MLPChainFn.apply(x.reshape(-1, shp[-1]), [bn for _, bn in layers], training, *params)
+    block = USE_BLOCK_CALLS and len(layers) <= 4 and shp[-1] % 4 == 0 and all(c.weight.shape[0] % 4 == 0 for c, _ in layers)
+    fn = MLPChainBlockFn if block else MLPChainFn
+    y = fn.apply(x.reshape(-1, shp[-1]), [bn for _, bn in layers], training, *params)
     return y.view(*shp[:-1], y.shape[-1])
 
 

@@ -337,6 +337,31 @@ int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
 /* Float offsets, inside `saved`, of the six per-layer BatchNorm blocks (mean | invstd | a | c, 4*C_l floats each). */
 int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6);
 
+/* [1x1 conv (no bias) + BatchNorm + ReLU] x L on a materialised input: the stacks of the flow / motion heads
+ * (utils/model_utils/radarflow_util.py:253-261,277-285: 512 -> 256 -> 128 -> 64) sequenced by the library like a set-conv
+ * block -- forward GEMM with train-mode statistics, fold; backward: BN-backward sums, BN backward in place, weight
+ * gradient (deterministic split-K), masked data gradient.  Issued from Python one kernel at a time these chains were host
+ * bound (25 launches of 5-45 us with 15-30 us between them: the two heads' backward passes took 1.0 ms of a 22 ms step with
+ * the GPU idle).  C[0] = input channels, C[l] = output channels of layer l (1..L, L <= 4, all multiples of 4).
+ * saved: z_1 .. z_L and the BN blocks (mean | invstd | a | c) ; scratch: partial sums, gradient buffers, split-K slabs. */
+typedef struct cmf_mlp_desc {
+    long long M; int L; int C[5]; int training;
+    float eps[4], momentum[4];
+    const float *x; long long ldx;                       /* (M, C[0]) activated input, row stride ldx */
+    const float *w[4];                                   /* (C[l], C[l-1]) dense */
+    const float *gamma[4], *beta[4];
+    float *rmean[4], *rvar[4]; long long *nbt[4];        /* running statistics (nbt NULL: counter not touched) */
+    float *saved, *scratch;
+    float *out; long long ldo;                           /* forward: relu(bn_L(z_L)), (M, C[L]) */
+    const float *dout; long long lddout;                 /* backward */
+    float *dx; long long lddx;                           /* (M, C[0]) or NULL */
+    float *dw[4]; int acc_w[4];
+    float *dgamma[4], *dbeta[4]; int acc_bn[4];
+} cmf_mlp_desc;
+int cmf_mlp_sizes(const cmf_mlp_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
+int cmf_mlp_forward(const cmf_mlp_desc *d, void *stream);
+int cmf_mlp_backward(const cmf_mlp_desc *d, void *stream);
+
 /* Deferred nn.BatchNorm2d running-statistics update.  A weight-shared encoder is called twice per step
  * (cmflow.py:72-73); to run the two calls CONCURRENTLY they are issued with rmean/rvar/nbt == NULL (batch statistics
  * only) and the momentum updates are applied afterwards, in call order, from each call's saved batch mean / invstd.

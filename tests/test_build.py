@@ -92,11 +92,12 @@ def test_ctypes_structs_match_the_header(tmp_path):
     from cmflow_amd import _lib
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "cmflow_hip.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(cmf_setconv_desc), offsetof(cmf_setconv_desc, acc_bn),'
-                   ' sizeof(cmf_bn_update_entry), offsetof(cmf_bn_update_entry, offset), sizeof(cmf_gemm_launch_record)); return 0; }\n')
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(cmf_setconv_desc), offsetof(cmf_setconv_desc, acc_bn),'
+                   ' sizeof(cmf_bn_update_entry), offsetof(cmf_bn_update_entry, offset), sizeof(cmf_gemm_launch_record),'
+                   ' sizeof(cmf_mlp_desc), offsetof(cmf_mlp_desc, acc_bn)); return 0; }\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
     want = [ctypes.sizeof(_lib.SetConvDesc), _lib.SetConvDesc.acc_bn.offset, ctypes.sizeof(_lib.BnUpdateEntry),
-            _lib.BnUpdateEntry.offset.offset, ctypes.sizeof(_lib.GemmLaunchRecord)]
+            _lib.BnUpdateEntry.offset.offset, ctypes.sizeof(_lib.GemmLaunchRecord), ctypes.sizeof(_lib.MlpDesc), _lib.MlpDesc.acc_bn.offset]
     assert got == want

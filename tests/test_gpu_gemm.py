@@ -545,3 +545,56 @@ def test_gemm_relu_epilogues_select_on_non_finite_values(dev, gemm_mode):
     keep = torch.ones(M, dtype=torch.bool); keep[7] = keep[295] = False
     want = torch.where(X > 0, dY @ Wb, torch.zeros(()))
     np.testing.assert_allclose(dx[keep].numpy(), want[keep].numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,chans,train", [(16384, (512, 256, 128, 64), True), (16384, (512, 256, 128, 64), False), (300, (16, 8, 4), True),
+                                            (1000, (64, 64, 64, 64, 64), True)])
+def test_mlp_chain_block_call_equals_python_sequence(dev, gemm_mode, M, chans, train):
+    """cmf_mlp_forward / _backward (the heads' [conv + BN + ReLU] stacks sequenced by the library) against the same kernels
+    sequenced from Python (fused_blocks.MLPChainFn): outputs, input gradient, every parameter gradient and the BN running
+    statistics bit-identical -- with gradients returned as tensors and with gradients accumulated into existing .grad."""
+    if gemm_mode != "fp32":
+        pytest.skip("one arithmetic is enough")
+    from cmflow_amd import fused_blocks as FB
+    torch.manual_seed(M + len(chans))
+
+    def build():
+        torch.manual_seed(7)
+        layers = []
+        for cin, cout in zip(chans[:-1], chans[1:]):
+            conv, bn = torch.nn.Conv2d(cin, cout, 1, bias=False), torch.nn.BatchNorm2d(cout)
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2); bn.running_mean.normal_(0, 0.3); bn.running_var.uniform_(0.5, 2.0)
+            layers.append((conv.to(dev), bn.to(dev).train(train)))
+        return layers
+
+    x0 = torch.randn(M, chans[0], device=dev)
+    dy = torch.randn(M, chans[-1], device=dev)
+    res = {}
+    for block in (False, True):
+        for sinks in (False, True):
+            layers = build()
+            FB.USE_BLOCK_CALLS = block
+            try:
+                params = [p for c, b in layers for p in (c.weight, b.weight, b.bias)]
+                if sinks:
+                    for p in params:
+                        p.grad = torch.full_like(p, 0.25)
+                x = x0.clone().requires_grad_(True)
+                y = FB.mlp_chain(x, layers, train)
+                y.backward(dy)
+            finally:
+                FB.USE_BLOCK_CALLS = True
+            torch.cuda.synchronize()
+            res[(block, sinks)] = (y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in params],
+                                   [t.clone() for c, b in layers for t in (b.running_mean, b.running_var, b.num_batches_tracked)])
+    for sinks in (False, True):
+        a, b = res[(False, sinks)], res[(True, sinks)]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        for g0, g1 in zip(a[2], b[2]):
+            assert torch.equal(g0, g1)
+        for t0, t1 in zip(a[3], b[3]):
+            assert torch.equal(t0, t1)
+    # accumulation into existing gradients = returned gradient + what was there
+    for g_ret, g_acc in zip(res[(True, False)][2], res[(True, True)][2]):
+        assert float((g_acc - 0.25 - g_ret).abs().max()) <= 1e-5 * max(1.0, float(g_ret.abs().max()))

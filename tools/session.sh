@@ -70,7 +70,8 @@ skiptail() {           # upper bound for fusing the per-point tails: the step wi
 }
 tail_ab() { for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batched tails', d['ms_per_step'], d['roofline_isolated']['frac'])";
     CMF_TAIL_BATCH=0 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('per-block tails', d['ms_per_step'])"; done > $R/tail_ab.txt; cat $R/tail_ab.txt; }
-model_quick() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "not full_size and not two_rank and not bench_two and not dense" 2>&1 | tail -5 > $R/model_quick.txt; cat $R/model_quick.txt; }
+model_quick() { python -m pytest tests/test_gpu_model.py tests/test_gpu_stress.py tests/test_gpu_raflow.py -x -q -m gpu -k "not full_size and not two_rank and not bench_two and not dense" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8 > $R/model_quick.txt; cat $R/model_quick.txt; }
+mlp_test() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "mlp_chain or small_m" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8 > $R/mlp_test.txt; cat $R/mlp_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
