@@ -221,7 +221,7 @@ def hbm_op_rooflines(dev, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100: a 2 s timed region; the driver passes its own)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["train", "fwd"], default="train")
     ap.add_argument("--model", choices=["cmflow", "cmflow_t", "raflow"], default="cmflow")
@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--clip", type=int, default=5, help="cmflow_t: frames per mini-clip (clip_util.py:34-62)")
     ap.add_argument("--gemm-table", default=None, help="write a markdown table of the bracketed cmf_gemm launches by shape to this file")
     a = ap.parse_args()
+    if a.steps is None:
+        a.steps = 100
 
     # stdout carries exactly ONE line (the JSON record): libraries that print to the C-level stdout (RCCL's version banner
     # at communicator creation) are sent to stderr, and the record is written to the saved descriptor at the end.  Done
@@ -342,6 +344,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     prof = _lib.profile_end()
+    # run-to-run spread: two more timed regions of the same length, back to back (not part of `value`)
+    spread = [dt / a.steps * 1e3]
+    for _ in range(2):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            one()
+        fence()
+        spread.append((time.perf_counter() - t1) / a.steps * 1e3)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -358,11 +369,21 @@ def main():
             # the opt-in bf16x3 arithmetic executes six bf16 MFMAs per fp32-equivalent product: its roof is the bf16 dense peak / 6
             peak = MFMA_F32_PEAK_TFLOPS if gemm_mode == "fp32" else round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1)
             achieved, unit = per_launch / (avg_ms * 1e-3) / 1e12, "TFLOP/s"
+        # PMC counters need rocprofv3 around the process: `traffic` is the per-launch HBM byte count of this kernel's
+        # >= 256-workgroup launches from the committed FETCH_SIZE / WRITE_SIZE passes over this same command (separate --pmc
+        # runs, gfx950 x2 correction on FETCH_SIZE; tools/session.sh pmc_gemm), beside the algorithmic bytes of the launches
+        # bracketed live (A + B + C once, + the Z operand of the backward epilogues)
+        traffic = alg_bytes = None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_gemm_traffic_instep.json")
+        if prof["bound"] == "mfma" and a.mode == "train" and a.model == "cmflow" and os.path.exists(tp):
+            traffic = json.load(open(tp))["traffic_bytes_per_launch"]
+        if prof.get("shapes"):
+            tot = sum(cnt * 4.0 * (M * K + K * N + M * N * (2 if kind >= 2 else 1))
+                      for (M, N, K, layout, kind, split_k, bm, bn), (cnt, _) in prof["shapes"].items())
+            alg_bytes = round(tot / prof["launches"])
         out = {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
-               "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
-               # PMC counters need rocprofv3 around the process; the per-launch FETCH_SIZE / WRITE_SIZE passes for this
-               # kernel are committed (separate --pmc runs, gfx950 x2 correction on FETCH_SIZE)
-               "traffic_profile": "profiles/r02_gemm_pmc.txt",
+               "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
+               "traffic_profile": "profiles/r03_gemm_traffic_instep.json", "algorithmic_bytes_per_launch": alg_bytes,
                "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
                "algorithmic_per_launch": per_launch,
                "launch_filter": "every tiled-kernel launch >= %.0e flop, bracketed inside libcmflow_hip.so (block-internal "
@@ -432,6 +453,8 @@ def main():
             # model-level rate against the reference's ALGORITHMIC work (25.52 GFLOP per frame pair forward,
             # x3 for fwd+bwd) -- the build's hoisted first convs execute fewer FLOPs than that
             "algorithmic_model_tflops": round(pairs / dt * 25.52e9 * (3.0 if a.mode == "train" else 1.0) / 1e12, 2),
+            # ms per step of three back-to-back timed regions of `steps` steps each (the first one is `value`): rank 0's clock
+            "extra": {"ms_per_step_regions": [round(v, 3) for v in spread]},
         }
         if a.gemm_table:
             with open(a.gemm_table, "w") as f:

@@ -72,6 +72,19 @@ tail_ab() { for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines
     CMF_TAIL_BATCH=0 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('per-block tails', d['ms_per_step'])"; done > $R/tail_ab.txt; cat $R/tail_ab.txt; }
 model_quick() { python -m pytest tests/test_gpu_model.py tests/test_gpu_stress.py tests/test_gpu_raflow.py -x -q -m gpu -k "not full_size and not two_rank and not bench_two and not dense" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8 > $R/model_quick.txt; cat $R/model_quick.txt; }
 mlp_test() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "mlp_chain or small_m" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8 > $R/mlp_test.txt; cat $R/mlp_test.txt; }
+phases() { python tools/phase_probe.py 2>&1 | filter > $R/phase_probe.txt; cat $R/phase_probe.txt; }
+serial_ab() { for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('streams', d['ms_per_step'])";
+    python bench.py --no-cpu-baseline --no-op-rooflines --serial 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('serial', d['ms_per_step'])";
+    CMF_SIDE_STREAMS=2 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('2 side streams', d['ms_per_step'])"; done > $R/serial_ab.txt; cat $R/serial_ab.txt; }
+pmc_gemm() {           # HBM traffic of cmf_gemm inside the training step: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slot limit)
+    for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/pm_$c
+        (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-op-rooflines > /dev/null 2>&1)
+        cp $(find /tmp/pm_$c -name "*counter_collection.csv" | head -1) $R/pmc_$c.csv
+    done
+    python tools/gemm_traffic.py $R/pmc_FETCH_SIZE.csv $R/pmc_WRITE_SIZE.csv > $R/gemm_traffic.json; cat $R/gemm_traffic.json
+    rm -f $R/pmc_FETCH_SIZE.csv $R/pmc_WRITE_SIZE.csv
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
