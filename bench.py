@@ -230,7 +230,7 @@ def main():
     ap.add_argument("--path", choices=["pm", "pm_torch"], default="pm",
                     help="pm: fused point-major HIP path (product); pm_torch: same layout, dense math through torch (debugging)")
     ap.add_argument("--serial", action="store_true",
-                    help="diagnostic: encoder scales on ONE stream (per-kernel durations free of contention)")
+                    help="diagnostic: every chain of the step on ONE stream (per-kernel durations free of contention)")
     ap.add_argument("--force-allreduce", action="store_true",
                     help="diagnostic at N=1: run the RCCL all-reduce of the gradient bucket (world size 1) inside every step")
     ap.add_argument("--no-op-rooflines", action="store_true", help="skip the roofline_hbm op benchmarks after the timed region")
@@ -328,11 +328,8 @@ def main():
         torch.cuda.synchronize()
 
     if a.serial:
-        from cmflow_amd.radarflow_util import FeatureCorrelator as _FC, MultiScaleEncoder as _MSE
-        from cmflow_amd.cmflow import CMFlow as _CM
-        _MSE.multi_stream = False
-        _FC.side_streams = False
-        _CM.head_streams = False
+        from cmflow_amd import fused_blocks as _FB
+        _FB.set_serial(net, True)
     for _ in range(a.warmup):
         one()
     frame[0] = 0                                     # the timed region starts at the first frame of a clip
@@ -400,13 +397,8 @@ def main():
     # Every rank runs it: a training step contains the gradient all-reduce, a collective all ranks must enter.
     iso = iso_prof = None
     if a.path == "pm":
-        from cmflow_amd.radarflow_util import FeatureCorrelator, MultiScaleEncoder
-        for m in net.modules():
-            if isinstance(m, MultiScaleEncoder):
-                m.multi_stream = False
-            if isinstance(m, FeatureCorrelator):
-                m.side_streams = False
-        net.head_streams = False
+        from cmflow_amd import fused_blocks as _FB
+        _FB.set_serial(net, True)                   # the SAME launches, every chain on the caller's stream
         one(); torch.cuda.synchronize()
         _lib.profile_begin()
         for _ in range(3):

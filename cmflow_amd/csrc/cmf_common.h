@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #define CMF_WAVE 64
@@ -17,8 +18,17 @@ static inline int cmf_divup(long long a, long long b) { return (int)((a + b - 1)
 // (device, stream, slot), grown on demand and kept for the life of the process: work on one stream is ordered, so the
 // next call on that stream may reuse it, and calls on different streams get different buffers.  [The first version
 // used hipMallocAsync / hipFreeAsync per call: normally a pool hit, but measured at 4.6 ms for one 64 MB request after
-// the pool had been trimmed -- 25x the kernel it served.]  Returns nullptr on allocation failure.  group_points.hip.
-void *cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes);
+// the pool had been trimmed -- 25x the kernel it served.]  group_points.hip.
+// The buffer comes as a LEASE: several host threads may enqueue onto one stream (two encoder scales share a side stream),
+// so the (device, stream, slot) entry stays locked from the hand-out until the lease goes out of scope -- which callers
+// arrange to be after the last launch that uses the pointer (build + use are then adjacent in stream order).  A buffer
+// that has to grow is retired, never freed (queued work of the stream may still use it), and grows by >= 1.5x.
+// ptr == nullptr on allocation failure.
+struct CmfScratchLease {
+    void *ptr = nullptr;
+    std::unique_lock<std::mutex> hold;
+};
+CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes);
 
 // ---- batched launches (round 3) -------------------------------------------------------------------------------------
 // The narrow layers of the set-conv chains are latency, not work: the per-point tail of a block is three 64-channel

@@ -891,25 +891,31 @@ static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int 
 #include <map>
 #include <mutex>
 #include <tuple>
-void *cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
+CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
 {
+    struct Entry { void *p = nullptr; size_t cap = 0; std::mutex in_use; };
     static std::mutex mu;
-    static std::map<std::tuple<int, hipStream_t, int>, std::pair<void *, size_t>> *table =
-        new std::map<std::tuple<int, hipStream_t, int>, std::pair<void *, size_t>>();      // leaked on purpose (runtime teardown order)
+    static std::map<std::tuple<int, hipStream_t, int>, Entry> *table =
+        new std::map<std::tuple<int, hipStream_t, int>, Entry>();      // leaked on purpose (runtime teardown order)
+    CmfScratchLease lease;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    auto &e = (*table)[std::make_tuple(dev, stream, slot)];
-    if (e.second < bytes) {
-        // the old buffer may still be in use by queued work of this stream: drain the stream before replacing it (rare:
-        // sizes only grow)
-        if (e.first) { (void)hipStreamSynchronize(stream); (void)hipFree(e.first); e = {nullptr, 0}; }
-        void *p = nullptr;
-        const size_t want = (bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
-        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        e = {p, want};
+    if (hipGetDevice(&dev) != hipSuccess) return lease;
+    Entry *e;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        e = &(*table)[std::make_tuple(dev, stream, slot)];              // map nodes do not move
     }
-    return e.first;
+    lease.hold = std::unique_lock<std::mutex>(e->in_use);
+    if (e->cap < bytes) {
+        // the old buffer may still be in use by queued work of this stream: it is retired (kept allocated), not freed
+        size_t want = bytes > e->cap + e->cap / 2 ? bytes : e->cap + e->cap / 2;
+        want = (want + ((size_t)1 << 20) - 1) >> 20 << 20;
+        void *p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); lease.hold.unlock(); return lease; }
+        e->p = p; e->cap = want;
+    }
+    lease.ptr = e->p;
+    return lease;
 }
 
 extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
@@ -932,7 +938,8 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         const int tiles = cmf_divup(total, GT_TILE);
         int key_bits = 4;
         while ((1 << key_bits) < n) key_bits += 4;
-        unsigned short *rec = (unsigned short *)cmf_stream_scratch(st, 0, (size_t)b * tiles * GT_REC * sizeof(unsigned short));
+        const CmfScratchLease lease = cmf_stream_scratch(st, 0, (size_t)b * tiles * GT_REC * sizeof(unsigned short));
+        unsigned short *rec = (unsigned short *)lease.ptr;
         if (!rec) return (int)hipErrorOutOfMemory;
         hipLaunchKernelGGL(gpg_tile_index_kernel, dim3(tiles, b), dim3(GT_THREADS), 0, st, (int)total, tiles, key_bits, idx, rec);
         int nch_wg = GT_CH;
@@ -965,7 +972,8 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         while (ch_per_wg > 2 && (long long)b * cmf_divup(c, ch_per_wg) < 1024) ch_per_wg /= 2;
         const int e_need = (int)cmf_divup(total, GG_THREADS);
         const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
-        unsigned *plan = (unsigned *)cmf_stream_scratch(st, 0, (size_t)b * gpg_plan_words(E, n) * sizeof(unsigned));
+        const CmfScratchLease lease = cmf_stream_scratch(st, 0, (size_t)b * gpg_plan_words(E, n) * sizeof(unsigned));
+        unsigned *plan = (unsigned *)lease.ptr;
         if (!plan) return (int)hipErrorOutOfMemory;
         if (E == 4) return launch_plan<4>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
         if (E == 8) return launch_plan<8>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
@@ -974,7 +982,8 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     }
     // per-stream library scratch for the inverse index (cmf_common.h)
     const size_t n_off = (size_t)b * (n + 1), n_inv = (size_t)b * total;
-    int *scratch = (int *)cmf_stream_scratch(st, 0, (n_off + n_inv) * sizeof(int));
+    const CmfScratchLease lease = cmf_stream_scratch(st, 0, (n_off + n_inv) * sizeof(int));
+    int *scratch = (int *)lease.ptr;
     if (!scratch) return (int)hipErrorOutOfMemory;
     int *offsets = scratch, *inv = scratch + n_off;
     int err = cmf_build_inverse_rows(b, n, npoints, nsample, idx, offsets, inv, stream, (int)total);

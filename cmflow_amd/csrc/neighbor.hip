@@ -559,9 +559,9 @@ static int ball_query_grid(int b, int n, int m, float radius, int nsample, const
     // The grid lives in the per-stream library scratch between the two launches.  The scales of an encoder call are enqueued
     // from several host threads, two of them onto the SAME stream: the pair of launches must be adjacent in the stream, or
     // another chain's build overwrites the grid before this query has read it.
-    static std::mutex pair_mutex;
-    std::lock_guard<std::mutex> pair_lock(pair_mutex);
-    char *scratch = (char *)cmf_stream_scratch(st, 1, off_sp + (size_t)b * n * sizeof(float4));
+    // (the lease keeps the stream's slot locked until both are enqueued).
+    const CmfScratchLease lease = cmf_stream_scratch(st, 1, off_sp + (size_t)b * n * sizeof(float4));
+    char *scratch = (char *)lease.ptr;
     if (!scratch) return (int)hipErrorOutOfMemory;
     BqGridHeader *hdr = (BqGridHeader *)scratch;
     int *cs = (int *)(scratch + off_cs);
@@ -606,7 +606,8 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
         const long long wgs = (long long)grid.x * grid.y;
         if (wgs > 3 * 256) {                                     // enough workgroups for LDS capacity to limit occupancy
             const size_t bytes = (size_t)wgs * BQM_NW * BQ_MAX_NS_LDS * CMF_WAVE * sizeof(unsigned short);
-            unsigned short *scratch = (unsigned short *)cmf_stream_scratch((hipStream_t)stream, 1, bytes);   // per-stream library scratch
+            const CmfScratchLease lease = cmf_stream_scratch((hipStream_t)stream, 1, bytes);   // per-stream library scratch
+            unsigned short *scratch = (unsigned short *)lease.ptr;
             if (!scratch) return (int)hipErrorOutOfMemory;
             hipLaunchKernelGGL(ball_query_multi_kernel<true>, grid, dim3(BQM_NW * CMF_WAVE), 0, (hipStream_t)stream,
                                n, m, radius * radius, nsample, seg, new_xyz, xyz, idx, scratch);
@@ -655,8 +656,10 @@ extern "C" int cmf_query_and_group(int b, int n, int m, float radius, int nsampl
     }
     // query (+ zero fill for empty balls: the reference pre-zeroes idx), then one gather launch for all planes
     int *ix = idx;
+    CmfScratchLease lease;                                   // held until the gather that reads ix is enqueued
     if (!ix) {
-        ix = (int *)cmf_stream_scratch(st, 2, (size_t)b * plane * sizeof(int));
+        lease = cmf_stream_scratch(st, 2, (size_t)b * plane * sizeof(int));
+        ix = (int *)lease.ptr;
         if (!ix) return (int)hipErrorOutOfMemory;
     }
     int err;

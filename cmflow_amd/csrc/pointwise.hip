@@ -347,8 +347,10 @@ __device__ __forceinline__ TileMap tile_map(int C)
     t.cg = C / 4; t.rl = PW_THREADS / t.cg; t.col = (threadIdx.x % t.cg) * 4; t.r0 = threadIdx.x / t.cg;
     return t;
 }
-__device__ __forceinline__ void tile_reduce_store(float4 s1, float4 s2, const TileMap &tm, int C, float *partial, float *red)
+__device__ __forceinline__ void tile_reduce_store(float4 s1, float4 s2, const TileMap &tm, int C, float *partial, float *red,
+                                                  long long tile = -1)
 {
+    if (tile < 0) tile = blockIdx.x;
     // red: [rl][2][C]
     float *r = red + (size_t)tm.r0 * 2 * C;
     *(float4 *)(r + tm.col) = s1;
@@ -357,8 +359,16 @@ __device__ __forceinline__ void tile_reduce_store(float4 s1, float4 s2, const Ti
     for (int i = threadIdx.x; i < 2 * C; i += PW_THREADS) {
         float s = 0.f;
         for (int l = 0; l < tm.rl; ++l) s += red[(size_t)l * 2 * C + i];
-        partial[(size_t)blockIdx.x * 2 * C + i] = s;
+        partial[(size_t)tile * 2 * C + i] = s;
     }
+}
+// Workgroup id -> XCD is round-robin (id % 8), each XCD with its own L2.  A kernel whose tiles gather from per-sample
+// sources wants the tiles of one sample on ONE XCD, or every XCD fetches every sample's sources from HBM: XCD x gets the
+// contiguous range of logical tiles [x * q + min(x, r), ...) with q = tiles / 8, r = tiles % 8, walked in launch order.
+__device__ __forceinline__ long long xcd_major_tile(long long bid, long long tiles)
+{
+    const long long q = tiles / 8, r = tiles % 8, x = bid % 8, slot = bid / 8;
+    return x * q + (x < r ? x : r) + slot;
 }
 static inline bool tile_ok(int C) { return C % 4 == 0 && C >= 4 && C / 4 <= PW_THREADS && PW_THREADS % (C / 4) == 0; }
 static inline size_t tile_lds(int C) { return (size_t)(PW_THREADS / (C / 4)) * 2 * C * sizeof(float); }
@@ -386,7 +396,10 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
 #pragma unroll
         for (int k = 0; k < 3; ++k) wx[j][k] = Wx[(size_t)(tm.col + j) * ldw + k];
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    const long long row0 = (long long)blockIdx.x * PW_ROWS;
+    // tiles of one sample on one XCD: the sample's n_src x C source rows (512 KB at C = 512) are fetched from HBM by that
+    // L2 only (round 2 counted 1.41x the algorithmic bytes: all eight XCDs pulled all sources)
+    const long long tile = xcd_major_tile(blockIdx.x, gridDim.x);
+    const long long row0 = tile * PW_ROWS;
     // Per-row quantities (source row, relative xyz) are computed ONCE per tile into LDS: with C = 512 the 128 threads
     // that share a row used to issue the same idx load and six scalar xyz loads each -- nine memory instructions per
     // useful 16-byte gather, and the kernel was bound by their issue rate (2.5 TB/s of stores at C = 512).
@@ -445,13 +458,13 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             }
         }
     }
-    if (partial) tile_reduce_store(s1, s2, tm, C, partial, red);
+    if (partial) tile_reduce_store(s1, s2, tm, C, partial, red, tile);
     if (partial_x) {
         // same tree as tile_reduce_store, for the 3 z*d_k column sums and the 3 scalar d_k sums: row
         // layout of partial_x is [tz0[C] | tz1[C] | tz2[C] | u0 u1 u2 0]
         __syncthreads();
         float *r = red + (size_t)tm.r0 * 2 * C;          // reuse [rl][2][C]: two passes
-        float *px = partial_x + (size_t)blockIdx.x * (3 * C + 4);
+        float *px = partial_x + (size_t)tile * (3 * C + 4);
         *(float4 *)(r + tm.col) = tz0; *(float4 *)(r + C + tm.col) = tz1;
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * C; i += PW_THREADS) {

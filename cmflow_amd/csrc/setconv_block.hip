@@ -569,7 +569,11 @@ static int setconv_multi(int n, const cmf_setconv_desc *descs, void *const *stre
         if (i > 0 && hipSetDevice(dev) != hipSuccess) { err[i] = (int)hipGetLastError(); return; }
         err[i] = backward ? setconv_backward_part(&descs[i], streams[i], part) : setconv_forward_part(&descs[i], streams[i], part);
     };
-    {
+    bool one_stream = true;                                 // every chain on the same stream (serialised diagnostic runs):
+    for (int i = 1; i < n; ++i) one_stream = one_stream && streams[i] == streams[0];    // nothing to feed in parallel
+    if (one_stream) {
+        for (int i = 0; i < n; ++i) run(i);
+    } else {
         std::lock_guard<std::mutex> pool_lock(g_pool_mutex);
         for (int i = 1; i < n; ++i) chain_worker((size_t)i - 1)->submit([&run, i] { run(i); });
         if (n > 0) run(0);                                  // the calling thread takes the first scale

@@ -28,6 +28,8 @@ class FlatGradBucket:
             self.views.append(p.grad)
             off += k
         self.numel = n
+        for p in self.params:                                 # = fused_blocks.enable_grad_sinks: the backward kernels
+            p._cmf_sink = True                                # accumulate straight into the bucket
 
     def zero(self):
         """optimizer.zero_grad() equivalent that keeps the views (set_to_none would break them).  The check is an

@@ -78,7 +78,22 @@ N_SIDE = max(1, int(os.environ.get("CMF_SIDE_STREAMS", "3")))
 _side_pool = {}
 
 
+SERIAL = False
+
+
+def set_serial(net, on):
+    """Diagnostic (bench.py --serial and its isolated-roofline pass): every chain of the product path on the caller's
+    stream -- the same launches with nothing running next to them.  Clears the streams the modules of `net` cached."""
+    global SERIAL
+    SERIAL = bool(on)
+    for m in net.modules():
+        for attr in ("_streams", "_streams2", "_side", "_head_stream"):
+            m.__dict__.pop(attr, None)
+
+
 def side_stream(slot, device=None):
+    if SERIAL:
+        return torch.cuda.current_stream(device)
     dev = torch.device(device if device is not None else torch.cuda.current_device())
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     pool = _side_pool.setdefault(key, [])
@@ -162,8 +177,18 @@ def scale_streams(n_scales, cloud=0):
     return [side_stream(s) for s in slots]
 
 
+def enable_grad_sinks(params, on=True):
+    """Opt the given parameters into in-place gradient accumulation (grad_sink).  dp.FlatGradBucket does this for the
+    parameters it owns; a caller with its own backward() / optimizer loop who opts in must call join_side_streams() after
+    backward() and before anything reads the .grad tensors: the kernels write them on the pool's side streams, bypassing
+    autograd's AccumulateGrad (no hooks, no leaf-stream synchronisation, invisible to torch.autograd.grad)."""
+    for p in params:
+        p._cmf_sink = bool(on)
+
+
 def grad_sink(t):
-    """The gradient buffer a parameter-gradient can be accumulated into directly, or None.
+    """The gradient buffer a parameter-gradient can be accumulated into directly, or None (= hand the gradient to autograd).
+    Only parameters opted in with enable_grad_sinks (the flat bucket's) have one.
 
     `t` is a Function input that is a leaf Parameter or the (out,in) view of a 1x1 conv weight.  When the
     parameter already owns a dense .grad (TrainStep keeps all of them as views into one flat bucket, zeroed
@@ -171,7 +196,7 @@ def grad_sink(t):
     for that input -- otherwise autograd launches one tiny `grad += g` kernel per parameter (~300 per step,
     each ~25 us of host time on the autograd thread)."""
     base = t._base if t._base is not None else t
-    if not base.is_leaf or base.grad is None or not base.grad.is_contiguous():
+    if not getattr(base, "_cmf_sink", False) or not base.is_leaf or base.grad is None or not base.grad.is_contiguous():
         return None
     if t is base:
         return base.grad

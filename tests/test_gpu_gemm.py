@@ -580,6 +580,7 @@ def test_mlp_chain_block_call_equals_python_sequence(dev, gemm_mode, M, chans, t
                 if sinks:
                     for p in params:
                         p.grad = torch.full_like(p, 0.25)
+                    FB.enable_grad_sinks(params)
                 x = x0.clone().requires_grad_(True)
                 y = FB.mlp_chain(x, layers, train)
                 y.backward(dy)

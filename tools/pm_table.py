@@ -10,7 +10,8 @@ def by_name(path, value):
     key = "Start_Timestamp" if "Start_Timestamp" in rows[0] else "Dispatch_Id"
     rows.sort(key=lambda r: int(r[key]))
     for r in rows:
-        d[r["Kernel_Name"].split("(")[0]].append(value(r))
+        name = r["Kernel_Name"].split("(")[0].split("<")[0]
+        d[name[5:] if name.startswith("void ") else name].append(value(r))
     return d
 D = by_name(trace, lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 F = by_name(fetch, lambda r: float(r["Counter_Value"]))

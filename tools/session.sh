@@ -85,6 +85,22 @@ pmc_gemm() {           # HBM traffic of cmf_gemm inside the training step: FETCH
     python tools/gemm_traffic.py $R/pmc_FETCH_SIZE.csv $R/pmc_WRITE_SIZE.csv > $R/gemm_traffic.json; cat $R/gemm_traffic.json
     rm -f $R/pmc_FETCH_SIZE.csv $R/pmc_WRITE_SIZE.csv
 }
+serial_profile() {     # the product's launches with every chain on one stream: bench line + per-kernel stats under rocprofv3
+    python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-op-rooflines --gemm-table $R/gemm_shapes_train.md > $R/bench_short.json 2>/dev/null
+    python -c "import json; d=json.load(open('$R/bench_short.json')); print(d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'], d['roofline_isolated']['launches'])"
+    rm -rf /tmp/p3
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --serial > $R/bench_serial.json 2>/dev/null)
+    cp $(find /tmp/p3 -name "*kernel_stats.csv" | head -1) $R/train_serial_kernel_stats.csv
+    python -c "import json; d=json.load(open('$R/bench_serial.json')); print('serial', d['ms_per_step'], d['roofline']['frac'])"
+}
+pm_hbm() {             # HBM-bound kernels of the product path: durations + FETCH_SIZE / WRITE_SIZE in separate passes -> markdown table
+    rm -rf /tmp/q1 /tmp/q2 /tmp/q3
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/q1 -- python3 $GRAFT_REPO_ROOT/tools/pm_probe.py > $R/pm_probe.out 2>/dev/null)
+    (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/q2 -- python3 $GRAFT_REPO_ROOT/tools/pm_probe.py > /dev/null 2>&1)
+    (cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/q3 -- python3 $GRAFT_REPO_ROOT/tools/pm_probe.py > /dev/null 2>&1)
+    python tools/pm_table.py $(find /tmp/q1 -name "*kernel_trace.csv" | head -1) $(find /tmp/q2 -name "*counter_collection.csv" | head -1) \
+        $(find /tmp/q3 -name "*counter_collection.csv" | head -1) $R/pm_probe.out > $R/pm_hbm_kernels.md; cat $R/pm_hbm_kernels.md
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
