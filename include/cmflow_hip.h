@@ -13,9 +13,11 @@
  *     buffer per (device, stream), allocated with hipMalloc on first use, grown on demand and kept for the life of the
  *     process: cmf_ball_query (spilled hit lists when nsample > 32 and more than 768 workgroups: 32 KB per workgroup,
  *     64 MB at b = 32, m = 4096; the cell grid of clouds with 4096-8192 points: 16 * b * n + 16 KB * b bytes, used by two
- *     launches that the library enqueues back to back under a lock, so calls from several host threads onto one stream
- *     are safe) and cmf_group_points_grad (inverse index: 4 * b * (n + 1 + npoints * nsample) bytes; one host thread per
- *     stream).  Nothing else is retained between calls.
+ *     launches) and cmf_group_points_grad (inverse index or scatter plan: <= 4 * b * (n + 1 + npoints * nsample) bytes);
+ *     cmf_query_and_group keeps the indices there when the caller passes idx == NULL.  The buffer of a (device, stream) is
+ *     handed out under a lock that is held until the last launch using it has been enqueued, so calls from several host
+ *     threads onto one stream are safe; a buffer that must grow is retired (kept allocated), never freed while work may
+ *     be queued on it.  Nothing else is retained between calls.
  *   - return value: hipError_t as int (0 = hipSuccess).  The reference launchers print and
  *     exit(-1) on a launch failure (lib/src/ball_query_gpu.cu:62-66); this library reports the
  *     error to the caller instead.  Invalid arguments return hipErrorInvalidValue (1).
@@ -52,8 +54,10 @@ int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
  * groups point 0, the reference's pre-zeroed idx) + grouped xyz minus the centre (:279-280) + grouped features (:283),
  * concatenated as the reference does (:285): out (b, 3*use_xyz + c, m, nsample), relative xyz planes first.
  * new_xyz (b,m,3) centres, xyz (b,n,3), features (b,c,n) or NULL with c == 0 (then use_xyz must be set), idx (b,m,nsample)
- * optional output (what GroupingOperation.backward needs, :204).  n <= 1024 and 3*use_xyz + c <= 160: ONE launch (the
- * waves that find the neighbour lists gather them); otherwise query + relative-xyz + LDS-staged feature gather. */
+ * optional output (what GroupingOperation.backward needs, :204).  n <= 1024 and 3*use_xyz + c <= 24: ONE launch (the
+ * waves that find the neighbour lists gather them; measured faster up to that width); otherwise the query followed by one
+ * gather launch that writes the relative-xyz planes and the LDS-staged feature planes.  idx == NULL: the indices live in the
+ * library's per-stream scratch between the two launches. */
 int cmf_query_and_group(int b, int n, int m, float radius, int nsample, int c, int use_xyz,
                         const float *new_xyz, const float *xyz, const float *features, int *idx, float *out, void *stream);
 
