@@ -44,6 +44,12 @@ constexpr int G_THREADS = 256;
 #define CMF_EPI_WAVE 1                    // bit 0: the backward kinds (2-5) of the 128 x 128 kernels finish their tiles per wave (wave_epilogue);
                                           // bit 1: kinds 0 / 1 as well (instead of the direct form) -- experiment
 #endif
+#ifndef CMF_GEMM_T256
+#define CMF_GEMM_T256 0
+#endif
+#ifndef CMF_GEMM_WPS
+#define CMF_GEMM_WPS 0              // experiment: register budget for this many waves per SIMD (4: 128 registers, so that one
+#endif                              // wave of another stream's kernel fits next to the three GEMM workgroups of a CU)
 #ifndef CMF_GEMM_PIPE
 #define CMF_GEMM_PIPE 1                   // 1: barrier in the middle of a chunk, first fragment reads of the next chunk under the second half
                                           //    (same-box A/B, 524288 x 256 x 512: fwd 120.7 -> 123.3, dX 120.1 -> 121.8, dW 122.9 -> 124.2 TF; 0: one barrier at the end)
@@ -152,7 +158,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
 template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
-__global__ __launch_bounds__(G_THREADS, (BM == 256 || (EMUL && CMF_EMUL_DIAG == 3)) ? 2 : ((BM == 128 && BN == 128) ? ((EPI <= 3 || CMF_GEMM_W3 || (CMF_EPI_WAVE & 1)) ? 3 : 2) : 3)) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 256 || (EMUL && CMF_EMUL_DIAG == 3)) ? 2 : ((BM == 128 && BN == 128) ? (CMF_GEMM_WPS ? CMF_GEMM_WPS : ((EPI <= 3 || CMF_GEMM_W3 || (CMF_EPI_WAVE & 1)) ? 3 : 2)) : 3)) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -1393,7 +1399,10 @@ static int launch(const GemmArgs &a, hipStream_t st)
     dim3 grid(a.split_k > 1 ? 8 * ((a.split_k + 7) / 8) * tiles_m * tiles_n : 8 * per * tiles_n);
     const size_t lds_reg = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
     const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + 32) * sizeof(float);
-    const size_t lds = lds_reg > lds_dir ? lds_reg : lds_dir;
+    // CMF_GEMM_LDS_PAD=bytes (experiment): request more LDS than the kernel uses so that fewer workgroups fit a CU and the
+    // kernels of other streams find free registers / LDS next to a GEMM (8192: two workgroups per CU instead of three)
+    static const size_t lds_pad = getenv("CMF_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CMF_GEMM_LDS_PAD")) : 0;
+    const size_t lds = (lds_reg > lds_dir ? lds_reg : lds_dir) + lds_pad;
     // the dynamic-LDS limit is a per-device attribute of the function: set once per (instantiation, device); cmf_gemm is
     // entered concurrently by the host threads of cmf_setconv_*_multi, hence the atomics
     static std::atomic<unsigned> set_mask[4];
@@ -1475,7 +1484,13 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz; g.split_k = split_k;
     g.accumulate = split_k > 1 ? 0 : accumulate;
     static const int no_direct = (getenv("CMF_GEMM_NO_DIRECT") && getenv("CMF_GEMM_NO_DIRECT")[0] == '1') ? 1 : 0;
-    g.no_direct = no_direct;
+    // weight-gradient layout (both operands contraction-major) with the producer's BN + ReLU applied to B: the register-staged
+    // loop applies it once per staged element, the LDS-direct loop on every wave's fragments inside the MFMA stream --
+    // measured in the step, isolated: 256 x 512 x 524288 / 262144 / 131072 at 117.6 / 117.9 / 114.4 TF staged against
+    // 111.7 / 110.3 / 108.7 direct; the short contractions (K = 16384) lose 2-3 % and stay direct.
+    // CMF_GEMM_DW_DIRECT=1 restores the LDS-direct loop for this layout (A/B).
+    static const int dw_direct = (getenv("CMF_GEMM_DW_DIRECT") && getenv("CMF_GEMM_DW_DIRECT")[0] == '1') ? 1 : 0;
+    g.no_direct = (no_direct || (a_t && !b_t && prob_a && K >= 32768 && !dw_direct)) ? 1 : 0;
     static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
     g.diag = diag_rt;
     g.trace = nullptr;
@@ -1495,6 +1510,14 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     (tall ? (wide ? (emul ? launch<128, 128, AT, BT, 1, EP>(g, st) : launch<128, 128, AT, BT, 0, EP>(g, st)) \
                   : launch<128, 64, AT, BT, 0, EP>(g, st))                                                 \
           : (wide ? launch<64, 128, AT, BT, 0, EP>(g, st) : launch<64, 64, AT, BT, 0, EP>(g, st)))
+#if CMF_GEMM_T256
+    // experiment: 256 x 256 tiles, one workgroup per CU, wave tile 128 x 128 (half the LDS and L2 bytes per flop)
+    const bool t256 = !emul && kind == 0 && M % 256 == 0 && N % 256 == 0 && M >= 256 && N >= 256;
+    if (!thin_done && t256 && !a_t && b_t) err = launch<256, 256, false, true, 0, 0>(g, st);
+    else if (!thin_done && t256 && a_t && !b_t) err = launch<256, 256, true, false, 0, 0>(g, st);
+    else if (!thin_done && t256 && !a_t && !b_t) err = launch<256, 256, false, false, 0, 0>(g, st);
+    else
+#endif
     if (thin_done)         err = 0;
     else if (!a_t && b_t)  err = kind == 1 ? CMF_PICK(false, true, 1) : CMF_PICK(false, true, 0);
     else if (!a_t && !b_t) err = kind == 2 ? CMF_PICK(false, false, 2) : kind == 3 ? CMF_PICK(false, false, 3) :

@@ -31,8 +31,14 @@ pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
 dZ = torch.randn(M, N, device=dev); Zs = torch.randn(M, K, device=dev)
 ea, ec, em, ei = (torch.rand(K, device=dev) + 0.5 for _ in range(4))
 dxyz = torch.randn(M, 4, device=dev)
+if os.environ.get("CMF_GEMM_DIAG_RT", "0") == "0":        # results are meaningful: check the plain forms against torch
+    torch.backends.cuda.matmul.allow_tf32 = False
+    for name, got, want in (("fwd", gemm(A[:4096], W), A[:4096] @ W.t()), ("dX", gemm(dZ[:4096], W, b_t=False), dZ[:4096] @ W),
+                            ("dW", gemm(dZ, A, a_t=True, b_t=False, split_k=int(os.environ.get("DW_SPLIT", "96"))), dZ.t() @ A)):
+        print("check %-4s max rel err %.2e" % (name, float((got - want).abs().max() / want.abs().max())), flush=True)
 report("fwd plain", M, N, K, lambda: gemm(A, W))
 report("fwd +prologue +stats", M, N, K, lambda: gemm(A, W, pro=(pa, pc), stats=True))
 report("dX plain (K=256)", M, K, N, lambda: gemm(dZ, W, b_t=False))
 report("dX BN+ReLU + dxyz sums (K=256)", M, K, N, lambda: gemm(dZ, W, b_t=False, bwd=(1, Zs, ea, ec, em, ei, dxyz)))
-report("dW split 96", N, K, M, lambda: gemm(dZ, A, a_t=True, b_t=False, split_k=96))
+sk = int(os.environ.get("DW_SPLIT", "96"))
+report("dW split %d" % sk, N, K, M, lambda: gemm(dZ, A, a_t=True, b_t=False, split_k=sk))

@@ -101,6 +101,27 @@ pm_hbm() {             # HBM-bound kernels of the product path: durations + FETC
     python tools/pm_table.py $(find /tmp/q1 -name "*kernel_trace.csv" | head -1) $(find /tmp/q2 -name "*counter_collection.csv" | head -1) \
         $(find /tmp/q3 -name "*counter_collection.csv" | head -1) $R/pm_probe.out > $R/pm_hbm_kernels.md; cat $R/pm_hbm_kernels.md
 }
+ldspad_ab() {          # GEMM at 2 workgroups per CU (LDS pad) so that other streams' kernels co-reside with it: step time A/B
+    for pad in 0 8192 0 8192; do CMF_GEMM_LDS_PAD=$pad python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pad $pad', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done | tee $R/ldspad_ab.txt
+}
+wps4_ab() {            # GEMM compiled for 128 registers (4 waves per SIMD): isolated rates and the step, against the product
+    for lib in "" $GRAFT_REPO_ROOT/tools/diag/libcmflow_wps4.so; do
+        echo "lib=$lib"; CMF_LIB=$lib python tools/gemm_diag.py 2>&1 | filter
+        for i in 1 2; do CMF_LIB=$lib python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
+    done | tee $R/wps4_ab.txt
+}
+density() {            # MFMA density of one workgroup's waves: the same kernels at 1 / 2 / 3 workgroups per CU (LDS pad)
+    for pad in 65536 8192 0; do echo "pad=$pad"; CMF_GEMM_LDS_PAD=$pad python tools/gemm_diag.py 2>&1 | filter; CMF_GEMM_LDS_PAD=$pad CMF_GEMM_DIAG_RT=8 python tools/gemm_diag.py 2>&1 | filter; done | tee $R/density.txt
+}
+t256() {               # experiment build with 256 x 256 tiles (one workgroup per CU) for the plain-store forms
+    for lib in "" $GRAFT_REPO_ROOT/tools/diag/libcmflow_t256.so; do for sk in 96 128; do for d in 0 8; do
+        echo "lib=$lib"; DW_SPLIT=$sk CMF_LIB=$lib CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter | grep -v "BN+ReLU\|prologue"; done; done; done | tee $R/t256.txt
+}
+dw_ab() {              # weight-gradient GEMMs on the register-staged loop (default) against the LDS-direct one
+    for v in 1 0; do echo "CMF_GEMM_DW_DIRECT=$v"; CMF_GEMM_DW_DIRECT=$v python tools/gemm_variants.py 2>&1 | filter | grep "dW"
+        for i in 1 2; do CMF_GEMM_DW_DIRECT=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
+    done | tee $R/dw_ab.txt
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
