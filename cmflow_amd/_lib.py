@@ -30,6 +30,8 @@ SIGNATURES = {
     "cmf_group_rows_grad": [_ci, _ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_gemm": [_ci, _ci, _ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp,
                  _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ci, _vp, _ci, _vp],
+    "cmf_gemm_dw_bn_bwd": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _ll, _ci, _vp,
+                           _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
     "cmf_gemm_set_mode": [_ci],
     "cmf_gemm_get_mode": [],

@@ -30,6 +30,21 @@ struct CmfScratchLease {
 };
 CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes);
 
+// Train-mode BatchNorm backward as an affine map of its two streams, per column:
+//   dZ = a * (dU - s1/M - zhat * s2/M),  zhat = (z - mean) * invstd      ==      dZ = al * dU + be * z + ga
+// One definition for every kernel that forms dZ (bn_bwd_apply_kernel, the weight-gradient GEMM that materialises dZ while
+// staging its A operand): the same operations in the same order, so the fused and the stand-alone forms are bit-identical.
+#ifdef __HIPCC__
+__device__ __forceinline__ void cmf_bnb_coef(float sa, float mu, float is, float t1, float t2, float ic, float &al, float &be, float &ga)
+{
+    const float k1 = t1 * ic, k2 = is * (t2 * ic);
+    al = sa;
+    be = -(sa * k2);
+    ga = sa * fmaf(mu, k2, -k1);
+}
+__device__ __forceinline__ float cmf_bnb_apply(float d, float v, float al, float be, float ga) { return fmaf(al, d, fmaf(be, v, ga)); }
+#endif
+
 // ---- batched launches (round 3) -------------------------------------------------------------------------------------
 // The narrow layers of the set-conv chains are latency, not work: the per-point tail of a block is three 64-channel
 // layers over B*N rows (128 workgroups per kernel), and the eight chains of an encoder call each issued their own ~10

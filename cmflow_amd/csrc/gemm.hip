@@ -218,6 +218,20 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
     constexpr int A_IT = A_T ? (G_BK / A_RPI) : (BM / G_RP);
     constexpr int B_IT = B_T ? (BN / G_RP) : (G_BK / B_RPI);
     float4 ra[A_IT], rb[B_IT];
+    // BN backward fused into the A staging of the weight-gradient layout (GemmArgs::bnb_*): interior tiles only, the host
+    // checks the shape.  A thread stages 4 fixed columns m of every chunk, so its coefficients are loop constants.
+    float4 rz[A_T ? A_IT : 1];
+    const bool bnbA = A_T && p.bnb_z != nullptr;
+    float bal[4] = {1.f, 1.f, 1.f, 1.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f}, bga[4] = {0.f, 0.f, 0.f, 0.f};
+    int k0_loaded = 0;
+    const int bnb_writers = tiles_n < G_BK ? tiles_n : G_BK;
+    if (A_T && bnbA) {
+        const int m = m0 + (tid % A_TPR) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            cmf_bnb_coef(p.bnb_a[m + j], p.bnb_mean[m + j], p.bnb_invstd[m + j], p.bnb_sums[m + j], p.bnb_sums[p.M + m + j], p.bnb_ic,
+                         bal[j], bbe[j], bga[j]);
+    }
     float4 psa = make_float4(1.f, 1.f, 1.f, 1.f), psc = make_float4(0.f, 0.f, 0.f, 0.f);   // A prologue (per chunk)
     float4 qsa = make_float4(1.f, 1.f, 1.f, 1.f), qsc = make_float4(0.f, 0.f, 0.f, 0.f);   // B prologue (per thread)
     unsigned kmask = 0xF;                               // which of this thread's 4 k are < K (edge chunks)
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
     auto load_tiles = [&](int kc) {
         const int k0 = kc * G_BK;
         const bool fast = !edge_mn && (k0 + G_BK <= p.K);
+        k0_loaded = k0;
         if (fast) {
             if (!A_T) {
                 const int kk = k0 + (tid % G_KT) * 4;
@@ -247,6 +262,11 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
                 const float *src = p.A + (long long)(k0 + tid / A_TPR) * p.lda + m0 + (tid % A_TPR) * 4;
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) ra[i] = *(const float4 *)(src + (long long)A_RPI * i * p.lda);
+                if (bnbA) {
+                    const float *zs = p.bnb_z + (long long)(k0 + tid / A_TPR) * p.ldbz + m0 + (tid % A_TPR) * 4;
+#pragma unroll
+                    for (int i = 0; i < A_IT; ++i) rz[A_T ? i : 0] = *(const float4 *)(zs + (long long)A_RPI * i * p.ldbz);
+                }
             }
             if (B_T) {
                 const float *src = p.B + (long long)(n0 + (tid / G_KT)) * p.ldb + k0 + (tid % G_KT) * 4;
@@ -326,7 +346,16 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
 #pragma unroll
             for (int i = 0; i < A_IT; ++i) {
                 const int k = tid / A_TPR + A_RPI * i, m = (tid % A_TPR) * 4;
-                *(float4 *)(dst + k * A_LD + m) = ra[i];
+                float4 v = ra[i];
+                if (bnbA) {
+                    const float4 zz = rz[A_T ? i : 0];
+                    v.x = cmf_bnb_apply(v.x, zz.x, bal[0], bbe[0], bga[0]); v.y = cmf_bnb_apply(v.y, zz.y, bal[1], bbe[1], bga[1]);
+                    v.z = cmf_bnb_apply(v.z, zz.z, bal[2], bbe[2], bga[2]); v.w = cmf_bnb_apply(v.w, zz.w, bal[3], bbe[3], bga[3]);
+                    // the column tiles that share this row panel stage the same chunk: each writes the rows k with
+                    // k % tiles == tn (one slow writer among them would set the pace of a one-round launch)
+                    if (p.bnb_out && (k % bnb_writers) == tn) *(float4 *)(p.bnb_out + (long long)(k0_loaded + k) * p.ldbo + m0 + m) = v;
+                }
+                *(float4 *)(dst + k * A_LD + m) = v;
             }
         }
     };
@@ -364,7 +393,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
     constexpr int D_ASLOTS = BM * (G_BK / 4), D_BSLOTS = BN * (G_BK / 4);     // 16-byte slots per operand chunk
     constexpr int D_ANI = D_ASLOTS / G_THREADS, D_BNI = D_BSLOTS / G_THREADS; // load instructions per thread
     constexpr int D_STAGE = (D_ASLOTS + D_BSLOTS) * 4 + 32;                   // floats: A | B | pro_a[16] pro_c[16]
-    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && CMF_GEMM_DIAG == 0 && !p.no_direct;
+    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && CMF_GEMM_DIAG == 0 && !p.no_direct && !bnbA;
     if (direct && kc_begin < kc_end) {
         const long long pro_delta = proA ? (long long)(p.pro_c - p.pro_a) : 0ll;
         // A plain s_barrier: __syncthreads() carries a workgroup fence, which makes the compiler drain EVERY outstanding
@@ -634,7 +663,11 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
             if (more) { store_A(buf ^ 1); store_B(buf ^ 1); }
 #endif
 #if CMF_GEMM_DIAG != 2 && CMF_GEMM_DIAG != 4                        /* 4: staged but no barrier */
-            __syncthreads();
+            // LDS-only barrier: __syncthreads() also drains every outstanding global store (vmcnt(0)), and with the fused BN
+            // backward this loop has stores in flight (the dZ by-product); the next chunk's loads were consumed by store_*()
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
 #endif
             buf ^= 1;
         }
@@ -1476,7 +1509,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     CMF_CHECK_ARG(lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0));
     CMF_CHECK_ARG(!pro_a || (((uintptr_t)pro_a | (uintptr_t)pro_c) % 16 == 0));
     hipStream_t st = (hipStream_t)stream;
-    GemmArgs g;
+    GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.B = B; g.ldb = ldb;
     g.C = split_k > 1 ? workspace : C; g.ldc = split_k > 1 ? N : ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.prob_a = prob_a; g.prob_c = prob_c;
@@ -1527,6 +1560,39 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
 #undef CMF_PICK
     if (err) return err;
     if (split_k > 1) return cmf_splitk_reduce(M, N, split_k, workspace, C, ldc, accumulate, st);
+    return 0;
+}
+
+// Weight gradient of a layer whose output gradient still has to go through the train-mode BatchNorm backward:
+//   dZ = al * dU + be * Z + ga  (cmf_common.h cmf_bnb_coef of a / mean / invstd / sums, 1 / rows),   dW (+)= dZ^T @ act(X)
+// formed while the A operand is staged -- the stand-alone cmf_bn_bwd_apply pass (read dU, read Z, write dZ) disappears and dZ
+// is written to dZ_out (a buffer of its own: other workgroups still read dU) as a by-product for the data-gradient GEMM that
+// follows.  Same operations as cmf_bn_bwd_apply + cmf_gemm(a_t = 1, b_t = 0) on the register-staged loop: bit-identical
+// results.  cout, cin multiples of 128, rows a multiple of 16; X activated by (prob_a, prob_c) or as stored (both NULL).
+extern "C" int cmf_gemm_dw_bn_bwd(int cout, int cin, long long rows, const float *dU, long long ldu, const float *Z, long long ldz,
+                                  const float *a, const float *mean, const float *invstd, const float *sums, float *dZ_out, long long ldo,
+                                  const float *X, long long ldx, const float *prob_a, const float *prob_c,
+                                  float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream)
+{
+    CMF_CHECK_ARG(cout > 0 && cin > 0 && rows > 0 && rows < (1ll << 31) && split_k >= 1);
+    CMF_CHECK_ARG(cout % 128 == 0 && cin % 128 == 0 && rows % G_BK == 0);
+    CMF_CHECK_ARG(dU && Z && a && mean && invstd && sums && X && dW && (split_k == 1 || workspace));
+    CMF_CHECK_ARG(ldu % 4 == 0 && ldz % 4 == 0 && ldx % 4 == 0 && (!dZ_out || ldo % 4 == 0));
+    CMF_CHECK_ARG((((uintptr_t)dU | (uintptr_t)Z | (uintptr_t)X | (uintptr_t)dZ_out) & 15) == 0);
+    CMF_CHECK_ARG(g_gemm_mode.load(std::memory_order_relaxed) == 0);          // fp32 main loop only
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{};
+    g.M = cout; g.N = cin; g.K = (int)rows; g.A = dU; g.lda = ldu; g.B = X; g.ldb = ldx;
+    g.C = split_k > 1 ? workspace : dW; g.ldc = split_k > 1 ? cin : lddw;
+    g.prob_a = prob_a; g.prob_c = prob_c; g.split_k = split_k; g.accumulate = split_k > 1 ? 0 : accumulate;
+    g.bnb_z = Z; g.ldbz = ldz; g.bnb_a = a; g.bnb_mean = mean; g.bnb_invstd = invstd; g.bnb_sums = sums;
+    g.bnb_ic = (float)(1.0 / (double)rows); g.bnb_out = dZ_out; g.ldbo = ldo;
+    g.no_direct = 1;
+    static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
+    g.diag = diag_rt;
+    const int err = launch<128, 128, true, false, 0, 0>(g, st);
+    if (err) return err;
+    if (split_k > 1) return cmf_splitk_reduce(cout, cin, split_k, workspace, dW, lddw, accumulate, st);
     return 0;
 }
 

@@ -59,12 +59,26 @@ struct Layout {
     float *bn[6];                 // per layer: mean | invstd | a | c   (4 * C_l)
     // scratch
     float *partial, *partial_x, *sums, *t6, *t5, *t4, *dx, *dU3, *dU2, *dU1, *splitk;
+    float *dZ2;                   // dZ of BN layer 1, written by the weight-gradient GEMM that fuses its BN backward (or null)
     size_t saved_floats, scratch_floats;
 };
 
 inline int chan(const cmf_setconv_desc *d, int layer)       // out channels of BN layer 0..5
 {
     return layer == 0 ? d->O1 : d->C[layer - 1];
+}
+
+// The wide backward layer (cout <- cin over `rows`) may fuse its BN backward into the weight-gradient GEMM
+// (cmf_gemm_dw_bn_bwd): shapes the fused kernel takes, and long enough that the unfused cmf_gemm would run the same
+// register-staged loop (K >= 32768, gemm.hip) -- the two forms are then bit-identical.  Opt-in (CMF_BNB_FUSED=1), measured
+// in four same-box A/B pairs of the training step: the stand-alone pass (0.48 ms per step) goes, the four weight-gradient
+// GEMMs that absorb it run 99.5 instead of 112 TF (+0.27 ms; two more operand loads per thread and chunk in the staging
+// loop) -- 21.33-21.43 against 21.42-21.53 ms per step, i.e. 0.1 ms, for a tiled kernel that is 2 points further from its
+// MFMA roof.  Not worth a second form of the layer as the default.
+inline bool bnb_fusable(long long rows, int cout, int cin)
+{
+    static const bool on = getenv("CMF_BNB_FUSED") && getenv("CMF_BNB_FUSED")[0] == '1';
+    return on && cout % 128 == 0 && cin % 128 == 0 && rows % 16 == 0 && rows >= 32768 && rows < (1ll << 31);
 }
 
 Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool backward)
@@ -102,6 +116,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         L.dU3 = t.take(M * C3);
         L.dU2 = t.take(M * C2);
         L.dU1 = t.take(M * O1);
+        L.dZ2 = (d->training && bnb_fusable(M, C2, O1)) ? t.take(M * C2) : nullptr;
         size_t sk = 0;
         sk = std::max(sk, (size_t)dw_split(P, C6, C5) * C6 * C5);
         sk = std::max(sk, (size_t)dw_split(P, C5, C4) * C5 * C4);
@@ -116,7 +131,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         if (cmf_thin_bwd_wide_supported(C3, C2)) sk = std::max(sk, (size_t)cmf_thin_bwd_wide_slabs(M, C2, nullptr) * 64 * C2);
         L.splitk = t.take(sk);
     } else {
-        L.t6 = L.t5 = L.t4 = L.dx = L.dU3 = L.dU2 = L.dU1 = L.splitk = nullptr;
+        L.t6 = L.t5 = L.t4 = L.dx = L.dU3 = L.dU2 = L.dU1 = L.splitk = L.dZ2 = nullptr;
     }
     L.scratch_floats = t.off;
     return L;
@@ -207,7 +222,8 @@ int dx_gemm(const cmf_setconv_desc *d, const Layout &L, long long rows, int cout
 // Narrow layers run the fused single-pass kernel (cmf_thin_bwd_layer: dZ is never stored); the wide ones of the second
 // encoder the BN backward in place followed by the two tiled GEMMs.  CMF_THIN_FUSED=0 forces the three-kernel form.
 int bwd_layer(const cmf_setconv_desc *d, const Layout &L, int l_out, long long rows, int cout, int cin, float *dU, const float *z_out,
-              const float *w, const float *x, int l_in, float *dU_in, const float *dxyz, float *dw, int acc_w, void *st)
+              const float *w, const float *x, int l_in, float *dU_in, const float *dxyz, float *dw, int acc_w, void *st,
+              float *dz_buf = nullptr)
 {
     const float *b = L.bn[l_out];
     if (d->acc_bn[l_out]) CMF_TRY(cmf_colsum_finalize(tiles128(rows), cout, L.partial, L.sums, d->dbeta[l_out], d->dgamma[l_out], st));
@@ -219,6 +235,14 @@ int bwd_layer(const cmf_setconv_desc *d, const Layout &L, int l_out, long long r
         return cmf_thin_bwd_layer(rows, cout, cin, dU, cout, z_out, cout, b + 2 * cout, b, b + cout, d->training ? L.sums : nullptr,
                                   w, cin, x, cin, l_in >= 0 ? 1 : 0, bi ? bi + 2 * ci : nullptr, bi ? bi + 3 * ci : nullptr, bi,
                                   bi ? bi + ci : nullptr, dxyz, dU_in, cin, l_in >= 0 ? L.partial : nullptr, dw, cin, acc_w, L.splitk, st);
+    }
+    if (dz_buf && dw && d->training && l_in >= 0 && bnb_fusable(rows, cout, cin)) {
+        // BN backward inside the weight-gradient GEMM's operand staging; dZ lands in dz_buf for the data-gradient GEMM
+        const float *bi = L.bn[l_in];
+        const int ci = chan(d, l_in), split = dw_split(rows, cout, cin);
+        CMF_TRY(cmf_gemm_dw_bn_bwd(cout, cin, rows, dU, cout, z_out, cout, b + 2 * cout, b, b + cout, L.sums, dz_buf, cout, x, cin,
+                                   bi + 2 * ci, bi + 3 * ci, dw, cin, split, split > 1 ? L.splitk : nullptr, acc_w, st));
+        return dx_gemm(d, L, rows, cout, cin, dz_buf, w, x, l_in, dU_in, dxyz, st);
     }
     CMF_TRY(cmf_bn_bwd_apply(rows, cout, dU, z_out, cout, b + 2 * cout, b, b + cout, d->training ? L.sums : nullptr, st));
     CMF_TRY(dw_gemm(d, L, rows, cout, cin, dU, x, l_in, dw, acc_w, st));
@@ -467,7 +491,7 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
         CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
         CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));
     }
-    CMF_TRY(bwd_layer(d, L, 1, M, C2, O1, L.dU2, L.z2, d->w[0], L.z1, 0, L.dU1, L.dxyz, d->dw[0], d->acc_w[0], st));
+    CMF_TRY(bwd_layer(d, L, 1, M, C2, O1, L.dU2, L.z2, d->w[0], L.z1, 0, L.dU1, L.dxyz, d->dw[0], d->acc_w[0], st, L.dZ2));
     // first layer: sums {s1,s2,q0,q1,q2}; dgamma/dbeta; dW_xyz from sums; BN backward folded into the scatter
     const float *b0 = L.bn[0];
     if (d->acc_bn[0]) CMF_TRY(cmf_colsum(tiles128(M), 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));

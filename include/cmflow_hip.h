@@ -105,6 +105,18 @@ int cmf_group_rows_grad(int b, int n, int c, int ldg, int entries, int accumulat
                         const float *grad_out, const int *offsets, const int *inv,
                         float *grad_feat, void *stream);
 
+/* Weight gradient of a [1x1 conv + train-mode BN] layer with the BatchNorm backward of its output gradient fused into the
+ * operand staging (replaces the torch-level BN backward + conv weight gradient of radarflow_util.py:151-153 in the backward
+ * pass):  dZ = a * (dU - s1/rows - zhat * s2/rows), zhat = (Z - mean) * invstd, (s1 | s2) = sums[2][cout];
+ * dW[cout][cin] (+)= dZ^T @ act(X), act = relu(prob_a * X + prob_c) per input channel or identity (both NULL).
+ * dU, Z (rows, cout), X (rows, cin); dZ_out (rows, cout) receives dZ (optional, must not alias dU).  cout, cin multiples of
+ * 128, rows a multiple of 16.  split_k > 1: deterministic split over the rows, workspace of split_k * cout * cin floats.
+ * Bit-identical to cmf_bn_bwd_apply followed by cmf_gemm(a_t = 1, b_t = 0) for rows >= 32768. */
+int cmf_gemm_dw_bn_bwd(int cout, int cin, long long rows, const float *dU, long long ldu, const float *Z, long long ldz,
+                       const float *a, const float *mean, const float *invstd, const float *sums, float *dZ_out, long long ldo,
+                       const float *X, long long ldx, const float *prob_a, const float *prob_c,
+                       float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream);
+
 /* ---- fp32 MFMA GEMM with fused BatchNorm/activation prologue and epilogues ---------------------- *
  * Every 1x1 Conv2d of the reference (utils/model_utils/radarflow_util.py:132-139,174,246-251,
  * 299-305) is  C[M,N] = epi( pro(A)[M,K] * B[K,N] )  on point-major matrices.

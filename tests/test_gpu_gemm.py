@@ -599,3 +599,47 @@ def test_mlp_chain_block_call_equals_python_sequence(dev, gemm_mode, M, chans, t
     # accumulation into existing gradients = returned gradient + what was there
     for g_ret, g_acc in zip(res[(True, False)][2], res[(True, True)][2]):
         assert float((g_acc - 0.25 - g_ret).abs().max()) <= 1e-5 * max(1.0, float(g_ret.abs().max()))
+
+
+@pytest.mark.parametrize("rows,cout,cin,split", [(32768, 256, 512, 16), (65536, 256, 512, 96), (32768, 128, 128, 8), (49152, 256, 512, 1)])
+def test_weight_gradient_gemm_with_fused_bn_backward(rows, cout, cin, split):
+    """cmf_gemm_dw_bn_bwd (BN backward formed while the weight-gradient GEMM stages its A operand, dZ written as a by-product)
+    against the two-kernel form it replaces -- cmf_bn_bwd_apply in place, then cmf_gemm(a_t, !b_t) with the producer's
+    BN + ReLU on B: bit-identical dW and dZ (same operations, same loop), and against an fp64 evaluation."""
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import gemm
+    if _lib.gemm_mode() != "fp32":
+        pytest.skip("fp32 main loop only")
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(rows + cout)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dU, Z, X = rnd(rows, cout), rnd(rows, cout) * 2 + 0.5, rnd(rows, cin)
+    a, mean, invstd = torch.rand(cout, generator=g).to(dev) + 0.5, rnd(cout) * 0.3 + 0.5, torch.rand(cout, generator=g).to(dev) + 0.4
+    pa, pc = torch.rand(cin, generator=g).to(dev) + 0.5, rnd(cin) * 0.2
+    zhat = (Z - mean) * invstd
+    sums = torch.stack((dU.sum(0), (dU * zhat).sum(0))).contiguous()            # what the producing kernel's epilogue leaves
+    L = _lib.lib()
+    # reference: the stand-alone pass, then the GEMM
+    dZ_ref = dU.clone()
+    _lib.check(L.cmf_bn_bwd_apply(rows, cout, dZ_ref.data_ptr(), Z.data_ptr(), cout, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                  sums.data_ptr(), _lib.stream_ptr()), "cmf_bn_bwd_apply")
+    dW_ref = gemm(dZ_ref, X, a_t=True, b_t=False, prob=(pa, pc), split_k=split)
+    for accumulate in (False, True):
+        dW = torch.full((cout, cin), 0.5, device=dev)
+        dZ = torch.full((rows, cout), float("nan"), device=dev)
+        ws = torch.empty(split, cout, cin, device=dev) if split > 1 else None
+        _lib.check(L.cmf_gemm_dw_bn_bwd(cout, cin, rows, dU.data_ptr(), cout, Z.data_ptr(), cout, a.data_ptr(), mean.data_ptr(),
+                                        invstd.data_ptr(), sums.data_ptr(), dZ.data_ptr(), cout, X.data_ptr(), cin, pa.data_ptr(),
+                                        pc.data_ptr(), dW.data_ptr(), cin, split, ws.data_ptr() if ws is not None else None,
+                                        int(accumulate), _lib.stream_ptr()), "cmf_gemm_dw_bn_bwd")
+        torch.cuda.synchronize()
+        assert torch.equal(dZ, dZ_ref), float((dZ - dZ_ref).abs().max())
+        if rows >= 32768 and not accumulate:
+            assert torch.equal(dW, dW_ref), float((dW - dW_ref).abs().max())
+        want = (dW_ref + 0.5) if accumulate else dW_ref
+        assert float((dW - want).abs().max()) <= 1e-5 * float(dW_ref.abs().max())
+    # fp64
+    d64 = a.double() * (dU.double() - sums[0].double() / rows - zhat.double() * (sums[1].double() / rows))
+    w64 = d64.t() @ torch.relu(pa.double() * X.double() + pc.double())
+    assert float((dZ_ref.double() - d64).abs().max()) <= 2e-5 * float(d64.abs().max())
+    assert float((dW_ref.double() - w64).abs().max()) <= 2e-5 * float(w64.abs().max())

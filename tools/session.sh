@@ -122,6 +122,10 @@ dw_ab() {              # weight-gradient GEMMs on the register-staged loop (defa
         for i in 1 2; do CMF_GEMM_DW_DIRECT=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
     done | tee $R/dw_ab.txt
 }
+bnb_ab() {             # BN backward of the 512 -> 256 layer inside the weight-gradient GEMM (default) against the stand-alone pass
+    python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "fused_bn_backward or block or setconv or set_conv" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
+    for v in 0 1 0 1; do CMF_BNB_FUSED=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused $v', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done | tee $R/bnb_ab.txt
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
