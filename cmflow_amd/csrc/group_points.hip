@@ -644,6 +644,283 @@ __global__ __launch_bounds__(GA_THREADS) void group_points_grad_stream_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Long rows made of per-centre lists, deterministic and without atomics: pad-folded CSR gather (round 3).
+// LDS fp32 atomics retire ~0.6 lanes per clock whatever the addresses (measured with a kernel that gave the S lanes of a
+// wave one list, summed the padded slots across the lanes and issued one atomic per DISTINCT target: 15 distinct targets
+// per instruction cost 24 clocks, 1331 us at BASELINE config 5 against 1081 us for the streamed kernel above), so every
+// form that ADDS into LDS is bound by its atomic lanes.  This form only READS LDS.  Per call, an index kernel cuts a sample's row into tiles of 32768 entries and builds, per tile,
+// (a) a 64-bit mask per list marking the slots that repeat the list's first entry (the reference's padding, three quarters
+// of all entries on LiDAR-like clouds) and (b) a CSR index target -> positions over the remaining entries (counting sort
+// in LDS with integer atomics, every target's short segment then sorted by position: a fixed order).  The gather kernel
+// owns (sample, a few channels): per channel and tile it stages the 128 KB of the row in LDS -- while a list passes
+// through the registers its padded slots are summed across the lanes (DPP) and folded into the list's first entry -- and
+// then a thread walks the segments of its targets and accumulates in registers.  No atomics, every sum in a fixed order:
+// bit-reproducible.  n <= 8192, lists of 16 / 32 / 64 slots.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int GC_THREADS = 512;
+#ifndef CMF_GC_SMALL
+#define CMF_GC_SMALL 0                                 // experiment: 16384-entry tiles, two 512-thread workgroups per CU
+#endif
+constexpr int GC_TILE = CMF_GC_SMALL ? 16384 : 32768;  // entries per tile
+constexpr int GC_MAX_N = 8192;
+constexpr int GC_SHORT = 32;                           // longest segment a single thread sorts
+
+template <int CTRL>
+__device__ __forceinline__ float gc_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// sum over the S lanes of a list (S = 16, 32, 64; lists are S-aligned in the wave), in a fixed order; valid in every lane
+template <int S>
+__device__ __forceinline__ float gc_list_sum(float x)
+{
+    x += gc_dpp<0xB1>(x);                              // quad_perm [1,0,3,2]
+    x += gc_dpp<0x4E>(x);                              // quad_perm [2,3,0,1]
+    x += gc_dpp<0x141>(x);                             // row_half_mirror
+    x += gc_dpp<0x140>(x);                             // row_mirror: every lane of a 16-lane row holds the row's sum
+    if (S >= 32) x += __shfl_xor(x, 16, 64);
+    if (S >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+template <int S>
+__global__ __launch_bounds__(GC_THREADS) void gpg_csr_index_kernel(
+    int n, int total, int tiles, const int *__restrict__ idx, unsigned long long *__restrict__ padmask,
+    unsigned short *__restrict__ off, unsigned short *__restrict__ pos)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char gc_smem[];
+    unsigned *start = (unsigned *)gc_smem;             // [n + 1] segment starts
+    unsigned *cur = start + (n + 1);                   // [n] counts, then cursors
+    unsigned short *spos = (unsigned short *)(cur + n);   // [GC_TILE]
+    __shared__ unsigned wsum[GC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x, bs = blockIdx.y;
+    const int base = tile * GC_TILE, len = min(GC_TILE, total - base);
+    const int *id = idx + (size_t)bs * total + base;
+    unsigned long long *pm = padmask + ((size_t)bs * total + base) / S;
+    for (int i = tid; i < n; i += GC_THREADS) cur[i] = 0u;
+    __syncthreads();
+    const int seg0 = lane & ~(S - 1);
+    for (int e0 = wave * 64; e0 < len; e0 += GC_THREADS) {
+        const int e = e0 + lane;
+        const bool valid = e < len;
+        const int t = valid ? id[e] : -1;
+        const int t0 = __shfl(t, seg0, 64);
+        const bool pad = valid && lane != seg0 && t == t0;
+        const unsigned long long m = __ballot(pad);
+        if (valid && lane == seg0) pm[e / S] = S == 64 ? m : ((m >> seg0) & ((1ull << (S & 63)) - 1ull));
+        if (valid && !pad) atomicAdd(&cur[t], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the counts (thread t owns the targets [t*nt, t*nt + nt))
+    const int nt = (n + GC_THREADS - 1) / GC_THREADS;
+    unsigned loc = 0;
+    for (int q = 0; q < nt; ++q) { const int j = tid * nt + q; if (j < n) loc += cur[j]; }
+    unsigned incl = loc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    unsigned run = wbase + incl - loc;
+    for (int q = 0; q < nt; ++q) {
+        const int j = tid * nt + q;
+        if (j < n) { const unsigned cnt = cur[j]; start[j] = run; cur[j] = run; run += cnt; }
+    }
+    if (tid == GC_THREADS - 1) start[n] = run;
+    __syncthreads();
+    // placement (any order inside a target's segment), then every segment sorted by position
+    for (int e0 = wave * 64; e0 < len; e0 += GC_THREADS) {
+        const int e = e0 + lane;
+        const bool valid = e < len;
+        const int t = valid ? id[e] : -1;
+        const int t0 = __shfl(t, seg0, 64);
+        const bool pad = valid && lane != seg0 && t == t0;
+        if (valid && !pad) spos[atomicAdd(&cur[t], 1u)] = (unsigned short)e;
+    }
+    __syncthreads();
+    // short segments (the rule on neighbour lists): insertion sort by their thread; long ones (arbitrary idx can put a whole
+    // tile on one target) are queued and rank-sorted by the whole workgroup below
+    __shared__ unsigned nlong;
+    __shared__ unsigned short longlist[GC_TILE / (GC_SHORT + 1) + 1];
+    if (tid == 0) nlong = 0u;
+    __syncthreads();
+    for (int j = tid; j < n; j += GC_THREADS) {
+        const int b0 = (int)start[j], b1 = (int)start[j + 1];
+        if (b1 - b0 > GC_SHORT) { longlist[atomicAdd(&nlong, 1u)] = (unsigned short)j; continue; }
+        for (int i = b0 + 1; i < b1; ++i) {
+            const unsigned short x = spos[i];
+            int k = i - 1;
+            while (k >= b0 && spos[k] > x) { spos[k + 1] = spos[k]; --k; }
+            spos[k + 1] = x;
+        }
+    }
+    __syncthreads();
+    unsigned short *o = off + ((size_t)bs * tiles + tile) * (n + 1);
+    for (int i = tid; i <= n; i += GC_THREADS) o[i] = (unsigned short)start[i];
+    unsigned short *ps = pos + ((size_t)bs * tiles + tile) * GC_TILE;
+    const int nnz = (int)start[n];
+    for (int i = tid; i < nnz; i += GC_THREADS) ps[i] = spos[i];
+    const int nl = (int)nlong;
+    if (nl == 0) return;
+    __syncthreads();                                                    // the copy above has landed (same addresses below)
+    for (int li = 0; li < nl; ++li) {
+        const int j = longlist[li];
+        const int b0 = (int)start[j], b1 = (int)start[j + 1];
+        for (int i = b0 + tid; i < b1; i += GC_THREADS) {               // positions are distinct: the rank is the place
+            const unsigned short x = spos[i];
+            int rank = 0;
+            for (int k = b0; k < b1; ++k) rank += spos[k] < x ? 1 : 0;
+            ps[b0 + rank] = x;
+        }
+    }
+}
+
+// LDS of the gather: the tile's floats | as many of its sorted positions as fit (the rest, if any, is read from global memory).
+// [16384-entry tiles with two 512-thread workgroups per CU were measured slower: 1633 against 1230-1270 us at config 5 --
+//  twice the per-(target, tile) segment overhead for half the staging latency.]
+constexpr int GCG_THREADS = CMF_GC_SMALL ? 512 : 1024;
+constexpr int GCG_EPT = GC_TILE / GCG_THREADS;         // entries per thread and tile (32 = 8 x float4)
+constexpr size_t GCG_LDS = CMF_GC_SMALL ? 80 * 1024 - 128 : 160 * 1024 - 256;
+constexpr int GCG_CAP = (int)((GCG_LDS - (size_t)GC_TILE * 4) / 2);
+
+template <int S, int NT>                               // NT targets per thread: n <= NT * GCG_THREADS
+__global__ __launch_bounds__(GCG_THREADS, 4) void gpg_csr_gather_kernel(
+    int c, int n, int total, int tiles, int ch_per_wg, const float *__restrict__ grad_out,
+    const unsigned long long *__restrict__ padmask, const unsigned short *__restrict__ off, const unsigned short *__restrict__ pos,
+    float *__restrict__ grad_points, int diag)
+{
+    extern __shared__ __attribute__((aligned(16))) float gc_buf[];   // [GC_TILE]
+    unsigned short *p_s = (unsigned short *)(gc_buf + GC_TILE);      // [GCG_CAP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bs = blockIdx.x;
+    const int c0 = blockIdx.y * ch_per_wg, c1 = min(c, c0 + ch_per_wg);
+    constexpr int LPL = S / 4;                                       // lanes per list: a lane holds 4 consecutive slots
+    const int l0 = lane & ~(LPL - 1);
+    const unsigned long long *pm_s = padmask + (size_t)bs * total / S;
+    auto lds_barrier = [&]() {                                       // __syncthreads() would drain the prefetches (vmcnt(0)) as well
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int ch = c0; ch < c1; ++ch) {
+        const float *g = grad_out + ((size_t)bs * c + ch) * total;
+        float acc[NT], acc2[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = acc2[q] = 0.f;
+        float4 v[GCG_EPT / 4];
+        unsigned long long pmv[GCG_EPT / 4];
+        // a thread stages the entries 4 * (tid + i * GCG_THREADS) .. + 3 of a tile (total % 4 == 0: a float4 is in or out)
+        auto load_tile = [&](int tile) {
+            const int base = tile * GC_TILE, len = min(GC_TILE, total - base);
+#pragma unroll
+            for (int i = 0; i < GCG_EPT / 4; ++i) {
+                const int e = 4 * (tid + i * GCG_THREADS);
+                const bool ok = e < len;
+                pmv[i] = ok ? pm_s[(base + e) / S] : 0ull;
+                v[i] = ok ? *(const float4 *)(g + base + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        load_tile(0);
+        for (int tile = 0; tile < tiles; ++tile) {
+            const int len = min(GC_TILE, total - tile * GC_TILE);
+            const unsigned short *o = off + ((size_t)bs * tiles + tile) * (n + 1);
+            const unsigned short *ps = pos + ((size_t)bs * tiles + tile) * GC_TILE;
+            // this thread's segments (needed behind the barrier: the loads fly under the staging)
+            int b0[NT], b1[NT];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int j = tid + q * GCG_THREADS;
+                b0[q] = j < n ? o[j] : 0; b1[q] = j < n ? o[j + 1] : 0;
+            }
+            const int nnz = o[n];
+            // fold every list's padded slots into its first entry (the lanes of a list are neighbours inside a DPP row), store
+#pragma unroll
+            for (int i = 0; i < GCG_EPT / 4; ++i) {
+                const int e = 4 * (tid + i * GCG_THREADS);
+                const unsigned bits = (unsigned)(pmv[i] >> (4 * (lane - l0))) & 0xFu;
+                float part = ((bits & 1u) ? v[i].x : 0.f) + ((bits & 2u) ? v[i].y : 0.f) + ((bits & 4u) ? v[i].z : 0.f) + ((bits & 8u) ? v[i].w : 0.f);
+                part += gc_dpp<0xB1>(part);                                         // 2 lanes
+                part += gc_dpp<0x4E>(part);                                         // 4 lanes = a list of 16 slots
+                if (S >= 32) part += gc_dpp<0x141>(part);                           // 8 lanes
+                if (S >= 64) part += gc_dpp<0x140>(part);                           // 16 lanes = a list of 64 slots
+                float4 w = v[i];
+                if (lane == l0) w.x += part;
+                if (e < len) *(float4 *)(gc_buf + e) = w;
+            }
+            if (!(diag & 2))
+                for (int i = tid; i < min(nnz, GCG_CAP); i += GCG_THREADS) p_s[i] = ps[i];
+            lds_barrier();
+            if (tile + 1 < tiles) load_tile(tile + 1);                              // in flight under the walk below
+            int maxl = 0;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) maxl = max(maxl, b1[q] - b0[q]);
+            if (diag & 1) maxl = 0;
+            // two interleaved chains per target (even / odd entries of its segment; four were measured slower: registers): the walk is bound by the latency of
+            // its dependent LDS reads (position, then value), not by their number; the order of every sum stays fixed
+            if (nnz <= GCG_CAP) {
+                for (int sI = 0; sI < maxl; sI += 2) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const int k = b0[q] + sI;
+                        const float x0 = k < b1[q] ? gc_buf[p_s[k]] : 0.f;
+                        const float x1 = k + 1 < b1[q] ? gc_buf[p_s[k + 1]] : 0.f;
+                        acc[q] += x0; acc2[q] += x1;
+                    }
+                }
+            } else {
+                for (int sI = 0; sI < maxl; ++sI) {
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const int k = b0[q] + sI;
+                        if (k < b1[q]) { const float x = gc_buf[k < GCG_CAP ? p_s[k] : ps[k]]; if (sI & 1) acc2[q] += x; else acc[q] += x; }
+                    }
+                }
+            }
+            lds_barrier();
+        }
+        float *gp = grad_points + ((size_t)bs * c + ch) * n;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) { const int j = tid + q * GCG_THREADS; if (j < n) gp[j] += acc[q] + acc2[q]; }
+    }
+}
+
+template <int S>
+static int launch_csr(int b, int c, int n, int total, const float *grad_out, const int *idx, float *grad_points, hipStream_t st)
+{
+    const int tiles = cmf_divup(total, GC_TILE);
+    const size_t n_mask = (size_t)b * total / S * sizeof(unsigned long long);
+    const size_t n_off = ((size_t)b * tiles * (n + 1) * sizeof(unsigned short) + 15) / 16 * 16;
+    const size_t n_pos = (size_t)b * tiles * GC_TILE * sizeof(unsigned short);
+    const CmfScratchLease lease = cmf_stream_scratch(st, 0, n_mask + n_off + n_pos);
+    if (!lease.ptr) return (int)hipErrorOutOfMemory;
+    unsigned long long *padmask = (unsigned long long *)lease.ptr;
+    unsigned short *off = (unsigned short *)((char *)lease.ptr + n_mask);
+    unsigned short *pos = (unsigned short *)((char *)lease.ptr + n_mask + n_off);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gpg_csr_index_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void *)gpg_csr_gather_kernel<S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCG_LDS);
+        (void)hipFuncSetAttribute((const void *)gpg_csr_gather_kernel<S, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCG_LDS);
+        attr_set = true;
+    }
+    const size_t lds_i = (size_t)(2 * n + 1) * sizeof(unsigned) + (size_t)GC_TILE * sizeof(unsigned short);
+    hipLaunchKernelGGL(gpg_csr_index_kernel<S>, dim3(tiles, b), dim3(GC_THREADS), lds_i, st, n, total, tiles, idx, padmask, off, pos);
+    static const int gdiag = getenv("CMF_GC_DIAG") ? atoi(getenv("CMF_GC_DIAG")) : 0;     // timing only: 1 no walk, 2 no index staging
+    int ch_per_wg = 8;                                  // >= 2 workgroups per CU over the launch
+    while (ch_per_wg > 1 && (long long)b * cmf_divup(c, ch_per_wg) < 512) ch_per_wg /= 2;
+    const dim3 grid(b, cmf_divup(c, ch_per_wg));
+    if (n <= 4 * GCG_THREADS)
+        hipLaunchKernelGGL((gpg_csr_gather_kernel<S, 4>), grid, dim3(GCG_THREADS), GCG_LDS, st, c, n, total, tiles, ch_per_wg, grad_out,
+                           padmask, off, pos, grad_points, gdiag);
+    else
+        hipLaunchKernelGGL((gpg_csr_gather_kernel<S, 8>), grid, dim3(GCG_THREADS), GCG_LDS, st, c, n, total, tiles, ch_per_wg, grad_out,
+                           padmask, off, pos, grad_points, gdiag);
+    return cmf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Long rows (N = 4096 x K = 64: 262 144 entries = 1 MB per (sample, channel) row), deterministic.
 // The row is cut into TILES of 8192 consecutive entries and each tile gets its own small inverse index, built once per
 // call and shared by all channels (gpg_tile_index_kernel): the tile's entries sorted by target with a stable 4-bit
@@ -933,6 +1210,16 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     // the two barriers per (tile, channel) at one workgroup per CU cost more than the same-address conflicts they remove.
     static const bool deterministic = getenv("CMF_GROUP_GRAD_DETERMINISTIC") && getenv("CMF_GROUP_GRAD_DETERMINISTIC")[0] == '1';
     const bool stream_fits = (size_t)GA_CH * n * sizeof(float) <= 128 * 1024;
+    // per-centre lists of 16 / 32 / 64 slots: the pad-folded CSR gather -- deterministic, no atomics, and faster than the
+    // LDS-atomic kernel (BASELINE config 5, C = 64 / 128: 859 / 1622 us against 1081 / 2148 us; the tiled deterministic
+    // kernel: 1747 / 3330 us).  CMF_GROUP_GRAD_CSR=0 falls through to the older kernels (A/B).
+    static const bool use_csr = !(getenv("CMF_GROUP_GRAD_CSR") && getenv("CMF_GROUP_GRAD_CSR")[0] == '0');
+    if (!balanced && use_csr && (nsample == 16 || nsample == 32 || nsample == 64) && n <= GC_MAX_N && total <= (1 << 30) &&
+        (((uintptr_t)grad_out) & 15) == 0) {
+        if (nsample == 64) return launch_csr<64>(b, c, n, (int)total, grad_out, idx, grad_points, st);
+        if (nsample == 32) return launch_csr<32>(b, c, n, (int)total, grad_out, idx, grad_points, st);
+        return launch_csr<16>(b, c, n, (int)total, grad_out, idx, grad_points, st);
+    }
     if (!balanced && n <= 16384 && (deterministic || !stream_fits)) {
         // per-tile inverse index (library scratch) + tiled deterministic scatter
         const int tiles = cmf_divup(total, GT_TILE);

@@ -81,7 +81,8 @@ def test_ball_query_edge_cases(dev):
                                        (1, 5, 100, 37, 3), (1, 2, 5000, 64, 16), (2, 9, 4096, 512, 64),
                                        (2, 33, 256, 256, 16), (1, 20, 300, 250, 32), (1, 2, 35000, 16, 8),
                                        (1, 17, 700, 1, 1), (2, 6, 4096, 4096, 64), (1, 5, 4096, 1000, 37),
-                                       (1, 3, 9000, 2000, 9)])
+                                       (1, 3, 9000, 2000, 9), (2, 5, 2048, 1024, 32), (1, 6, 3000, 1024, 16), (1, 9, 4096, 130, 64),
+                                       (1, 3, 2, 1100, 64), (2, 4, 8192, 2048, 32), (1, 2, 70, 4097, 16)])
 def test_group_points_and_grad(dev, B, C, N, P, S):
     from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
     g = torch.Generator().manual_seed(B + C + N)
@@ -97,13 +98,17 @@ def test_group_points_and_grad(dev, B, C, N, P, S):
     # the reference's atomicAdd order is undefined; ours is a fixed chunked order (balanced kernel: rows <= 8192 entries;
     # tiled kernel: longer rows, n <= 16384): equal to the oracle's scan-order sum to fp32 rounding of the partial sums
     np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(S * P / N + 1) ** 0.5 * 4)
-    if (P * S <= 8192 and N <= 4096) or 8192 < N <= 16384:             # balanced / tiled kernels: bit-reproducible run to run
+    # balanced / tiled kernels, and the pad-folded CSR gather when it is selected (lists of 16 / 32 / 64 slots, n <= 8192;
+    # test_group_points_grad_csr_form runs this test under CMF_GROUP_GRAD_CSR=1): bit-reproducible run to run
+    import os
+    csr = os.environ.get("CMF_GROUP_GRAD_CSR") != "0" and S in (16, 32, 64) and N <= 8192
+    if (P * S <= 8192 and N <= 4096) or 8192 < N <= 16384 or csr:
         gp2 = torch.zeros(B, C, N, device=dev)
         ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp2)
         assert torch.equal(gp2.cpu(), gp.cpu())
     # accumulates INTO grad_points (lib/pointnet2_utils.py:218 zero-fills first)
     ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp)
-    np.testing.assert_allclose(gp.cpu().numpy(), 2 * ref.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(gp.cpu().numpy(), 2 * ref.numpy(), rtol=1e-5, atol=2e-5 * max(1.0, float(S * P / N) ** 0.5))
 
 
 @pytest.mark.parametrize("B,N,M,r,ns", [(3, 512, 512, 4.0, 16), (2, 1024, 300, 2.0, 64), (2, 700, 701 - 1, 8.0, 100), (5, 257, 33, 3.0, 7),
@@ -534,16 +539,28 @@ def test_weighted_ksum_matches_torch(dev, B, N1, N2, K, C):
     np.testing.assert_allclose(gp.cpu().numpy(), p.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+def test_group_points_grad_atomic_forms():
+    """Long rows take the pad-folded CSR gather by default (test_group_points_and_grad covers it: random indices incl. whole
+    tiles on two targets -- the workgroup-wide rank sort --, lists of 16 / 32 / 64 slots, n up to 8192, bit-reproducible).
+    The LDS-atomic kernels behind it (CMF_GROUP_GRAD_CSR=0, read once per process, so a child process) stay tested on the
+    same shapes."""
+    import subprocess, sys, os
+    env = dict(os.environ, CMF_GROUP_GRAD_CSR="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-m", "gpu", "-k", "test_group_points_and_grad"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_group_points_grad_long_rows_real_indices(dev):
     """BASELINE config 5's row length (N = 4096, K = 64: 262 144 entries per row) with real ball-query indices -- first-hit
-    padding gives long runs of equal targets.  The deterministic tiled kernel (opt-in, CMF_GROUP_GRAD_DETERMINISTIC=1: read
-    once per process, so a child process) against the oracle, twice (bit-reproducible); the default kernel against the
-    oracle."""
+    padding gives long runs of equal targets.  The default (pad-folded CSR gather) against the oracle, twice
+    (bit-reproducible), incl. lists of 32 and 16 slots; the tiled deterministic kernel that serves the shapes the gather does
+    not take (CMF_GROUP_GRAD_CSR=0 CMF_GROUP_GRAD_DETERMINISTIC=1: read once per process, so a child process) likewise."""
     import subprocess, sys, os
     from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
     from cmflow_amd import synth
     if os.environ.get("CMF_GROUP_GRAD_DETERMINISTIC") != "1":
-        env = dict(os.environ, CMF_GROUP_GRAD_DETERMINISTIC="1")
+        env = dict(os.environ, CMF_GROUP_GRAD_DETERMINISTIC="1", CMF_GROUP_GRAD_CSR="0")
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__ + "::test_group_points_grad_long_rows_real_indices",
                             "-m", "gpu"], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -556,6 +573,13 @@ def test_group_points_grad_long_rows_real_indices(dev):
         gp = torch.zeros(2, 7, 4096, device=dev)
         ext.group_points_grad_wrapper(2, 7, 4096, 4096, 64, go.to(dev), idx.to(dev), gp)
         outs.append(gp.cpu())
-    if os.environ.get("CMF_GROUP_GRAD_DETERMINISTIC") == "1":
-        assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1])                               # lists of 64 slots: the pad-folded CSR gather (default)
     np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    # lists of 32 and 16 slots (two / four lists per wave in the list-per-lanes kernel), padded tails included
+    for r, ns in ((1.2, 32), (0.8, 16)):
+        idx = orc.ball_query(r, ns, xyz, xyz)
+        go = torch.randn(2, 5, 4096, ns, generator=torch.Generator().manual_seed(ns))
+        ref = orc.group_points_grad(go, idx, 4096)
+        gp = torch.zeros(2, 5, 4096, device=dev)
+        ext.group_points_grad_wrapper(2, 5, 4096, 4096, ns, go.to(dev), idx.to(dev), gp)
+        np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6 * float(ref.abs().max()))

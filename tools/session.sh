@@ -126,6 +126,12 @@ bnb_ab() {             # BN backward of the 512 -> 256 layer inside the weight-g
     python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "fused_bn_backward or block or setconv or set_conv" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
     for v in 0 1 0 1; do CMF_BNB_FUSED=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused $v', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done | tee $R/bnb_ab.txt
 }
+scatter_ab() {         # long-row scatter: list-per-lanes kernel (default) against the streamed kernel
+    python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "group_points or config5" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
+    for v in 1 0; do for C in 64 128; do CMF_GROUP_GRAD_CSR=$v python tools/scatter_probe.py $C 2>&1 | grep "C="; done; done | tee $R/scatter_ab.txt
+    rm -rf /tmp/sp; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -- python3 $GRAFT_REPO_ROOT/tools/scatter_probe.py 64 > /dev/null 2>&1)
+    python -c "import csv,sys; [print(r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3) for r in csv.DictReader(open(sys.argv[1])) if 'gpg' in r['Name'] or 'group_points' in r['Name']]" $(find /tmp/sp -name "*kernel_stats.csv" | head -1) | tee -a $R/scatter_ab.txt
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
