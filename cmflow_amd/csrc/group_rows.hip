@@ -375,9 +375,13 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
     const float *__restrict__ sums, float inv_count,
     const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg)
 {
-    const int wave = (blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
-    if (wave >= total_waves) return;
+    // a wave owns (source point, block of 256 columns): the inverse lists are skewed (first-hit padding: some are 10x the
+    // mean), and one wave walking a long list once per column block set the pace of the launch's tail
+    const int gwave = (blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
+    if (gwave >= total_waves) return;
     const int lane = threadIdx.x % CMF_WAVE;
+    const int cblocks = (c + CMF_WAVE * 4 - 1) / (CMF_WAVE * 4);
+    const int wave = gwave / cblocks, cb = gwave - wave * cblocks;
     const int bs = wave / n, j = wave - bs * n;
     const int *off = offsets + (size_t)bs * (n + 1);
     const int beg = off[j], end = off[j + 1];
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
         for (int m = CMF_WAVE / 2; m > 0; m >>= 1) { Dx += __shfl_xor(Dx, m, CMF_WAVE); Dy += __shfl_xor(Dy, m, CMF_WAVE); Dz += __shfl_xor(Dz, m, CMF_WAVE); }
     }
     const float cnt = (float)(end - beg);
-    for (int col = lane * 4; col < c; col += CMF_WAVE * 4) {
+    for (int col = cb * CMF_WAVE * 4 + lane * 4; col < min(c, (cb + 1) * CMF_WAVE * 4); col += CMF_WAVE * 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int t = beg;
         for (; DEEP && t + 16 <= end; t += 16) {            // 16 rows in flight; the sum keeps ascending entry order
@@ -463,7 +467,8 @@ extern "C" int cmf_group_rows_grad_bn_cf(int b, int n, int c, int entries, int S
     CMF_CHECK_ARG(dU && a && offsets && inv && grad_feat);
     CMF_CHECK_ARG(!sums || (y && wx && xyz_src && xyz_ctr && mean && invstd && ldy >= c && ldy % 4 == 0 && ldw >= 3));
     CMF_CHECK_ARG((((uintptr_t)dU | (uintptr_t)y | (uintptr_t)grad_feat | (uintptr_t)a) & 15) == 0);
-    const long long waves = (long long)b * n;
+    const long long waves = (long long)b * n * ((c + CMF_WAVE * 4 - 1) / (CMF_WAVE * 4));
+    CMF_CHECK_ARG(waves * CMF_WAVE < (1ll << 31));
     const int grid = (int)((waves * CMF_WAVE + GR_THREADS - 1) / GR_THREADS);
     if (S >= 32)
         hipLaunchKernelGGL(group_rows_grad_bn_cf_kernel<true>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
