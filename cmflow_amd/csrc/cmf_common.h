@@ -45,6 +45,9 @@ __device__ __forceinline__ void cmf_bnb_coef(float sa, float mu, float is, float
 __device__ __forceinline__ float cmf_bnb_apply(float d, float v, float al, float be, float ga) { return fmaf(al, d, fmaf(be, v, ga)); }
 #endif
 
+// neighbor.hip: cmf_ball_query that also defines the rows of empty balls (zeros), without a memset launch on small clouds
+int cmf_ball_query_defined(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx, void *stream);
+
 // ---- batched launches (round 3) -------------------------------------------------------------------------------------
 // The narrow layers of the set-conv chains are latency, not work: the per-point tail of a block is three 64-channel
 // layers over B*N rows (128 workgroups per kernel), and the eight chains of an encoder call each issued their own ~10

@@ -585,6 +585,20 @@ static int ball_query_ballot(int b, int n, int m, float radius, int nsample, int
     return cmf_launch_status();
 }
 
+// cmf_ball_query with EVERY entry of idx defined: an empty ball's row reads 0 (the reference pre-zeroes idx,
+// lib/pointnet2_utils.py:246).  Small clouds: the ballot kernel writes the zeros itself (no memset launch in front of it).
+int cmf_ball_query_defined(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample > 0);
+    if (b == 0 || m == 0) return 0;
+    CMF_CHECK_ARG(new_xyz && xyz && idx);
+    static const bool use_ballot = !(getenv("CMF_BALL_QUERY_BALLOT") && getenv("CMF_BALL_QUERY_BALLOT")[0] == '0');
+    if (use_ballot && n > 0 && n <= BQB_MAX_N && nsample <= 256)
+        return ball_query_ballot(b, n, m, radius, nsample, 1, new_xyz, xyz, idx, (hipStream_t)stream);
+    if (hipMemsetAsync(idx, 0, (size_t)b * m * nsample * sizeof(int), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+    return cmf_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
+}
+
 extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
                               const float *new_xyz, const float *xyz, int *idx, void *stream)
 {

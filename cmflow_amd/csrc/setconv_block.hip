@@ -271,8 +271,7 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     const int O1 = d->O1, C2 = d->C[0], C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
     // idx is pre-zeroed like the reference's BallQuery.forward (every point is its own neighbour here, but keep the contract)
     if (!d->training) CMF_TRY(fold_all_eval(d, L, st));
-    CMF_TRY((int)hipMemsetAsync(L.idx, 0, M * sizeof(int), (hipStream_t)st));
-    CMF_TRY(cmf_ball_query(d->B, d->N, d->N, d->radius, d->S, d->xyz, d->xyz, L.idx, st));
+    CMF_TRY(cmf_ball_query_defined(d->B, d->N, d->N, d->radius, d->S, d->xyz, d->xyz, L.idx, st));
     CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
                              L.z1, L.dxyz, d->training ? L.partial : nullptr, d->training ? L.partial_x : nullptr, st));
     if (d->training) CMF_TRY(cmf_colsum(tiles128(M), 3 * O1 + 4, L.partial_x, L.fwd_sums, 0, nullptr, nullptr, st));
