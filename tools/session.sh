@@ -132,6 +132,10 @@ scatter_ab() {         # long-row scatter: list-per-lanes kernel (default) again
     rm -rf /tmp/sp; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -- python3 $GRAFT_REPO_ROOT/tools/scatter_probe.py 64 > /dev/null 2>&1)
     python -c "import csv,sys; [print(r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3) for r in csv.DictReader(open(sys.argv[1])) if 'gpg' in r['Name'] or 'group_points' in r['Name']]" $(find /tmp/sp -name "*kernel_stats.csv" | head -1) | tee -a $R/scatter_ab.txt
 }
+deals() {              # scale -> side-stream deals of the two encoders (CMF_SCALE_SLOTS), two rounds each
+    for rep in 1 2; do for deal in "0,1,1,2|1,2,2,0" "0,1,2,2|1,2,0,0" "0,0,1,2|1,1,2,0" "0,1,2,0|1,2,0,1" "2,1,1,0|0,2,2,1" "0,2,1,2|1,0,2,0" "1,1,2,0|2,2,0,1" "0,1,1,2|0,1,1,2" "0,1,1,2|2,0,0,1"; do
+        CMF_SCALE_SLOTS="$deal" python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$deal', d['ms_per_step'])"; done; done | tee $R/deals.txt
+}
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
