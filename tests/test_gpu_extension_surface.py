@@ -115,3 +115,15 @@ def test_integration_md_stub_runs_as_written(dev):
     gp = torch.zeros(2, 5, 200, device=dev)
     mod.group_points_grad_wrapper(2, 5, 200, 64, 8, go.to(dev), idx, gp)
     torch.testing.assert_close(gp.cpu(), orc.group_points_grad(go, idx.cpu(), 200), rtol=1e-5, atol=1e-5)
+    # the second stub: QueryAndGroup.forward bound to cmf_query_and_group, executed in the same namespace and attached to a
+    # bare object carrying the module's three attributes; against the reference's op sequence on the oracle's kernels
+    code2 = re.search(r"```python\n# lib/pointnet2_utils.py:269-292, body of QueryAndGroup.forward.*?```", text, flags=re.S).group(0)
+    exec(compile(code2[len("```python\n"):-3], "INTEGRATION.md", "exec"), mod.__dict__)
+    for use_xyz, with_feats in ((True, True), (True, False), (False, True)):
+        qg = types.SimpleNamespace(radius=3.0, nsample=8, use_xyz=use_xyz)
+        f = feats if with_feats else None
+        got = mod.forward(qg, xyz.to(dev), new.to(dev), f.to(dev) if with_feats else None)
+        ref_idx = orc.ball_query(3.0, 8, xyz, new)
+        gx = orc.group_points(xyz.transpose(1, 2).contiguous(), ref_idx) - new.transpose(1, 2).unsqueeze(-1)
+        parts = ([gx] if (use_xyz or not with_feats) else []) + ([orc.group_points(f, ref_idx)] if with_feats else [])
+        assert torch.equal(got.cpu(), torch.cat(parts, dim=1))
