@@ -32,7 +32,6 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense peak (the experimental bf16x3 mode spends 6 bf16 MFMAs per fp32 product)
 
 
 class Args:
@@ -280,7 +279,6 @@ def main():
     from cmflow_amd.dp import broadcast_module
     from cmflow_amd.train import TrainStep
     _lib.lib()                                       # fail loudly if the HIP extension is missing
-    gemm_mode = _lib.gemm_mode()                     # "fp32" (product) or the opt-in "bf16x3" (CMF_GEMM_MODE)
 
     from cmflow_amd.raflow import RaFlow
     net = {"cmflow": CMFlow, "cmflow_t": CMFlow_T, "raflow": RaFlow}[a.model](Args())
@@ -363,8 +361,7 @@ def main():
         if prof["bound"] == "hbm":
             achieved, peak, unit = per_launch / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
-            # the opt-in bf16x3 arithmetic executes six bf16 MFMAs per fp32-equivalent product: its roof is the bf16 dense peak / 6
-            peak = MFMA_F32_PEAK_TFLOPS if gemm_mode == "fp32" else round(MFMA_BF16_PEAK_TFLOPS / 6.0, 1)
+            peak = MFMA_F32_PEAK_TFLOPS
             achieved, unit = per_launch / (avg_ms * 1e-3) / 1e12, "TFLOP/s"
         # PMC counters need rocprofv3 around the process: `traffic` is the per-launch HBM byte count of this kernel's
         # >= 256-workgroup launches from the committed FETCH_SIZE / WRITE_SIZE passes over this same command (separate --pmc
@@ -427,7 +424,7 @@ def main():
             "value": round(pairs / dt, 2), "unit": "frame-pairs/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if gemm_mode == "fp32" else "f32 (bf16x3 MFMA, fp32 accumulate; experimental opt-in, DESIGN.md section 9)",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": ("%s %s step, N=256, B=%d per GPU (global %d), ball-query r=2/4/8/16 K=4/8/16/32, "
                                     "kNN K=8%s; synthetic clouds, seeded random-init weights" %

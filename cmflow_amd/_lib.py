@@ -33,8 +33,6 @@ SIGNATURES = {
     "cmf_gemm_dw_bn_bwd": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _ll, _ci, _vp,
                            _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
-    "cmf_gemm_set_mode": [_ci],
-    "cmf_gemm_get_mode": [],
     "cmf_gemm_trace_arm": [],
     "cmf_gemm_trace_read": [_vp, _ll],
     "cmf_gemm_profile_begin": [ctypes.c_double],
@@ -176,19 +174,6 @@ def lib():
             fn.restype = RESTYPES.get(name, _ci)
         _lib.cmf_version.restype = ctypes.c_char_p
     return _lib
-
-
-GEMM_MODES = {"fp32": 0, "bf16x3": 1}
-
-
-def set_gemm_mode(mode):
-    """'fp32' | 'bf16x3' (cmf_gemm_set_mode); returns the previous mode's name."""
-    prev = lib().cmf_gemm_set_mode(GEMM_MODES[mode])
-    return {v: k for k, v in GEMM_MODES.items()}[prev]
-
-
-def gemm_mode():
-    return {v: k for k, v in GEMM_MODES.items()}[lib().cmf_gemm_get_mode()]
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

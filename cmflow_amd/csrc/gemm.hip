@@ -27,43 +27,12 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef CMF_GEMM_DIAG
-#define CMF_GEMM_DIAG 0
-#endif
 constexpr int G_THREADS = 256;
-#ifndef CMF_EMUL_DIAG
-#define CMF_EMUL_DIAG 0                   // diagnostics of the bf16x3 loop (tools/diag builds)
-#endif
-#ifndef CMF_EPI_DIRECT
-#define CMF_EPI_DIRECT 1                  // 1: kinds 0 / 1 (plain store, forward) store straight from the accumulator layout, no LDS
-                                          //    transposition: epilogue 6.7 vs 10.4 us (plain) / 13.7 vs 14.6 us (forward + statistics) per tile.
-                                          //    The backward kinds keep the transposed form: their Z tile wants 16-byte loads issued a band
-                                          //    ahead (direct: 36 vs 17 us per tile).
-#endif
-#ifndef CMF_EPI_WAVE
-#define CMF_EPI_WAVE 1                    // bit 0: the backward kinds (2-5) of the 128 x 128 kernels finish their tiles per wave (wave_epilogue);
-                                          // bit 1: kinds 0 / 1 as well (instead of the direct form) -- experiment
-#endif
-#ifndef CMF_GEMM_T256
-#define CMF_GEMM_T256 0
-#endif
-#ifndef CMF_GEMM_WPS
-#define CMF_GEMM_WPS 0              // experiment: register budget for this many waves per SIMD (4: 128 registers, so that one
-#endif                              // wave of another stream's kernel fits next to the three GEMM workgroups of a CU)
-#ifndef CMF_GEMM_PIPE
-#define CMF_GEMM_PIPE 1                   // 1: barrier in the middle of a chunk, first fragment reads of the next chunk under the second half
-                                          //    (same-box A/B, 524288 x 256 x 512: fwd 120.7 -> 123.3, dX 120.1 -> 121.8, dW 122.9 -> 124.2 TF; 0: one barrier at the end)
-#endif
-#ifndef CMF_GEMM_PRIO
-#define CMF_GEMM_PRIO 1                   // n > 0: s_setprio n for the main loop, 0 again for the epilogue: a wave in its epilogue does not take issue
-                                          //    slots from the MFMA streams of the other workgroups (+1 % on its own, +2-3 % with the pipelined loop)
-#endif
-#ifndef CMF_GEMM_W3
-#define CMF_GEMM_W3 0                     // 1: the backward-epilogue kernels (kinds 2, 3) are also held to 3 waves per SIMD
-#endif
-#ifndef CMF_GEMM_DEFAULT_MODE
-#define CMF_GEMM_DEFAULT_MODE 0           // see cmf_gemm_set_mode
-#endif
+// Fixed design choices, each measured against its alternative in an earlier round (DESIGN.md "ruled out"):
+//  * kinds 0 / 1 (plain store, forward) store straight from the accumulator layout (direct_epilogue): 6.7 vs 10.4 us per tile;
+//  * the backward kinds (2-5) of the 128 x 128 kernels finish their tiles per wave (wave_epilogue);
+//  * the chunk barrier sits in the middle of a chunk's MFMAs, the first fragment reads of the next chunk run under the second half;
+//  * s_setprio 1 for the main loop, 0 for the epilogue.
 #ifndef CMF_GEMM_BK
 #define CMF_GEMM_BK 16
 #endif
@@ -125,25 +94,6 @@ __device__ __forceinline__ unsigned long long g_where()         // HW_REG_XCC_ID
 
 // A_T: A stored [K][M] (contraction-major) instead of [M][K].  B_T: B stored [N][K] (i.e. W[out][in],
 // the forward layout) instead of [K][N].
-// EMUL (experimental, opt-in via CMF_GEMM_MODE=bf16x3; never the default): the interior-tile main loop evaluates the
-// fp32 product on the bf16 matrix cores.  Every fp32 operand is split exactly into three bf16 pieces
-// (x = hi + mid + lo, 8 + 8 + 8 significand bits) and a chunk of 16 k becomes six v_mfma_f32_32x32x16_bf16
-// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the three dropped terms are below 2^-26 |a||b|), accumulated in
-// fp32 -- fp32-grade results at 16x the per-instruction rate of v_mfma_f32_32x32x2_f32.
-typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void g_split3(const f32x4 a, const f32x4 b, g_bf16x8 &hi, g_bf16x8 &mid, g_bf16x8 &lo)
-{
-    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const __bf16 h = (__bf16)x[i];
-        const float r1 = x[i] - (float)h;                 // exact
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;                   // exact, <= 8 significant bits left
-        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
-    }
-}
-
 // 0 raw store (split-K slabs, plain GEMM); 1 forward (bias / none-ReLU-leaky activation / BN statistics); 2 backward
 // through BN + ReLU; 3 backward through (leaky) ReLU; 4 / 5 = 2 / 3 with the three dxyz column sums
 __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
@@ -157,8 +107,8 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
-template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
-__global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 256 || (EMUL && CMF_EMUL_DIAG == 3)) ? 2 : ((BM == 128 && BN == 128) ? (CMF_GEMM_WPS ? CMF_GEMM_WPS : ((EPI <= 3 || CMF_GEMM_W3 || (CMF_EPI_WAVE & 1)) ? 3 : 2)) : 3)) void gemm_kernel(const GemmArgs p)
+template <int BM, int BN, bool A_T, bool B_T, int EPI = 0>
+__global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
 {
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
@@ -393,7 +343,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
     constexpr int D_ASLOTS = BM * (G_BK / 4), D_BSLOTS = BN * (G_BK / 4);     // 16-byte slots per operand chunk
     constexpr int D_ANI = D_ASLOTS / G_THREADS, D_BNI = D_BSLOTS / G_THREADS; // load instructions per thread
     constexpr int D_STAGE = (D_ASLOTS + D_BSLOTS) * 4 + 32;                   // floats: A | B | pro_a[16] pro_c[16]
-    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && CMF_GEMM_DIAG == 0 && !p.no_direct && !bnbA;
+    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && !p.no_direct && !bnbA;
     if (direct && kc_begin < kc_end) {
         const long long pro_delta = proA ? (long long)(p.pro_c - p.pro_a) : 0ll;
         // A plain s_barrier: __syncthreads() carries a workgroup fence, which makes the compiler drain EVERY outstanding
@@ -504,15 +454,12 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
                 }
         };
         int st = 0;
-#if CMF_GEMM_PRIO
-        __builtin_amdgcn_s_setprio(CMF_GEMM_PRIO);
-#endif
-#if CMF_GEMM_PIPE
+        __builtin_amdgcn_s_setprio(1);
         // Software-pipelined form: the barrier sits in the MIDDLE of a chunk's MFMAs.  When a wave arrives there it has read
         // all of chunk c (its second fragment set was awaited just before), so the barrier still means "stage c is free and
         // chunk c + 1 is visible" -- but the first fragment reads of chunk c + 1 are issued right behind it and land under
         // the 16 MFMAs of the second half of chunk c, instead of being waited for with nothing to issue.
-        if (!EMUL) {
+        {
             {
                 const float *sa = smem, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
                 read_frags(sa, sb, sp, 0, 0);
@@ -538,76 +485,8 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
                 st = sn;
             }
             __builtin_amdgcn_s_barrier();                                            // the epilogue reuses the staging buffers
-        } else
-#endif
-        for (int c = 0; c < nch; ++c) {
-            if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);       // (st + 2) % 3
-            const float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
-            if (EMUL) {
-                read_frags(sa, sb, sp, 0, 0);
-                read_frags(sa, sb, sp, 8, 1);
-                g_lds_wait(); pin_frags(0); pin_frags(1);
-                prologue_step(0); prologue_step(1);
-                // a lane's two 4-k groups (k8 = 0 and 8) are exactly the 8 consecutive operands of ONE 32x32x16 MFMA
-                g_bf16x8 bh[TN], bm[TN], bl[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) g_split3(bf[0][j], bf[1][j], bh[j], bm[j], bl[j]);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    g_bf16x8 ah, am, al;
-                    g_split3(af[0][i], af[1][i], ah, am, al);
-#if CMF_EMUL_DIAG == 1
-                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#elif CMF_EMUL_DIAG == 2
-                    __builtin_amdgcn_sched_barrier(0);
-#endif
-#if CMF_EMUL_DIAG == 4
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-                    continue;
-#elif CMF_EMUL_DIAG == 5
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int w = 0; w < 2; ++w) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].x, bf[w][j].x, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].y, bf[w][j].y, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].z, bf[w][j].z, acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i].w, bf[w][j].w, acc[i][j], 0, 0, 0);
-                        }
-                    continue;
-#endif
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
-#if CMF_EMUL_DIAG == 6
-                        asm volatile("s_nop 7" ::: "memory");
-#endif
-                    }
-#if CMF_EMUL_DIAG == 7
-                    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-                }
-            } else {
-            read_frags(sa, sb, sp, 0, 0);
-            g_lds_wait(); pin_frags(0);
-            read_frags(sa, sb, sp, 8, 1);                                       // in flight under the first 16 MFMAs
-            mfma_step(0);
-            g_lds_wait(); pin_frags(1);
-            mfma_step(1);
-            }
-            if (c + 1 < nch && !(p.diag & 3)) wait_prev(c + 2 < nch);           // chunk c+1 has landed (this wave's part)
-            if (!(p.diag & 4)) __builtin_amdgcn_s_barrier();                    // ... and everybody else's; stage st is free again
-            st = st == 2 ? 0 : st + 1;
         }
-#if CMF_GEMM_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
     } else
     if (kc_begin < kc_end) {
         load_tiles(kc_begin);
@@ -617,11 +496,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
         const int frow = lane & 31, fk = (lane >> 5) * 4;
         for (int kc = kc_begin; kc < kc_end; ++kc) {
             const bool more = kc + 1 < kc_end;
-#if CMF_GEMM_DIAG == 1                                              /* diagnostic: no global loads after the first chunk */
-            (void)0;
-#else
             if (more) load_tiles(kc + 1);                           // global loads in flight under the MFMAs
-#endif
             const float *a_s = As + buf * A_SZ + (A_T ? fk * A_LD + wm * WM + frow : (wm * WM + frow) * A_LD + fk);
             const float *b_s = Bs + buf * B_SZ + (B_T ? (wn * WN + frow) * B_LD + fk : fk * B_LD + wn * WN + frow);
 #pragma unroll
@@ -651,24 +526,13 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
                 // stage the NEXT chunk into the other LDS buffer three quarters of the way through this
                 // chunk's MFMAs: its global loads have had ~3/4 of a chunk to land, and the LDS writes
                 // retire under the remaining MFMAs instead of in front of the barrier.
-#if CMF_GEMM_DIAG == 2 || CMF_GEMM_DIAG == 5                        /* diagnostic: loads issued but never staged (2: and no barrier) */
-                (void)0;
-#elif CMF_GEMM_DIAG == 3                                            /* diagnostic: stage at the END of the chunk */
-                if (k8 == G_BK - 8 + 0 && false) {}
-#else
                 if (k8 == (G_BK >= 32 ? G_BK - 16 : G_BK - 8) && more) { store_A(buf ^ 1); store_B(buf ^ 1); }
-#endif
             }
-#if CMF_GEMM_DIAG == 3
-            if (more) { store_A(buf ^ 1); store_B(buf ^ 1); }
-#endif
-#if CMF_GEMM_DIAG != 2 && CMF_GEMM_DIAG != 4                        /* 4: staged but no barrier */
             // LDS-only barrier: __syncthreads() also drains every outstanding global store (vmcnt(0)), and with the fused BN
             // backward this loop has stores in flight (the dZ by-product); the next chunk's loads were consumed by store_*()
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-#endif
             buf ^= 1;
         }
     }
@@ -835,7 +699,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
         if (p.trace) t_e[2] = wall_clock64();
         if (want_stats) lds_barrier();                   // all tile reads done: the LDS is reused for the column reduction
     };
-    // ---- direct form of the fast path (CMF_EPI_DIRECT): no transposition.  In the accumulator layout a store instruction
+    // ---- direct form of the fast path (kinds 0 / 1): no transposition.  In the accumulator layout a store instruction
     // of register r already writes two full 128-byte row segments (lanes 0-31: row rho(r), lanes 32-63: row rho(r) + 4), a
     // lane owns ONE column per accumulator block (its statistics are plain per-lane sums), and the producer's Z tile is read
     // with the same map -- every load of the epilogue is issued before its first store, there is no band loop, no LDS round
@@ -940,7 +804,7 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
         }
         stats_done = true;
     };
-    // ---- wave-private form of the fast path (backward kinds; CMF_EPI_WAVE): every wave transposes ITS OWN 32 x 64 block
+    // ---- wave-private form of the fast path (backward kinds): every wave transposes ITS OWN 32 x 64 block
     // rows through a private LDS tile and finishes them alone -- LDS operations of one wave execute in order, so between
     // the accumulator stores and the row reads there is no barrier and no wait, the four waves never meet until the column
     // sums are combined, and nobody idles while two of them spill a band (the banded form above: 2.5 us until the first
@@ -1079,9 +943,9 @@ __global__ __launch_bounds__(G_THREADS, (BM == 256 && BN == 256) ? 1 : (BM == 25
         }
         stats_done = true;
     };
-    if (fast_epi && epilogue_kind(p) == EPI && CMF_EMUL_DIAG != 8) {
-        if constexpr (CMF_EPI_DIRECT && BM == 128 && EPI <= 1 && !(CMF_EPI_WAVE & 2)) direct_epilogue(std::integral_constant<int, EPI>{});
-        else if constexpr ((CMF_EPI_WAVE & 1) && BM == 128 && BN == 128) wave_epilogue(std::integral_constant<int, EPI>{});
+    if (fast_epi && epilogue_kind(p) == EPI) {
+        if constexpr (BM == 128 && EPI <= 1) direct_epilogue(std::integral_constant<int, EPI>{});
+        else if constexpr (BM == 128 && BN == 128) wave_epilogue(std::integral_constant<int, EPI>{});
         else fast_epilogue(std::integral_constant<int, EPI>{});
     } else {
     if (p.split_k == 1)
@@ -1424,7 +1288,7 @@ extern "C" long long cmf_gemm_profile_records(cmf_gemm_launch_record *out, long 
     return (long long)g_gprof.used;
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EMUL = 0, int EPI = 0>
+template <int BM, int BN, bool A_T, bool B_T, int EPI = 0>
 static int launch(const GemmArgs &a, hipStream_t st)
 {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -1432,10 +1296,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
     dim3 grid(a.split_k > 1 ? 8 * ((a.split_k + 7) / 8) * tiles_m * tiles_n : 8 * per * tiles_n);
     const size_t lds_reg = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
     const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + 32) * sizeof(float);
-    // CMF_GEMM_LDS_PAD=bytes (experiment): request more LDS than the kernel uses so that fewer workgroups fit a CU and the
-    // kernels of other streams find free registers / LDS next to a GEMM (8192: two workgroups per CU instead of three)
-    static const size_t lds_pad = getenv("CMF_GEMM_LDS_PAD") ? (size_t)atoi(getenv("CMF_GEMM_LDS_PAD")) : 0;
-    const size_t lds = (lds_reg > lds_dir ? lds_reg : lds_dir) + lds_pad;
+    const size_t lds = lds_reg > lds_dir ? lds_reg : lds_dir;
     // the dynamic-LDS limit is a per-device attribute of the function: set once per (instantiation, device); cmf_gemm is
     // entered concurrently by the host threads of cmf_setconv_*_multi, hence the atomics
     static std::atomic<unsigned> set_mask[4];
@@ -1443,7 +1304,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
     (void)hipGetDevice(&dev);
     const unsigned bit = 1u << (dev & 31);
     if (dev >= 128 || !(set_mask[dev >> 5].load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EMUL, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return (int)hipGetLastError();
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
@@ -1460,35 +1321,15 @@ static int launch(const GemmArgs &a, hipStream_t st)
             g_trace_n = grid.x;
             GemmArgs t = a;
             t.trace = g_trace_buf;
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL, EPI>), grid, dim3(G_THREADS), lds, st, t);
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, t);
             gprof_close(pe, st);
             return cmf_launch_status();
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EMUL, EPI>), grid, dim3(G_THREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, a);
     gprof_close(pe, st);
     return cmf_launch_status();
 }
-
-// Arithmetic of the interior-tile main loop of the 128 x 128 kernels: 0 = v_mfma_f32_32x32x2_f32 (exact fp32 products),
-// 1 = "bf16x3": every fp32 operand split exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per 16 k with fp32
-// accumulation (fp32-grade: the dropped terms are below 2^-26 |a||b|).  Initial value from CMF_GEMM_MODE.
-namespace {
-int initial_gemm_mode()
-{
-    const char *e = getenv("CMF_GEMM_MODE");
-    if (e && !strcmp(e, "bf16x3")) return 1;
-    if (e && (!strcmp(e, "fp32") || !strcmp(e, "f32"))) return 0;
-    return CMF_GEMM_DEFAULT_MODE;
-}
-std::atomic<int> g_gemm_mode{initial_gemm_mode()};
-}
-extern "C" int cmf_gemm_set_mode(int mode)
-{
-    if (mode != 0 && mode != 1) return -1;
-    return g_gemm_mode.exchange(mode);
-}
-extern "C" int cmf_gemm_get_mode(void) { return g_gemm_mode.load(); }
 
 extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
                         const float *A, long long lda, const float *B, long long ldb, float *C, long long ldc,
@@ -1521,9 +1362,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     // loop applies it once per staged element, the LDS-direct loop on every wave's fragments inside the MFMA stream --
     // measured in the step, isolated: 256 x 512 x 524288 / 262144 / 131072 at 117.6 / 117.9 / 114.4 TF staged against
     // 111.7 / 110.3 / 108.7 direct; the short contractions (K = 16384) lose 2-3 % and stay direct.
-    // CMF_GEMM_DW_DIRECT=1 restores the LDS-direct loop for this layout (A/B).
-    static const int dw_direct = (getenv("CMF_GEMM_DW_DIRECT") && getenv("CMF_GEMM_DW_DIRECT")[0] == '1') ? 1 : 0;
-    g.no_direct = (no_direct || (a_t && !b_t && prob_a && K >= 32768 && !dw_direct)) ? 1 : 0;
+    g.no_direct = (no_direct || (a_t && !b_t && prob_a && K >= 32768)) ? 1 : 0;
     static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
     g.diag = diag_rt;
     g.trace = nullptr;
@@ -1532,7 +1371,6 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     const bool thin_done = (err == 0);
     if (thin_done) gprof_count(2.0 * M * N * K);         // thin kernels: counted in flops_all, never bracketed
     const bool wide = N > 64, tall = M > 64;
-    const bool emul = g_gemm_mode.load(std::memory_order_relaxed) == 1;
     // instantiated (layout, kind) pairs: forward GEMMs (A[M][K], W[N][K]) carry kind 0 / 1, data gradients (dZ[M][N], W[N][K])
     // kind 0 / 2 / 3, weight gradients and the rest kind 0; any other pairing runs the kind-0 kernel, whose generic loop
     // handles every epilogue
@@ -1540,17 +1378,8 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     // [256 x 128 tiles at 2 workgroups per CU (wave tile 128 x 64) were measured against this: 107 vs 118 TF on
     //  524288 x 256 x 512, 26.2 vs 24.6 ms per training step -- two waves per SIMD do not cover each other's stalls.]
 #define CMF_PICK(AT, BT, EP)                                                                               \
-    (tall ? (wide ? (emul ? launch<128, 128, AT, BT, 1, EP>(g, st) : launch<128, 128, AT, BT, 0, EP>(g, st)) \
-                  : launch<128, 64, AT, BT, 0, EP>(g, st))                                                 \
-          : (wide ? launch<64, 128, AT, BT, 0, EP>(g, st) : launch<64, 64, AT, BT, 0, EP>(g, st)))
-#if CMF_GEMM_T256
-    // experiment: 256 x 256 tiles, one workgroup per CU, wave tile 128 x 128 (half the LDS and L2 bytes per flop)
-    const bool t256 = !emul && kind == 0 && M % 256 == 0 && N % 256 == 0 && M >= 256 && N >= 256;
-    if (!thin_done && t256 && !a_t && b_t) err = launch<256, 256, false, true, 0, 0>(g, st);
-    else if (!thin_done && t256 && a_t && !b_t) err = launch<256, 256, true, false, 0, 0>(g, st);
-    else if (!thin_done && t256 && !a_t && !b_t) err = launch<256, 256, false, false, 0, 0>(g, st);
-    else
-#endif
+    (tall ? (wide ? launch<128, 128, AT, BT, EP>(g, st) : launch<128, 64, AT, BT, EP>(g, st)) \
+          : (wide ? launch<64, 128, AT, BT, EP>(g, st) : launch<64, 64, AT, BT, EP>(g, st)))
     if (thin_done)         err = 0;
     else if (!a_t && b_t)  err = kind == 1 ? CMF_PICK(false, true, 1) : CMF_PICK(false, true, 0);
     else if (!a_t && !b_t) err = kind == 2 ? CMF_PICK(false, false, 2) : kind == 3 ? CMF_PICK(false, false, 3) :
@@ -1579,7 +1408,6 @@ extern "C" int cmf_gemm_dw_bn_bwd(int cout, int cin, long long rows, const float
     CMF_CHECK_ARG(dU && Z && a && mean && invstd && sums && X && dW && (split_k == 1 || workspace));
     CMF_CHECK_ARG(ldu % 4 == 0 && ldz % 4 == 0 && ldx % 4 == 0 && (!dZ_out || ldo % 4 == 0));
     CMF_CHECK_ARG((((uintptr_t)dU | (uintptr_t)Z | (uintptr_t)X | (uintptr_t)dZ_out) & 15) == 0);
-    CMF_CHECK_ARG(g_gemm_mode.load(std::memory_order_relaxed) == 0);          // fp32 main loop only
     hipStream_t st = (hipStream_t)stream;
     GemmArgs g{};
     g.M = cout; g.N = cin; g.K = (int)rows; g.A = dU; g.lda = ldu; g.B = X; g.ldb = ldx;
@@ -1590,7 +1418,7 @@ extern "C" int cmf_gemm_dw_bn_bwd(int cout, int cin, long long rows, const float
     g.no_direct = 1;
     static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
     g.diag = diag_rt;
-    const int err = launch<128, 128, true, false, 0, 0>(g, st);
+    const int err = launch<128, 128, true, false, 0>(g, st);
     if (err) return err;
     if (split_k > 1) return cmf_splitk_reduce(cout, cin, split_k, workspace, dW, lddw, accumulate, st);
     return 0;

@@ -143,11 +143,6 @@ int cmf_gemm(int M, int N, int K, int a_t, int b_t,
              const float *ea, const float *ec, const float *emean, const float *einvstd,
              const float *dxyz, int split_k, float *workspace, int accumulate, void *stream);
 int cmf_gemm_tiles_m(int M);
-/* Arithmetic of the tiled kernel's main loop: 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = "bf16x3" (each fp32 operand
- * split exactly into three bf16 pieces, six bf16 MFMAs per 16 k, fp32 accumulation: fp32-grade results).  _set returns
- * the previous mode (-1: invalid argument).  Process-wide; the initial value comes from CMF_GEMM_MODE=fp32|bf16x3. */
-int cmf_gemm_set_mode(int mode);
-int cmf_gemm_get_mode(void);
 
 /* Live timing of the tiled GEMM kernel for bench.py's `roofline` object.  Between _begin and _end every launch of the
  * tiled kernel with 2*M*N*K >= min_flops is bracketed by a HIP event pair on the stream it is launched on -- inside

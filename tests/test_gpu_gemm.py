@@ -14,18 +14,6 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["fp32", "bf16x3"])
-def gemm_mode(request):
-    """Every kernel-level check runs under both arithmetic modes of the tiled kernel's main loop (cmf_gemm_set_mode)."""
-    from cmflow_amd import _lib
-    if request.param == "bf16x3" and "emulation_is_fp32_grade" in request.node.name:
-        pytest.skip("compares the two modes itself (child processes)")
-    prev = _lib.set_gemm_mode(request.param)
-    yield request.param
-    _lib.set_gemm_mode(prev)
-
-
-
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available()
@@ -208,54 +196,12 @@ def test_thin_gemm_weight_gradient(dev, M, N, K):
     np.testing.assert_allclose(acc[:, 4:].cpu().numpy(), (base[:, 4:] + dW).cpu().numpy(), rtol=1e-6, atol=1e-4 * float(dW.abs().max()))
 
 
-def test_bf16x3_emulation_is_fp32_grade(dev):
-    """The opt-in main loop on the bf16 matrix cores (CMF_GEMM_MODE=bf16x3): exact 3-way split of
-    every fp32 operand, six bf16 MFMAs per 16 k.  Its error against an fp64 product must sit in the same bound as the
-    fp32 MFMA path's.  The mode is read once per process, hence the child process."""
-    import subprocess
-    import sys
-    code = r'''
-import torch, sys
-sys.path.insert(0, %r)
-from cmflow_amd.fused import gemm
-from cmflow_amd.fused_blocks import gemm_dw
-dev = torch.device("cuda:0")
-torch.manual_seed(0)
-worst = 0.0
-for (M, N, K) in ((4096, 256, 512), (8192, 512, 256), (2048, 384, 1040)):
-    A = torch.randn(M, K, device=dev) * torch.logspace(-3, 3, K, device=dev)       # wide dynamic range across k
-    W = torch.randn(N, K, device=dev)
-    ref = A.double() @ W.double().t()
-    bound = A.double().abs() @ W.double().abs().t()
-    err = ((gemm(A, W).double() - ref).abs() / bound).max().item()
-    dZ = torch.randn(M, N, device=dev)
-    refx = dZ.double() @ W.double()
-    errx = ((gemm(dZ, W, b_t=False).double() - refx).abs() / (dZ.double().abs() @ W.double().abs())).max().item()
-    refw = dZ.double().t() @ A.double()
-    errw = ((gemm_dw(dZ, A).double() - refw).abs() / (dZ.double().abs().t() @ A.double().abs())).max().item()
-    worst = max(worst, err, errx, errw)
-print("WORST", worst)
-''' % REPO
-    env = dict(os.environ)
-    out = {}
-    for mode in ("bf16x3", "f32"):
-        env["CMF_GEMM_MODE"] = mode
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out[mode] = float(r.stdout.strip().split("WORST")[-1])
-    print("max |err| / (|A||B|): fp32 MFMA %.3g, bf16x3 %.3g" % (out["f32"], out["bf16x3"]))
-    assert out["f32"] < 2e-6 and out["bf16x3"] < 2e-6
-    assert out["bf16x3"] < 4 * out["f32"] + 1e-7
-
-
 @pytest.mark.parametrize("rows,cout,cin", [(65536, 64, 32), (4096, 32, 32), (16384, 64, 64), (1000, 64, 64), (333, 24, 20), (128 * 1030 + 5, 32, 64)])
 @pytest.mark.parametrize("train,in_mode,dxyz", [(True, 1, False), (True, 1, True), (True, 0, False), (False, 1, False)])
-def test_thin_bwd_layer_matches_fp64_and_three_kernel_form(dev, gemm_mode, rows, cout, cin, train, in_mode, dxyz):
+def test_thin_bwd_layer_matches_fp64_and_three_kernel_form(dev, rows, cout, cin, train, in_mode, dxyz):
     """cmf_thin_bwd_layer (BN backward + weight gradient + masked data gradient in one pass) against (a) the fp64
     formulas of its header comment, tolerance 2e-6 * sum|terms|, and (b) the three kernels it replaces
     (cmf_bn_bwd_apply, cmf_gemm a_t, cmf_gemm with the backward epilogue): the masks must agree exactly."""
-    if gemm_mode != "fp32":
-        pytest.skip("thin kernels have one arithmetic")
     import ctypes
     from cmflow_amd import _lib
     from cmflow_amd.fused import gemm
@@ -323,11 +269,9 @@ def test_thin_bwd_layer_matches_fp64_and_three_kernel_form(dev, gemm_mode, rows,
 
 
 @pytest.mark.parametrize("n_tail,cin,Kp", [(0, 3, 4), (0, 64, 64), (4, 1028, 1040), (2, 10, 12)])
-def test_stacked_first_conv_weight_gather_and_gradient_scatter(dev, gemm_mode, n_tail, cin, Kp):
+def test_stacked_first_conv_weight_gather_and_gradient_scatter(dev, n_tail, cin, Kp):
     """cmf_stack_first_conv / cmf_unstack_first_conv_grad against the slice / cat / pad expressions they replace
     (radarflow_util.py:132-139 by linearity): pure data movement, so bit-exact."""
-    if gemm_mode != "fp32":
-        pytest.skip("no GEMM involved")
     import ctypes
     from cmflow_amd import _lib
     L = _lib.lib()
@@ -360,12 +304,10 @@ def test_stacked_first_conv_weight_gather_and_gradient_scatter(dev, gemm_mode, n
 
 @pytest.mark.parametrize("P,S,cout,cin,train", [(4096, 4, 64, 32, True), (2048, 32, 64, 32, True), (1024, 8, 64, 64, True),
                                                (2048, 16, 32, 32, False)])
-def test_pooled_thin_bwd_layer_matches_materialised_gradient(dev, gemm_mode, P, S, cout, cin, train):
+def test_pooled_thin_bwd_layer_matches_materialised_gradient(dev, P, S, cout, cin, train):
     """cmf_maxpool_bwd_point + cmf_thin_bwd_layer_pooled (the gradient of the pooled tensor kept per point) against
     cmf_maxpool_bwd + cmf_thin_bwd_layer on the materialised [P*S, C] gradient: same masks, same non-zero entries; the
     BN-backward sums are grouped differently (per 128 points vs per 128 rows), hence tolerances of a few fp32 ulps."""
-    if gemm_mode != "fp32":
-        pytest.skip("thin kernels have one arithmetic")
     import ctypes
     from cmflow_amd import _lib, fused_blocks as FB
     L = _lib.lib()
@@ -413,12 +355,10 @@ def test_pooled_thin_bwd_layer_matches_materialised_gradient(dev, gemm_mode, P, 
 
 @pytest.mark.parametrize("P,S,cin,train,pooled", [(2048, 8, 256, True, True), (1024, 32, 128, True, True), (4096, 4, 256, False, True),
                                                   (2048, 16, 256, True, False), (512, 4, 384, True, False)])
-def test_wide_thin_bwd_layer_matches_three_kernel_form(dev, gemm_mode, P, S, cin, train, pooled):
+def test_wide_thin_bwd_layer_matches_three_kernel_form(dev, P, S, cin, train, pooled):
     """cmf_thin_bwd_wide_layer (64 <- cin in {128, 256, ...}: the 256 -> 64 conv of a second-encoder block, backward in one
     pass, optionally straight from the per-point max-pool gradient) against max-pool backward + BN backward in place + the
     two tiled GEMMs it replaces.  Same masks; sums regrouped: tolerance of a few fp32 ulps of the accumulated magnitudes."""
-    if gemm_mode != "fp32":
-        pytest.skip("thin kernels have one arithmetic")
     import ctypes
     from cmflow_amd import _lib, fused_blocks as FB
     from cmflow_amd.fused import gemm
@@ -468,14 +408,12 @@ def test_wide_thin_bwd_layer_matches_three_kernel_form(dev, gemm_mode, P, S, cin
 
 
 @pytest.mark.parametrize("N,S", [(40, 16), (48, 16), (56, 16), (24, 32), (250, 4)])
-def test_setconv_block_small_m_matches_python_sequence_and_stays_inside_its_arena(dev, gemm_mode, N, S, monkeypatch):
+def test_setconv_block_small_m_matches_python_sequence_and_stays_inside_its_arena(dev, N, S, monkeypatch):
     """A second-encoder set-conv block (512 -> 256 -> 64 | 64 -> 64 -> 64) whose neighbourhood matrix has 640 ... 1000
     rows: the fused wide backward layer writes tiles128(M) weight-gradient slabs of 64 x 256 floats, more than the split-K
     rule of the tiled kernels asks for at that size -- the arena of cmf_setconv_backward must be sized for them (round-2
     advisor finding).  The block call (one C-ABI call per direction) against the same kernels sequenced from Python
     (SetConvFn, separately allocated buffers), and a guard band behind the block's scratch arena that must stay untouched."""
-    if gemm_mode != "fp32":
-        pytest.skip("one arithmetic is enough")
     from cmflow_amd import fused_blocks as FB
     from cmflow_amd.radarflow_util import PointLocalFeature
     torch.manual_seed(N * 100 + S)
@@ -516,12 +454,10 @@ def test_setconv_block_small_m_matches_python_sequence_and_stays_inside_its_aren
         assert float((a[2][k] - b[2][k]).abs().max()) <= 2e-5 * scale(a[2][k]), k
 
 
-def test_gemm_relu_epilogues_select_on_non_finite_values(dev, gemm_mode):
+def test_gemm_relu_epilogues_select_on_non_finite_values(dev):
     """ReLU / masks in the fast epilogues are selects, not multiplications by a zero slope: a pre-activation of -inf gives 0
     (0 * -inf would be NaN) and an infinite gradient at a masked position gives 0, in interior tiles (fast path) and edge
     tiles (generic loop) alike -- the same values torch.relu and a boolean mask produce (round-2 advisor finding)."""
-    if gemm_mode != "fp32":
-        pytest.skip("the experimental bf16 split has no defined result for infinite operands (inf - inf in the split)")
     from cmflow_amd.fused import gemm
     g = torch.Generator().manual_seed(9)
     M, N, K = 300, 256, 64                                           # two interior row tiles + one edge tile
@@ -549,12 +485,10 @@ def test_gemm_relu_epilogues_select_on_non_finite_values(dev, gemm_mode):
 
 @pytest.mark.parametrize("M,chans,train", [(16384, (512, 256, 128, 64), True), (16384, (512, 256, 128, 64), False), (300, (16, 8, 4), True),
                                             (1000, (64, 64, 64, 64, 64), True)])
-def test_mlp_chain_block_call_equals_python_sequence(dev, gemm_mode, M, chans, train):
+def test_mlp_chain_block_call_equals_python_sequence(dev, M, chans, train):
     """cmf_mlp_forward / _backward (the heads' [conv + BN + ReLU] stacks sequenced by the library) against the same kernels
     sequenced from Python (fused_blocks.MLPChainFn): outputs, input gradient, every parameter gradient and the BN running
     statistics bit-identical -- with gradients returned as tensors and with gradients accumulated into existing .grad."""
-    if gemm_mode != "fp32":
-        pytest.skip("one arithmetic is enough")
     from cmflow_amd import fused_blocks as FB
     torch.manual_seed(M + len(chans))
 
@@ -608,8 +542,6 @@ def test_weight_gradient_gemm_with_fused_bn_backward(rows, cout, cin, split):
     BN + ReLU on B: bit-identical dW and dZ (same operations, same loop), and against an fp64 evaluation."""
     from cmflow_amd import _lib
     from cmflow_amd.fused import gemm
-    if _lib.gemm_mode() != "fp32":
-        pytest.skip("fp32 main loop only")
     dev = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(rows + cout)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev)

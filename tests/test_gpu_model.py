@@ -25,22 +25,6 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["fp32"])
-def gemm_mode(request):
-    """The arithmetic mode of cmf_gemm's main loop the model-level parity tests run under (cmf_gemm_set_mode).  Only the
-    product's mode, the fp32 MFMA.  The experimental 3-way bf16 split ("bf16x3") was put through this whole file in round
-    2 (add it to `params`): the goldens at B <= 8 pass, but at the benchmark's size it exceeds the bounds written in
-    test_full_size_* (rotation 2.3e-6 rad, single-point flow 6e-4) and -- with the encoder scales on side streams -- its
-    results are not bit-reproducible from run to run (test_side_streams_do_not_change_results, test_two_rank_*), so it
-    stays an opt-in experiment.  The kernel-level checks of tests/test_gpu_gemm.py run both modes."""
-    from cmflow_amd import _lib
-    if request.param == "bf16x3" and any(k in request.node.name for k in ("-ref", "-pm_torch", "rccl", "[ref", "[pm_torch")):
-        pytest.skip("path without cmf_gemm: one mode is enough")
-    prev = _lib.set_gemm_mode(request.param)
-    yield request.param
-    _lib.set_gemm_mode(prev)
-
-
 def _load(golden_dir, name):
     with np.load(os.path.join(golden_dir, name + ".npz")) as z:
         return {k: z[k] for k in z.files}
@@ -710,7 +694,7 @@ def test_dense_cloud_forward_matches_oracle(dev, manifest, golden_dir, args):
     assert float((got[2].cpu() - want[2]).abs().max()) < 1e-4
 
 
-def test_bench_two_ranks_control_flow(dev, gemm_mode):
+def test_bench_two_ranks_control_flow(dev):
     """bench.py under torch.distributed.run with two ranks (both on cuda:0 over gloo, CMF_BENCH_ONE_GPU=1): every
     collective of the script -- parameter broadcast, the gradient all-reduce inside every step INCLUDING the extra
     isolated-roofline steps after the timed region, the max-over-ranks of the time -- is entered by both ranks, rank 0
@@ -723,7 +707,7 @@ def test_bench_two_ranks_control_flow(dev, gemm_mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, CMF_BENCH_ONE_GPU="1", CMF_GEMM_MODE=gemm_mode)
+    env = dict(os.environ, CMF_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
@@ -735,7 +719,7 @@ def test_bench_two_ranks_control_flow(dev, gemm_mode):
     assert rec["roofline"] is not None and rec["roofline_isolated"] is not None and rec["value"] > 0
 
 
-def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path, gemm_mode):
+def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path):
     """SURVEY 8e's parity check on the REAL model: a 2-rank data-parallel training step (both ranks on cuda:0 over gloo,
     tests/dp_worker.py; global B=8 -> 4+4) against single-process runs on each shard.
       * rank r's forward outputs, loss and LOCAL gradient bucket == a single-process run on shard r (same kernels:
@@ -757,7 +741,7 @@ def test_two_rank_cmflow_step_matches_single_rank_shards(dev, tmp_path, gemm_mod
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "tests", "dp_worker.py"), str(tmp_path), "8"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, CMF_GEMM_MODE=gemm_mode))
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ))
     assert out.returncode == 0, out.stderr[-3000:]
     ranks = [torch.load(os.path.join(tmp_path, "rank%d.pt" % r)) for r in range(2)]
     assert torch.equal(ranks[0]["averaged"], ranks[1]["averaged"])

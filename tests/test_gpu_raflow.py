@@ -22,17 +22,6 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(autouse=True, params=["fp32"])
-def gemm_mode(request):
-    """The product's arithmetic mode of cmf_gemm (see tests/test_gpu_model.py::gemm_mode for the experimental second one)."""
-    from cmflow_amd import _lib
-    if request.param == "bf16x3" and "ref" in request.node.name:
-        pytest.skip("path without cmf_gemm: one mode is enough")
-    prev = _lib.set_gemm_mode(request.param)
-    yield request.param
-    _lib.set_gemm_mode(prev)
-
-
 class A:
     num_points = 256
     rigid_thres = 0.15
