@@ -113,9 +113,9 @@ def gemm_shape_table(prof, title):
     rows = []
     for (M, N, K, layout, kind, split, bm, bn), (n, ms) in prof["shapes"].items():
         fl = 2.0 * M * N * K * n
-        rows.append((ms, "| %d x %d x %d | %s | %s | %d | %dx%d | %d | %.3f | %.1f | %.3f |" % (
-            M, N, K, ("A[M,K] W[N,K]", "A[M,K] B[K,N]", "A[K,M] B[K,N]", "A[K,M] B[N,K]")[(1, 0, 2, 3)[layout]],
-            ("store", "fwd bias/act/stats", "bwd BN+ReLU", "bwd (leaky) ReLU", "bwd BN+ReLU + dxyz sums", "bwd (leaky) ReLU + dxyz sums")[kind], split, bm, bn, n, ms,
+        rows.append((ms, "| %d x %d x %d | %s | %s | %d | %dx%s | %d | %.3f | %.1f | %.3f |" % (
+            M, N, K, ("A[M,K] W[N,K]", "A[M,K] B[K,N]", "A[K,M] B[K,N]", "A[K,M] B[N,K]")[(1, 0, 2, 3)[layout & 3]],
+            ("store", "fwd bias/act/stats", "bwd BN+ReLU", "bwd (leaky) ReLU", "bwd BN+ReLU + dxyz sums", "bwd (leaky) ReLU + dxyz sums")[kind], split, bm, ("%dp" % bn) if layout & 4 else str(bn), n, ms,
             fl / (ms * 1e-3) / 1e12, fl / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS)))
     rows.sort(reverse=True)
     tot_ms = prof["ms"]

@@ -33,6 +33,7 @@ SIGNATURES = {
     "cmf_gemm_dw_bn_bwd": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _ll, _ci, _vp,
                            _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
+    "cmf_gemm_persist_config": [_ci, _ci],
     "cmf_gemm_trace_arm": [],
     "cmf_gemm_trace_read": [_vp, _ll],
     "cmf_gemm_profile_begin": [ctypes.c_double],

@@ -1380,7 +1380,13 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
 #define CMF_PICK(AT, BT, EP)                                                                               \
     (tall ? (wide ? launch<128, 128, AT, BT, EP>(g, st) : launch<128, 64, AT, BT, EP>(g, st)) \
           : (wide ? launch<64, 128, AT, BT, EP>(g, st) : launch<64, 64, AT, BT, EP>(g, st)))
+    const int pgrid = thin_done ? 0 : cmf_pgemm_grid(g, a_t, b_t, kind);
     if (thin_done)         err = 0;
+    else if (pgrid) {
+        const long long pe = gprof_open(2.0 * M * N * K, st, &g, (a_t ? 2 : 0) | (b_t ? 1 : 0) | 4, 128, 128);      // layout bit 2: persistent kernel
+        err = cmf_pgemm_launch(g, kind, pgrid, st);
+        gprof_close(pe, st);
+    }
     else if (!a_t && b_t)  err = kind == 1 ? CMF_PICK(false, true, 1) : CMF_PICK(false, true, 0);
     else if (!a_t && !b_t) err = kind == 2 ? CMF_PICK(false, false, 2) : kind == 3 ? CMF_PICK(false, false, 3) :
                                  kind == 4 ? CMF_PICK(false, false, 4) : kind == 5 ? CMF_PICK(false, false, 5) : CMF_PICK(false, false, 0);

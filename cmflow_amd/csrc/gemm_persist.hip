@@ -1,0 +1,516 @@
+// Persistent form of the fp32 MFMA GEMM for the data-gradient / forward 1x1 convolutions of the set-conv stacks
+// (utils/model_utils/radarflow_util.py:151-153,215-221 and their autograd backward):
+//
+//     C[M,N] = epi( pro(A)[M,K] * B )        A[M][K] row-major, B = B[K][N] (data gradient) or W[N][K] (forward)
+//
+// Why a second kernel next to gemm.hip's: at K = 256 a 128 x 128 tile is 16 chunks of MFMAs (~37 us with three workgroups
+// sharing a CU) followed by an epilogue that reads 64 KB of the producer's Z, masks, sums statistics and writes 64 KB --
+// 20-23 us during which the workgroup issues no MFMA (profiles/r03_gemm_timeline_bwd.txt: on average 1.8 of a CU's three
+// workgroups are in their main loop).  Here a workgroup is PERSISTENT (grid = 2 per CU, tiles dealt statically, XCD-aware)
+// and keeps TWO accumulator sets: while tile t+1 accumulates, the finished tile t is written out in eight 8-row
+// sub-pieces, one per chunk, placed between the MFMA groups of chunks 1..8 of tile t+1 -- the Z rows of sub-piece s+1 are
+// requested a whole chunk before they are used, stores drain behind the MFMAs, and the operand pipeline (LDS-direct loads,
+// three stages, prefetch distance two) runs straight through tile boundaries, so the matrix pipe never sees an epilogue.
+// At two waves per SIMD each wave owns 256 registers: 64 + 64 accumulators, 32 fragment registers, the sub-piece's
+// working set.  Same MFMA sequence per output element as gemm.hip (same chunk order, same K-permutation) and the same
+// per-lane / per-wave / per-workgroup summation order of the column statistics: results are BIT-IDENTICAL to the
+// non-persistent kernel (tests/test_gpu_gemm.py::test_persistent_gemm_*).
+//
+// Scope: interior problems only (M, N multiples of 128, K a multiple of 16 with >= P_MIN_CHUNKS chunks, split_k = 1,
+// 16-byte aligned rows, no C +=); everything else stays on gemm.hip's kernels (cmf_pgemm_launch returns -1).
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include "cmf_common.h"
+#include "gemm_args.h"
+
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void *p_gptr;
+typedef __attribute__((address_space(3))) void *p_lptr;
+
+constexpr int P_THREADS = 256, P_BM = 128, P_BN = 128, P_BK = 16, P_NST = 3;
+constexpr int P_SLOTS = 128 * (P_BK / 4);                 // 16-byte slots of one operand chunk (A and B alike)
+constexpr int P_STAGE = 2 * P_SLOTS * 4 + 32;             // floats: A | B | pro_a[16] pro_c[16]
+constexpr int P_WDQ = 64 * 4, P_WFOLD = 10 * 64;
+constexpr int P_WSZ = P_WDQ + P_WFOLD;                    // per wave: dxyz rows of its 64 tile rows | half-wave fold of the column sums
+constexpr int P_RED = 2 * 5 * 128;                        // [wave row][statistic][column]
+constexpr int P_LDS_FLOATS = P_NST * P_STAGE + 4 * P_WSZ + P_RED;
+constexpr int P_MIN_CHUNKS = 12;                          // chunks 0..10 of a tile carry the previous tile's epilogue
+constexpr int P_NSUB = 8;                                 // 8-row sub-pieces of a wave's 64 x 64 tile
+
+#define P_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0F70)
+
+__device__ __forceinline__ int p_swz(int row) { return (((row >> 2) & 1) << 1) | (((row >> 1) & 1) ^ ((row >> 3) & 1)); }
+__device__ __forceinline__ unsigned p_lds_addr(const float *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const float *)p; }
+// Every LDS access of this kernel is inline asm: the compiler's waitcnt pass treats an LDS access it can see as possibly
+// aliasing the in-flight LDS-direct loads and drains them (vmcnt(0)) first.  Completion is awaited explicitly.
+template <int OFF>
+__device__ __forceinline__ pf32x4 p_read128(unsigned addr)
+{
+    pf32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ float p_read32(unsigned addr)
+{
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void p_write32(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void p_write128(unsigned addr, pf32x4 v) { asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(addr), "v"(v), "n"(OFF) : "memory"); }
+__device__ __forceinline__ void p_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void p_pin(pf32x4 &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void p_pin1(float &v) { asm volatile("" : "+v"(v)); }
+#define P_SB() __builtin_amdgcn_sched_barrier(0)
+
+// Streaming accesses (operand requests, the producer's Z, the output) are BUFFER instructions: a descriptor in four scalar
+// registers (rebuilt per tile from a uniform pointer), a scalar byte offset and ONE 32-bit per-lane offset.  With plain
+// pointers loop strength reduction turns every stream of the peeled loop into a per-lane 64-bit address: two registers
+// each, spilled, reloaded behind a vmcnt(0) in the middle of the MFMA stream.  A tile's rows lie within 4 GB of its first.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t p_rsrc(const void *q) { return __builtin_amdgcn_make_buffer_rsrc((void *)q, 0, -1, 0x00020000); }
+__device__ __forceinline__ int p_spin(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }   // opaque scalar
+
+// EPI: 2 backward through BN + ReLU, 3 backward through (leaky) ReLU, 4 / 5 the same with the three dxyz column sums
+// (gemm.hip epilogue_kind).  B_T: B stored [N][K] (forward layout) instead of [K][N].
+template <bool B_T, int EPI>
+__global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, const int grid_w)
+{
+    constexpr bool BNR = EPI == 2 || EPI == 4, WQ = EPI >= 4;
+    constexpr int NSTAT = WQ ? 5 : 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;                               // wave tile 64 x 64 at (wm, wn)
+    const int h = lane >> 5, cl = lane & 31;
+
+    // ---- tile walk: workgroup b lives on XCD b % 8 (round-robin dispatch); the column tiles that share an A row panel
+    // sit on consecutive slots of ONE XCD and are worked on at the same time by neighbouring workgroups of that XCD ----
+    const int tiles_m = p.M / P_BM, tiles_n = p.N / P_BN;
+    const int xcd = blockIdx.x & 7, w_in = blockIdx.x >> 3;
+    const int per = (tiles_m + 7) / 8;
+    const int rows_here = max(0, min(per, tiles_m - xcd * per));
+    const int nslots = rows_here * tiles_n;
+    const int n_my = w_in < nslots ? (nslots - w_in + grid_w - 1) / grid_w : 0;
+    if (n_my == 0) return;
+    const int nch = p.K / P_BK;
+
+    // ---- per-lane pieces of the LDS-direct source addresses (bytes) ----
+    // A (and B in the [N][K] layout): 16-byte slot sl = (q*4 + wid)*64 + lane -> row = sl >> 2, k-quad (sl & 3) ^ swz(row)
+    // B[K][N]: slot sl -> k = sl / 32, x = sl % 32 -> column quad x ^ (((k >> 2) & 1) * 8)
+    unsigned offA, offB;
+    {
+        const int row = wid * 16 + (lane >> 2);
+        offA = (unsigned)((row * (int)p.lda + 4 * ((lane & 3) ^ p_swz(row))) * 4);
+        if (B_T) offB = (unsigned)((row * (int)p.ldb + 4 * ((lane & 3) ^ p_swz(row))) * 4);
+        else {
+            const int k = wid * 2 + (lane >> 5);
+            offB = (unsigned)((k * (int)p.ldb + 4 * ((lane & 31) ^ (((k >> 2) & 1) * 8))) * 4);
+        }
+    }
+
+    // ---- fragment read addresses (bytes inside a stage) ----
+    // A rows [128][16] swizzled: row r, k-quad kq at slot r*4 + (kq ^ swz(r)); set w reads kq = 2w + h
+    unsigned fa[2], fb[2];
+    {
+        const int arow = wm * 64 + cl;
+        fa[0] = (unsigned)((arow * 4 + ((0 + h) ^ p_swz(arow))) * 16);
+        fa[1] = (unsigned)((arow * 4 + ((2 + h) ^ p_swz(arow))) * 16);                 // block row i = 1: + 32 rows = + 2048 bytes (same swizzle)
+        const int brow = wn * 64 + cl;
+        if (B_T) {
+            fb[0] = (unsigned)(P_SLOTS * 16 + (brow * 4 + ((0 + h) ^ p_swz(brow))) * 16);
+            fb[1] = (unsigned)(P_SLOTS * 16 + (brow * 4 + ((2 + h) ^ p_swz(brow))) * 16);
+        } else {                                                       // [16][128]: k rows of 512 bytes, column quads swizzled by (k >> 2) & 1 = h
+            fb[0] = (unsigned)(P_SLOTS * 16 + (4 * h) * 512 + (((((brow) >> 2) ^ (h * 8)) << 2) | (brow & 3)) * 4);
+            fb[1] = (unsigned)(P_SLOTS * 16 + (4 * h) * 512 + (((((brow + 32) >> 2) ^ (h * 8)) << 2) | (brow & 3)) * 4);   // j = 1
+        }
+    }
+    // ---- wave-private epilogue LDS (byte addresses) ----
+    const unsigned wbase = (unsigned)((P_NST * P_STAGE + wid * P_WSZ) * 4);
+    const unsigned w_dq = wbase + (unsigned)(h * 64);                                  // dxyz row 8 S + rr + 4 h: + (8 S + rr) * 16
+    const unsigned w_fold = wbase + (unsigned)(P_WDQ * 4 + cl * 4);                    // + (which * 2 + j) * 128
+    const unsigned red_base = (unsigned)((P_NST * P_STAGE + 4 * P_WSZ) * 4);
+
+    pf32x16 acc[2][2], accp[2][2];
+    pf32x4 af[2][2], bf[2][2];
+    float zq[4][2];                                                     // the producer's Z at the sub-piece's 4 registers x 2 block columns
+    float kc[4][2];                                                     // ea, ec, mean, invstd of the lane's two columns (previous tile)
+    float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f}, qs[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const float slope = p.bwd_mode == 2 ? 0.1f : 0.f;
+    const bool want_stats = p.stats != nullptr;
+
+    // tile coordinates: cur (accumulating), prv (being written out)
+    auto tile_of = [&](int j, int &tm, int &tn) { const int s = w_in + j * grid_w; tm = xcd * per + s / tiles_n; tn = s % tiles_n; };
+    int tm_c, tn_c, tm_p = 0, tn_p = 0;
+    tile_of(0, tm_c, tn_c);
+    // operand stream: descriptors of the tile's A row panel / B column panel, scalar byte offsets of the NEXT chunk to request
+    __amdgpu_buffer_rsrc_t rA, rB;
+    int soA = 0, soB = 0;
+    const int strideA_q = 64 * (int)p.lda * 4, strideB_q = (B_T ? 64 : 8) * (int)p.ldb * 4;      // q = 1: + 64 rows (A, B[N][K]) / + 8 k-rows (B[K][N])
+    const int chunkA = P_BK * 4, chunkB = B_T ? P_BK * 4 : P_BK * (int)p.ldb * 4;                // bytes per chunk along K
+    auto set_stream = [&](int tm, int tn) {
+        rA = p_rsrc(p.A + (long long)tm * P_BM * p.lda);
+        rB = p_rsrc(B_T ? p.B + (long long)tn * P_BN * p.ldb : p.B + tn * P_BN);
+        soA = 0; soB = 0;
+    };
+    set_stream(tm_c, tn_c);
+    int st_issue = 0;                                                  // stage the next request goes to
+    auto issue = [&]() {
+        float *sa = smem + st_issue * P_STAGE, *sb = sa + P_SLOTS * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p_lptr)(sa + wid * 256), 16, offA, soA, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p_lptr)(sa + (4 + wid) * 256), 16, offA, soA + strideA_q, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p_lptr)(sb + wid * 256), 16, offB, soB, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p_lptr)(sb + (4 + wid) * 256), 16, offB, soB + strideB_q, 0, 0);
+        soA = p_spin(soA + chunkA); soB = p_spin(soB + chunkB);
+        st_issue = st_issue == 2 ? 0 : st_issue + 1;
+    };
+    constexpr int DMA = 4;                                              // LDS-direct requests per wave and chunk
+
+    // fragment reads of set w (k-quads 2w + h) from the stage at byte offset sbyte: issued, not awaited
+    auto read_frags = [&](unsigned sbyte, auto wc) {
+        constexpr int w = decltype(wc)::value;
+        const unsigned a = sbyte + fa[w];
+        af[w][0] = p_read128<0>(a); af[w][1] = p_read128<2048>(a);
+        if (B_T) {
+            const unsigned b = sbyte + fb[w];
+            bf[w][0] = p_read128<0>(b); bf[w][1] = p_read128<2048>(b);
+        } else {
+            const unsigned b0 = sbyte + fb[0], b1 = sbyte + fb[1];
+            bf[w][0].x = p_read32<w * 4096 + 0>(b0); bf[w][0].y = p_read32<w * 4096 + 512>(b0);
+            bf[w][0].z = p_read32<w * 4096 + 1024>(b0); bf[w][0].w = p_read32<w * 4096 + 1536>(b0);
+            bf[w][1].x = p_read32<w * 4096 + 0>(b1); bf[w][1].y = p_read32<w * 4096 + 512>(b1);
+            bf[w][1].z = p_read32<w * 4096 + 1024>(b1); bf[w][1].w = p_read32<w * 4096 + 1536>(b1);
+        }
+    };
+    auto pin_frags = [&](int w) { p_pin(af[w][0]); p_pin(af[w][1]); p_pin(bf[w][0]); p_pin(bf[w][1]); };
+    // 4 MFMAs: component t of fragment set w against the four accumulator blocks; first: the tile's first product (C = 0)
+    auto mfma4 = [&](int w, int t, bool first) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (first) { const pf32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], z, 0, 0, 0); }
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], acc[i][j], 0, 0, 0);
+            }
+    };
+
+    // ---- epilogue of the PREVIOUS tile, in pieces, in the accumulator layout ----
+    // register r of block (I, j) holds row 32 I + (r & 3) + 8 (r >> 2) + 4 h, column 32 j + cl: a store of one register writes
+    // two full 128-byte row segments, a lane owns ONE column per block column -- its statistics are plain per-lane sums and
+    // its four constants sit in registers.  Sub-piece S = 4 I + Q: registers 4 Q .. 4 Q + 3 of blocks (I, 0), (I, 1) = rows
+    // 8 S + rr + 4 h of the wave tile.
+    __amdgpu_buffer_rsrc_t rZ, rC;                                       // descriptors at the wave tile's first row, first column
+    const unsigned lane_z = (unsigned)((4 * h * (int)p.ldz + cl) * 4), lane_c = (unsigned)((4 * h * (int)p.ldc + cl) * 4);
+    const int ldzb = (int)p.ldz * 4, ldcb = (int)p.ldc * 4;
+    int z_so = 0, c_so = 0;                                              // byte offsets of the next sub-piece to load / to store (rows 8 S)
+    auto set_prev = [&]() {
+        const long long r0 = (long long)tm_p * P_BM + wm * 64;
+        const int n0 = tn_p * P_BN + wn * 64;
+        rZ = p_rsrc(p.Z + r0 * p.ldz + n0);
+        rC = p_rsrc(p.C + r0 * p.ldc + n0);
+        z_so = 0; c_so = 0;
+    };
+    // (a) per-tile constants: the lane's two columns of (ea, ec, mean, invstd) -> registers; the wave's 64 dxyz rows -> LDS
+    pf32x4 dqv;
+    auto const_load = [&]() {
+        const int c = tn_p * P_BN + wn * 64 + cl;
+        if (BNR) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { kc[0][j] = p.ea[c + 32 * j]; kc[1][j] = p.ec[c + 32 * j]; kc[2][j] = p.emean[c + 32 * j]; kc[3][j] = p.einvstd[c + 32 * j]; }
+        }
+        if (WQ) dqv = *(const pf32x4 *)(p.dxyz + ((long long)tm_p * P_BM + wm * 64 + lane) * 4);
+    };
+    constexpr int CONST_VM = (BNR ? 8 : 0) + (WQ ? 1 : 0);
+    auto const_store = [&]() { if (WQ) p_write128<0>(wbase + (unsigned)(lane * 16), dqv); };
+    auto load_z = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        (void)S;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) zq[rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, lane_z + j * 128, z_so + rr * ldzb, 0));
+        z_so = p_spin(z_so + 8 * ldzb);
+    };
+    pf32x4 d4[2];
+    auto sub_lds_read = [&](auto sc, int rr0) {                          // dxyz rows of registers rr0, rr0 + 1 (two rows per read: h)
+        constexpr int S = decltype(sc)::value;
+        if (WQ) {
+            if (rr0 == 0) { d4[0] = p_read128<(8 * S + 0) * 16>(w_dq); d4[1] = p_read128<(8 * S + 1) * 16>(w_dq); }
+            else          { d4[0] = p_read128<(8 * S + 2) * 16>(w_dq); d4[1] = p_read128<(8 * S + 3) * 16>(w_dq); }
+        }
+    };
+    auto sub_pin = [&]() { if (WQ) { p_pin(d4[0]); p_pin(d4[1]); } };
+    // (b) arithmetic + stores of registers rr0, rr0 + 1 of sub-piece S (same operations per element as gemm.hip's epilogues)
+    float xo[4][2];
+    auto sub_compute = [&](auto sc, int rr0) {
+        constexpr int S = decltype(sc)::value, I = S >> 2, Q = S & 3;
+#pragma unroll
+        for (int rr = rr0; rr < rr0 + 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float x = j == 0 ? accp[I][0][4 * Q + rr] : accp[I][1][4 * Q + rr];
+                const float z = zq[rr][j];
+                if (BNR) {
+                    x = (fmaf(kc[0][j], z, kc[1][j]) > 0.f) ? x : 0.f;
+                    t1[j] += x; t2[j] += x * ((z - kc[2][j]) * kc[3][j]);
+                } else {
+                    x = z > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
+                    t1[j] += x;
+                }
+                if (WQ) { qs[0][j] += x * d4[rr - rr0].x; qs[1][j] += x * d4[rr - rr0].y; qs[2][j] += x * d4[rr - rr0].z; }
+                xo[rr][j] = x;
+            }
+    };
+    auto sub_store = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        (void)S;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xo[rr][j]), rC, lane_c + j * 128, c_so + rr * ldcb, 0);
+        c_so = p_spin(c_so + 8 * ldcb);
+    };
+    // (c) statistics: the lane's 32 rows -> the two half-waves (h = 0 + h = 1, what t + shfl_xor(t, 32) gives) ->
+    // [wave row][statistic][column] in LDS; after a workgroup barrier the two wave rows are added and stored per 128-row tile
+    auto stats_fold = [&]() {
+        auto fold = [&](float v0, float v1, auto whichc) {
+            constexpr int which = decltype(whichc)::value;
+            if (h == 1) { p_write32<(which * 2 + 0) * 128>(w_fold, v0); p_write32<(which * 2 + 1) * 128>(w_fold, v1); }
+            float u0 = p_read32<(which * 2 + 0) * 128>(w_fold), u1 = p_read32<(which * 2 + 1) * 128>(w_fold);
+            p_lds_wait();
+            p_pin1(u0); p_pin1(u1);
+            if (h == 0) {
+                const unsigned a = red_base + (unsigned)(((wm * NSTAT + which) * 128 + wn * 64 + cl) * 4);
+                p_write32<0>(a, v0 + u0); p_write32<128>(a, v1 + u1);
+            }
+        };
+        fold(t1[0], t1[1], std::integral_constant<int, 0>{});
+        fold(t2[0], t2[1], std::integral_constant<int, 1>{});
+        if (WQ) {
+            fold(qs[0][0], qs[0][1], std::integral_constant<int, 2>{});
+            fold(qs[1][0], qs[1][1], std::integral_constant<int, 3>{});
+            fold(qs[2][0], qs[2][1], std::integral_constant<int, 4>{});
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { t1[j] = 0.f; t2[j] = 0.f; qs[0][j] = 0.f; qs[1][j] = 0.f; qs[2][j] = 0.f; }
+    };
+    auto stats_store = [&]() {                                          // after a workgroup barrier behind stats_fold
+        for (int c = tid; c < NSTAT * 128; c += P_THREADS) {
+            const int which = c >> 7, cc = c & 127;
+            const unsigned a = red_base + (unsigned)((which * 128 + cc) * 4);
+            float v0 = p_read32<0>(a), v1 = p_read32<NSTAT * 128 * 4>(a);
+            p_lds_wait();
+            p_pin1(v0); p_pin1(v1);
+            p.stats[((long long)tm_p * NSTAT + which) * p.N + tn_p * P_BN + cc] = v0 + v1;
+        }
+    };
+
+    // ---- one chunk of the main loop ----
+    // HP: a previous tile is being written out.  CI: position in the tile (0..10 peeled, -1 rolled: no epilogue work).
+    int st_read = 0;                                                    // stage of the chunk being multiplied
+    auto chunk = [&](auto hpc, auto cic, bool do_issue) {
+        constexpr bool HP = decltype(hpc)::value;
+        constexpr int CI = decltype(cic)::value;
+        constexpr bool SUB = HP && CI >= 1 && CI <= P_NSUB;
+        constexpr int S = SUB ? CI - 1 : 0;
+        using SC = std::integral_constant<int, S>;
+        // vector-memory operations of this wave that are YOUNGER than the requests the chunk barrier has to cover (those were
+        // issued in the first half of the previous chunk): the second half of the previous chunk
+        constexpr int VM_PREV = !HP ? 0 : (CI == 1 ? CONST_VM + 8 : (CI >= 2 && CI <= P_NSUB ? 16 : (CI == P_NSUB + 1 ? 8 : 0)));
+        // ---- first half: fragment set 0 ----
+        mfma4(0, 0, CI == 0);
+        P_SB();
+        if (do_issue) issue();
+        P_SB();
+        mfma4(0, 1, false);
+        P_SB();
+        if (SUB) sub_lds_read(SC{}, 0);
+        P_SB();
+        mfma4(0, 2, false);
+        mfma4(0, 3, false);
+        P_SB();
+        p_lds_wait(); pin_frags(1);                                     // every LDS read of this chunk by this wave is complete
+        if (SUB) sub_pin();
+        // the next chunk's operands have landed (this wave's requests, then everybody's)
+        if (do_issue) { P_WAIT_VMCNT(DMA + VM_PREV); } else { P_WAIT_VMCNT(VM_PREV); }
+        __builtin_amdgcn_s_barrier();
+        const int sn = st_read == 2 ? 0 : st_read + 1;
+        const unsigned sbyte = (unsigned)(sn * P_STAGE * 4);
+        read_frags(sbyte, std::integral_constant<int, 0>{});            // in flight under the second half
+        P_SB();
+        // ---- second half: fragment set 1 ----
+        mfma4(1, 0, false);
+        P_SB();
+        if (HP && CI == 0) { const_load(); load_z(std::integral_constant<int, 0>{}); }
+        if (SUB) { sub_compute(SC{}, 0); sub_lds_read(SC{}, 2); }
+        if (HP && CI == P_NSUB + 1 && want_stats) stats_fold();
+        P_SB();
+        mfma4(1, 1, false);
+        P_SB();
+        if (SUB) { if (WQ) { p_lds_wait(); sub_pin(); } sub_compute(SC{}, 2); }
+        if (HP && CI == P_NSUB + 2 && want_stats) stats_store();
+        P_SB();
+        mfma4(1, 2, false);
+        P_SB();
+        if (SUB && S + 1 < P_NSUB) load_z(std::integral_constant<int, (S + 1 < P_NSUB ? S + 1 : 0)>{});
+        if (SUB) sub_store(SC{});
+        if (HP && CI == 0) const_store();
+        P_SB();
+        mfma4(1, 3, false);
+        P_SB();
+        p_lds_wait(); pin_frags(0);
+        read_frags(sbyte, std::integral_constant<int, 1>{});            // in flight under the next chunk's first half
+        st_read = sn;
+    };
+
+    // ---- pipeline start: two chunks requested, the first one visible, its fragments on the way ----
+    issue(); issue();
+    P_WAIT_VMCNT(DMA);
+    __builtin_amdgcn_s_barrier();
+    read_frags(0u, std::integral_constant<int, 0>{});
+    p_lds_wait(); pin_frags(0);
+    read_frags(0u, std::integral_constant<int, 1>{});
+
+    auto tile_body = [&](auto hpc, bool has_next, int tm_n, int tn_n) {
+        using HPC = decltype(hpc);
+        chunk(hpc, std::integral_constant<int, 0>{}, true);
+        chunk(hpc, std::integral_constant<int, 1>{}, true);
+        chunk(hpc, std::integral_constant<int, 2>{}, true);
+        chunk(hpc, std::integral_constant<int, 3>{}, true);
+        chunk(hpc, std::integral_constant<int, 4>{}, true);
+        chunk(hpc, std::integral_constant<int, 5>{}, true);
+        chunk(hpc, std::integral_constant<int, 6>{}, true);
+        chunk(hpc, std::integral_constant<int, 7>{}, true);
+        chunk(hpc, std::integral_constant<int, 8>{}, true);
+        chunk(hpc, std::integral_constant<int, 9>{}, true);
+#pragma unroll 1
+        for (int c = 10; c < nch; ++c) {
+            if (c + 2 == nch) set_stream(tm_n, tn_n);                   // the next two requests belong to the next tile
+            const bool go = c + 2 < nch || has_next;
+            if (c == 10) chunk(hpc, std::integral_constant<int, 10>{}, go);
+            else chunk(HPC{}, std::integral_constant<int, -1>{}, go);
+        }
+    };
+
+    for (int t = 0; t < n_my; ++t) {
+        const bool has_next = t + 1 < n_my;
+        int tm_n = 0, tn_n = 0;
+        if (has_next) tile_of(t + 1, tm_n, tn_n);
+        if (t == 0) tile_body(std::false_type{}, has_next, tm_n, tn_n);
+        else tile_body(std::true_type{}, has_next, tm_n, tn_n);
+        // tile switch: the finished accumulators become the previous tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
+        tm_p = tm_c; tn_p = tn_c; tm_c = tm_n; tn_c = tn_n;
+        set_prev();
+    }
+
+    // ---- drain: the last tile's epilogue, nothing to hide it behind ----
+    P_WAIT_VMCNT(0);
+    const_load(); load_z(std::integral_constant<int, 0>{});
+    const_store();
+    auto drain_sub = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        sub_lds_read(sc, 0);
+        p_lds_wait(); sub_pin();
+        sub_compute(sc, 0);
+        sub_lds_read(sc, 2);
+        p_lds_wait(); sub_pin();
+        sub_compute(sc, 2);
+        if (S + 1 < P_NSUB) load_z(std::integral_constant<int, (S + 1 < P_NSUB ? S + 1 : 0)>{});
+        sub_store(sc);
+    };
+    drain_sub(std::integral_constant<int, 0>{}); drain_sub(std::integral_constant<int, 1>{});
+    drain_sub(std::integral_constant<int, 2>{}); drain_sub(std::integral_constant<int, 3>{});
+    drain_sub(std::integral_constant<int, 4>{}); drain_sub(std::integral_constant<int, 5>{});
+    drain_sub(std::integral_constant<int, 6>{}); drain_sub(std::integral_constant<int, 7>{});
+    if (want_stats) {
+        stats_fold();
+        p_lds_wait();
+        __builtin_amdgcn_s_barrier();
+        stats_store();
+    }
+}
+
+// ---- host side ----
+namespace {
+std::atomic<int> g_pmode{-1};        // -1: from the environment on first use; 0 off; 1 auto (default); 2 wherever the shape allows
+std::atomic<int> g_pgrid{0};         // 0: two workgroups per CU
+int pmode()
+{
+    int m = g_pmode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *e = getenv("CMF_GEMM_PERSIST");
+        m = e ? atoi(e) : 1;
+        if (m < 0 || m > 2) m = 1;
+        g_pmode.store(m);
+    }
+    return m;
+}
+}  // namespace
+
+// mode: 0 never, 1 where it pays (default), 2 wherever the shape allows (tests); grid: workgroups (multiple of 8), 0 = 2 per CU
+extern "C" int cmf_gemm_persist_config(int mode, int grid)
+{
+    if (mode < 0 || mode > 2 || grid < 0 || (grid % 8) != 0) return -1;
+    g_pmode.store(mode); g_pgrid.store(grid);
+    return 0;
+}
+
+template <bool B_T, int EPI>
+static int plaunch(const GemmArgs &a, int grid, hipStream_t st)
+{
+    const size_t lds = (size_t)P_LDS_FLOATS * sizeof(float);
+    static std::atomic<unsigned> set_mask[4];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (dev >= 128 || !(set_mask[dev >> 5].load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute((const void *)pgemm_kernel<B_T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return (int)hipGetLastError();
+        if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((pgemm_kernel<B_T, EPI>), dim3(grid), dim3(P_THREADS), lds, st, a, grid / 8);
+    return cmf_launch_status();
+}
+
+// Workgroups of the persistent kernel for this call, or 0 when the call is not one it takes (the caller then uses gemm.hip's
+// kernels).  kind: gemm.hip epilogue_kind of the call.
+int cmf_pgemm_grid(const GemmArgs &g, int a_t, int b_t, int kind)
+{
+    const int mode = pmode();
+    if (mode == 0 || a_t || b_t || kind < 2 || kind > 5) return 0;
+    if (g.M % P_BM || g.N % P_BN || g.K % P_BK || g.K / P_BK < P_MIN_CHUNKS || g.split_k != 1 || g.accumulate || g.no_direct) return 0;
+    if (g.ldc % 4 || g.ldz % 4 || ((uintptr_t)g.C | (uintptr_t)g.Z) % 16 || g.pro_a || g.prob_a || g.diag || g.trace) return 0;
+    // 32-bit byte offsets inside a tile's panels: operand streams (rows of the panel + the whole contraction), 64 output rows
+    const long long lim = 1ll << 31;
+    if (128 * g.lda * 4 + (long long)g.K * 4 >= lim || ((long long)g.K + 16) * g.ldb * 4 >= lim || 72 * g.ldz * 4 >= lim || 72 * g.ldc * 4 >= lim) return 0;
+    if (kind >= 4 && !g.dxyz) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::atomic<int> cus[64];
+    int n = dev < 64 ? cus[dev].load(std::memory_order_relaxed) : 0;
+    if (!n) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) != hipSuccess) { (void)hipGetLastError(); return 0; } n = pr.multiProcessorCount; if (dev < 64) cus[dev].store(n); }
+    int grid = g_pgrid.load(std::memory_order_relaxed);
+    if (grid <= 0) grid = 2 * n;
+    grid = (grid + 7) / 8 * 8;
+    const long long tiles = (long long)(g.M / P_BM) * (g.N / P_BN);
+    if (mode == 1 && tiles < 3ll * grid) return 0;                   // fewer than three tiles per workgroup: the pipeline never fills
+    return grid;
+}
+
+int cmf_pgemm_launch(const GemmArgs &g, int kind, int grid, hipStream_t st)
+{
+    switch (kind) {
+    case 2: return plaunch<false, 2>(g, grid, st);
+    case 3: return plaunch<false, 3>(g, grid, st);
+    case 4: return plaunch<false, 4>(g, grid, st);
+    default: return plaunch<false, 5>(g, grid, st);
+    }
+}

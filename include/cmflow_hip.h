@@ -143,6 +143,13 @@ int cmf_gemm(int M, int N, int K, int a_t, int b_t,
              const float *ea, const float *ec, const float *emean, const float *einvstd,
              const float *dxyz, int split_k, float *workspace, int accumulate, void *stream);
 int cmf_gemm_tiles_m(int M);
+/* The persistent form of the tiled kernel (csrc/gemm_persist.hip: workgroups stay resident and write tile t out between the
+ * MFMAs of tile t + 1) takes the data-gradient calls with a backward epilogue on interior shapes (M, N multiples of 128,
+ * K a multiple of 16, K >= 192).  mode 0: never; 1: where a workgroup gets at least three tiles (default; also
+ * CMF_GEMM_PERSIST=0|1|2); 2: wherever the shape allows.  grid: its workgroup count (multiple of 8), 0 = two per CU.
+ * Outputs are bit-identical to the non-persistent kernel's; the column statistics are summed in a different (fixed) order.
+ * Returns 0, -1 on an invalid argument.  Process-wide. */
+int cmf_gemm_persist_config(int mode, int grid);
 
 /* Live timing of the tiled GEMM kernel for bench.py's `roofline` object.  Between _begin and _end every launch of the
  * tiled kernel with 2*M*N*K >= min_flops is bracketed by a HIP event pair on the stream it is launched on -- inside
@@ -158,7 +165,7 @@ int cmf_gemm_trace_arm(void);
 long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups);
 typedef struct cmf_gemm_launch_record {
     int M, N, K;          /* as passed to cmf_gemm (C is M x N, contraction K) */
-    int layout;           /* bit 1: a_t, bit 0: b_t */
+    int layout;           /* bit 1: a_t, bit 0: b_t, bit 2: persistent kernel */
     int split_k, kind;    /* epilogue kind: 0 raw store, 1 forward (bias/act/stats), 2 backward BN+ReLU, 3 backward (leaky) ReLU */
     int bm, bn;           /* block tile */
     float ms;             /* duration between the two events */

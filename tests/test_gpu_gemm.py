@@ -575,3 +575,57 @@ def test_weight_gradient_gemm_with_fused_bn_backward(rows, cout, cin, split):
     w64 = d64.t() @ torch.relu(pa.double() * X.double() + pc.double())
     assert float((dZ_ref.double() - d64).abs().max()) <= 2e-5 * float(d64.abs().max())
     assert float((dW_ref.double() - w64).abs().max()) <= 2e-5 * float(w64.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,grid", [(2048, 256, 256, 8), (1024, 384, 512, 16), (4096, 128, 192, 8), (2048, 256, 1040, 24),
+                                        (65536, 512, 256, 0)])
+@pytest.mark.parametrize("mode,dxyz", [(1, False), (1, True), (2, False), (3, True), (2, True)])
+def test_persistent_gemm_matches_tiled_kernel(dev, M, N, K, grid, mode, dxyz):
+    """csrc/gemm_persist.hip (persistent workgroups, the epilogue of tile t between the MFMAs of tile t + 1) against the
+    non-persistent kernel on the same call: the outputs must be BIT-identical (same MFMA sequence per element, masks decided
+    from the same Z), the column statistics equal up to their fp32 summation order (bound: 1e-6 * sum |terms|) and
+    bit-reproducible from run to run.  Small grids force several tiles per workgroup (tile switch, pipeline across tiles,
+    first and last tile); grid 0 is the product's (two workgroups per CU) on one of the model's shapes."""
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K + mode)
+    ldz = N + 8
+    dZ = torch.randn(M, K, generator=g).to(dev)
+    W = torch.randn(K, N + 4, generator=g).to(dev)[:, :N]                  # B[K][N] with a padded row stride
+    Zp = torch.randn(M, ldz, generator=g).to(dev)[:, :N]
+    ea, ec = (torch.rand(N, generator=g) + 0.5).to(dev), (0.3 * torch.randn(N, generator=g)).to(dev)
+    mean, invstd = torch.randn(N, generator=g).to(dev), (torch.rand(N, generator=g) + 0.5).to(dev)
+    d4 = torch.randn(M, 4, generator=g).to(dev) if dxyz else None
+    bwd = (mode, Zp, ea, ec, mean, invstd) if mode == 1 else (mode, Zp, None, None, None, None)
+    if dxyz:
+        bwd = bwd + (d4,)
+    want_stats = mode == 1 or dxyz
+
+    def run():
+        out = torch.full((M, N + 12), 7.0, device=dev)                     # the padding columns must stay untouched
+        r = gemm(dZ, W, b_t=False, bwd=bwd, stats=want_stats, out=out[:, 4:4 + N])
+        torch.cuda.synchronize()
+        return (out, r[1]) if want_stats else (out, None)
+
+    try:
+        assert L.cmf_gemm_persist_config(0, 0) == 0
+        ref, ref_st = run()
+        assert L.cmf_gemm_persist_config(2, grid) == 0
+        got, got_st = run()
+        got2, got2_st = run()
+    finally:
+        L.cmf_gemm_persist_config(1, 0)
+    assert torch.equal(got, ref)
+    assert torch.equal(got2, got)
+    if want_stats:
+        assert torch.equal(got_st, got2_st)
+        x = ref[:, 4:4 + N].double()
+        terms = [x.abs(), (x * ((Zp.double() - mean.double()) * invstd.double())).abs() if mode == 1 else x.abs() * 0]
+        if dxyz:
+            terms += [(x * d4[:, k:k + 1].double()).abs() for k in range(3)]
+        tiles = ref_st.shape[0]
+        for which, t in enumerate(terms):
+            bound = 1e-6 * t.view(tiles, 128, N).sum(1) + 1e-6
+            err = (got_st[:, which].double() - ref_st[:, which].double()).abs()
+            assert bool((err <= bound).all()), (which, float((err / bound).max()))

@@ -18,6 +18,10 @@ gemm_diag() {
     CMF_GEMM_DIAG_RT=8 python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq_noepi.txt
     python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq.txt
 }
+pgemm() {              # persistent GEMM: parity against the tiled kernel, then A/B rates on the model's data-gradient shapes
+    timeout 600 python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "persistent" 2>&1 | tail -15 > $R/pgemm_tests.txt; cat $R/pgemm_tests.txt
+    timeout 600 python tools/pgemm_bench.py 2>&1 | filter > $R/pgemm_bench.txt; cat $R/pgemm_bench.txt
+}
 gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
 gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment build (tools/diag/libcmflow_w3.so)
     for d in 0 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
