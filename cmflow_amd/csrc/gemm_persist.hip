@@ -32,8 +32,9 @@ typedef __attribute__((address_space(3))) void *p_lptr;
 constexpr int P_THREADS = 256, P_BM = 128, P_BN = 128, P_BK = 16, P_NST = 3;
 constexpr int P_SLOTS = 128 * (P_BK / 4);                 // 16-byte slots of one operand chunk (A and B alike)
 constexpr int P_STAGE = 2 * P_SLOTS * 4 + 32;             // floats: A | B | pro_a[16] pro_c[16]
-constexpr int P_WDQ = 64 * 4, P_WFOLD = 10 * 64;
-constexpr int P_WSZ = P_WDQ + P_WFOLD;                    // per wave: dxyz rows of its 64 tile rows | half-wave fold of the column sums
+constexpr int P_WDQ = 64 * 4, P_WZ = 2 * 8 * 64;
+constexpr int P_WSZ = P_WDQ + P_WZ;                       // per wave: dxyz rows of its 64 tile rows | two 8 x 64 buffers: the producer's Z rows of a
+                                                          // sub-piece arrive here (LDS-direct), its outputs leave through the same rows
 constexpr int P_RED = 2 * 5 * 128;                        // [wave row][statistic][column]
 constexpr int P_LDS_FLOATS = P_NST * P_STAGE + 4 * P_WSZ + P_RED;
 constexpr int P_MIN_CHUNKS = 12;                          // chunks 0..10 of a tile carry the previous tile's epilogue
@@ -131,12 +132,14 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     // ---- wave-private epilogue LDS (byte addresses) ----
     const unsigned wbase = (unsigned)((P_NST * P_STAGE + wid * P_WSZ) * 4);
     const unsigned w_dq = wbase + (unsigned)(h * 64);                                  // dxyz row 8 S + rr + 4 h: + (8 S + rr) * 16
-    const unsigned w_fold = wbase + (unsigned)(P_WDQ * 4 + cl * 4);                    // + (which * 2 + j) * 128
+    const unsigned w_za = wbase + (unsigned)(P_WDQ * 4 + h * 1024 + cl * 4);           // Z buffer, accumulator layout: + b * 2048 + rr * 256 + j * 128
+    const unsigned w_zr = wbase + (unsigned)(P_WDQ * 4 + lane * 16);                   // Z buffer, row layout (16 bytes per lane): + b * 2048 + u * 1024
+    const unsigned w_fold = wbase + (unsigned)(P_WDQ * 4 + cl * 4);                    // + (which * 2 + j) * 128 (over the idle Z buffers)
     const unsigned red_base = (unsigned)((P_NST * P_STAGE + 4 * P_WSZ) * 4);
 
     pf32x16 acc[2][2], accp[2][2];
     pf32x4 af[2][2], bf[2][2];
-    float zq[4][2];                                                     // the producer's Z at the sub-piece's 4 registers x 2 block columns
+    float zq[4][2];                                                     // the producer's Z at the sub-piece's 4 registers x 2 block columns (transient)
     float kc[4][2];                                                     // ea, ec, mean, invstd of the lane's two columns (previous tile)
     float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f}, qs[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const float slope = p.bwd_mode == 2 ? 0.1f : 0.f;
@@ -186,27 +189,38 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         }
     };
     auto pin_frags = [&](int w) { p_pin(af[w][0]); p_pin(af[w][1]); p_pin(bf[w][0]); p_pin(bf[w][1]); };
-    // 4 MFMAs: component t of fragment set w against the four accumulator blocks; first: the tile's first product (C = 0)
-    auto mfma4 = [&](int w, int t, bool first) {
+    // 4 MFMAs: component t of fragment set w against the four accumulator blocks.  first: the tile's first product (C = 0);
+    // with `keep` the finished tile's block moves to the second accumulator set right in front of the MFMA that overwrites
+    // it, so the 64 register moves of a tile switch run in the shadow of the first MFMAs instead of in front of them
+    auto mfma4 = [&](int w, int t, bool first, bool keep) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (first) { const pf32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                             if (keep) accp[i][j] = acc[i][j];
                              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], z, 0, 0, 0); }
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], acc[i][j], 0, 0, 0);
             }
+        if (first && keep) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { __builtin_amdgcn_sched_group_barrier(0x2, 16, 0); __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
+        }
     };
 
-    // ---- epilogue of the PREVIOUS tile, in pieces, in the accumulator layout ----
-    // register r of block (I, j) holds row 32 I + (r & 3) + 8 (r >> 2) + 4 h, column 32 j + cl: a store of one register writes
-    // two full 128-byte row segments, a lane owns ONE column per block column -- its statistics are plain per-lane sums and
-    // its four constants sit in registers.  Sub-piece S = 4 I + Q: registers 4 Q .. 4 Q + 3 of blocks (I, 0), (I, 1) = rows
-    // 8 S + rr + 4 h of the wave tile.
+    // ---- epilogue of the PREVIOUS tile, in pieces ----
+    // Arithmetic in the ACCUMULATOR layout: register r of block (I, j) holds row 32 I + (r & 3) + 8 (r >> 2) + 4 h, column
+    // 32 j + cl, so a lane owns ONE column per block column -- its statistics are plain per-lane sums and its four constants
+    // sit in registers.  Sub-piece S = 4 I + Q: registers 4 Q .. 4 Q + 3 of blocks (I, 0), (I, 1) = rows 8 S + rr + 4 h of the
+    // wave tile.  Memory in the ROW layout, through a wave-private 8 x 64 LDS buffer: the producer's Z rows of sub-piece S
+    // are requested LDS-direct two chunks ahead (two 1 KB requests, no registers, the HBM latency of a whole chunk and a
+    // half hidden -- measured: Z loaded into registers one chunk ahead cost 5 % of the kernel, eight 4-byte loads and
+    // stores per chunk another 4 %), read back element-wise, the results overwrite them in place and leave as 16-byte
+    // pieces of 256-byte row segments.
     __amdgpu_buffer_rsrc_t rZ, rC;                                       // descriptors at the wave tile's first row, first column
-    const unsigned lane_z = (unsigned)((4 * h * (int)p.ldz + cl) * 4), lane_c = (unsigned)((4 * h * (int)p.ldc + cl) * 4);
+    const unsigned lane_zr = (unsigned)(((lane >> 4) * (int)p.ldz + (lane & 15) * 4) * 4), lane_cr = (unsigned)(((lane >> 4) * (int)p.ldc + (lane & 15) * 4) * 4);
     const int ldzb = (int)p.ldz * 4, ldcb = (int)p.ldc * 4;
-    int z_so = 0, c_so = 0;                                              // byte offsets of the next sub-piece to load / to store (rows 8 S)
+    int z_so = 0, c_so = 0;                                              // byte offsets of the next sub-piece to request / to store (rows 8 S)
     auto set_prev = [&]() {
         const long long r0 = (long long)tm_p * P_BM + wm * 64;
         const int n0 = tn_p * P_BN + wn * 64;
@@ -226,14 +240,22 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     };
     constexpr int CONST_VM = (BNR ? 8 : 0) + (WQ ? 1 : 0);
     auto const_store = [&]() { if (WQ) p_write128<0>(wbase + (unsigned)(lane * 16), dqv); };
-    auto load_z = [&](auto sc) {
+    // Z rows of sub-piece S -> buffer S & 1 (rows 8 S .. 8 S + 3 and + 4 .. + 7: 16 lanes per row)
+    auto zdma = [&](auto sc) {
         constexpr int S = decltype(sc)::value;
-        (void)S;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) zq[rr][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rZ, lane_z + j * 128, z_so + rr * ldzb, 0));
+        float *zb = smem + P_NST * P_STAGE + wid * P_WSZ + P_WDQ + (S & 1) * 512;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (p_lptr)zb, 16, lane_zr, z_so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rZ, (p_lptr)(zb + 256), 16, lane_zr, z_so + 4 * ldzb, 0, 0);
         z_so = p_spin(z_so + 8 * ldzb);
+    };
+    auto z_read = [&](auto sc) {                                         // after the vmcnt wait that covers zdma(S)
+        constexpr int S = decltype(sc)::value, B = (S & 1) * 2048;
+        zq[0][0] = p_read32<B + 0>(w_za); zq[0][1] = p_read32<B + 128>(w_za); zq[1][0] = p_read32<B + 256>(w_za); zq[1][1] = p_read32<B + 384>(w_za);
+        zq[2][0] = p_read32<B + 512>(w_za); zq[2][1] = p_read32<B + 640>(w_za); zq[3][0] = p_read32<B + 768>(w_za); zq[3][1] = p_read32<B + 896>(w_za);
+    };
+    auto z_pin = [&]() {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { p_pin1(zq[rr][0]); p_pin1(zq[rr][1]); }
     };
     pf32x4 d4[2];
     auto sub_lds_read = [&](auto sc, int rr0) {                          // dxyz rows of registers rr0, rr0 + 1 (two rows per read: h)
@@ -244,10 +266,11 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         }
     };
     auto sub_pin = [&]() { if (WQ) { p_pin(d4[0]); p_pin(d4[1]); } };
-    // (b) arithmetic + stores of registers rr0, rr0 + 1 of sub-piece S (same operations per element as gemm.hip's epilogues)
-    float xo[4][2];
+    // (b) arithmetic of registers rr0, rr0 + 1 of sub-piece S (same operations per element as gemm.hip's epilogues); the results
+    // replace the Z values in the buffer
     auto sub_compute = [&](auto sc, int rr0) {
-        constexpr int S = decltype(sc)::value, I = S >> 2, Q = S & 3;
+        constexpr int S = decltype(sc)::value, I = S >> 2, Q = S & 3, B = (S & 1) * 2048;
+        float xo[2][2];
 #pragma unroll
         for (int rr = rr0; rr < rr0 + 2; ++rr)
 #pragma unroll
@@ -262,38 +285,47 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
                     t1[j] += x;
                 }
                 if (WQ) { qs[0][j] += x * d4[rr - rr0].x; qs[1][j] += x * d4[rr - rr0].y; qs[2][j] += x * d4[rr - rr0].z; }
-                xo[rr][j] = x;
+                xo[rr - rr0][j] = x;
             }
+        if (rr0 == 0) { p_write32<B + 0>(w_za, xo[0][0]); p_write32<B + 128>(w_za, xo[0][1]); p_write32<B + 256>(w_za, xo[1][0]); p_write32<B + 384>(w_za, xo[1][1]); }
+        else          { p_write32<B + 512>(w_za, xo[0][0]); p_write32<B + 640>(w_za, xo[0][1]); p_write32<B + 768>(w_za, xo[1][0]); p_write32<B + 896>(w_za, xo[1][1]); }
     };
-    auto sub_store = [&](auto sc) {
-        constexpr int S = decltype(sc)::value;
-        (void)S;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, xo[rr][j]), rC, lane_c + j * 128, c_so + rr * ldcb, 0);
+    pf32x4 t4[2];
+    auto out_read = [&](auto sc) { constexpr int B = (decltype(sc)::value & 1) * 2048; t4[0] = p_read128<B>(w_zr); t4[1] = p_read128<B + 1024>(w_zr); };
+    auto out_store = [&]() {                                             // behind the lgkmcnt wait + pin of t4
+        typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, t4[0]), rC, lane_cr, c_so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, t4[1]), rC, lane_cr, c_so + 4 * ldcb, 0);
         c_so = p_spin(c_so + 8 * ldcb);
     };
     // (c) statistics: the lane's 32 rows -> the two half-waves (h = 0 + h = 1, what t + shfl_xor(t, 32) gives) ->
     // [wave row][statistic][column] in LDS; after a workgroup barrier the two wave rows are added and stored per 128-row tile
     auto stats_fold = [&]() {
-        auto fold = [&](float v0, float v1, auto whichc) {
-            constexpr int which = decltype(whichc)::value;
-            if (h == 1) { p_write32<(which * 2 + 0) * 128>(w_fold, v0); p_write32<(which * 2 + 1) * 128>(w_fold, v1); }
-            float u0 = p_read32<(which * 2 + 0) * 128>(w_fold), u1 = p_read32<(which * 2 + 1) * 128>(w_fold);
-            p_lds_wait();
-            p_pin1(u0); p_pin1(u1);
-            if (h == 0) {
-                const unsigned a = red_base + (unsigned)(((wm * NSTAT + which) * 128 + wn * 64 + cl) * 4);
-                p_write32<0>(a, v0 + u0); p_write32<128>(a, v1 + u1);
-            }
-        };
-        fold(t1[0], t1[1], std::integral_constant<int, 0>{});
-        fold(t2[0], t2[1], std::integral_constant<int, 1>{});
+        float v[NSTAT][2];
+        v[0][0] = t1[0]; v[0][1] = t1[1]; v[1][0] = t2[0]; v[1][1] = t2[1];
         if (WQ) {
-            fold(qs[0][0], qs[0][1], std::integral_constant<int, 2>{});
-            fold(qs[1][0], qs[1][1], std::integral_constant<int, 3>{});
-            fold(qs[2][0], qs[2][1], std::integral_constant<int, 4>{});
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v[(2 + k) % NSTAT][0] = qs[k][0]; v[(2 + k) % NSTAT][1] = qs[k][1]; }
+        }
+        float u[NSTAT][2];
+        if (h == 1) {
+            p_write32<0 * 128>(w_fold, v[0][0]); p_write32<1 * 128>(w_fold, v[0][1]); p_write32<2 * 128>(w_fold, v[1][0]); p_write32<3 * 128>(w_fold, v[1][1]);
+            if (WQ) { p_write32<4 * 128>(w_fold, v[2 % NSTAT][0]); p_write32<5 * 128>(w_fold, v[2 % NSTAT][1]); p_write32<6 * 128>(w_fold, v[3 % NSTAT][0]);
+                      p_write32<7 * 128>(w_fold, v[3 % NSTAT][1]); p_write32<8 * 128>(w_fold, v[4 % NSTAT][0]); p_write32<9 * 128>(w_fold, v[4 % NSTAT][1]); }
+        }
+        u[0][0] = p_read32<0 * 128>(w_fold); u[0][1] = p_read32<1 * 128>(w_fold); u[1][0] = p_read32<2 * 128>(w_fold); u[1][1] = p_read32<3 * 128>(w_fold);
+        if (WQ) { u[2 % NSTAT][0] = p_read32<4 * 128>(w_fold); u[2 % NSTAT][1] = p_read32<5 * 128>(w_fold); u[3 % NSTAT][0] = p_read32<6 * 128>(w_fold);
+                  u[3 % NSTAT][1] = p_read32<7 * 128>(w_fold); u[4 % NSTAT][0] = p_read32<8 * 128>(w_fold); u[4 % NSTAT][1] = p_read32<9 * 128>(w_fold); }
+        p_lds_wait();
+#pragma unroll
+        for (int k = 0; k < NSTAT; ++k) { p_pin1(u[k][0]); p_pin1(u[k][1]); }
+        if (h == 0) {
+            const unsigned a = red_base + (unsigned)((wm * NSTAT * 128 + wn * 64 + cl) * 4);
+            p_write32<0 * 512>(a, v[0][0] + u[0][0]); p_write32<0 * 512 + 128>(a, v[0][1] + u[0][1]);
+            p_write32<1 * 512>(a, v[1][0] + u[1][0]); p_write32<1 * 512 + 128>(a, v[1][1] + u[1][1]);
+            if (WQ) { p_write32<2 * 512>(a, v[2 % NSTAT][0] + u[2 % NSTAT][0]); p_write32<2 * 512 + 128>(a, v[2 % NSTAT][1] + u[2 % NSTAT][1]);
+                      p_write32<3 * 512>(a, v[3 % NSTAT][0] + u[3 % NSTAT][0]); p_write32<3 * 512 + 128>(a, v[3 % NSTAT][1] + u[3 % NSTAT][1]);
+                      p_write32<4 * 512>(a, v[4 % NSTAT][0] + u[4 % NSTAT][0]); p_write32<4 * 512 + 128>(a, v[4 % NSTAT][1] + u[4 % NSTAT][1]); }
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) { t1[j] = 0.f; t2[j] = 0.f; qs[0][j] = 0.f; qs[1][j] = 0.f; qs[2][j] = 0.f; }
@@ -311,59 +343,73 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
 
     // ---- one chunk of the main loop ----
     // HP: a previous tile is being written out.  CI: position in the tile (0..10 peeled, -1 rolled: no epilogue work).
+    // last (rolled chunks): the tile's final chunk -- the tile becomes the "previous" one and its first Z rows are requested.
     int st_read = 0;                                                    // stage of the chunk being multiplied
-    auto chunk = [&](auto hpc, auto cic, bool do_issue) {
+    auto chunk = [&](auto hpc, auto cic, bool do_issue, bool last) {
         constexpr bool HP = decltype(hpc)::value;
         constexpr int CI = decltype(cic)::value;
         constexpr bool SUB = HP && CI >= 1 && CI <= P_NSUB;
         constexpr int S = SUB ? CI - 1 : 0;
         using SC = std::integral_constant<int, S>;
-        // vector-memory operations of this wave that are YOUNGER than the requests the chunk barrier has to cover (those were
-        // issued in the first half of the previous chunk): the second half of the previous chunk
-        constexpr int VM_PREV = !HP ? 0 : (CI == 1 ? CONST_VM + 8 : (CI >= 2 && CI <= P_NSUB ? 16 : (CI == P_NSUB + 1 ? 8 : 0)));
+        using SC2 = std::integral_constant<int, (S + 2 < P_NSUB ? S + 2 : 0)>;
+        // vector-memory LOADS of this wave that are YOUNGER than the requests the chunk barrier has to cover (those were issued in
+        // the first half of the previous chunk): the second half of the previous chunk.  Must never be over-counted -- and stores
+        // must not be counted at all: loads retire in order among themselves, but a store may retire before an older load, so
+        // "at most N operations outstanding" proves the requests landed only if N counts loads alone (with the 2 stores of a
+        // sub-piece counted, one launch in ten had a wave multiply a stale fragment: tools/pgemm_race.py).
+        //   final chunk of a tile: 2 (Z rows 0); chunk 0: constants + 2 (Z rows 1); chunks 1..6: 2 (Z rows S + 2)
+        constexpr int VM_PREV = !HP ? 0 : (CI == 0 ? 2 : (CI == 1 ? CONST_VM + 2 : (CI >= 2 && CI <= 7 ? 2 : 0)));
         // ---- first half: fragment set 0 ----
-        mfma4(0, 0, CI == 0);
+        // (set 1 of THIS chunk is requested here, not at the end of the previous chunk: no asynchronous LDS read may be in
+        // flight at a control-flow edge -- at the loop back-edges the compiler copies fragment registers between its
+        // per-block assignments, and a copy of a register whose data has not landed yet copies garbage: one launch in ten
+        // multiplied a stale fragment, tools/pgemm_race.py)
+        read_frags((unsigned)(st_read * P_STAGE * 4), std::integral_constant<int, 1>{});
+        mfma4(0, 0, CI == 0, HP);
         P_SB();
         if (do_issue) issue();
         P_SB();
-        mfma4(0, 1, false);
+        mfma4(0, 1, false, false);
         P_SB();
         if (SUB) sub_lds_read(SC{}, 0);
         P_SB();
-        mfma4(0, 2, false);
-        mfma4(0, 3, false);
+        mfma4(0, 2, false, false);
+        mfma4(0, 3, false, false);
         P_SB();
         p_lds_wait(); pin_frags(1);                                     // every LDS read of this chunk by this wave is complete
         if (SUB) sub_pin();
-        // the next chunk's operands have landed (this wave's requests, then everybody's)
+        // the next chunk's operands have landed (this wave's requests, then everybody's) -- and with them everything this
+        // wave requested earlier: the Z rows of this chunk's sub-piece (two chunks old)
         if (do_issue) { P_WAIT_VMCNT(DMA + VM_PREV); } else { P_WAIT_VMCNT(VM_PREV); }
         __builtin_amdgcn_s_barrier();
         const int sn = st_read == 2 ? 0 : st_read + 1;
         const unsigned sbyte = (unsigned)(sn * P_STAGE * 4);
         read_frags(sbyte, std::integral_constant<int, 0>{});            // in flight under the second half
+        if (SUB) z_read(SC{});
         P_SB();
         // ---- second half: fragment set 1 ----
-        mfma4(1, 0, false);
+        mfma4(1, 0, false, false);
         P_SB();
-        if (HP && CI == 0) { const_load(); load_z(std::integral_constant<int, 0>{}); }
-        if (SUB) { sub_compute(SC{}, 0); sub_lds_read(SC{}, 2); }
+        if (HP && CI == 0) const_load();
+        if (SUB) { p_lds_wait(); z_pin(); sub_compute(SC{}, 0); sub_lds_read(SC{}, 2); }
         if (HP && CI == P_NSUB + 1 && want_stats) stats_fold();
         P_SB();
-        mfma4(1, 1, false);
+        mfma4(1, 1, false, false);
         P_SB();
-        if (SUB) { if (WQ) { p_lds_wait(); sub_pin(); } sub_compute(SC{}, 2); }
+        if (SUB) { if (WQ) { p_lds_wait(); sub_pin(); } sub_compute(SC{}, 2); out_read(SC{}); }
         if (HP && CI == P_NSUB + 2 && want_stats) stats_store();
         P_SB();
-        mfma4(1, 2, false);
+        mfma4(1, 2, false, false);
         P_SB();
-        if (SUB && S + 1 < P_NSUB) load_z(std::integral_constant<int, (S + 1 < P_NSUB ? S + 1 : 0)>{});
-        if (SUB) sub_store(SC{});
         if (HP && CI == 0) const_store();
+        if (CI < 0 && last) { tm_p = tm_c; tn_p = tn_c; set_prev(); zdma(std::integral_constant<int, 0>{}); }
         P_SB();
-        mfma4(1, 3, false);
+        mfma4(1, 3, false, false);
         P_SB();
         p_lds_wait(); pin_frags(0);
-        read_frags(sbyte, std::integral_constant<int, 1>{});            // in flight under the next chunk's first half
+        if (SUB) { p_pin(t4[0]); p_pin(t4[1]); out_store(); }
+        if (HP && CI == 0) zdma(std::integral_constant<int, 1>{});
+        if (SUB && S + 2 < P_NSUB) zdma(SC2{});
         st_read = sn;
     };
 
@@ -373,26 +419,25 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     __builtin_amdgcn_s_barrier();
     read_frags(0u, std::integral_constant<int, 0>{});
     p_lds_wait(); pin_frags(0);
-    read_frags(0u, std::integral_constant<int, 1>{});
 
     auto tile_body = [&](auto hpc, bool has_next, int tm_n, int tn_n) {
         using HPC = decltype(hpc);
-        chunk(hpc, std::integral_constant<int, 0>{}, true);
-        chunk(hpc, std::integral_constant<int, 1>{}, true);
-        chunk(hpc, std::integral_constant<int, 2>{}, true);
-        chunk(hpc, std::integral_constant<int, 3>{}, true);
-        chunk(hpc, std::integral_constant<int, 4>{}, true);
-        chunk(hpc, std::integral_constant<int, 5>{}, true);
-        chunk(hpc, std::integral_constant<int, 6>{}, true);
-        chunk(hpc, std::integral_constant<int, 7>{}, true);
-        chunk(hpc, std::integral_constant<int, 8>{}, true);
-        chunk(hpc, std::integral_constant<int, 9>{}, true);
+        chunk(hpc, std::integral_constant<int, 0>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 1>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 2>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 3>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 4>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 5>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 6>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 7>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 8>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 9>{}, true, false);
 #pragma unroll 1
         for (int c = 10; c < nch; ++c) {
             if (c + 2 == nch) set_stream(tm_n, tn_n);                   // the next two requests belong to the next tile
             const bool go = c + 2 < nch || has_next;
-            if (c == 10) chunk(hpc, std::integral_constant<int, 10>{}, go);
-            else chunk(HPC{}, std::integral_constant<int, -1>{}, go);
+            if (c == 10) chunk(hpc, std::integral_constant<int, 10>{}, go, false);
+            else chunk(HPC{}, std::integral_constant<int, -1>{}, go, c + 1 == nch);
         }
     };
 
@@ -402,29 +447,31 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         if (has_next) tile_of(t + 1, tm_n, tn_n);
         if (t == 0) tile_body(std::false_type{}, has_next, tm_n, tn_n);
         else tile_body(std::true_type{}, has_next, tm_n, tn_n);
-        // tile switch: the finished accumulators become the previous tile
+        tm_c = tm_n; tn_c = tn_n;           // (the finished tile became the previous one in its final chunk; its accumulators move at the
+    }                                       //  head of the next tile's first chunk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
-        tm_p = tm_c; tn_p = tn_c; tm_c = tm_n; tn_c = tn_n;
-        set_prev();
-    }
+        for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
 
-    // ---- drain: the last tile's epilogue, nothing to hide it behind ----
-    P_WAIT_VMCNT(0);
-    const_load(); load_z(std::integral_constant<int, 0>{});
+    // ---- drain: the last tile's epilogue, nothing to hide it behind (its Z rows 0 are on their way) ----
+    const_load();
+    zdma(std::integral_constant<int, 1>{});
     const_store();
     auto drain_sub = [&](auto sc) {
         constexpr int S = decltype(sc)::value;
-        sub_lds_read(sc, 0);
-        p_lds_wait(); sub_pin();
+        // Z rows S have landed: younger LOADS than their request are (S = 0) the constants + Z rows 1, (S >= 1) Z rows S + 1
+        if (S == 0) { P_WAIT_VMCNT(CONST_VM + 2); } else if (S + 1 < P_NSUB) { P_WAIT_VMCNT(2); } else { P_WAIT_VMCNT(0); }
+        z_read(sc); sub_lds_read(sc, 0);
+        p_lds_wait(); z_pin(); sub_pin();
         sub_compute(sc, 0);
         sub_lds_read(sc, 2);
         p_lds_wait(); sub_pin();
         sub_compute(sc, 2);
-        if (S + 1 < P_NSUB) load_z(std::integral_constant<int, (S + 1 < P_NSUB ? S + 1 : 0)>{});
-        sub_store(sc);
+        out_read(sc);
+        p_lds_wait(); p_pin(t4[0]); p_pin(t4[1]);
+        out_store();
+        if (S + 2 < P_NSUB) zdma(std::integral_constant<int, (S + 2 < P_NSUB ? S + 2 : 0)>{});
     };
     drain_sub(std::integral_constant<int, 0>{}); drain_sub(std::integral_constant<int, 1>{});
     drain_sub(std::integral_constant<int, 2>{}); drain_sub(std::integral_constant<int, 3>{});

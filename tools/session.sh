@@ -22,6 +22,13 @@ pgemm() {              # persistent GEMM: parity against the tiled kernel, then 
     timeout 600 python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "persistent" 2>&1 | tail -15 > $R/pgemm_tests.txt; cat $R/pgemm_tests.txt
     timeout 600 python tools/pgemm_bench.py 2>&1 | filter > $R/pgemm_bench.txt; cat $R/pgemm_bench.txt
 }
+pexp() {               # experiment builds of the persistent kernel (tools/diag/libcmflow_<name>.so, VARIANTS="...") against the product, one shape
+    for v in product $VARIANTS; do
+        L=$GRAFT_REPO_ROOT/tools/diag/libcmflow_$v.so; [ $v = product ] && L=
+        echo "== $v"; CMF_LIB=$L timeout 300 python tools/pgemm_bench.py ${PSHAPES:-524288x512x256} 2>&1 | filter
+    done | tee $R/pexp.txt
+}
+prace() { for a in "65536x512x256 2 1 60" "65536x512x256 1 1 60" "65536x512x256 1 0 60" "131072x512x256 2 0 60"; do echo "== $a"; timeout 300 python tools/pgemm_race.py $a 2>&1 | filter | tail -12; done | tee $R/prace.txt; }
 gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
 gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment build (tools/diag/libcmflow_w3.so)
     for d in 0 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
