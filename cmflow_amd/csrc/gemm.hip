@@ -1240,6 +1240,21 @@ long long g_trace_cap = 0, g_trace_n = 0;
 bool g_trace_armed = false;
 }
 extern "C" int cmf_gemm_trace_arm(void) { g_trace_armed = true; return 0; }
+// The record buffer (8 x u64 per workgroup, zeroed on the launch's stream) if the next launch is to be traced, else NULL
+static unsigned long long *trace_take(unsigned grid, hipStream_t st)
+{
+    if (!g_trace_armed) return nullptr;
+    g_trace_armed = false;                               // diagnostics only: one launch, single-threaded use
+    if ((long long)grid > g_trace_cap) {
+        if (g_trace_buf) (void)hipFree(g_trace_buf);
+        g_trace_cap = grid;
+        if (hipMalloc((void **)&g_trace_buf, (size_t)g_trace_cap * 64) != hipSuccess) { g_trace_buf = nullptr; g_trace_cap = 0; }
+    }
+    if (!g_trace_buf) return nullptr;
+    (void)hipMemsetAsync(g_trace_buf, 0, (size_t)grid * 64, st);
+    g_trace_n = grid;
+    return g_trace_buf;
+}
 // Copies the records of the traced launch (8 x u64 per workgroup) to host memory; returns the workgroup count.
 extern "C" long long cmf_gemm_trace_read(unsigned long long *host_out, long long max_workgroups)
 {
@@ -1309,22 +1324,12 @@ static int launch(const GemmArgs &a, hipStream_t st)
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
     const long long pe = gprof_open(2.0 * a.M * a.N * a.K, st, &a, (A_T ? 2 : 0) | (B_T ? 1 : 0), BM, BN);
-    if (g_trace_armed) {                                 // diagnostics only: one launch, single-threaded use
-        g_trace_armed = false;
-        if ((long long)grid.x > g_trace_cap) {
-            if (g_trace_buf) (void)hipFree(g_trace_buf);
-            g_trace_cap = grid.x;
-            if (hipMalloc((void **)&g_trace_buf, (size_t)g_trace_cap * 64) != hipSuccess) { g_trace_buf = nullptr; g_trace_cap = 0; }
-        }
-        if (g_trace_buf) {
-            (void)hipMemsetAsync(g_trace_buf, 0, (size_t)grid.x * 64, st);
-            g_trace_n = grid.x;
-            GemmArgs t = a;
-            t.trace = g_trace_buf;
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, t);
-            gprof_close(pe, st);
-            return cmf_launch_status();
-        }
+    if (unsigned long long *tb = trace_take(grid.x, st)) {
+        GemmArgs t = a;
+        t.trace = tb;
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, t);
+        gprof_close(pe, st);
+        return cmf_launch_status();
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, a);
     gprof_close(pe, st);
@@ -1384,6 +1389,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     if (thin_done)         err = 0;
     else if (pgrid) {
         const long long pe = gprof_open(2.0 * M * N * K, st, &g, (a_t ? 2 : 0) | (b_t ? 1 : 0) | 4, 128, 128);      // layout bit 2: persistent kernel
+        g.trace = trace_take((unsigned)pgrid, st);
         err = cmf_pgemm_launch(g, kind, pgrid, st);
         gprof_close(pe, st);
     }

@@ -36,7 +36,7 @@ constexpr int P_WDQ = 64 * 4, P_WZ = 2 * 8 * 64;
 constexpr int P_WSZ = P_WDQ + P_WZ;                       // per wave: dxyz rows of its 64 tile rows | two 8 x 64 buffers: the producer's Z rows of a
                                                           // sub-piece arrive here (LDS-direct), its outputs leave through the same rows
 constexpr int P_RED = 2 * 5 * 128;                        // [wave row][statistic][column]
-constexpr int P_LDS_FLOATS = P_NST * P_STAGE + 4 * P_WSZ + P_RED;
+constexpr int P_LDS_FLOATS = P_NST * P_STAGE + 4 * P_WSZ + P_RED + 4;   // + the claimed tile (one word)
 constexpr int P_MIN_CHUNKS = 12;                          // chunks 0..10 of a tile carry the previous tile's epilogue
 constexpr int P_NSUB = 8;                                 // 8-row sub-pieces of a wave's 64 x 64 tile
 
@@ -79,7 +79,7 @@ __device__ __forceinline__ int p_spin(int v) { v = __builtin_amdgcn_readfirstlan
 // EPI: 2 backward through BN + ReLU, 3 backward through (leaky) ReLU, 4 / 5 the same with the three dxyz column sums
 // (gemm.hip epilogue_kind).  B_T: B stored [N][K] (forward layout) instead of [K][N].
 template <bool B_T, int EPI>
-__global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, const int grid_w)
+__global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, int *__restrict__ sched)
 {
     constexpr bool BNR = EPI == 2 || EPI == 4, WQ = EPI >= 4;
     constexpr int NSTAT = WQ ? 5 : 2;
@@ -88,16 +88,46 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     const int wm = wid >> 1, wn = wid & 1;                               // wave tile 64 x 64 at (wm, wn)
     const int h = lane >> 5, cl = lane & 31;
 
-    // ---- tile walk: workgroup b lives on XCD b % 8 (round-robin dispatch); the column tiles that share an A row panel
-    // sit on consecutive slots of ONE XCD and are worked on at the same time by neighbouring workgroups of that XCD ----
+    // ---- tile walk ----
+    // Workgroup b lives on XCD b % 8 (round-robin dispatch; a placement assumed for speed only).  The row panels are dealt to
+    // the XCDs in 8 contiguous ranges; inside a range the tiles are numbered column tile fastest, so the column tiles that
+    // share an A row panel are worked on at the same time by workgroups of ONE XCD.  Tiles are CLAIMED, not dealt: one
+    // counter per XCD (sched[0..7], zero at launch; the last workgroup to leave zeroes the block again).  With a static deal
+    // the two workgroups of a CU do not advance at the same pace -- the older one wins the arbitration for the SIMD's matrix
+    // pipe -- and finished 14 % of the kernel apart, the younger one alone on its CU for that long
+    // (tools/pgemm_timeline.py).  A tile is claimed one tile ahead: wave 0 adds to the counter at the head of a tile, the
+    // result goes through LDS (behind two chunk barriers) and is the next tile from chunk 4 on.
     const int tiles_m = p.M / P_BM, tiles_n = p.N / P_BN;
-    const int xcd = blockIdx.x & 7, w_in = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
     const int per = (tiles_m + 7) / 8;
-    const int rows_here = max(0, min(per, tiles_m - xcd * per));
-    const int nslots = rows_here * tiles_n;
-    const int n_my = w_in < nslots ? (nslots - w_in + grid_w - 1) / grid_w : 0;
-    if (n_my == 0) return;
+    const int nslots = max(0, min(per, tiles_m - xcd * per)) * tiles_n;
+    const unsigned sched_lds = (unsigned)((P_NST * P_STAGE + 4 * P_WSZ + P_RED) * 4);
+    int claim = 0;                                                       // wave 0, lane 0: the counter value a claim returned
+    auto claim_issue = [&]() { if (wid == 0 && lane == 0) claim = __hip_atomic_fetch_add(sched + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto claim_publish = [&]() { if (wid == 0 && lane == 0) p_write32<0>(sched_lds, __builtin_bit_cast(float, claim)); };
+    auto claim_read = [&]() {                                            // behind a workgroup barrier that follows claim_publish
+        float v = p_read32<0>(sched_lds);
+        p_lds_wait(); p_pin1(v);
+        return __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v));
+    };
+    auto leave = [&]() {                                                 // every workgroup, once: the last one resets the block
+        if (tid == 0) {
+            const int d = __hip_atomic_fetch_add(sched + 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (int)gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) __hip_atomic_store(sched + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    claim_issue();
+    claim_publish();
+    p_lds_wait();
+    __builtin_amdgcn_s_barrier();
+    int slot_c = claim_read();
+    if (slot_c >= nslots) { leave(); return; }
     const int nch = p.K / P_BK;
+    const unsigned long long t_start = p.trace ? wall_clock64() : 0ull;
+    unsigned long long t_first = 0ull, t_drain = 0ull;
 
     // ---- per-lane pieces of the LDS-direct source addresses (bytes) ----
     // A (and B in the [N][K] layout): 16-byte slot sl = (q*4 + wid)*64 + lane -> row = sl >> 2, k-quad (sl & 3) ^ swz(row)
@@ -146,9 +176,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     const bool want_stats = p.stats != nullptr;
 
     // tile coordinates: cur (accumulating), prv (being written out)
-    auto tile_of = [&](int j, int &tm, int &tn) { const int s = w_in + j * grid_w; tm = xcd * per + s / tiles_n; tn = s % tiles_n; };
-    int tm_c, tn_c, tm_p = 0, tn_p = 0;
-    tile_of(0, tm_c, tn_c);
+    auto tile_of = [&](int s, int &tm, int &tn) { tm = xcd * per + s / tiles_n; tn = s % tiles_n; };
+    int tm_c, tn_c, tm_p = 0, tn_p = 0, tm_n = 0, tn_n = 0, n_done = 0;
+    bool has_next = false;
+    tile_of(slot_c, tm_c, tn_c);
     // operand stream: descriptors of the tile's A row panel / B column panel, scalar byte offsets of the NEXT chunk to request
     __amdgpu_buffer_rsrc_t rA, rB;
     int soA = 0, soB = 0;
@@ -161,15 +192,18 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     };
     set_stream(tm_c, tn_c);
     int st_issue = 0;                                                  // stage the next request goes to
-    auto issue = [&]() {
+    auto issue_part = [&](int q) {                                     // the four requests of a chunk, one per call
         float *sa = smem + st_issue * P_STAGE, *sb = sa + P_SLOTS * 4;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p_lptr)(sa + wid * 256), 16, offA, soA, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p_lptr)(sa + (4 + wid) * 256), 16, offA, soA + strideA_q, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p_lptr)(sb + wid * 256), 16, offB, soB, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p_lptr)(sb + (4 + wid) * 256), 16, offB, soB + strideB_q, 0, 0);
-        soA = p_spin(soA + chunkA); soB = p_spin(soB + chunkB);
-        st_issue = st_issue == 2 ? 0 : st_issue + 1;
+        if (q == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p_lptr)(sa + wid * 256), 16, offA, soA, 0, 0);
+        if (q == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (p_lptr)(sa + (4 + wid) * 256), 16, offA, soA + strideA_q, 0, 0);
+        if (q == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p_lptr)(sb + wid * 256), 16, offB, soB, 0, 0);
+        if (q == 3) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (p_lptr)(sb + (4 + wid) * 256), 16, offB, soB + strideB_q, 0, 0);
+            soA = p_spin(soA + chunkA); soB = p_spin(soB + chunkB);
+            st_issue = st_issue == 2 ? 0 : st_issue + 1;
+        }
     };
+    auto issue = [&]() { issue_part(0); issue_part(1); issue_part(2); issue_part(3); };
     constexpr int DMA = 4;                                              // LDS-direct requests per wave and chunk
 
     // fragment reads of set w (k-quads 2w + h) from the stage at byte offset sbyte: issued, not awaited
@@ -189,23 +223,21 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         }
     };
     auto pin_frags = [&](int w) { p_pin(af[w][0]); p_pin(af[w][1]); p_pin(bf[w][0]); p_pin(bf[w][1]); };
-    // 4 MFMAs: component t of fragment set w against the four accumulator blocks.  first: the tile's first product (C = 0);
-    // with `keep` the finished tile's block moves to the second accumulator set right in front of the MFMA that overwrites
-    // it, so the 64 register moves of a tile switch run in the shadow of the first MFMAs instead of in front of them
-    auto mfma4 = [&](int w, int t, bool first, bool keep) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (first) { const pf32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                             if (keep) accp[i][j] = acc[i][j];
-                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], z, 0, 0, 0); }
-                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], acc[i][j], 0, 0, 0);
-            }
-        if (first && keep) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { __builtin_amdgcn_sched_group_barrier(0x2, 16, 0); __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); }
-        }
+    // MFMA number m (0..15) of a half chunk: component t = m / 4 of fragment set w against accumulator block (i, j) = (m / 2 % 2,
+    // m % 2).  first: the tile's first products (C = 0); with `keep` the finished tile's block moves to the second accumulator
+    // set right in front of the MFMA that overwrites it (in practice the compiler renames the registers instead).
+    // Every MFMA is its own scheduling region (P_SB on both sides at the call sites): the fillers of a chunk -- operand
+    // requests, fragment reads, the previous tile's epilogue -- sit BETWEEN single MFMAs, a handful of instructions in each
+    // 64-cycle shadow, so a wave never stops feeding the matrix pipe for longer than a barrier or a wait takes.  [With four
+    // MFMAs and then a block of 50-60 filler instructions per region the pipe was 78 % busy at 2.28 GHz (rocprofv3:
+    // SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE): two waves per SIMD do not cover each other's filler blocks.]
+    auto mf = [&](int w, int m, bool first, bool keep) {
+        const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+        if (first) { const pf32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                     if (keep) accp[i][j] = acc[i][j];
+                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], z, 0, 0, 0); }
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[w][i][t], bf[w][j][t], acc[i][j], 0, 0, 0);
+        P_SB();
     };
 
     // ---- epilogue of the PREVIOUS tile, in pieces ----
@@ -266,27 +298,25 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         }
     };
     auto sub_pin = [&]() { if (WQ) { p_pin(d4[0]); p_pin(d4[1]); } };
-    // (b) arithmetic of registers rr0, rr0 + 1 of sub-piece S (same operations per element as gemm.hip's epilogues); the results
-    // replace the Z values in the buffer
-    auto sub_compute = [&](auto sc, int rr0) {
-        constexpr int S = decltype(sc)::value, I = S >> 2, Q = S & 3, B = (S & 1) * 2048;
-        float xo[2][2];
-#pragma unroll
-        for (int rr = rr0; rr < rr0 + 2; ++rr)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float x = j == 0 ? accp[I][0][4 * Q + rr] : accp[I][1][4 * Q + rr];
-                const float z = zq[rr][j];
-                if (BNR) {
-                    x = (fmaf(kc[0][j], z, kc[1][j]) > 0.f) ? x : 0.f;
-                    t1[j] += x; t2[j] += x * ((z - kc[2][j]) * kc[3][j]);
-                } else {
-                    x = z > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
-                    t1[j] += x;
-                }
-                if (WQ) { qs[0][j] += x * d4[rr - rr0].x; qs[1][j] += x * d4[rr - rr0].y; qs[2][j] += x * d4[rr - rr0].z; }
-                xo[rr - rr0][j] = x;
-            }
+    // (b) arithmetic of one element (register rr, block column j) of sub-piece S (same operations per element as gemm.hip's
+    // epilogues); sub_write puts the results of registers rr0, rr0 + 1 over the Z values in the buffer
+    float xo[2][2];
+    auto sub_elem = [&](auto sc, int rr, int j) {
+        constexpr int S = decltype(sc)::value, I = S >> 2, Q = S & 3;
+        float x = j == 0 ? accp[I][0][4 * Q + rr] : accp[I][1][4 * Q + rr];
+        const float z = zq[rr][j];
+        if (BNR) {
+            x = (fmaf(kc[0][j], z, kc[1][j]) > 0.f) ? x : 0.f;
+            t1[j] += x; t2[j] += x * ((z - kc[2][j]) * kc[3][j]);
+        } else {
+            x = z > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
+            t1[j] += x;
+        }
+        if (WQ) { qs[0][j] += x * d4[rr & 1].x; qs[1][j] += x * d4[rr & 1].y; qs[2][j] += x * d4[rr & 1].z; }
+        xo[rr & 1][j] = x;
+    };
+    auto sub_write = [&](auto sc, int rr0) {
+        constexpr int B = (decltype(sc)::value & 1) * 2048;
         if (rr0 == 0) { p_write32<B + 0>(w_za, xo[0][0]); p_write32<B + 128>(w_za, xo[0][1]); p_write32<B + 256>(w_za, xo[1][0]); p_write32<B + 384>(w_za, xo[1][1]); }
         else          { p_write32<B + 512>(w_za, xo[0][0]); p_write32<B + 640>(w_za, xo[0][1]); p_write32<B + 768>(w_za, xo[1][0]); p_write32<B + 896>(w_za, xo[1][1]); }
     };
@@ -365,17 +395,27 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         // per-block assignments, and a copy of a register whose data has not landed yet copies garbage: one launch in ten
         // multiplied a stale fragment, tools/pgemm_race.py)
         read_frags((unsigned)(st_read * P_STAGE * 4), std::integral_constant<int, 1>{});
-        mfma4(0, 0, CI == 0, HP);
+        if (CI == 2) claim_publish();
+        if (CI == 4) { const int sl = claim_read(); has_next = sl < nslots; if (has_next) tile_of(sl, tm_n, tn_n); }
         P_SB();
-        if (do_issue) issue();
+        mf(0, 0, CI == 0, HP);
+        if (do_issue) issue_part(0);
         P_SB();
-        mfma4(0, 1, false, false);
+        mf(0, 1, CI == 0, HP);
+        if (do_issue) issue_part(1);
         P_SB();
+        mf(0, 2, CI == 0, HP);
+        if (do_issue) issue_part(2);
+        P_SB();
+        mf(0, 3, CI == 0, HP);
+        if (do_issue) issue_part(3);
+        P_SB();
+        mf(0, 4, false, false); mf(0, 5, false, false);
         if (SUB) sub_lds_read(SC{}, 0);
         P_SB();
-        mfma4(0, 2, false, false);
-        mfma4(0, 3, false, false);
-        P_SB();
+        mf(0, 6, false, false); mf(0, 7, false, false); mf(0, 8, false, false); mf(0, 9, false, false);
+        mf(0, 10, false, false); mf(0, 11, false, false); mf(0, 12, false, false); mf(0, 13, false, false);
+        mf(0, 14, false, false); mf(0, 15, false, false);
         p_lds_wait(); pin_frags(1);                                     // every LDS read of this chunk by this wave is complete
         if (SUB) sub_pin();
         // the next chunk's operands have landed (this wave's requests, then everybody's) -- and with them everything this
@@ -388,24 +428,45 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         if (SUB) z_read(SC{});
         P_SB();
         // ---- second half: fragment set 1 ----
-        mfma4(1, 0, false, false);
-        P_SB();
+        mf(1, 0, false, false);
+        if (CI == 0) claim_issue();       // wave 0: one returning operation more than VM_PREV of chunk 1 counts (under-counting is safe)
         if (HP && CI == 0) const_load();
-        if (SUB) { p_lds_wait(); z_pin(); sub_compute(SC{}, 0); sub_lds_read(SC{}, 2); }
+        P_SB();
+        mf(1, 1, false, false);
         if (HP && CI == P_NSUB + 1 && want_stats) stats_fold();
-        P_SB();
-        mfma4(1, 1, false, false);
-        P_SB();
-        if (SUB) { if (WQ) { p_lds_wait(); sub_pin(); } sub_compute(SC{}, 2); out_read(SC{}); }
         if (HP && CI == P_NSUB + 2 && want_stats) stats_store();
         P_SB();
-        mfma4(1, 2, false, false);
+        mf(1, 2, false, false);
+        if (SUB) { p_lds_wait(); z_pin(); }
         P_SB();
+        mf(1, 3, false, false);
+        if (SUB) sub_elem(SC{}, 0, 0);
+        P_SB();
+        mf(1, 4, false, false);
+        if (SUB) sub_elem(SC{}, 0, 1);
+        P_SB();
+        mf(1, 5, false, false);
+        if (SUB) sub_elem(SC{}, 1, 0);
+        P_SB();
+        mf(1, 6, false, false);
+        if (SUB) { sub_elem(SC{}, 1, 1); sub_write(SC{}, 0); sub_lds_read(SC{}, 2); }
+        P_SB();
+        mf(1, 7, false, false);
+        mf(1, 8, false, false);
+        if (SUB) { if (WQ) { p_lds_wait(); sub_pin(); } sub_elem(SC{}, 2, 0); }
+        P_SB();
+        mf(1, 9, false, false);
+        if (SUB) sub_elem(SC{}, 2, 1);
+        P_SB();
+        mf(1, 10, false, false);
+        if (SUB) sub_elem(SC{}, 3, 0);
+        P_SB();
+        mf(1, 11, false, false);
+        if (SUB) { sub_elem(SC{}, 3, 1); sub_write(SC{}, 2); out_read(SC{}); }
         if (HP && CI == 0) const_store();
         if (CI < 0 && last) { tm_p = tm_c; tn_p = tn_c; set_prev(); zdma(std::integral_constant<int, 0>{}); }
         P_SB();
-        mfma4(1, 3, false, false);
-        P_SB();
+        mf(1, 12, false, false); mf(1, 13, false, false); mf(1, 14, false, false); mf(1, 15, false, false);
         p_lds_wait(); pin_frags(0);
         if (SUB) { p_pin(t4[0]); p_pin(t4[1]); out_store(); }
         if (HP && CI == 0) zdma(std::integral_constant<int, 1>{});
@@ -420,13 +481,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
     read_frags(0u, std::integral_constant<int, 0>{});
     p_lds_wait(); pin_frags(0);
 
-    auto tile_body = [&](auto hpc, bool has_next, int tm_n, int tn_n) {
+    auto tile_body = [&](auto hpc) {
         using HPC = decltype(hpc);
         chunk(hpc, std::integral_constant<int, 0>{}, true, false);
         chunk(hpc, std::integral_constant<int, 1>{}, true, false);
         chunk(hpc, std::integral_constant<int, 2>{}, true, false);
         chunk(hpc, std::integral_constant<int, 3>{}, true, false);
-        chunk(hpc, std::integral_constant<int, 4>{}, true, false);
+        chunk(hpc, std::integral_constant<int, 4>{}, true, false);      // has_next, (tm_n, tn_n) known from here on
         chunk(hpc, std::integral_constant<int, 5>{}, true, false);
         chunk(hpc, std::integral_constant<int, 6>{}, true, false);
         chunk(hpc, std::integral_constant<int, 7>{}, true, false);
@@ -441,19 +502,20 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         }
     };
 
-    for (int t = 0; t < n_my; ++t) {
-        const bool has_next = t + 1 < n_my;
-        int tm_n = 0, tn_n = 0;
-        if (has_next) tile_of(t + 1, tm_n, tn_n);
-        if (t == 0) tile_body(std::false_type{}, has_next, tm_n, tn_n);
-        else tile_body(std::true_type{}, has_next, tm_n, tn_n);
+    tile_body(std::false_type{});
+    if (p.trace) t_first = wall_clock64();
+    n_done = 1;
+    while (has_next) {
         tm_c = tm_n; tn_c = tn_n;           // (the finished tile became the previous one in its final chunk; its accumulators move at the
-    }                                       //  head of the next tile's first chunk)
+        tile_body(std::true_type{});        //  head of the next tile's first chunk)
+        ++n_done;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
 
+    if (p.trace) t_drain = wall_clock64();
     // ---- drain: the last tile's epilogue, nothing to hide it behind (its Z rows 0 are on their way) ----
     const_load();
     zdma(std::integral_constant<int, 1>{});
@@ -464,10 +526,10 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         if (S == 0) { P_WAIT_VMCNT(CONST_VM + 2); } else if (S + 1 < P_NSUB) { P_WAIT_VMCNT(2); } else { P_WAIT_VMCNT(0); }
         z_read(sc); sub_lds_read(sc, 0);
         p_lds_wait(); z_pin(); sub_pin();
-        sub_compute(sc, 0);
+        sub_elem(sc, 0, 0); sub_elem(sc, 0, 1); sub_elem(sc, 1, 0); sub_elem(sc, 1, 1); sub_write(sc, 0);
         sub_lds_read(sc, 2);
         p_lds_wait(); sub_pin();
-        sub_compute(sc, 2);
+        sub_elem(sc, 2, 0); sub_elem(sc, 2, 1); sub_elem(sc, 3, 0); sub_elem(sc, 3, 1); sub_write(sc, 2);
         out_read(sc);
         p_lds_wait(); p_pin(t4[0]); p_pin(t4[1]);
         out_store();
@@ -482,6 +544,13 @@ __global__ __launch_bounds__(P_THREADS, 2) void pgemm_kernel(const GemmArgs p, c
         p_lds_wait();
         __builtin_amdgcn_s_barrier();
         stats_store();
+    }
+    leave();
+    if (p.trace && tid == 0) {                                           // diagnostics (tools/pgemm_timeline.py)
+        unsigned long long *r = p.trace + 8ull * blockIdx.x;
+        r[0] = t_start; r[1] = t_drain; r[2] = wall_clock64();
+        r[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        r[4] = t_first; r[5] = (unsigned long long)n_done; r[6] = 0ull; r[7] = 0ull;
     }
 }
 
@@ -510,6 +579,24 @@ extern "C" int cmf_gemm_persist_config(int mode, int grid)
     return 0;
 }
 
+// One block of tile counters per (device, stream): kernels of one stream run one after the other and each leaves the block
+// zeroed, so no launch ever sees another one's counts (two launches sharing a block would have to run concurrently).
+#include <map>
+#include <mutex>
+static int *sched_block(hipStream_t st)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int *> *table = new std::map<std::pair<int, hipStream_t>, int *>();   // leaked on purpose
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    int *&e = (*table)[std::make_pair(dev, st)];
+    if (!e) {
+        if (hipMalloc((void **)&e, 64) != hipSuccess || hipMemset(e, 0, 64) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+    }
+    return e;
+}
+
 template <bool B_T, int EPI>
 static int plaunch(const GemmArgs &a, int grid, hipStream_t st)
 {
@@ -523,7 +610,9 @@ static int plaunch(const GemmArgs &a, int grid, hipStream_t st)
             return (int)hipGetLastError();
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((pgemm_kernel<B_T, EPI>), dim3(grid), dim3(P_THREADS), lds, st, a, grid / 8);
+    int *sched = sched_block(st);
+    if (!sched) return (int)hipErrorOutOfMemory;
+    hipLaunchKernelGGL((pgemm_kernel<B_T, EPI>), dim3(grid), dim3(P_THREADS), lds, st, a, sched);
     return cmf_launch_status();
 }
 
@@ -534,7 +623,7 @@ int cmf_pgemm_grid(const GemmArgs &g, int a_t, int b_t, int kind)
     const int mode = pmode();
     if (mode == 0 || a_t || b_t || kind < 2 || kind > 5) return 0;
     if (g.M % P_BM || g.N % P_BN || g.K % P_BK || g.K / P_BK < P_MIN_CHUNKS || g.split_k != 1 || g.accumulate || g.no_direct) return 0;
-    if (g.ldc % 4 || g.ldz % 4 || ((uintptr_t)g.C | (uintptr_t)g.Z) % 16 || g.pro_a || g.prob_a || g.diag || g.trace) return 0;
+    if (g.ldc % 4 || g.ldz % 4 || ((uintptr_t)g.C | (uintptr_t)g.Z) % 16 || g.pro_a || g.prob_a || g.diag) return 0;
     // 32-bit byte offsets inside a tile's panels: operand streams (rows of the panel + the whole contraction), 64 output rows
     const long long lim = 1ll << 31;
     if (128 * g.lda * 4 + (long long)g.K * 4 >= lim || ((long long)g.K + 16) * g.ldb * 4 >= lim || 72 * g.ldz * 4 >= lim || 72 * g.ldc * 4 >= lim) return 0;

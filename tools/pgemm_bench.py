@@ -22,6 +22,7 @@ def timed(fn, n=10):
 shapes = [(524288, 512, 256), (262144, 512, 256), (131072, 512, 256), (65536, 512, 256), (131072, 512, 512)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
+GRID = int(os.environ.get("PGRID", "0"))            # workgroups of the persistent kernel (0: two per CU)
 for (M, N, K) in shapes:
     dZ = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev); Zs = torch.randn(M, N, device=dev)
     ea, ec, em, ei = (torch.rand(N, device=dev) + 0.5 for _ in range(4))
@@ -33,7 +34,7 @@ for (M, N, K) in shapes:
         res = []
         for rep in range(2):
             for mode in (0, 2):
-                L.cmf_gemm_persist_config(mode, 0)
+                L.cmf_gemm_persist_config(mode, GRID)
                 t = timed(lambda: gemm(dZ, W, b_t=False, bwd=bwd, stats=st, out=out))
                 res.append(2.0 * M * N * K / t / 1e12)
         L.cmf_gemm_persist_config(1, 0)

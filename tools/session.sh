@@ -29,6 +29,16 @@ pexp() {               # experiment builds of the persistent kernel (tools/diag/
     done | tee $R/pexp.txt
 }
 prace() { for a in "65536x512x256 2 1 60" "65536x512x256 1 1 60" "65536x512x256 1 0 60" "131072x512x256 2 0 60"; do echo "== $a"; timeout 300 python tools/pgemm_race.py $a 2>&1 | filter | tail -12; done | tee $R/prace.txt; }
+pclock() {             # effective clock + MFMA busy of the persistent kernel (product and experiment builds): GRBM_GUI_ACTIVE / duration
+    for v in product $VARIANTS; do
+        L=$GRAFT_REPO_ROOT/tools/diag/libcmflow_$v.so; [ $v = product ] && L=
+        rm -rf /tmp/pc_$v
+        (cd /tmp && CMF_LIB=$L rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d /tmp/pc_$v -- python3 $GRAFT_REPO_ROOT/tools/pgemm_bench.py 524288x512x256 > /dev/null 2>&1)
+        echo "== $v"; python3 tools/pclock.py $(find /tmp/pc_$v -name "*kernel_trace.csv" | head -1) $(find /tmp/pc_$v -name "*counter_collection.csv" | head -1)
+    done | tee $R/pclock.txt
+}
+ptimeline() { for a in "524288x512x256 1 1" "524288x512x256 2 0" "65536x512x256 1 1" "131072x512x512 2 1"; do echo "== $a"; timeout 300 python tools/pgemm_timeline.py $a 2>&1 | filter; done | tee $R/ptimeline.txt; }
+pgrid() { for g in 256 512 256 512; do echo "== grid $g"; PGRID=$g timeout 300 python tools/pgemm_bench.py 524288x512x256 131072x512x512 2>&1 | filter; done | tee $R/pgrid.txt; }
 gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
 gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment build (tools/diag/libcmflow_w3.so)
     for d in 0 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
