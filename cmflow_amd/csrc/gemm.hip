@@ -464,9 +464,16 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 const float *sa = smem, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
                 read_frags(sa, sb, sp, 0, 0);
                 g_lds_wait(); pin_frags(0);
-                read_frags(sa, sb, sp, 8, 1);
             }
             for (int c = 0; c < nch; ++c) {
+                // the second fragment set of THIS chunk is requested here, not at the end of the previous iteration: the reads are
+                // inline asm the compiler cannot see completing, and at a loop back-edge it may copy fragment registers between
+                // its per-block assignments -- a copy of a register whose LDS data has not landed yet copies garbage (found in
+                // gemm_persist.hip: one launch in ten multiplied a stale fragment)
+                {
+                    const float *sa = smem + st * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
+                    read_frags(sa, sb, sp, 8, 1);
+                }
                 mfma_step(0);
                 g_lds_wait(); pin_frags(1);                                         // every LDS read of chunk c by this wave is complete
                 if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);   // (st + 2) % 3: the stage of chunk c - 1
@@ -478,10 +485,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                     read_frags(sa, sb, sp, 0, 0);                                   // in flight under the second half of chunk c
                 }
                 mfma_step(1);
-                if (c + 1 < nch) {
-                    g_lds_wait(); pin_frags(0);
-                    read_frags(sa, sb, sp, 8, 1);
-                }
+                if (c + 1 < nch) { g_lds_wait(); pin_frags(0); }
                 st = sn;
             }
             __builtin_amdgcn_s_barrier();                                            // the epilogue reuses the staging buffers
@@ -1367,7 +1371,9 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     // loop applies it once per staged element, the LDS-direct loop on every wave's fragments inside the MFMA stream --
     // measured in the step, isolated: 256 x 512 x 524288 / 262144 / 131072 at 117.6 / 117.9 / 114.4 TF staged against
     // 111.7 / 110.3 / 108.7 direct; the short contractions (K = 16384) lose 2-3 % and stay direct.
-    g.no_direct = (no_direct || (a_t && !b_t && prob_a && K >= 32768)) ? 1 : 0;
+    // (when the persistent kernel takes the call -- below -- the prologue sits between single MFMAs and costs nothing)
+    const bool staged_dw = a_t && !b_t && prob_a && K >= 32768;
+    g.no_direct = no_direct ? 1 : 0;
     static const int diag_rt = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
     g.diag = diag_rt;
     g.trace = nullptr;
@@ -1386,11 +1392,12 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     (tall ? (wide ? launch<128, 128, AT, BT, EP>(g, st) : launch<128, 64, AT, BT, EP>(g, st)) \
           : (wide ? launch<64, 128, AT, BT, EP>(g, st) : launch<64, 64, AT, BT, EP>(g, st)))
     const int pgrid = thin_done ? 0 : cmf_pgemm_grid(g, a_t, b_t, kind);
+    if (!pgrid && staged_dw) g.no_direct = 1;
     if (thin_done)         err = 0;
     else if (pgrid) {
         const long long pe = gprof_open(2.0 * M * N * K, st, &g, (a_t ? 2 : 0) | (b_t ? 1 : 0) | 4, 128, 128);      // layout bit 2: persistent kernel
         g.trace = trace_take((unsigned)pgrid, st);
-        err = cmf_pgemm_launch(g, kind, pgrid, st);
+        err = cmf_pgemm_launch(g, a_t, b_t, kind, pgrid, st);
         gprof_close(pe, st);
     }
     else if (!a_t && b_t)  err = kind == 1 ? CMF_PICK(false, true, 1) : CMF_PICK(false, true, 0);
@@ -1400,7 +1407,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     else                   err = CMF_PICK(true, true, 0);
 #undef CMF_PICK
     if (err) return err;
-    if (split_k > 1) return cmf_splitk_reduce(M, N, split_k, workspace, C, ldc, accumulate, st);
+    if (split_k > 1) return cmf_splitk_reduce(M, N, g.split_k, workspace, C, ldc, accumulate, st);     // (the persistent kernel may have lowered it)
     return 0;
 }
 

@@ -47,5 +47,5 @@ int cmf_thin_gemm(const GemmArgs &g, int a_t, int b_t, hipStream_t st);
 int cmf_splitk_reduce(int M, int N, int split_k, const float *workspace, float *C, long long ldc, int accumulate, hipStream_t st);
 void cmf_gemm_count_flops(double flops);
 // gemm_persist.hip: the persistent kernel (overlapped epilogue) for the calls it takes; grid = 0: not this call
-int cmf_pgemm_grid(const GemmArgs &g, int a_t, int b_t, int kind);
-int cmf_pgemm_launch(const GemmArgs &g, int kind, int grid, hipStream_t st);
+int cmf_pgemm_grid(GemmArgs &g, int a_t, int b_t, int kind);      // may lower g.split_k (weight gradients)
+int cmf_pgemm_launch(const GemmArgs &g, int a_t, int b_t, int kind, int grid, hipStream_t st);

@@ -629,3 +629,80 @@ def test_persistent_gemm_matches_tiled_kernel(dev, M, N, K, grid, mode, dxyz):
             bound = 1e-6 * t.view(tiles, 128, N).sum(1) + 1e-6
             err = (got_st[:, which].double() - ref_st[:, which].double()).abs()
             assert bool((err <= bound).all()), (which, float((err / bound).max()))
+
+
+@pytest.mark.parametrize("M,N,K,grid", [(2048, 256, 512, 8), (1024, 384, 256, 16), (4096, 128, 1024, 8), (131072, 512, 512, 0)])
+@pytest.mark.parametrize("pro,bias,act,stats", [(False, False, 0, False), (True, True, 1, True), (True, False, 0, True), (False, True, 2, False)])
+def test_persistent_gemm_forward_matches_tiled_kernel(dev, M, N, K, grid, pro, bias, act, stats):
+    """The forward layout (A[M][K], W[N][K]) of the persistent kernel -- plain store and the bias / activation / BN-statistics
+    epilogue, with and without the producer's BN + ReLU on A -- against the tiled kernel: outputs bit-identical, statistics
+    equal up to their fp32 summation order (1e-6 * sum |terms|) and bit-reproducible."""
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M + N + K + act)
+    A = torch.randn(M, K + 8, generator=g).to(dev)[:, :K]
+    W = torch.randn(N, K + 4, generator=g).to(dev)[:, :K]
+    pa, pc = (torch.rand(K, generator=g) + 0.5).to(dev), (0.3 * torch.randn(K, generator=g)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+
+    def run():
+        out = torch.full((M, N + 12), 7.0, device=dev)
+        r = gemm(A, W, pro=(pa, pc) if pro else None, bias=b if bias else None, act=act, stats=stats, out=out[:, 4:4 + N])
+        torch.cuda.synchronize()
+        return (out, r[1]) if stats else (out, None)
+
+    try:
+        assert L.cmf_gemm_persist_config(0, 0) == 0
+        ref, ref_st = run()
+        assert L.cmf_gemm_persist_config(2, grid) == 0
+        got, got_st = run()
+        got2, got2_st = run()
+    finally:
+        L.cmf_gemm_persist_config(1, 0)
+    assert torch.equal(got, ref) and torch.equal(got2, got)
+    if stats:
+        assert torch.equal(got2_st, got_st)
+        x = ref[:, 4:4 + N].double()
+        tiles = ref_st.shape[0]
+        for which, t in enumerate((x.abs(), x * x)):
+            bound = 1e-6 * t.view(tiles, 128, N).sum(1) + 1e-6
+            err = (got_st[:, which].double() - ref_st[:, which].double()).abs()
+            assert bool((err <= bound).all()), (which, float((err / bound).max()))
+
+
+@pytest.mark.parametrize("rows,M,N,split,grid", [(8192, 256, 256, 16, 64), (16384, 128, 384, 8, 24), (65536, 256, 512, 96, 0), (16384, 512, 512, 48, 0)])
+@pytest.mark.parametrize("prob", [False, True])
+def test_persistent_gemm_weight_gradient_matches_tiled_kernel(dev, rows, M, N, split, grid, prob):
+    """The weight-gradient layout (A[K][M], B[K][N], split-K slabs, optional BN + ReLU on B) of the persistent kernel against an
+    fp64 product (2e-6 * sum |a b|) and -- where it keeps the caller's slab count -- bit for bit against the tiled kernel."""
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(rows + M + N)
+    dZ = torch.randn(rows, M + 4, generator=g).to(dev)[:, :M]
+    X = torch.randn(rows, N + 8, generator=g).to(dev)[:, :N]
+    qa, qc = (torch.rand(N, generator=g) + 0.5).to(dev), (0.3 * torch.randn(N, generator=g)).to(dev)
+    Xa = torch.relu(X * qa + qc) if prob else X
+    ref64 = dZ.double().t() @ Xa.double()
+    bound = dZ.double().abs().t() @ Xa.double().abs()
+
+    def run():
+        r = gemm(dZ, X, a_t=True, b_t=False, prob=(qa, qc) if prob else None, split_k=split)
+        torch.cuda.synchronize()
+        return r
+
+    try:
+        assert L.cmf_gemm_persist_config(0, 0) == 0
+        ref = run()
+        assert L.cmf_gemm_persist_config(2, grid) == 0
+        got = run()
+        got2 = run()
+    finally:
+        L.cmf_gemm_persist_config(1, 0)
+    _check(got, ref64, bound)
+    assert torch.equal(got2, got)
+    tiles = (M // 128) * (N // 128)
+    g_eff = grid if grid else 512
+    if min(split, g_eff // tiles) // 8 * 8 == split and not (prob and rows >= 32768):
+        assert torch.equal(got, ref)             # same slabs, same loop arithmetic

@@ -40,3 +40,29 @@ for (M, N, K) in shapes:
         L.cmf_gemm_persist_config(1, 0)
         print("%-26s M=%7d N=%4d K=%4d  tiled %6.1f %6.1f TF   persistent %6.1f %6.1f TF" % (name, M, N, K, res[0], res[2], res[1], res[3]), flush=True)
     del dZ, W, Zs, out
+# forward (A[M][K] W[N][K]) and weight-gradient (A[K][M] B[K][N], split-K) forms on the model's shapes
+fshapes = [(524288, 256, 512), (131072, 512, 512), (262144, 256, 512)] if len(sys.argv) <= 1 else []
+for (M, N, K) in fshapes:
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev)
+    pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
+    out = torch.empty(M, N, device=dev)
+    for name, kw in (("fwd plain", {}), ("fwd +stats", dict(stats=True)), ("fwd +BN/ReLU prologue +stats", dict(pro=(pa, pc), stats=True))):
+        res = []
+        for rep in range(2):
+            for mode in (0, 2):
+                L.cmf_gemm_persist_config(mode, GRID)
+                t = timed(lambda: gemm(A, W, out=out, **kw))
+                res.append(2.0 * M * N * K / t / 1e12)
+        L.cmf_gemm_persist_config(1, 0)
+        print("%-30s M=%7d N=%4d K=%4d  tiled %6.1f %6.1f TF   persistent %6.1f %6.1f TF" % (name, M, N, K, res[0], res[2], res[1], res[3]), flush=True)
+    dZ = torch.randn(M, N, device=dev)
+    for name, kw in (("dW split 96", dict(split_k=96)), ("dW split 96 +BN/ReLU on B", dict(split_k=96, prob=(pa, pc)))):
+        res = []
+        for rep in range(2):
+            for mode in (0, 2):
+                L.cmf_gemm_persist_config(mode, GRID)
+                t = timed(lambda: gemm(dZ, A, a_t=True, b_t=False, **kw))
+                res.append(2.0 * M * N * K / t / 1e12)
+        L.cmf_gemm_persist_config(1, 0)
+        print("%-30s M=%7d N=%4d K=%4d  tiled %6.1f %6.1f TF   persistent %6.1f %6.1f TF" % (name, N, K, M, res[0], res[2], res[1], res[3]), flush=True)
+    del A, W, out, dZ
