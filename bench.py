@@ -31,6 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_PROFILE = "r03_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
 
@@ -260,7 +261,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1 and not one_gpu:
         from cmflow_amd.dp import pin_rank_to_cores
-        pin_rank_to_cores(local_rank, world)          # before the library creates its chain-worker threads (they inherit the mask)
+        # opt-in (CMF_PIN_CORES=1), before the library creates its chain-worker threads (they inherit the mask); ranks on THIS host
+        pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world == 1 and a.force_allreduce:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -367,17 +369,20 @@ def main():
         # >= 256-workgroup launches from the committed FETCH_SIZE / WRITE_SIZE passes over this same command (separate --pmc
         # runs, gfx950 x2 correction on FETCH_SIZE; tools/session.sh pmc_gemm), beside the algorithmic bytes of the launches
         # bracketed live (A + B + C once, + the Z operand of the backward epilogues)
-        traffic = alg_bytes = None
-        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_gemm_traffic_instep.json")
+        traffic = alg_bytes = traffic_source = None
+        tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_PROFILE)
         if prof["bound"] == "mfma" and a.mode == "train" and a.model == "cmflow" and os.path.exists(tp):
-            traffic = json.load(open(tp))["traffic_bytes_per_launch"]
+            rec = json.load(open(tp))
+            traffic = rec["traffic_bytes_per_launch"]
+            traffic_source = ("NOT measured by this run: constant from the committed rocprofv3 PMC passes in profiles/%s (%s)"
+                              % (TRAFFIC_PROFILE, rec.get("measured_at", "round 3 build")))
         if prof.get("shapes"):
             tot = sum(cnt * 4.0 * (M * K + K * N + M * N * (2 if kind >= 2 else 1))
                       for (M, N, K, layout, kind, split_k, bm, bn), (cnt, _) in prof["shapes"].items())
             alg_bytes = round(tot / prof["launches"])
         out = {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
                "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
-               "traffic_profile": "profiles/r03_gemm_traffic_instep.json", "algorithmic_bytes_per_launch": alg_bytes,
+               "traffic_source": traffic_source, "traffic_profile": "profiles/" + TRAFFIC_PROFILE, "algorithmic_bytes_per_launch": alg_bytes,
                "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
                "algorithmic_per_launch": per_launch,
                "launch_filter": "every tiled-kernel launch >= %.0e flop, bracketed inside libcmflow_hip.so (block-internal "

@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 kernels (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include <stdint.h>
 
@@ -13,6 +14,15 @@ static inline int cmf_launch_status() { return (int)hipGetLastError(); }
 
 static inline int cmf_divup(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is an attribute of (function, DEVICE): a process-wide `static bool` would
+// leave a second device without it (launch failure above 64 KB).  One bit per device, atomics (entry points are called from
+// several host threads):   static CmfPerDevice once; int dev;  if (once.need(dev)) { ...set attributes...; once.done(dev); }
+struct CmfPerDevice {
+    std::atomic<unsigned> mask[4] = {};
+    bool need(int &dev) { dev = 0; (void)hipGetDevice(&dev); return dev >= 128 || !(mask[dev >> 5].load(std::memory_order_acquire) & (1u << (dev & 31))); }
+    void done(int dev) { if (dev < 128) mask[dev >> 5].fetch_or(1u << (dev & 31), std::memory_order_release); }
+};
+
 // Library-owned scratch for the few entry points that need more working memory than their reference signature
 // carries (cmf_ball_query: spilled hit lists at nsample > 32; cmf_group_points_grad: the inverse index).  One buffer per
 // (device, stream, slot), grown on demand and kept for the life of the process: work on one stream is ordered, so the
@@ -22,7 +32,8 @@ static inline int cmf_divup(long long a, long long b) { return (int)((a + b - 1)
 // The buffer comes as a LEASE: several host threads may enqueue onto one stream (two encoder scales share a side stream),
 // so the (device, stream, slot) entry stays locked from the hand-out until the lease goes out of scope -- which callers
 // arrange to be after the last launch that uses the pointer (build + use are then adjacent in stream order).  A buffer
-// that has to grow is retired, never freed (queued work of the stream may still use it), and grows by >= 1.5x.
+// that has to grow is retired behind an event recorded on its stream and freed at a later lease once that event has
+// completed (queued work of the stream may still use it until then); it grows by >= 1.5x.
 // ptr == nullptr on allocation failure.
 struct CmfScratchLease {
     void *ptr = nullptr;
@@ -30,19 +41,22 @@ struct CmfScratchLease {
 };
 CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes);
 
-// Train-mode BatchNorm backward as an affine map of its two streams, per column:
-//   dZ = a * (dU - s1/M - zhat * s2/M),  zhat = (z - mean) * invstd      ==      dZ = al * dU + be * z + ga
+// Train-mode BatchNorm backward of its two streams, per column:
+//   dZ = a * (dU - s1/M - zhat * s2/M),  zhat = (z - mean) * invstd      ==      dZ = al * dU + be * (z - mean) + ga
+// with al = a, be = -a * invstd * s2/M, ga = -a * s1/M.  The CENTRED form: (z - mean) is formed first, so the zhat term has no
+// cancellation (the uncentred  be * z + (ga + a*mean*k2)  adds two large nearly cancelling terms and loses eps*|mean|/std).
 // One definition for every kernel that forms dZ (bn_bwd_apply_kernel, the weight-gradient GEMM that materialises dZ while
 // staging its A operand): the same operations in the same order, so the fused and the stand-alone forms are bit-identical.
 #ifdef __HIPCC__
 __device__ __forceinline__ void cmf_bnb_coef(float sa, float mu, float is, float t1, float t2, float ic, float &al, float &be, float &ga)
 {
+    (void)mu;
     const float k1 = t1 * ic, k2 = is * (t2 * ic);
     al = sa;
     be = -(sa * k2);
-    ga = sa * fmaf(mu, k2, -k1);
+    ga = -(sa * k1);
 }
-__device__ __forceinline__ float cmf_bnb_apply(float d, float v, float al, float be, float ga) { return fmaf(al, d, fmaf(be, v, ga)); }
+__device__ __forceinline__ float cmf_bnb_apply(float d, float v, float mu, float al, float be, float ga) { return fmaf(al, d, fmaf(be, v - mu, ga)); }
 #endif
 
 // neighbor.hip: cmf_ball_query that also defines the rows of empty balls (zeros), without a memset launch on small clouds

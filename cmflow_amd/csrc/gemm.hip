@@ -172,15 +172,17 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
     // checks the shape.  A thread stages 4 fixed columns m of every chunk, so its coefficients are loop constants.
     float4 rz[A_T ? A_IT : 1];
     const bool bnbA = A_T && p.bnb_z != nullptr;
-    float bal[4] = {1.f, 1.f, 1.f, 1.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f}, bga[4] = {0.f, 0.f, 0.f, 0.f};
+    float bal[4] = {1.f, 1.f, 1.f, 1.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f}, bga[4] = {0.f, 0.f, 0.f, 0.f}, bmu[4] = {0.f, 0.f, 0.f, 0.f};
     int k0_loaded = 0;
     const int bnb_writers = tiles_n < G_BK ? tiles_n : G_BK;
     if (A_T && bnbA) {
         const int m = m0 + (tid % A_TPR) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            cmf_bnb_coef(p.bnb_a[m + j], p.bnb_mean[m + j], p.bnb_invstd[m + j], p.bnb_sums[m + j], p.bnb_sums[p.M + m + j], p.bnb_ic,
+        for (int j = 0; j < 4; ++j) {
+            bmu[j] = p.bnb_mean[m + j];
+            cmf_bnb_coef(p.bnb_a[m + j], bmu[j], p.bnb_invstd[m + j], p.bnb_sums[m + j], p.bnb_sums[p.M + m + j], p.bnb_ic,
                          bal[j], bbe[j], bga[j]);
+        }
     }
     float4 psa = make_float4(1.f, 1.f, 1.f, 1.f), psc = make_float4(0.f, 0.f, 0.f, 0.f);   // A prologue (per chunk)
     float4 qsa = make_float4(1.f, 1.f, 1.f, 1.f), qsc = make_float4(0.f, 0.f, 0.f, 0.f);   // B prologue (per thread)
@@ -299,8 +301,8 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 float4 v = ra[i];
                 if (bnbA) {
                     const float4 zz = rz[A_T ? i : 0];
-                    v.x = cmf_bnb_apply(v.x, zz.x, bal[0], bbe[0], bga[0]); v.y = cmf_bnb_apply(v.y, zz.y, bal[1], bbe[1], bga[1]);
-                    v.z = cmf_bnb_apply(v.z, zz.z, bal[2], bbe[2], bga[2]); v.w = cmf_bnb_apply(v.w, zz.w, bal[3], bbe[3], bga[3]);
+                    v.x = cmf_bnb_apply(v.x, zz.x, bmu[0], bal[0], bbe[0], bga[0]); v.y = cmf_bnb_apply(v.y, zz.y, bmu[1], bal[1], bbe[1], bga[1]);
+                    v.z = cmf_bnb_apply(v.z, zz.z, bmu[2], bal[2], bbe[2], bga[2]); v.w = cmf_bnb_apply(v.w, zz.w, bmu[3], bal[3], bbe[3], bga[3]);
                     // the column tiles that share this row panel stage the same chunk: each writes the rows k with
                     // k % tiles == tn (one slow writer among them would set the pace of a one-round launch)
                     if (p.bnb_out && (k % bnb_writers) == tn) *(float4 *)(p.bnb_out + (long long)(k0_loaded + k) * p.ldbo + m0 + m) = v;
@@ -1412,7 +1414,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
 }
 
 // Weight gradient of a layer whose output gradient still has to go through the train-mode BatchNorm backward:
-//   dZ = al * dU + be * Z + ga  (cmf_common.h cmf_bnb_coef of a / mean / invstd / sums, 1 / rows),   dW (+)= dZ^T @ act(X)
+//   dZ = al * dU + be * (Z - mean) + ga  (cmf_common.h cmf_bnb_coef of a / mean / invstd / sums, 1 / rows),   dW (+)= dZ^T @ act(X)
 // formed while the A operand is staged -- the stand-alone cmf_bn_bwd_apply pass (read dU, read Z, write dZ) disappears and dZ
 // is written to dZ_out (a buffer of its own: other workgroups still read dU) as a by-product for the data-gradient GEMM that
 // follows.  Same operations as cmf_bn_bwd_apply + cmf_gemm(a_t = 1, b_t = 0) on the register-staged loop: bit-identical

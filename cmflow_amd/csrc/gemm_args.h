@@ -27,7 +27,7 @@ struct GemmArgs {
     const float *dxyz;          // bwd_mode 1 only, optional: rows of (dx,dy,dz,0); adds partials q_k = sum dU * d_k (k=0..2)
                                 // -> stats is then [tiles_m][5][N] (s1, s2, q0, q1, q2): the set-conv dW_xyz without a pass
     // A_KM (weight-gradient) layout only: the A operand is formed while staging as the train-mode BN backward of two streams,
-    //   A[k][m] = al[m] * A[k][m] + be[m] * bnb_z[k][m] + ga[m]   (cmf_common.h cmf_bnb_coef from bnb_a / mean / invstd / sums)
+    //   A[k][m] = al[m] * A[k][m] + be[m] * (bnb_z[k][m] - mean[m]) + ga[m]   (cmf_common.h cmf_bnb_coef from bnb_a / mean / invstd / sums)
     // and the workgroups of the first column tile write it to bnb_out (the dZ the data-gradient GEMM reads next)
     const float *bnb_z; long long ldbz;
     const float *bnb_a, *bnb_mean, *bnb_invstd, *bnb_sums;      // sums: [2][M] (s1 | s2)

@@ -162,13 +162,14 @@ int cmf_group_points_xyz(int b, int c, int n, int npoints, int nsample, const fl
     } else if (n <= GP_MAX_N_LDS) {
         // 4 rows when they fit in 64 KB (two workgroups per CU), else 2
         const bool four = (size_t)4 * n * sizeof(float) <= 64 * 1024;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static CmfPerDevice attr_set;
+        int attr_dev;
+        if (attr_set.need(attr_dev)) {
             (void)hipFuncSetAttribute((const void *)group_points_kernel<true, 2, 512>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GP_MAX_N_LDS * 4);
             (void)hipFuncSetAttribute((const void *)group_points_kernel<true, 4, 512>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-            attr_set = true;
+            attr_set.done(attr_dev);
         }
         tiles = cmf_divup(total, 512 * GP_VEC * GP_STEPS);                 // 512 threads: twice the waves per CU for the LDS gather
         if (four) {
@@ -559,12 +560,13 @@ template <int E>
 static int launch_plan(int b, int c, int n, int P, int S, int ch_per_wg, size_t lds_plan, const float *grad_out, const int *idx,
                        unsigned *plan, float *grad_points, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmfPerDevice attr_set;
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
         (void)hipFuncSetAttribute((const void *)gpg_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
         (void)hipFuncSetAttribute((const void *)group_points_grad_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   ((GG_THREADS * E + 4) + 2 * GG_MAX_N_BAL + GG_THREADS) * 4);
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     hipLaunchKernelGGL(gpg_plan_kernel<E>, dim3(b), dim3(GG_THREADS), lds_plan, st, n, P, S, idx, plan);
     const size_t lds = (size_t)((GG_THREADS * E + 4) + 2 * n + GG_THREADS) * 4;
@@ -898,12 +900,13 @@ static int launch_csr(int b, int c, int n, int total, const float *grad_out, con
     unsigned long long *padmask = (unsigned long long *)lease.ptr;
     unsigned short *off = (unsigned short *)((char *)lease.ptr + n_mask);
     unsigned short *pos = (unsigned short *)((char *)lease.ptr + n_mask + n_off);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmfPerDevice attr_set;
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
         (void)hipFuncSetAttribute((const void *)gpg_csr_index_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         (void)hipFuncSetAttribute((const void *)gpg_csr_gather_kernel<S, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCG_LDS);
         (void)hipFuncSetAttribute((const void *)gpg_csr_gather_kernel<S, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCG_LDS);
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     const size_t lds_i = (size_t)(2 * n + 1) * sizeof(unsigned) + (size_t)GC_TILE * sizeof(unsigned short);
     hipLaunchKernelGGL(gpg_csr_index_kernel<S>, dim3(tiles, b), dim3(GC_THREADS), lds_i, st, n, total, tiles, idx, padmask, off, pos);
@@ -1154,11 +1157,12 @@ template <int E>
 static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int total, int ch_per_wg, const float *grad_out,
                        const int *offsets, const int *inv, float *grad_points)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmfPerDevice attr_set;
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
         (void)hipFuncSetAttribute((const void *)group_points_grad_bal_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   ((GG_THREADS * E + 4) + 3 * GG_MAX_N_BAL + GG_THREADS + 16) * 4);
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     hipLaunchKernelGGL(group_points_grad_bal_kernel<E>, grid, dim3(GG_THREADS), lds, st, c, n, total, ch_per_wg, grad_out, offsets,
                        inv, grad_points);
@@ -1168,9 +1172,11 @@ static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int 
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
 {
-    struct Entry { void *p = nullptr; size_t cap = 0; std::mutex in_use; };
+    struct Retired { void *p; hipEvent_t done; };
+    struct Entry { void *p = nullptr; size_t cap = 0; std::mutex in_use; std::vector<Retired> retired; };
     static std::mutex mu;
     static std::map<std::tuple<int, hipStream_t, int>, Entry> *table =
         new std::map<std::tuple<int, hipStream_t, int>, Entry>();      // leaked on purpose (runtime teardown order)
@@ -1183,12 +1189,26 @@ CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
         e = &(*table)[std::make_tuple(dev, stream, slot)];              // map nodes do not move
     }
     lease.hold = std::unique_lock<std::mutex>(e->in_use);
+    // buffers retired by an earlier growth: free the ones whose last possible user (work queued before the retirement) is done
+    for (size_t i = 0; i < e->retired.size();) {
+        if (hipEventQuery(e->retired[i].done) == hipSuccess) {
+            (void)hipFree(e->retired[i].p);
+            (void)hipEventDestroy(e->retired[i].done);
+            e->retired[i] = e->retired.back();
+            e->retired.pop_back();
+        } else { (void)hipGetLastError(); ++i; }
+    }
     if (e->cap < bytes) {
-        // the old buffer may still be in use by queued work of this stream: it is retired (kept allocated), not freed
+        // the old buffer may still be in use by queued work of this stream: it is retired behind an event, not freed here
         size_t want = bytes > e->cap + e->cap / 2 ? bytes : e->cap + e->cap / 2;
         want = (want + ((size_t)1 << 20) - 1) >> 20 << 20;
         void *p = nullptr;
         if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); lease.hold.unlock(); return lease; }
+        if (e->p) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, stream) == hipSuccess) e->retired.push_back({e->p, ev});
+            else { (void)hipGetLastError(); if (ev) (void)hipEventDestroy(ev); }       // could not fence it: keep it allocated (the old behaviour)
+        }
         e->p = p; e->cap = want;
     }
     lease.ptr = e->p;
@@ -1239,11 +1259,12 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         return cmf_launch_status();
     }
     if (!balanced && stream_fits) {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static CmfPerDevice attr_set;
+        int attr_dev;
+        if (attr_set.need(attr_dev)) {
             (void)hipFuncSetAttribute((const void *)group_points_grad_stream_kernel,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_set = true;
+            attr_set.done(attr_dev);
         }
         hipLaunchKernelGGL(group_points_grad_stream_kernel, dim3(b, cmf_divup(c, GA_CH)), dim3(GA_THREADS),
                            (size_t)GA_CH * n * sizeof(float), st, c, n, (int)total, grad_out, idx, grad_points);

@@ -783,10 +783,10 @@ __global__ __launch_bounds__(PW_THREADS) void bn_bwd_apply_kernel(
             const float4 t1 = *(const float4 *)(sums + col), t2 = *(const float4 *)(sums + C + col);
             const float4 v = *(const float4 *)(z + (size_t)m * ldz + col);
             float al, be, ga;                                    // cmf_common.h: shared with the GEMM that fuses this pass
-            cmf_bnb_coef(sa.x, mu.x, is.x, t1.x, t2.x, inv_count, al, be, ga); d.x = cmf_bnb_apply(d.x, v.x, al, be, ga);
-            cmf_bnb_coef(sa.y, mu.y, is.y, t1.y, t2.y, inv_count, al, be, ga); d.y = cmf_bnb_apply(d.y, v.y, al, be, ga);
-            cmf_bnb_coef(sa.z, mu.z, is.z, t1.z, t2.z, inv_count, al, be, ga); d.z = cmf_bnb_apply(d.z, v.z, al, be, ga);
-            cmf_bnb_coef(sa.w, mu.w, is.w, t1.w, t2.w, inv_count, al, be, ga); d.w = cmf_bnb_apply(d.w, v.w, al, be, ga);
+            cmf_bnb_coef(sa.x, mu.x, is.x, t1.x, t2.x, inv_count, al, be, ga); d.x = cmf_bnb_apply(d.x, v.x, mu.x, al, be, ga);
+            cmf_bnb_coef(sa.y, mu.y, is.y, t1.y, t2.y, inv_count, al, be, ga); d.y = cmf_bnb_apply(d.y, v.y, mu.y, al, be, ga);
+            cmf_bnb_coef(sa.z, mu.z, is.z, t1.z, t2.z, inv_count, al, be, ga); d.z = cmf_bnb_apply(d.z, v.z, mu.z, al, be, ga);
+            cmf_bnb_coef(sa.w, mu.w, is.w, t1.w, t2.w, inv_count, al, be, ga); d.w = cmf_bnb_apply(d.w, v.w, mu.w, al, be, ga);
         } else { d.x *= sa.x; d.y *= sa.y; d.z *= sa.z; d.w *= sa.w; }
         *(float4 *)(dU + (size_t)m * C + col) = d;
     }

@@ -115,23 +115,51 @@ class SegmentedReducer:
         self.active = False
 
 
-def pin_rank_to_cores(local_rank=None, local_world=None):
-    """Restrict this rank (and every thread it creates later: the library's chain workers, the autograd thread) to its own
-    block of host cores: with 8 ranks x 5 enqueueing threads on one host the launch path otherwise migrates across
-    sockets.  Cores are dealt in contiguous blocks by LOCAL_RANK (on the usual two-socket hosts the lower ranks' GPUs
-    hang off the first socket).  CMF_NO_AFFINITY=1 opts out.  Returns the core list or None."""
+def _gpu_local_cpus(index):
+    """Host CPUs local to GPU `index` (its PCI device's NUMA node): /sys/bus/pci/devices/<domain:bus:device.0>/local_cpulist,
+    or None when the property or the file is missing."""
     import os
-    if os.environ.get("CMF_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open(os.path.join("/sys/bus/pci/devices", bdf, "local_cpulist")) as f:
+            text = f.read().strip()
+    except Exception:
+        return None
+    cpus = []
+    for part in text.split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus or None
+
+
+def pin_rank_to_cores(local_rank=None, local_world=None):
+    """OPT-IN (CMF_PIN_CORES=1; unmeasured -- no multi-GPU box so far): restrict this rank (and every thread it creates later:
+    the library's chain workers, the autograd thread) to host cores of ITS GPU's NUMA node.  The cores local to the GPU come
+    from sysfs (logical CPU ids are not laid out socket by socket: on SMT hosts the second half of the ids are the siblings of
+    the first); the ranks whose GPUs share a node split that node's cores evenly, in local-rank order.  local_world is the
+    number of ranks on THIS host (LOCAL_WORLD_SIZE), not the job's world size.  Returns the core list or None (not enabled,
+    no locality information, or fewer than two cores per rank: the scheduler is left alone)."""
+    import os
+    if os.environ.get("CMF_PIN_CORES") != "1" or not hasattr(os, "sched_setaffinity"):
         return None
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if local_rank is None else local_rank
-    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))) if local_world is None else local_world
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1")) if local_world is None else local_world
     if local_world <= 1:
         return None
-    avail = sorted(os.sched_getaffinity(0))
-    per = len(avail) // local_world
-    if per < 2:                                          # fewer than two cores per rank: leave the scheduler alone
+    avail = set(os.sched_getaffinity(0))
+    mine = _gpu_local_cpus(local_rank)
+    if not mine:
         return None
-    cores = avail[local_rank * per:(local_rank + 1) * per]
+    key = tuple(mine)
+    sharing = [r for r in range(local_world) if tuple(_gpu_local_cpus(r) or ()) == key]     # ranks whose GPUs hang off the same node
+    cores = sorted(c for c in mine if c in avail)
+    per = len(cores) // max(len(sharing), 1)
+    if per < 2 or local_rank not in sharing:
+        return None
+    i = sharing.index(local_rank)
+    cores = cores[i * per:(i + 1) * per]
     os.sched_setaffinity(0, cores)
     return cores
 

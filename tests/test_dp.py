@@ -115,22 +115,36 @@ def test_segmented_reducer_matches_whole_bucket_allreduce_world2():
     assert ok and bad_cover and diff > 0
 
 
-def test_pin_rank_to_cores_deals_disjoint_blocks():
-    from cmflow_amd.dp import pin_rank_to_cores
+def test_pin_rank_to_cores_is_opt_in_and_follows_gpu_locality(monkeypatch):
+    """dp.pin_rank_to_cores: off unless CMF_PIN_CORES=1; the cores come from the GPU's NUMA node (sysfs), ranks that share a
+    node split it evenly, a rank whose GPU has no locality information is left alone.  (sysfs is faked: no GPU here.)"""
+    from cmflow_amd import dp
     if not hasattr(os, "sched_getaffinity"):
         return
     before = os.sched_getaffinity(0)
+    cpus = sorted(before)
     try:
-        if len(before) < 4:
-            assert pin_rank_to_cores(0, 2) is None
+        monkeypatch.delenv("CMF_PIN_CORES", raising=False)
+        assert dp.pin_rank_to_cores(0, 2) is None                          # not enabled
+        monkeypatch.setenv("CMF_PIN_CORES", "1")
+        monkeypatch.setattr(dp, "_gpu_local_cpus", lambda i: None)
+        assert dp.pin_rank_to_cores(0, 2) is None                          # no locality information
+        if len(cpus) < 4:
             return
-        a = pin_rank_to_cores(0, 2)
+        half = len(cpus) // 2
+        # four ranks: GPUs 0, 1 on the first node, 2, 3 on the second
+        monkeypatch.setattr(dp, "_gpu_local_cpus", lambda i: cpus[:half] if i < 2 else cpus[half:2 * half])
+        got = []
+        for r in range(4):
+            os.sched_setaffinity(0, before)
+            got.append(dp.pin_rank_to_cores(r, 4))
+        if half >= 4:
+            assert all(got) and len({tuple(g) for g in got}) == 4
+            assert set(got[0]) | set(got[1]) <= set(cpus[:half]) and set(got[2]) | set(got[3]) <= set(cpus[half:2 * half])
+            assert not (set(got[0]) & set(got[1])) and not (set(got[2]) & set(got[3]))
+        else:
+            assert got == [None] * 4                                       # fewer than two cores per rank: scheduler left alone
         os.sched_setaffinity(0, before)
-        b = pin_rank_to_cores(1, 2)
-        assert a and b and not (set(a) & set(b)) and len(a) == len(b) == len(before) // 2
-        os.environ["CMF_NO_AFFINITY"] = "1"
-        os.sched_setaffinity(0, before)
-        assert pin_rank_to_cores(1, 2) is None
+        assert dp.pin_rank_to_cores(0, 1) is None                          # one rank on the host
     finally:
-        os.environ.pop("CMF_NO_AFFINITY", None)
         os.sched_setaffinity(0, before)
