@@ -211,8 +211,18 @@ def hbm_op_rooflines(dev, iters=20):
                          "group_grad": {"bytes": ng, "us": round(t_gg * 1e6, 1), "achieved": round(ng / t_gg / 1e9, 1),
                                         "frac": round(ng / t_gg / 1e9 / HBM_PEAK_GBS, 4)}})
             del feats, out, gp
+    # counted HBM bytes per call from the committed PMC passes over the same calls (tools/session.sh op_pmc): constants of a
+    # profiled build, NOT measured by this run
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_op_hbm_pmc.json")
+    if os.path.exists(tj):
+        table = {(r["op"], tuple(r["shape_BNKC"])): r["traffic_bytes"] for r in json.load(open(tj))["rows"]}
+        for row in rows:
+            key = tuple(row["shape_BNKC"])
+            row["query_and_group"]["traffic_committed"] = table.get(("query_and_group", key))
+            row["group_grad"]["traffic_committed"] = table.get(("group_points_grad", key))
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-            "traffic_profile": "profiles/r02_op_hbm_pmc.md",
+            "traffic_source": "per-row traffic_committed: constants from the committed rocprofv3 PMC passes (profiles/r04_op_hbm_pmc.md), not measured by this run",
+            "traffic_profile": "profiles/r04_op_hbm_pmc.md",
             "kernels": ["ball_query_ballot_kernel / bq_grid_*", "group_points_kernel", "query_and_group_kernel", "group_points_grad_*_kernel"],
             "method": "%d back-to-back launches per op between one HIP event pair; bytes = SURVEY 8d algorithmic bytes" % iters,
             "rows": rows}

@@ -39,6 +39,14 @@ pclock() {             # effective clock + MFMA busy of the persistent kernel (p
 }
 ptimeline() { for a in "524288x512x256 1 1" "524288x512x256 2 0" "65536x512x256 1 1" "131072x512x512 2 1"; do echo "== $a"; timeout 300 python tools/pgemm_timeline.py $a 2>&1 | filter; done | tee $R/ptimeline.txt; }
 pgrid() { for g in 256 512 256 512; do echo "== grid $g"; PGRID=$g timeout 300 python tools/pgemm_bench.py 524288x512x256 131072x512x512 2>&1 | filter; done | tee $R/pgrid.txt; }
+op_pmc() {              # the drop-in calls of the bench line's roofline_hbm rows: durations + FETCH_SIZE / WRITE_SIZE (separate passes) -> table
+    rm -rf /tmp/o1 /tmp/o2 /tmp/o3
+    (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/o1 -- python3 $GRAFT_REPO_ROOT/tools/op_probe.py > $R/op_probe.out 2>/dev/null)
+    (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/o2 -- python3 $GRAFT_REPO_ROOT/tools/op_probe.py > /dev/null 2>&1)
+    (cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/o3 -- python3 $GRAFT_REPO_ROOT/tools/op_probe.py > /dev/null 2>&1)
+    python tools/op_table.py $(find /tmp/o1 -name "*kernel_trace.csv" | head -1) $(find /tmp/o2 -name "*counter_collection.csv" | head -1) \
+        $(find /tmp/o3 -name "*counter_collection.csv" | head -1) $R/op_probe.out $R/op_hbm_pmc.json > $R/op_hbm_pmc.md; cat $R/op_hbm_pmc.md
+}
 gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
 gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment build (tools/diag/libcmflow_w3.so)
     for d in 0 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
