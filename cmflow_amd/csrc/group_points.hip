@@ -406,14 +406,33 @@ __global__ __launch_bounds__(GG_THREADS) void gpg_plan_kernel(int n, int P, int 
     unsigned *plan = plan_all + (size_t)bs * gpg_plan_words(E, n);
     for (int i = t; i < (int)(((size_t)P * ld * 2 + 15) / 16); i += GG_THREADS) reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
-    // A: row p counts its targets; the running count is the entry's rank inside (row, target) -- one owner per row: no atomics
-    if (t < P)
-        for (int sl = 0; sl < S; ++sl) {
-            const int j = ix[t * S + sl];
-            const unsigned short c = cnt[t * ld + j];
-            rk[t * S + sl] = (unsigned char)c;
-            cnt[t * ld + j] = (unsigned short)(c + 1);
-        }
+    // A: row p counts its targets; the running count is the entry's rank inside (row, target) -- one owner per row: no atomics.
+    // The row's indices come as 16-byte loads, the next four requested before the current four are counted: with one 4-byte
+    // load per step the loop was S dependent L2 round trips (and phase C the same again): 17-18 us per call, 37 % of the
+    // C = 64 call and 68 % of the C = 3 call of (64,256,32) (profiles/r04_op_kernels.txt).
+    const bool v4 = (S & 3) == 0 && (((uintptr_t)ix) & 15) == 0;
+    if (t < P) {
+        if (v4) {
+            int4 nx = *(const int4 *)(ix + t * S);
+            for (int sl = 0; sl < S; sl += 4) {
+                const int4 cur = nx;
+                if (sl + 4 < S) nx = *(const int4 *)(ix + t * S + sl + 4);
+                const int jj[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned short c = cnt[t * ld + jj[u]];
+                    rk[t * S + sl + u] = (unsigned char)c;
+                    cnt[t * ld + jj[u]] = (unsigned short)(c + 1);
+                }
+            }
+        } else
+            for (int sl = 0; sl < S; ++sl) {
+                const int j = ix[t * S + sl];
+                const unsigned short c = cnt[t * ld + j];
+                rk[t * S + sl] = (unsigned char)c;
+                cnt[t * ld + j] = (unsigned short)(c + 1);
+            }
+    }
     __syncthreads();
     // B: column j -> exclusive prefix over the rows (8 loads in flight, then 8 stores: the loads of a serial read-modify-write
     // loop cannot be overlapped by the compiler, it must assume the store aliases the next load); column totals -> offsets
@@ -440,11 +459,25 @@ __global__ __launch_bounds__(GG_THREADS) void gpg_plan_kernel(int n, int P, int 
     if (t == 0) offs[n] = base;
     __syncthreads();
     // C: every entry to its slot: ascending (row, slot) order inside a target's list
-    if (t < P)
-        for (int sl = 0; sl < S; ++sl) {
-            const int j = ix[t * S + sl];
-            sorted[offs[j] + cnt[t * ld + j] + rk[t * S + sl]] = (unsigned short)(t * S + sl);
-        }
+    if (t < P) {
+        if (v4) {
+            int4 nx = *(const int4 *)(ix + t * S);
+            for (int sl = 0; sl < S; sl += 4) {
+                const int4 cur = nx;
+                if (sl + 4 < S) nx = *(const int4 *)(ix + t * S + sl + 4);
+                const int jj[4] = {cur.x, cur.y, cur.z, cur.w};
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dst[u] = offs[jj[u]] + cnt[t * ld + jj[u]] + rk[t * S + sl + u];     // four independent chains
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sorted[dst[u]] = (unsigned short)(t * S + sl + u);
+            }
+        } else
+            for (int sl = 0; sl < S; ++sl) {
+                const int j = ix[t * S + sl];
+                sorted[offs[j] + cnt[t * ld + j] + rk[t * S + sl]] = (unsigned short)(t * S + sl);
+            }
+    }
     __syncthreads();
     // D: the scatter workgroup's register image
     for (int i = t; i < (total + 3) / 4; i += GG_THREADS) reinterpret_cast<unsigned *>(flags)[i] = 0u;
