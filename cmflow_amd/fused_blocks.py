@@ -1007,11 +1007,13 @@ def _multi_call(backward, n, plan, sp, streams, main):
     descs = ctypes.addressof(plan.descs)
     if backward:
         _lib.check(L().cmf_setconv_tail_backward(n, descs, main.cuda_stream), "cmf_setconv_tail_backward")
+        stress_point([main])                    # (tests) between the tails and the bodies that consume their gradients
     for st in streams:
         st.wait_stream(main)
     stress_point(streams)
     fn = L().cmf_setconv_backward_bodies_multi if backward else L().cmf_setconv_forward_heads_multi
     _lib.check(fn(n, descs, ctypes.addressof(sp)), "cmf_setconv_*_multi")
+    stress_point(streams)                       # (tests) at the END of each chain: between a block's body and its tail / the join
     for st in streams:
         main.wait_stream(st)
     if not backward:

@@ -490,6 +490,47 @@ def test_single_rank_rccl_all_reduce(dev, manifest, golden_dir, args):
         dist.destroy_process_group()
 
 
+def test_rccl_step_three_ways_bit_identical(dev, manifest, golden_dir, args):
+    """The exact path N > 1 GPUs would run, on the REAL model over backend 'nccl' (= RCCL; world size 1 on this box): one CMFlow
+    B = 8 optimizer step (a) without a collective, (b) with one all-reduce of the whole bucket after backward, (c) with the
+    three overlapped segments (ReduceOp.AVG, async_op=True, launched from tensor hooks inside backward).  Gradient bucket and
+    parameters after Adam must be bit-identical in all three (models/model.py:40-42 is what this replaces)."""
+    import os
+    import torch.distributed as dist
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.fused_blocks import join_side_streams
+    from cmflow_amd.train import TrainStep
+    sd = _weights(manifest, golden_dir)
+    b = {k: v.to(dev) for k, v in synth.make_batch(8, seed=11, train_extras=True).items()}
+
+    def run(overlap, force):
+        net = CMFlow(args)
+        net.load_state_dict(sd)
+        net = net.to(dev).train()
+        step = TrainStep(net, vr_thres=args.vr_thres)
+        step.overlap_allreduce, step.force_allreduce = overlap, force
+        loss, _, _, _ = step(b)
+        join_side_streams()
+        torch.cuda.synchronize()
+        early = step.reducer.early if (overlap and step.reducer is not None) else None
+        return loss.clone(), step.bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone(), early
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29513")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        none = run(False, False)
+        one = run(False, True)
+        three = run(True, True)
+    finally:
+        dist.destroy_process_group()
+    assert three[3] == 2                                 # two of the three segments were launched while backward was still running
+    assert float(none[1].abs().sum()) > 0
+    for i, what in enumerate(("loss", "gradient bucket", "parameters after Adam")):
+        assert torch.equal(one[i], none[i]), "one bucket vs none: %s" % what
+        assert torch.equal(three[i], none[i]), "three overlapped segments vs none: %s" % what
+
+
 def test_encoder_plan_follows_parameter_reallocation_and_guards_grad_sinks(dev, manifest, golden_dir, args):
     """The cached call plan of an encoder (fused_blocks.EncoderPlan) holds raw parameter pointers: it must notice when
     the parameters are re-allocated, and the in-place gradient sinks must refuse to run once the .grad buffers they

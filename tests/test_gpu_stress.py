@@ -88,6 +88,55 @@ def test_fork_point_delays_do_not_change_results(B, model, monkeypatch):
         FB.stress_seed(None)
 
 
+@pytest.mark.parametrize("model", ["cmflow"])
+def test_delays_do_not_change_a_full_step_with_overlapped_rccl_all_reduce(model, monkeypatch):
+    """The whole optimizer step (TrainStep.__call__) with the gradient bucket reduced in three segments launched from tensor hooks
+    DURING backward on RCCL's stream (ReduceOp.AVG, async_op; world size 1 on this box: the collective is real, its result
+    the identity) and random delays at every fork point, chain end and tail: bucket after the reduction and parameters
+    after Adam must be bit-identical to the undelayed single-stream step without a collective."""
+    import torch.distributed as dist
+    import bench
+    from cmflow_amd import fused_blocks as FB
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    torch.backends.cuda.matmul.allow_tf32 = False
+    sd = bench.load_weights(model)
+    batch = {k: v.to(dev) for k, v in synth.make_batch(8, seed=1234, train_extras=True).items()}
+
+    def run(overlap, force, seed):
+        net = CMFlow(bench.Args())
+        net.load_state_dict(sd)
+        net = net.to(dev).train()
+        step = TrainStep(net, vr_thres=bench.Args.vr_thres)
+        step.overlap_allreduce, step.force_allreduce = overlap, force
+        FB.stress_seed(seed)
+        try:
+            loss, _, _, _ = step(batch)
+        finally:
+            FB.stress_seed(None)
+        FB.join_side_streams()
+        torch.cuda.synchronize()
+        early = step.reducer.early if (overlap and step.reducer is not None) else None
+        return loss.clone(), step.bucket.flat.clone(), torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone(), early
+
+    real = FB.side_stream
+    monkeypatch.setattr(FB, "side_stream", lambda slot, device=None: torch.cuda.current_stream())
+    want = run(False, False, None)
+    monkeypatch.setattr(FB, "side_stream", real)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for seed in [None] + list(range(min(SEEDS, 20))):
+            got = run(True, True, seed)
+            assert got[3] == 2, "segments launched from inside backward: %r" % (got[3],)
+            for i, what in enumerate(("loss", "gradient bucket", "parameters after Adam")):
+                assert torch.equal(got[i], want[i]), "seed %r: %s differs (max %.3g)" % (seed, what, float((got[i] - want[i]).abs().max()))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_spin_kernel_delays_only_its_stream():
     """cmf_debug_spin occupies the stream it is given for about the requested time and nothing else."""
     from cmflow_amd import _lib
