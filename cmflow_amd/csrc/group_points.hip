@@ -208,9 +208,11 @@ int cmf_group_points_xyz(int b, int c, int n, int npoints, int nsample, const fl
 //    chunks are stitched from per-chunk tails in fixed order: no atomics, bit-reproducible (the
 //    association differs from a sequential scan, so equal to the oracle to rounding, not bitwise).
 //    The next channel's row is fetched into registers while the current one is reduced.
-//  * longer rows (N = 4096 x K = 64: 1 MB per row): workgroup per (sample, 4 channels), the row
-//    streamed with 16-byte loads, idx read once per 4 channels, sums kept in LDS per target with
-//    ds_add_f32 (order undefined, like the reference; LDS atomics instead of HBM atomics).
+//  * longer rows (N = 4096 x K = 64: 1 MB per row), per-centre lists of 16 / 32 / 64 slots: the pad-folded CSR gather
+//    (gpg_csr_index_kernel + gpg_csr_gather_kernel below; the DEFAULT since round 3): deterministic, no atomics.
+//    Other list lengths / n > 8192: workgroup per (sample, 4 channels), the row streamed with 16-byte loads, idx read
+//    once per 4 channels, sums kept in LDS per target with ds_add_f32 (order undefined, like the reference; LDS atomics
+//    instead of HBM atomics), or the tiled deterministic kernel (opt-in).
 // ---------------------------------------------------------------------------------------------
 int cmf_build_inverse_rows(int b, int n, int P, int S, const int *idx, int *offsets, int *inv, void *stream, int entries);
 

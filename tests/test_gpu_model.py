@@ -251,7 +251,7 @@ def _check_transform(got, want, pc1, weight):
     return float(ang.max()), float(dt.max())
 
 
-def _check_gradients(net, gref, what, bounds=(1e-2, 2e-4, 6e-2)):
+def _check_gradients(net, gref, what, bounds=(1e-2, 2e-4, 6e-2), loose=None):
     """Every parameter gradient against the oracle's, three ways: the norm, the DIRECTION (1 - cosine: a permutation, a
     swapped column block or a missing term inside a tensor keeps the norm and moves this to 1e-2 ... 1) and the largest
     single element relative to the tensor's largest entry.  bounds = (norm, 1 - cos, element).  They are set from
@@ -264,20 +264,24 @@ def _check_gradients(net, gref, what, bounds=(1e-2, 2e-4, 6e-2)):
     the 8-thread run had < 1e-5.  Defaults: 2-3x above those floors, still 100x below what a structural error produces.
     -> (count, worst norm error, worst 1 - cos, worst element error), each with the parameter's name."""
     wn, wc, we, n = ("", 0.0), ("", 0.0), ("", 0.0), 0
+    over = []
     for k, p in net.named_parameters():
         if gref[k] is None:
             assert p.grad is None, k
             continue
         a, r = p.grad.detach().double().cpu().reshape(-1), gref[k].double().reshape(-1)
         na, nr = float(a.norm()), float(r.norm())
-        wn = max(wn, (k, abs(na - nr) / max(nr, 1e-3)), key=lambda t: t[1])
-        if nr > 1e-6:                                  # direction of a numerically-zero gradient is undefined
-            wc = max(wc, (k, 1.0 - float(a @ r) / (na * nr)), key=lambda t: t[1])
-        we = max(we, (k, float((a - r).abs().max()) / max(float(r.abs().max()), 1e-6)), key=lambda t: t[1])
+        en = abs(na - nr) / max(nr, 1e-3)
+        ec = 1.0 - float(a @ r) / (na * nr) if nr > 1e-6 else 0.0          # direction of a numerically-zero gradient is undefined
+        ee = float((a - r).abs().max()) / max(float(r.abs().max()), 1e-6)
+        # `loose`: (name prefixes, bounds) for the tensors that are allowed more (named, with the reason, at the call site);
+        # every other tensor is held to `bounds`
+        bd = loose[1] if (loose is not None and k.startswith(tuple(loose[0]))) else bounds
+        if en > bd[0] or ec > bd[1] or ee > bd[2]:
+            over.append((k, en, ec, ee))
+        wn = max(wn, (k, en), key=lambda t: t[1]); wc = max(wc, (k, ec), key=lambda t: t[1]); we = max(we, (k, ee), key=lambda t: t[1])
         n += 1
-    assert wn[1] <= bounds[0], (what, "norm", wn)
-    assert wc[1] <= bounds[1], (what, "direction", wc)
-    assert we[1] <= bounds[2], (what, "element", we)
+    assert not over, (what, "tensors over their bounds (name, norm, 1 - cos, element)", over)
     return n, wn, wc, we
 
 
@@ -412,7 +416,12 @@ def test_full_size_cmflow_t_clip_matches_oracle(dev):
         np.testing.assert_allclose(step.gfeat.detach().cpu().numpy(), out[4].detach().numpy(), rtol=0, atol=1e-4)
         gref = {k: p.grad for k, p in ref.named_parameters()}
         # later frames: weights after Adam steps, saturating motion-head BCE -- the oracle's own fp32 floor is 10-40x the first frame's
-        n, worst, wcos, welem = _check_gradients(net, gref, "CMFlow-T frame %d" % f, (1e-2, 2e-4, 6e-2) if f == 0 else (4e-2, 5e-3, 0.4))
+        # Frame 0 is held to the defaults.  Later frames (weights after Adam steps): every tensor to the ORACLE's own fp32-vs-fp64
+        # floor of a second frame (tests/grad_noise_floor.py: 1.2e-2 / 9.5e-4 / 0.115) -- measured here 3.7e-3 / 1.2e-4 / 5.2e-2 --
+        # except the motion head ("mp.": its BCE saturates after a step, single elements of its small tensors are pure
+        # cancellation), which alone keeps the wide bounds.
+        n, worst, wcos, welem = _check_gradients(net, gref, "CMFlow-T frame %d" % f, (1e-2, 2e-4, 6e-2) if f == 0 else (1.5e-2, 1e-3, 0.12),
+                                                 loose=None if f == 0 else (("mp.",), (4e-2, 5e-3, 0.4)))
         assert n >= 184                                               # 182 + the four GRU tensors
         want, have = ref.state_dict(), net.state_dict()
         for k, v in want.items():

@@ -164,7 +164,8 @@ def test_config5_shapes_match_oracle(dev, C):
     """BASELINE config 5 at its own op shape -- N = 4096 LiDAR-like points, K = 64, r = 2.0, C in {64, 128} -- the first
     two samples of the very tensors bench.py's `roofline_hbm` times (same generator, seed 1234, B = 32): cell-grid ball
     query bit-exact, group_points a bit-exact copy, group_points_grad within fp32 rounding of the oracle's scan-order sum
-    (its order is the LDS-atomic kernel's: undefined, like the reference's atomicAdd, group_points_gpu.cu:8-25)."""
+    (the default kernel here is the pad-folded CSR gather: a fixed order of additions, bit-reproducible, but not the
+    oracle's scan order; the reference's atomicAdd order is undefined, group_points_gpu.cu:8-25)."""
     from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
     B, N, K, r = 2, 4096, 64, 2.0
     xyz = synth.make_batch(32, N=N, seed=1234, lidar=True)["pc1"][:B].contiguous()       # (B,3,N) as bench.py builds it
@@ -186,6 +187,25 @@ def test_config5_shapes_match_oracle(dev, C):
     ext.group_points_grad_wrapper(B, C, N, N, K, go.to(dev), idx, gp)
     ref = orc.group_points_grad(go, want_idx, N)
     np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_config5_full_batch_matches_oracle(dev):
+    """BASELINE config 5 at its FULL batch: all 32 samples of the tensors bench.py's `roofline_hbm` times (seed 1234, N = 4096,
+    K = 64, r = 2.0) -- the cell-grid ball query bit-exact on every sample, and the whole (32,128,4096,64) gather of the C = 128
+    row against the oracle, sample by sample (the 4.3 GB output stays on the device)."""
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    B, N, K, r, C = 32, 4096, 64, 2.0, 128
+    xyz = synth.make_batch(B, N=N, seed=1234, lidar=True)["pc1"].contiguous()            # (B,3,N) as bench.py builds it
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    idx = torch.zeros(B, N, K, dtype=torch.int32, device=dev)
+    ext.ball_query_wrapper(B, N, N, r, K, xyz_t.to(dev), xyz_t.to(dev), idx)
+    want_idx = orc.ball_query(r, K, xyz_t, xyz_t)
+    assert torch.equal(idx.cpu(), want_idx)
+    feats = torch.randn(B, C, N, generator=torch.Generator().manual_seed(C))
+    out = torch.empty(B, C, N, K, device=dev)
+    ext.group_points_wrapper(B, C, N, N, K, feats.to(dev), idx, out)
+    for i in range(B):
+        assert torch.equal(out[i].cpu(), orc.group_points(feats[i:i + 1], want_idx[i:i + 1])[0]), i
 
 
 @pytest.mark.parametrize("B,C,N,P,S", [(64, 3, 256, 256, 32), (8, 64, 256, 256, 32), (2, 70, 256, 128, 64), (3, 5, 100, 256, 8), (2, 9, 290, 256, 4),
