@@ -237,8 +237,7 @@ def main():
     ap.add_argument("--model", choices=["cmflow", "cmflow_t", "raflow"], default="cmflow")
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", choices=["pm", "pm_torch"], default="pm",
-                    help="pm: fused point-major HIP path (product); pm_torch: same layout, dense math through torch (debugging)")
+    ap.add_argument("--path", choices=["pm"], default="pm", help="pm: the fused point-major HIP path (the product has one path)")
     ap.add_argument("--serial", action="store_true",
                     help="diagnostic: every chain of the step on ONE stream (per-kernel durations free of contention)")
     ap.add_argument("--force-allreduce", action="store_true",

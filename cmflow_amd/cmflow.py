@@ -17,20 +17,11 @@ from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScale
 
 class CMFlow(nn.Module):
     score_eps = 1e-4            # models/cmflow.py:105; CMFlow_T has none (cmflow_t.py:119)
-    # "pm": point-major fused path on the hand-written GEMM / BN / pooling kernels (default).
-    # "pm_torch": same layout and hoisting, dense math through torch (debugging aid).
-    # (The reference's own op sequence in its (B,C,N,ns) layout over the drop-in kernels is a test fixture:
-    # the oracle's modules bound to pointnet2_utils, tests/hip_ops.py.)
+    # One execution path: the point-major fused path on the hand-written GEMM / BN / pooling kernels.  (Two cross-checks are
+    # TEST fixtures, not product code: the same layout with its dense math through torch -- tests/pm_torch.py -- and the
+    # reference's own op sequence in its (B,C,N,ns) layout over the drop-in kernels, the oracle's modules bound to
+    # pointnet2_utils -- tests/hip_ops.py.)
     path = "pm"
-
-    def _set_blocks(self, on):
-        # called every forward: walking ~400 submodules costs 0.7 ms of host time, so only when the setting changes
-        if getattr(self, "_blocks_on", None) is on:
-            return
-        for m in self.modules():
-            if hasattr(m, "use_blocks"):
-                m.use_blocks = on
-        self._blocks_on = on
 
     def __init__(self, args):
         super().__init__()
@@ -76,26 +67,22 @@ class CMFlow(nn.Module):
 
     def _propagate(self, pc1, pc2, feature1, feature2):
         """cmflow.py:59-88: everything of Backbone up to prop_features."""
-        if self.path not in ("pm", "pm_torch"):
-            raise ValueError("unknown path %r (pm | pm_torch)" % (self.path,))
-        self._set_blocks(self.path == "pm")
+        if self.path != "pm":
+            raise ValueError("unknown path %r: the product has one path, 'pm'" % (self.path,))
         return self._propagate_pm(pc1, pc2, feature1, feature2)
 
     def _propagate_pm(self, pc1, pc2, feature1, feature2):
         """Same computation in point-major layout; returns prop_features as (B,256,N)."""
         x1, x2 = pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous()       # (B,N,3)
         a1, a2 = feature1.transpose(1, 2).contiguous(), feature2.transpose(1, 2).contiguous()
-        if self.path == "pm" and not self.mse_layer.training and x1.shape == x2.shape:
+        if not self.mse_layer.training and x1.shape == x2.shape:
             # eval-mode BN has no batch statistics: the two clouds share one call of the (weight-shared) encoder
             B = x1.shape[0]
             f12 = self.mse_layer.forward_pm(torch.cat((x1, x2), dim=0), torch.nn.functional.pad(torch.cat((a1, a2), dim=0), (0, 1)))
             f1, f2 = f12[:B], f12[B:]
-        elif self.path == "pm":                                 # one zero column: rows of 4 floats for the stacked first-conv GEMM
+        else:                                                   # one zero column: rows of 4 floats for the stacked first-conv GEMM
             f1, f2 = self.mse_layer.forward_pm_pair(x1, torch.nn.functional.pad(a1, (0, 1)),
                                                     x2, torch.nn.functional.pad(a2, (0, 1)))   # (B,N,256) each
-        else:
-            f1 = self.mse_layer.forward_pm(x1, a1)
-            f2 = self.mse_layer.forward_pm(x2, a2)
         # train.TrainStep reduces the gradient bucket in segments as backward completes them.  Every autograd node of the cost
         # volume, the second encoder and the heads is created AFTER the first encoder's node and depends only on gradients that
         # exist before that node becomes ready, so the engine (highest sequence number first among ready nodes, AccumulateGrad
@@ -106,34 +93,24 @@ class CMFlow(nn.Module):
             for t in (f1, f2):
                 if t.requires_grad:
                     t.register_hook(lambda g: ready(1))
-        if self.path == "pm":
-            f1, f2 = FB.global_max_cat(f1), FB.global_max_cat(f2)                          # (B,N,512): features + global max
-        else:
-            f1 = torch.cat((f1, f1.max(dim=1, keepdim=True)[0].expand(-1, f1.shape[1], -1)), dim=2)
-            f2 = torch.cat((f2, f2.max(dim=1, keepdim=True)[0].expand(-1, f2.shape[1], -1)), dim=2)
+        f1, f2 = FB.global_max_cat(f1), FB.global_max_cat(f2)                              # (B,N,512): features + global max
         cor = self.fc_layer.forward_pm(x1, x2, f1, f2)                                     # (B,N,512)
-        if self.path == "pm":
-            # embeddings as [f1 | cor | ft1 | zero pad], K = 1040: the columns that need a gradient come first (the
-            # data-gradient GEMM of the stacked first conv is 1024 wide and f1 / cor read their blocks of it in place),
-            # the raw input channels (cmflow.py:82 puts them first) go behind, rows padded to a multiple of 16 floats
-            n_grad, n_tail = f1.shape[2] + cor.shape[2], a1.shape[2]
-            pad = -(n_grad + n_tail) % 16
-            emb = torch.cat((f1, cor, a1, a1.new_zeros(a1.shape[0], a1.shape[1], pad)), dim=2)
-            if ready is not None and emb.requires_grad:
-                emb.register_hook(lambda g: ready(0))      # heads + second encoder have run their backward
-            prop = self._second_encoder().forward_pm(x1, emb, n_tail=n_tail, n_grad=n_grad)       # (B,N,256)
-        else:
-            prop = self._second_encoder().forward_pm(x1, torch.cat((a1, f1, cor), dim=2))
+        # embeddings as [f1 | cor | ft1 | zero pad], K = 1040: the columns that need a gradient come first (the
+        # data-gradient GEMM of the stacked first conv is 1024 wide and f1 / cor read their blocks of it in place),
+        # the raw input channels (cmflow.py:82 puts them first) go behind, rows padded to a multiple of 16 floats
+        n_grad, n_tail = f1.shape[2] + cor.shape[2], a1.shape[2]
+        pad = -(n_grad + n_tail) % 16
+        emb = torch.cat((f1, cor, a1, a1.new_zeros(a1.shape[0], a1.shape[1], pad)), dim=2)
+        if ready is not None and emb.requires_grad:
+            emb.register_hook(lambda g: ready(0))      # heads + second encoder have run their backward
+        prop = self._second_encoder().forward_pm(x1, emb, n_tail=n_tail, n_grad=n_grad)       # (B,N,256)
         self.last = {"pc1_features": f1[:, :, :256].transpose(1, 2), "pc2_features": f2[:, :, :256].transpose(1, 2),
                      "cor_features": cor.transpose(1, 2), "prop_features": prop.transpose(1, 2)}
         return prop.transpose(1, 2)
 
     def Backbone(self, pc1, pc2, feature1, feature2):
         prop_features = self._propagate(pc1, pc2, feature1, feature2)
-        if self.path == "pm":                                   # prop_features is the (B,256,N) view of point-major rows
-            return FB.global_max_cat(prop_features.transpose(1, 2)).transpose(1, 2)
-        gfeat = torch.max(prop_features, -1)[0].unsqueeze(2).expand(-1, -1, pc1.size(2))
-        return torch.cat((prop_features, gfeat), dim=1)
+        return FB.global_max_cat(prop_features.transpose(1, 2)).transpose(1, 2)      # prop_features is the (B,256,N) view of point-major rows
 
     def EgoMotionHead(self, flow, pc1, score):
         """cmflow.py:96-110"""
@@ -152,7 +129,7 @@ class CMFlow(nn.Module):
         return weighted_kabsch(A, B, W)
 
     def _heads(self, final_features, pc1, label_m, mode):
-        if self.path == "pm" and self.head_streams and final_features.is_cuda:
+        if self.head_streams and final_features.is_cuda:
             # the two heads are independent chains of small GEMMs (N = 256: a third of the CUs each): the motion head
             # runs on a side stream next to the flow head; autograd replays each backward on its forward stream
             ff = final_features.transpose(1, 2)                       # (B,N,512) view

@@ -83,17 +83,6 @@ def group_rows(feat, nbr: Neighbors):
     return _GroupRows.apply(feat, nbr)
 
 
-def bn_pm(bn, x):
-    """BatchNorm2d semantics on a point-major tensor (..., C): statistics over every leading
-    position (= over (B, N, ns) of the reference's (B,C,N,ns) tensor)."""
-    shape = x.shape
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
-    y = F.batch_norm(x.reshape(-1, shape[-1]), bn.running_mean, bn.running_var, bn.weight, bn.bias,
-                     bn.training, bn.momentum, bn.eps)
-    return y.view(shape)
-
-
 def w2d(conv):
     """1x1 conv weight (out,in,1,1) as the (out,in) matrix of the equivalent GEMM."""
     return conv.weight.view(conv.weight.shape[0], conv.weight.shape[1])

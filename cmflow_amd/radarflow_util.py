@@ -26,7 +26,7 @@ from torch.autograd import Function
 
 from . import _lib
 from . import pointnet2_utils as pointutils
-from .fused import Neighbors, bn_pm, group_rows, w2d
+from .fused import Neighbors, group_rows, w2d
 from . import fused_blocks as FB
 
 _f32, _i32 = torch.float32, torch.int32
@@ -120,7 +120,7 @@ class MultiScaleEncoder(nn.Module):
 
     def forward(self, xyz, features):
         """Reference contract (:111-118): xyz (B,3,N), features (B,C,N) -> (B, 64*scales, N)."""
-        return self.forward_pm(_rows(xyz), _rows(features, pad4=self.use_blocks)).transpose(1, 2)
+        return self.forward_pm(_rows(xyz), _rows(features, pad4=True)).transpose(1, 2)
 
     def forward_pm(self, xyz_t, feats, n_tail=0, n_grad=0):
         """Point-major: xyz_t (B,N,3), feats (B,N,C) -> (B,N,4*64).  The feature half of the four
@@ -128,7 +128,7 @@ class MultiScaleEncoder(nn.Module):
         n_tail / n_grad (fused path only): feats holds the module's input channels as [head, first n_tail channels,
         zero pad] and only its first n_grad columns need a gradient (fused_blocks.StackedFirstConvFn)."""
         o1 = self.ms_ls[0].mlp_convs[0].weight.shape[0]
-        if self.use_blocks and self.multi_stream and FB.USE_BLOCK_CALLS and self.threaded_enqueue and feats.shape[2] % 4 == 0:
+        if self.multi_stream and FB.USE_BLOCK_CALLS and self.threaded_enqueue and feats.shape[2] % 4 == 0:
             B, N, Kp = feats.shape
             y_all = FB.StackedFirstConvFn.apply(feats.reshape(B * N, Kp), n_tail, n_grad,
                                                 *[sa.mlp_convs[0].weight for sa in self.ms_ls]).view(B, N, -1)
@@ -138,13 +138,9 @@ class MultiScaleEncoder(nn.Module):
         if n_tail:                      # permuted layout handed to one of the unstacked paths: back to the module's own order
             cin = self.ms_ls[0].mlp_convs[0].weight.shape[1] - 3
             feats = torch.cat((feats[:, :, cin - n_tail:cin], feats[:, :, :cin - n_tail]), dim=2)
-            if self.use_blocks and cin % 4:
+            if cin % 4:
                 feats = F.pad(feats, (0, 4 - cin % 4))
         wf_all = torch.cat([w2d(sa.mlp_convs[0])[:, 3:] for sa in self.ms_ls], dim=0)
-        if not self.use_blocks:
-            y_all = F.linear(feats, wf_all)                               # (B,N,4*o1)
-            outs = [sa.forward_pm(xyz_t, y_all[:, :, i * o1:(i + 1) * o1]) for i, sa in enumerate(self.ms_ls)]
-            return torch.cat(outs, dim=2)
         kpad = feats.shape[2] - wf_all.shape[1]            # caller may hand over K zero-padded to a multiple of 4
         if kpad:
             wf_all = F.pad(wf_all, (0, kpad))
@@ -177,7 +173,7 @@ class MultiScaleEncoder(nn.Module):
         """Two calls of this (weight-shared) encoder -- forward_pm(xyz1_t, feats1), forward_pm(xyz2_t, feats2) in this
         order as far as BN running statistics go -- issued concurrently when that is possible (fused path, training with
         in-place gradient sinks: fused_blocks.DualCloudBlockFn)."""
-        fused = self.use_blocks and self.multi_stream and FB.USE_BLOCK_CALLS and self.threaded_enqueue and \
+        fused = self.multi_stream and FB.USE_BLOCK_CALLS and self.threaded_enqueue and \
             feats1.shape[2] % 4 == 0 and feats1.shape == feats2.shape
         if fused and self.training:
             ws = [sa.mlp_convs[0].weight for sa in self.ms_ls]
@@ -198,8 +194,6 @@ class MultiScaleEncoder(nn.Module):
     multi_stream = True
     _streams = None
     _streams2 = None
-
-    use_blocks = True
 
 
 class PointLocalFeature(nn.Module):
@@ -226,33 +220,16 @@ class PointLocalFeature(nn.Module):
             last_channel = out_channel
         self.queryandgroup = pointutils.QueryAndGroup(radius, nsample)
 
-    use_blocks = True
-
     def forward(self, xyz, points):
         """Reference contract (:144-162): xyz (B,3,N), points (B,C,N) -> (B,64,N).  The feature columns of the first
         conv are applied per point (one GEMM), the rest is the fused block."""
         xyz_t, feats = _rows(xyz), _rows(points)
-        wf = w2d(self.mlp_convs[0])[:, 3:]
-        if self.use_blocks:
-            return FB.set_conv(self, xyz_t, FB.linear(feats, wf)).transpose(1, 2)
-        return self.forward_pm(xyz_t, F.linear(feats, wf)).transpose(1, 2)
+        return self.forward_pm(xyz_t, FB.linear(feats, w2d(self.mlp_convs[0])[:, 3:])).transpose(1, 2)
 
     def forward_pm(self, xyz_t, y):
-        """Point-major set-conv.  xyz_t (B,N,3); y (B,N,O1) = feats @ W_f^T, the feature half of
-        the first conv already applied per point (conv is linear: W [dxyz; f[idx]] =
-        W_xyz dxyz + (W_f f)[idx]).  -> (B,N,64)."""
-        B, N, _ = xyz_t.shape
-        idx = pointutils.ball_query(self.radius, self.nsample, xyz_t, xyz_t)
-        nbr = Neighbors(idx, N)
-        dxyz = group_rows(xyz_t, nbr) - xyz_t.unsqueeze(2)                # (B,N,ns,3) relative xyz
-        x = group_rows(y, nbr) + F.linear(dxyz, w2d(self.mlp_convs[0])[:, :3])
-        x = F.relu(bn_pm(self.mlp_bns[0], x))
-        for conv, bn in zip(list(self.mlp_convs)[1:], list(self.mlp_bns)[1:]):
-            x = F.relu(bn_pm(bn, F.linear(x, w2d(conv))))
-        x = torch.max(x, dim=2)[0]                                        # over the ball
-        for conv, bn in zip(self.mlp2_convs, self.mlp2_bns):
-            x = F.relu(bn_pm(bn, F.linear(x, w2d(conv))))
-        return x
+        """Point-major set-conv.  xyz_t (B,N,3); y (B,N,O1) = feats @ W_f^T, the feature half of the first conv already
+        applied per point (conv is linear: W [dxyz; f[idx]] = W_xyz dxyz + (W_f f)[idx]).  -> (B,N,64)."""
+        return FB.set_conv(self, xyz_t, y)
 
 
 class WeightNet(nn.Module):
@@ -273,17 +250,16 @@ class WeightNet(nn.Module):
 
     def forward(self, localized_xyz):
         """Reference contract (:307-318): (B,3,K,N) -> (B,out,K,N)."""
-        return self.forward_pm(localized_xyz.permute(0, 3, 2, 1), use_blocks=localized_xyz.is_cuda).permute(0, 3, 2, 1)
+        return self.forward_pm(localized_xyz.permute(0, 3, 2, 1)).permute(0, 3, 2, 1)
 
-    def forward_pm(self, dxyz, use_blocks=False, preact_grad=False):
+    def forward_pm(self, dxyz, preact_grad=False):
         """dxyz (B,N,K,3) -> (B,N,K,out).  preact_grad: the consumer (WeightedKSumFn relu_w=True) returns the gradient
         of the last layer's pre-activation."""
         assert not self.bn
         w = dxyz
         last = len(self.mlp_convs) - 1
         for i, conv in enumerate(self.mlp_convs):
-            w = FB.linear(w, w2d(conv), conv.bias, act=1, preact_grad=preact_grad and i == last) if use_blocks else \
-                F.relu(F.linear(w, w2d(conv), conv.bias))
+            w = FB.linear(w, w2d(conv), conv.bias, act=1, preact_grad=preact_grad and i == last)
         return w
 
     def weighted_ksum(self, dxyz, x, nbr, leaky, x_bias=None, hidden=None):
@@ -355,29 +331,7 @@ class FeatureCorrelator(nn.Module):
         """Point-major cost volume.  xyz*_t (B,N,3), f1/f2 (B,N,D) -> (B,N,512).  The first conv
         over cat[f1, f2[idx], dxyz] is split by linearity into per-point GEMMs."""
         assert not self.bn
-        if self.use_blocks:
-            return self._forward_blocks(xyz1_t, xyz2_t, f1, f2)
-        B, N1, _ = xyz1_t.shape
-        D1, D2 = f1.shape[2], f2.shape[2]
-        K = self.nsample
-        act = self.relu
-        w0 = w2d(self.mlp_convs[0])
-        # point-to-patch
-        nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])
-        dxyz = group_rows(xyz2_t, nbr) - xyz1_t.unsqueeze(2)                               # (B,N1,K,3)
-        p1 = F.linear(f1, w0[:, :D1], self.mlp_convs[0].bias)                              # (B,N1,512)
-        p2 = F.linear(f2, w0[:, D1:D1 + D2])                                               # (B,N2,512)
-        x = p1.unsqueeze(2) + group_rows(p2, nbr) + F.linear(dxyz, w0[:, D1 + D2:])
-        x = act(x)
-        for conv in list(self.mlp_convs)[1:]:
-            x = act(F.linear(x, w2d(conv), conv.bias))
-        weights = self.weightnet1.forward_pm(dxyz)
-        p2p = torch.sum(weights * x, dim=2)                                                # (B,N1,512)
-        # patch-to-patch
-        nbr = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), N1)
-        dxyz = group_rows(xyz1_t, nbr) - xyz1_t.unsqueeze(2)
-        weights = self.weightnet2.forward_pm(dxyz)
-        return torch.sum(weights * group_rows(p2p, nbr), dim=2)
+        return self._forward_blocks(xyz1_t, xyz2_t, f1, f2)
 
 
 def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
@@ -430,7 +384,6 @@ FeatureCorrelator.side_streams = True
 
 
 FeatureCorrelator._forward_blocks = _fc_blocks
-FeatureCorrelator.use_blocks = True
 
 
 class FlowHead(nn.Module):
@@ -452,14 +405,8 @@ class FlowHead(nn.Module):
 
     def forward_pm(self, feat):
         """feat (B,N,512) -> (B,N,3)"""
-        if self.use_blocks:
-            feat = FB.mlp_chain(feat, [(blk[0], blk[1]) for blk in self.sf_mlp], self.sf_mlp[0][1].training)
-            return FB.linear(feat, w2d(self.conv2))
-        for blk in self.sf_mlp:
-            feat = F.relu(bn_pm(blk[1], F.linear(feat, w2d(blk[0]))))
-        return F.linear(feat, w2d(self.conv2))
-
-    use_blocks = True
+        feat = FB.mlp_chain(feat, [(blk[0], blk[1]) for blk in self.sf_mlp], self.sf_mlp[0][1].training)
+        return FB.linear(feat, w2d(self.conv2))
 
 
 class MotionHead(nn.Module):
@@ -482,14 +429,8 @@ class MotionHead(nn.Module):
 
     def forward_pm(self, feat):
         """feat (B,N,512) -> (B,N,1)"""
-        if self.use_blocks:
-            feat = FB.mlp_chain(feat, [(blk[0], blk[1]) for blk in self.sf_mlp], self.sf_mlp[0][1].training)
-            return FB.linear(feat, w2d(self.conv2), None, act=3)
-        for blk in self.sf_mlp:
-            feat = F.relu(bn_pm(blk[1], F.linear(feat, w2d(blk[0]))))
-        return torch.sigmoid(F.linear(feat, w2d(self.conv2)))
-
-    use_blocks = True
+        feat = FB.mlp_chain(feat, [(blk[0], blk[1]) for blk in self.sf_mlp], self.sf_mlp[0][1].training)
+        return FB.linear(feat, w2d(self.conv2), None, act=3)
 
 
 FlowPredictor = FlowHead        # radarflow_util.py:388-409: same layers and parameter names as FlowHead (:240-261)
@@ -511,8 +452,5 @@ class FlowDecoder(nn.Module):
     def forward(self, pc1, feature1, pc1_features, cor_features):
         """Reference contract (:339-350): (B,3,N), (B,3,N), (B,512,N), (B,512,N) -> flow (B,3,N)."""
         emb = torch.cat((_rows(feature1), _rows(pc1_features), _rows(cor_features)), dim=2)
-        prop = self.mse.forward_pm(_rows(pc1), F.pad(emb, (0, -emb.shape[2] % 4)) if self.mse.use_blocks else emb)
-        if self.mse.use_blocks:
-            return self.fp.forward_pm(FB.global_max_cat(prop)).transpose(1, 2)
-        glob = prop.max(dim=1, keepdim=True)[0].expand(-1, prop.shape[1], -1)
-        return self.fp.forward_pm(torch.cat((prop, glob), dim=2)).transpose(1, 2)
+        prop = self.mse.forward_pm(_rows(pc1), F.pad(emb, (0, -emb.shape[2] % 4)))
+        return self.fp.forward_pm(FB.global_max_cat(prop)).transpose(1, 2)

@@ -37,8 +37,9 @@ def _weights(manifest, golden_dir, t=False):
 
 def _build(path, args, sd, dev, monkeypatch):
     """pm: the product (fused point-major path, one C-ABI call per set-conv block); pm_py: same kernels sequenced from
-    Python; pm_torch: same layout, dense math through torch; ref: the reference's own op sequence in its (B,C,N,ns)
-    layout -- the oracle's modules on the GPU with their native ops bound to the DROP-IN kernels (tests/hip_ops.py)."""
+    Python; pm_torch: same layout, dense math through torch (a test fixture: tests/pm_torch.py installs torch bodies on the
+    block modules of this instance); ref: the reference's own op sequence in its (B,C,N,ns) layout -- the oracle's modules on
+    the GPU with their native ops bound to the DROP-IN kernels (tests/hip_ops.py)."""
     from cmflow_amd import fused_blocks as FB
     from cmflow_amd.cmflow import CMFlow
     if path == "ref":
@@ -46,9 +47,12 @@ def _build(path, args, sd, dev, monkeypatch):
         return hip_ops.reference_layout_net(O.CMFlow, args, sd, dev, monkeypatch)
     monkeypatch.setattr(FB, "USE_BLOCK_CALLS", path != "pm_py")
     net = CMFlow(args)
-    net.path = "pm" if path == "pm_py" else path
     net.load_state_dict(sd)
-    return net.to(dev)
+    net = net.to(dev)
+    if path == "pm_torch":
+        import pm_torch
+        pm_torch.install(net)
+    return net
 
 
 def _epe(a, b):

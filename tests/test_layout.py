@@ -53,3 +53,11 @@ def test_nothing_reads_the_reference_at_run_time():
     for f in ("bench.py", "__graft_entry__.py"):
         text = open(os.path.join(REPO, f)).read()
         assert "sys.path.insert(0, \"/root/reference\")" not in text and "open(\"/root/reference" not in text
+
+
+def test_product_has_no_torch_math_path():
+    """The block modules of the product run on the HIP kernels only: the torch-math twin of the point-major path is a test
+    fixture (tests/pm_torch.py), not a dispatch option inside cmflow_amd/ (no vendor GEMM / BatchNorm behind the modules)."""
+    for f in ("radarflow_util.py", "cmflow.py", "raflow.py", "fused.py", "fused_blocks.py"):
+        text = open(os.path.join(REPO, "cmflow_amd", f)).read()
+        assert "F.linear" not in text and "batch_norm" not in text and "use_blocks" not in text and '"pm_torch"' not in text, f

@@ -12,7 +12,6 @@ b = {k: v.to(dev) for k, v in synth.make_batch(64, seed=1).items()}
 x1, x2 = b["pc1"].transpose(1, 2).contiguous(), b["pc2"].transpose(1, 2).contiguous()
 a1 = torch.nn.functional.pad(b["ft1"].transpose(1, 2).contiguous(), (0, 1))
 a2 = torch.nn.functional.pad(b["ft2"].transpose(1, 2).contiguous(), (0, 1))
-net._set_blocks(True)
 
 
 def one():

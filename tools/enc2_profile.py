@@ -15,7 +15,6 @@ emb = torch.randn(64, 256, 1040, generator=g).to(dev)
 emb[:, :, 1027:] = 0
 emb.requires_grad_(True)
 go = torch.randn(64, 256, 256, generator=g).to(dev)
-net._set_blocks(True)
 
 
 def one():

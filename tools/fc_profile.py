@@ -13,7 +13,6 @@ x1, x2 = b["pc1"].transpose(1, 2).contiguous(), b["pc2"].transpose(1, 2).contigu
 g = torch.Generator().manual_seed(0)
 f1 = torch.randn(64, 256, 512, generator=g).to(dev).requires_grad_(True)
 f2 = torch.randn(64, 256, 512, generator=g).to(dev).requires_grad_(True)
-net._set_blocks(True)
 go = torch.randn(64, 256, 512, generator=g).to(dev)
 
 
