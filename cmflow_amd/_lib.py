@@ -53,9 +53,6 @@ SIGNATURES = {
     "cmf_setconv_tail_forward": [_ci, _vp, _vp],
     "cmf_setconv_tail_backward": [_ci, _vp, _vp],
     "cmf_setconv_backward_bodies_multi": [_ci, _vp, _vp],
-    "cmf_setconv_forward_on": [_ci, _vp, _vp, _vp],
-    "cmf_setconv_backward_on": [_ci, _vp, _vp, _vp],
-    "cmf_graph_stats": [_vp, _vp],
     "cmf_gather_points": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_gather_points_grad": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_furthest_point_sampling": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],

@@ -945,7 +945,7 @@ static int launch_csr(int b, int c, int n, int total, const float *grad_out, con
     }
     const size_t lds_i = (size_t)(2 * n + 1) * sizeof(unsigned) + (size_t)GC_TILE * sizeof(unsigned short);
     hipLaunchKernelGGL(gpg_csr_index_kernel<S>, dim3(tiles, b), dim3(GC_THREADS), lds_i, st, n, total, tiles, idx, padmask, off, pos);
-    static const int gdiag = getenv("CMF_GC_DIAG") ? atoi(getenv("CMF_GC_DIAG")) : 0;     // timing only: 1 no walk, 2 no index staging
+    const int gdiag = 0;                                // (kernel argument of the timing ablations of round 3: 1 no walk, 2 no index staging)
     int ch_per_wg = 8;                                  // >= 2 workgroups per CU over the launch
     while (ch_per_wg > 1 && (long long)b * cmf_divup(c, ch_per_wg) < 512) ch_per_wg /= 2;
     const dim3 grid(b, cmf_divup(c, ch_per_wg));

@@ -283,8 +283,6 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     CMF_TRY(cmf_bn_relu_maxpool(P, d->S, C3, L.z3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, L.x, C3, L.argmax, st));
     if (part == 1) return 0;
     // timing diagnostic (results are garbage): the per-point tail left out -- an upper bound for what fusing it can save
-    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
-    if (skip_tail) return cmf_affine_relu(P, C6, L.x, C3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, d->out, d->ldo, st);
     CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, st));
     CMF_TRY(fold(d, L, 3, P, st));
     CMF_TRY(fwd_gemm(d, L, P, C4, C5, L.z4, 3, d->w[3], L.z5, st));
@@ -319,14 +317,12 @@ extern "C" int cmf_setconv_tail_forward(int n, const cmf_setconv_desc *descs, vo
     CMF_CHECK_ARG(n >= 0 && (n == 0 || descs));
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
-    if (!tail_batchable(n, descs) || skip_tail) {                    // one block after the other, unbatched kernels
+    if (!tail_batchable(n, descs)) {                    // one block after the other, unbatched kernels
         for (int i = 0; i < n; ++i) {
             const cmf_setconv_desc *d = &descs[i];
             const Layout L = make_layout(d, d->saved, d->scratch, false);
             const long long P = (long long)d->B * d->N;
             const int C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
-            if (skip_tail) { CMF_TRY(cmf_affine_relu(P, C6, L.x, C3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, d->out, d->ldo, stream)); continue; }
             CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, stream));
             CMF_TRY(fold(d, L, 3, P, stream));
             CMF_TRY(fwd_gemm(d, L, P, C4, C5, L.z4, 3, d->w[3], L.z5, stream));
@@ -378,8 +374,6 @@ extern "C" int cmf_setconv_tail_backward(int n, const cmf_setconv_desc *descs, v
     CMF_CHECK_ARG(n >= 0 && (n == 0 || descs));
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
-    if (skip_tail) return 0;
     if (!tail_batchable(n, descs)) {
         for (int i = 0; i < n; ++i) {
             const cmf_setconv_desc *d = &descs[i];
@@ -453,8 +447,7 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
     // it runs next to the small per-point kernels and is long done when the scatter needs it.
     if (d->dy) CMF_TRY(cmf_build_inverse_ps(d->B, d->N, d->N, d->S, L.idx, L.offsets, L.inv, st));
     // layer 6 .. 4 (per point)
-    static const bool skip_tail = getenv("CMF_DIAG_SKIP_TAIL") && getenv("CMF_DIAG_SKIP_TAIL")[0] == '1';
-    if (!skip_tail && part != 2) {
+    if (part != 2) {
     CMF_TRY(cmf_act_bwd_stats(P, C6, d->dout, d->lddout, L.z6, C6, b5 + 2 * C6, b5 + 3 * C6, b5, b5 + C6, L.t6, L.partial, st));
     CMF_TRY(bwd_layer(d, L, 5, P, C6, C5, L.t6, L.z6, d->w[4], L.z5, 4, L.t5, nullptr, d->dw[4], d->acc_w[4], st));
     CMF_TRY(bwd_layer(d, L, 4, P, C5, C4, L.t5, L.z5, d->w[3], L.z4, 3, L.t4, nullptr, d->dw[3], d->acc_w[3], st));
@@ -627,159 +620,6 @@ extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *de
 extern "C" int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
     return setconv_multi(n, descs, streams, true, 2);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// HIP-graph replay of a multi-scale call.  The chains of the first encoder are ~150 (forward) / ~360 (backward) kernels
-// of 5-40 us: the host's launch rate, not the GPU, sets their duration, and launches from several host threads do not
-// scale (the runtime serialises them).  The whole call -- every chain, forked from and joined back into `main` -- is
-// captured once into a hipGraph and replayed with one hipGraphLaunch.  A graph bakes in the kernel arguments, so the
-// cache key is the raw bytes of the descriptors (geometry AND every pointer): in steady-state training the caching
-// allocator hands out the same addresses step after step; a new set of addresses simply records another graph
-// (small LRU).  Any failure falls back to the threaded direct launch.
-// ---------------------------------------------------------------------------------------------------------------
-#include <chrono>
-#include <list>
-#include <mutex>
-#include <string>
-
-namespace {
-struct GraphEntry { std::string key; hipGraphExec_t exec; hipEvent_t done; };
-std::list<GraphEntry> g_graphs;
-std::mutex g_graph_mutex;
-constexpr size_t GRAPH_CACHE = 24;
-long long g_graph_captures = 0, g_graph_replays = 0;
-double g_capture_us = 0.0;
-
-int capture_multi(int n, const cmf_setconv_desc *descs, void *const *streams, hipStream_t /*caller's stream: may be the legacy default stream, which cannot capture*/,
-                  bool backward, hipGraphExec_t *out)
-{
-    static hipStream_t main = nullptr;                  // private origin stream of every capture
-    if (!main && hipStreamCreateWithFlags(&main, hipStreamNonBlocking) != hipSuccess) { main = nullptr; return (int)hipGetLastError(); }
-    hipEvent_t fork = nullptr, join[16] = {nullptr};
-    hipGraph_t graph = nullptr;
-    int err = 0;
-    auto fail = [&](int e) { err = e ? e : (int)hipErrorUnknown; };
-    if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-    for (int i = 0; i < n; ++i)
-        if (hipEventCreateWithFlags(&join[i], hipEventDisableTiming) != hipSuccess) fail((int)hipGetLastError());
-    if (!err && hipStreamBeginCapture(main, hipStreamCaptureModeThreadLocal) != hipSuccess) fail((int)hipGetLastError());
-    if (!err) {
-        bool capturing = true;
-        if (hipEventRecord(fork, main) != hipSuccess) fail((int)hipGetLastError());
-        for (int i = 0; i < n && !err; ++i) {
-            hipStream_t s = (hipStream_t)streams[i];
-            if (hipStreamWaitEvent(s, fork, 0) != hipSuccess) { fail((int)hipGetLastError()); break; }
-            const int e = backward ? cmf_setconv_backward(&descs[i], s) : cmf_setconv_forward(&descs[i], s);
-            if (e) { fail(e); break; }
-            if (hipEventRecord(join[i], s) != hipSuccess || hipStreamWaitEvent(main, join[i], 0) != hipSuccess) fail((int)hipGetLastError());
-        }
-        if (capturing) {
-            const hipError_t ee = hipStreamEndCapture(main, &graph);
-            if (ee != hipSuccess && !err) fail((int)ee);
-        }
-    }
-    if (!err && hipGraphInstantiate(out, graph, nullptr, nullptr, 0) != hipSuccess) fail((int)hipGetLastError());
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipEventDestroy(fork);
-    for (int i = 0; i < n; ++i) if (join[i]) (void)hipEventDestroy(join[i]);
-    (void)hipGetLastError();
-    return err;
-}
-
-int graph_multi(int n, const cmf_setconv_desc *descs, void *const *streams, void *main_stream, bool backward)
-{
-    CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
-    if (n == 0) return 0;
-    // Opt-in (CMF_GRAPHS=1).  Measured on this stack (ROCm 7, torch 2.10): recording + launching a graph per call is
-    // within +-1 ms of the threaded direct launch in a 30 ms training step (sometimes ahead, sometimes behind), a
-    // re-launched cached exec runs its branches with LESS overlap than a fresh one, and under rocprofv3 a capture costs
-    // ~10 ms -- so the direct launch stays the default.
-    static const bool enabled = getenv("CMF_GRAPHS") && getenv("CMF_GRAPHS")[0] == '1';
-    if (!enabled) return -1;
-    std::string key((const char *)descs, (size_t)n * sizeof(cmf_setconv_desc));
-    key.append((const char *)streams, (size_t)n * sizeof(void *));
-    key.push_back(backward ? 'b' : 'f');
-    std::lock_guard<std::mutex> lock(g_graph_mutex);
-    // Replaying a cached exec is opt-in (CMF_GRAPH_CACHE=1): measured on this stack a freshly instantiated graph runs its
-    // branches with more overlap than a re-launched one (29.4 vs 30.5 ms per training step; direct launches 31.3), and
-    // the ~1.4 ms of host time a capture costs hides under the GPU's backlog.  Replays also need stable addresses,
-    // i.e. persistent arenas on the caller's side.
-    static const bool use_cache = getenv("CMF_GRAPH_CACHE") && getenv("CMF_GRAPH_CACHE")[0] == '1';
-    if (use_cache)
-    for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
-        if (it->key == key) {
-            g_graphs.splice(g_graphs.begin(), g_graphs, it);                     // most recently used first
-            ++g_graph_replays;
-            return hipGraphLaunch(g_graphs.front().exec, (hipStream_t)main_stream) == hipSuccess ? 0 : -1;
-        }
-    hipGraphExec_t exec = nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    if (capture_multi(n, descs, streams, (hipStream_t)main_stream, backward, &exec) != 0 || !exec) return -1;
-    g_capture_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    ++g_graph_captures;
-    if (!use_cache) {
-        // one-shot: launch, then hand the exec to a short retirement queue (destroyed a few calls later, when the GPU
-        // is certainly done with it: destroying an exec whose launch is still queued is not allowed)
-        const bool ok = hipGraphLaunch(exec, (hipStream_t)main_stream) == hipSuccess;
-        hipEvent_t done = nullptr;
-        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(done, (hipStream_t)main_stream);
-        g_graphs.push_front(GraphEntry{std::string(), exec, done});
-        // retire executed graphs (no synchronisation: an exec is destroyed only once its completion event has fired)
-        while (g_graphs.size() > 2) {
-            GraphEntry &old = g_graphs.back();
-            if (old.done && hipEventQuery(old.done) != hipSuccess) break;
-            (void)hipGraphExecDestroy(old.exec);
-            if (old.done) (void)hipEventDestroy(old.done);
-            g_graphs.pop_back();
-        }
-        (void)hipGetLastError();
-        return ok ? 0 : -1;
-    }
-    g_graphs.push_front(GraphEntry{std::move(key), exec, nullptr});
-    if (g_graphs.size() > GRAPH_CACHE) { (void)hipGraphExecDestroy(g_graphs.back().exec); g_graphs.pop_back(); }
-    return hipGraphLaunch(exec, (hipStream_t)main_stream) == hipSuccess ? 0 : -1;
-}
-}  // namespace
-
-// Like the _multi calls, but everything is ordered against `main_stream` by the library: the call behaves as if all the
-// work had been enqueued on main_stream (graph replay when possible, else fork/join with events around the threaded
-// launch).  streams[] are only used as fork targets.
-static int multi_on_main(int n, const cmf_setconv_desc *descs, void *const *streams, void *main_stream, bool backward)
-{
-    if (graph_multi(n, descs, streams, main_stream, backward) == 0) return 0;
-    // fallback: explicit fork / join around the threaded direct launch
-    hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
-    int err = 0;
-    if (hipEventRecord(ev, (hipStream_t)main_stream) != hipSuccess) err = (int)hipGetLastError();
-    for (int i = 0; i < n && !err; ++i)
-        if (hipStreamWaitEvent((hipStream_t)streams[i], ev, 0) != hipSuccess) err = (int)hipGetLastError();
-    if (!err) err = setconv_multi(n, descs, streams, backward);
-    for (int i = 0; i < n && !err; ++i) {
-        if (hipEventRecord(ev, (hipStream_t)streams[i]) != hipSuccess || hipStreamWaitEvent((hipStream_t)main_stream, ev, 0) != hipSuccess)
-            err = (int)hipGetLastError();
-    }
-    (void)hipEventDestroy(ev);
-    return err;
-}
-
-// diagnostics: graphs recorded / replayed so far
-extern "C" int cmf_graph_stats(long long *captures, long long *replays)
-{
-    if (captures) *captures = g_graph_captures;
-    if (replays) *replays = g_graph_replays;
-    return (int)(g_capture_us / 1000.0);                      // total milliseconds spent recording + instantiating
-}
-
-extern "C" int cmf_setconv_forward_on(int n, const cmf_setconv_desc *descs, void *const *streams, void *main_stream)
-{
-    return multi_on_main(n, descs, streams, main_stream, false);
-}
-
-extern "C" int cmf_setconv_backward_on(int n, const cmf_setconv_desc *descs, void *const *streams, void *main_stream)
-{
-    return multi_on_main(n, descs, streams, main_stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

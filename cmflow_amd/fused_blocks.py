@@ -166,11 +166,9 @@ def scale_streams(n_scales, cloud=0):
     scales on three streams the two middle scales share a stream, the smallest and the largest (half of the rows) have
     one each; the second cloud's call is rotated by one stream.  Re-measured after the narrow layers were fused
     (tools/r02_session33.sh, three runs per deal): 23.1 ms per step against 23.5 for "largest shares with smallest"
-    (the round-1 choice), 23.2-23.6 for five other deals, 24.0 with three scales on one stream.
-    CMF_SCALE_SLOTS="a,b,c,d|e,f,g,h" overrides the deal (diagnostics)."""
-    if n_scales == 4 and os.environ.get("CMF_SCALE_SLOTS"):
-        slots = [int(v) for v in os.environ["CMF_SCALE_SLOTS"].split("|")[cloud % 2].split(",")]
-    elif n_scales == 4:
+    (the round-1 choice), 23.2-23.6 for five other deals, 24.0 with three scales on one stream; re-checked in round 3 (nine
+    deals): 21.6-22.0 ms for all of them -- with the tails batched the deal no longer matters."""
+    if n_scales == 4:
         slots = ([0, 1, 1, 2], [1, 2, 2, 0])[cloud % 2]
     else:
         slots = [(i + cloud) % N_SIDE for i in range(n_scales)]
@@ -420,7 +418,6 @@ class LinearFn(Function):
         return dx, dw, db, None, None, dib
 
 
-_STACK_KERNELS = os.environ.get("CMF_STACK_KERNELS", "1") == "1"      # 0: the torch slice / cat / add_ form (diagnostics)
 
 
 class StackedFirstConvFn(Function):
@@ -436,7 +433,7 @@ class StackedFirstConvFn(Function):
     @staticmethod
     def _uniform(weights):
         w0 = weights[0]
-        return _STACK_KERNELS and len(weights) <= 8 and all(w.shape == w0.shape and w.is_contiguous() and w.dtype == _f32 for w in weights)
+        return len(weights) <= 8 and all(w.shape == w0.shape and w.is_contiguous() and w.dtype == _f32 for w in weights)
 
     @staticmethod
     def forward(ctx, feats, n_tail, n_grad, *weights):
@@ -989,18 +986,10 @@ class EncoderPlan:
         return None
 
 
-_LIB_FORK_JOIN = _os.environ.get("CMF_LIB_FORK_JOIN", "0") == "1"
-
-
 def _multi_call(backward, n, plan, sp, streams, main):
-    """Issue the n chains of a plan on their streams, forked from and joined back into `main`.  Default: fork / join with
-    torch stream waits around cmf_setconv_*_multi.  CMF_LIB_FORK_JOIN=1: the library does it (cmf_setconv_*_on; required
-    for the experimental hipGraph path, CMF_GRAPHS=1)."""
+    """Issue the n chains of a plan on their streams, forked from and joined back into `main` with torch stream waits around
+    cmf_setconv_*_multi."""
     import ctypes
-    if _LIB_FORK_JOIN:
-        fn = L().cmf_setconv_backward_on if backward else L().cmf_setconv_forward_on
-        _lib.check(fn(n, ctypes.addressof(plan.descs), ctypes.addressof(sp), main.cuda_stream), "cmf_setconv_*_on")
-        return
     # The per-point tails of the n blocks (three <= 64-channel layers over the B*N points: latency, not work) run as batched
     # launches on the caller's stream -- behind the joined chains in forward, in front of the fork in backward; the chains on
     # the side streams carry the neighbourhood layers only (cmflow_hip.h, cmf_setconv_tail_*).

@@ -410,14 +410,6 @@ int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *
 int cmf_setconv_tail_forward(int n, const cmf_setconv_desc *descs, void *stream);
 int cmf_setconv_tail_backward(int n, const cmf_setconv_desc *descs, void *stream);
 int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
-/* The same, ordered against main_stream by the library (as if everything had been enqueued on main_stream): the whole
- * fork/join events around the threaded direct launch.  With CMF_GRAPHS=1 (opt-in, experimental) the call is recorded
- * into a hipGraph and launched as one (CMF_GRAPH_CACHE=1 additionally replays a cached exec when the descriptor
- * contents -- geometry and pointers -- repeat); a capture failure falls back to the direct launch. */
-int cmf_setconv_forward_on(int n, const cmf_setconv_desc *descs, void *const *streams, void *main_stream);
-int cmf_setconv_backward_on(int n, const cmf_setconv_desc *descs, void *const *streams, void *main_stream);
-/* diagnostics: number of graphs recorded / replayed by the two calls above */
-int cmf_graph_stats(long long *captures, long long *replays);
 
 /* Cost-volume weighting (radarflow_util.py:219-221,235-236): out[m,c] = sum_k w[m,k,c] * x[m,k,c] over rows
  * m = sample*n1 + point.  idx == NULL: x is (M,K,C) dense.  idx (M,K) int32: x is (samples*n_src, C) per-point rows

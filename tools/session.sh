@@ -8,11 +8,6 @@ NAME=$1; shift
 R=$GRAFT_REPO_ROOT/gpurun_out/$NAME; mkdir -p $R
 filter() { grep -v "amdgpu.ids\|_warn_once\|Warning:" ; }
 
-tests_new() {          # the round-3 tests, one by one so that a failure does not hide the others
-    python -m pytest tests/test_gpu_stress.py -x -q -m gpu -s 2>&1 | tail -25 > $R/stress.txt
-    python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size or two_rank_cmflow_t" 2>&1 | tail -40 > $R/model.txt
-    python -m pytest tests/test_gpu_ops.py tests/test_gpu_gemm.py -q -m gpu -k "config5 or small_m or non_finite" 2>&1 | tail -25 > $R/ops.txt
-}
 gemm_diag() {
     for d in 0 8 9 12 1; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
     CMF_GEMM_DIAG_RT=8 python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq_noepi.txt
@@ -48,12 +43,6 @@ op_pmc() {              # the drop-in calls of the bench line's roofline_hbm row
         $(find /tmp/o3 -name "*counter_collection.csv" | head -1) $R/op_probe.out $R/op_hbm_pmc.json > $R/op_hbm_pmc.md; cat $R/op_hbm_pmc.md
 }
 gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
-gemm_w() {             # the product build against the CMF_EPI_WAVE=3 experiment build (tools/diag/libcmflow_w3.so)
-    for d in 0 8; do CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter; done > $R/gemm_diag.txt
-    CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_w3.so python tools/gemm_diag.py 2>&1 | filter > $R/gemm_diag_w3.txt
-    python tools/gemm_timeline.py dxq 524288 256 512 2>&1 | filter > $R/timeline_dxq.txt
-    python tools/gemm_variants.py 2>&1 | filter > $R/gemm_variants.txt
-}
 model_tests() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size or two_rank" 2>&1 | tail -30 > $R/model.txt; }
 bench3() { for i in 1 2 3; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null; done > $R/bench3.json; cat $R/bench3.json | python -c "import sys,json; [print(json.loads(l)['ms_per_step'], json.loads(l)['roofline']['frac'], json.loads(l)['roofline_isolated']['frac']) for l in sys.stdin]"; }
 ops_tests() { python -m pytest tests/test_gpu_ops.py tests/test_gpu_extension_surface.py tests/test_gpu_modules.py -q -m gpu 2>&1 | tail -15 > $R/ops_tests.txt; }
@@ -62,21 +51,6 @@ epi_diag() {           # which part of the backward epilogue costs: 16 no C stor
 }
 model_full() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train or full_size_cmflow_t" 2>&1 | grep -v "^  \|^$" | tail -60 > $R/model_full.txt; }
 opbench() { python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>$R/opbench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); [print(r) for r in d['roofline_hbm']['rows']]" > $R/opbench.txt; tail -3 $R/opbench.err; }
-variants() {           # kernel experiment builds (tools/diag/libcmflow_<name>.so) against the product: correctness, then rates, then the step
-    for v in $VARIANTS; do
-        L=$GRAFT_REPO_ROOT/tools/diag/libcmflow_$v.so
-        CMF_LIB=$L python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -3 > $R/var_${v}_tests.txt
-        CMF_LIB=$L python tools/gemm_diag.py 2>&1 | filter > $R/var_${v}_diag.txt
-        CMF_LIB=$L python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null > $R/var_${v}_bench.json
-    done
-    python tools/gemm_diag.py 2>&1 | filter > $R/var_product_diag.txt
-    python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null > $R/var_product_bench.json
-    for f in $R/var_*_bench.json; do echo $f; python -c "import sys,json; d=json.loads(open('$f').read()); print(d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
-}
-grad_ab() {            # the directional gradient check with the round-2 epilogue (libcmflow_w0) and with the product, same box
-    CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_w0.so python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train" 2>&1 | grep -E "full-size train|AssertionError|passed|failed" > $R/grad_w0.txt
-    python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size_train" 2>&1 | grep -E "full-size train|AssertionError|passed|failed" > $R/grad_product.txt
-}
 trace() {              # kernel trace of 10 timed steps (csv copied back for tools/trace_overlap.py / offline analysis) + aten attribution
     rm -rf /tmp/p1
     (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines > /dev/null 2>&1)
@@ -92,10 +66,6 @@ allreduce_ab() {       # world-1 RCCL all-reduce inside every step: none / overl
     CMF_OVERLAP_ALLREDUCE=1 python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_overlap.json
     python bench.py --no-cpu-baseline --no-op-rooflines --force-allreduce 2>/dev/null > $R/ar_single.json
     for f in none overlap single; do python -c "import json; print('$f', json.loads(open('$R/ar_$f.json').read())['ms_per_step'])"; done
-}
-skiptail() {           # upper bound for fusing the per-point tails: the step without them (garbage results, timing only)
-    for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; print('full', json.loads(sys.stdin.read())['ms_per_step'])"; 
-    CMF_DIAG_SKIP_TAIL=1 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; print('no tail', json.loads(sys.stdin.read())['ms_per_step'])"; done > $R/skiptail.txt; cat $R/skiptail.txt
 }
 tail_ab() { for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('batched tails', d['ms_per_step'], d['roofline_isolated']['frac'])";
     CMF_TAIL_BATCH=0 python bench.py --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('per-block tails', d['ms_per_step'])"; done > $R/tail_ab.txt; cat $R/tail_ab.txt; }
@@ -130,40 +100,9 @@ pm_hbm() {             # HBM-bound kernels of the product path: durations + FETC
     python tools/pm_table.py $(find /tmp/q1 -name "*kernel_trace.csv" | head -1) $(find /tmp/q2 -name "*counter_collection.csv" | head -1) \
         $(find /tmp/q3 -name "*counter_collection.csv" | head -1) $R/pm_probe.out > $R/pm_hbm_kernels.md; cat $R/pm_hbm_kernels.md
 }
-ldspad_ab() {          # GEMM at 2 workgroups per CU (LDS pad) so that other streams' kernels co-reside with it: step time A/B
-    for pad in 0 8192 0 8192; do CMF_GEMM_LDS_PAD=$pad python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('pad $pad', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done | tee $R/ldspad_ab.txt
-}
-wps4_ab() {            # GEMM compiled for 128 registers (4 waves per SIMD): isolated rates and the step, against the product
-    for lib in "" $GRAFT_REPO_ROOT/tools/diag/libcmflow_wps4.so; do
-        echo "lib=$lib"; CMF_LIB=$lib python tools/gemm_diag.py 2>&1 | filter
-        for i in 1 2; do CMF_LIB=$lib python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
-    done | tee $R/wps4_ab.txt
-}
-density() {            # MFMA density of one workgroup's waves: the same kernels at 1 / 2 / 3 workgroups per CU (LDS pad)
-    for pad in 65536 8192 0; do echo "pad=$pad"; CMF_GEMM_LDS_PAD=$pad python tools/gemm_diag.py 2>&1 | filter; CMF_GEMM_LDS_PAD=$pad CMF_GEMM_DIAG_RT=8 python tools/gemm_diag.py 2>&1 | filter; done | tee $R/density.txt
-}
-t256() {               # experiment build with 256 x 256 tiles (one workgroup per CU) for the plain-store forms
-    for lib in "" $GRAFT_REPO_ROOT/tools/diag/libcmflow_t256.so; do for sk in 96 128; do for d in 0 8; do
-        echo "lib=$lib"; DW_SPLIT=$sk CMF_LIB=$lib CMF_GEMM_DIAG_RT=$d python tools/gemm_diag.py 2>&1 | filter | grep -v "BN+ReLU\|prologue"; done; done; done | tee $R/t256.txt
-}
-dw_ab() {              # weight-gradient GEMMs on the register-staged loop (default) against the LDS-direct one
-    for v in 1 0; do echo "CMF_GEMM_DW_DIRECT=$v"; CMF_GEMM_DW_DIRECT=$v python tools/gemm_variants.py 2>&1 | filter | grep "dW"
-        for i in 1 2; do CMF_GEMM_DW_DIRECT=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done
-    done | tee $R/dw_ab.txt
-}
 bnb_ab() {             # BN backward of the 512 -> 256 layer inside the weight-gradient GEMM (default) against the stand-alone pass
     python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "fused_bn_backward or block or setconv or set_conv" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
     for v in 0 1 0 1; do CMF_BNB_FUSED=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused $v', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done | tee $R/bnb_ab.txt
-}
-scatter_ab() {         # long-row scatter: list-per-lanes kernel (default) against the streamed kernel
-    python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "group_points or config5" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
-    for v in 1 0; do for C in 64 128; do CMF_GROUP_GRAD_CSR=$v python tools/scatter_probe.py $C 2>&1 | grep "C="; done; done | tee $R/scatter_ab.txt
-    rm -rf /tmp/sp; (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/sp -- python3 $GRAFT_REPO_ROOT/tools/scatter_probe.py 64 > /dev/null 2>&1)
-    python -c "import csv,sys; [print(r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3) for r in csv.DictReader(open(sys.argv[1])) if 'gpg' in r['Name'] or 'group_points' in r['Name']]" $(find /tmp/sp -name "*kernel_stats.csv" | head -1) | tee -a $R/scatter_ab.txt
-}
-deals() {              # scale -> side-stream deals of the two encoders (CMF_SCALE_SLOTS), two rounds each
-    for rep in 1 2; do for deal in "0,1,1,2|1,2,2,0" "0,1,2,2|1,2,0,0" "0,0,1,2|1,1,2,0" "0,1,2,0|1,2,0,1" "2,1,1,0|0,2,2,1" "0,2,1,2|1,0,2,0" "1,1,2,0|2,2,0,1" "0,1,1,2|0,1,1,2" "0,1,1,2|2,0,0,1"; do
-        CMF_SCALE_SLOTS="$deal" python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$deal', d['ms_per_step'])"; done; done | tee $R/deals.txt
 }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
