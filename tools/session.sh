@@ -41,6 +41,7 @@ op_pmc() {              # the drop-in calls of the bench line's roofline_hbm row
     (cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/o3 -- python3 $GRAFT_REPO_ROOT/tools/op_probe.py > /dev/null 2>&1)
     python tools/op_table.py $(find /tmp/o1 -name "*kernel_trace.csv" | head -1) $(find /tmp/o2 -name "*counter_collection.csv" | head -1) \
         $(find /tmp/o3 -name "*counter_collection.csv" | head -1) $R/op_probe.out $R/op_hbm_pmc.json > $R/op_hbm_pmc.md; cat $R/op_hbm_pmc.md
+    python tools/op_kernels.py $(find /tmp/o1 -name "*kernel_trace.csv" | head -1) > $R/op_kernels.txt; cat $R/op_kernels.txt
 }
 gemm_tests() { python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -8 > $R/gemm_tests.txt; }
 model_tests() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_size or two_rank" 2>&1 | tail -30 > $R/model.txt; }
