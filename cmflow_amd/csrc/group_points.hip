@@ -377,7 +377,7 @@ __global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_bal_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Plan form of the balanced kernel (idx of shape (P <= 256 rows) x (S <= 64), the model's ball-query / kNN lists).
+// Plan form of the balanced kernel (rows of up to 8192 entries over up to 2048 targets: the model's ball-query / kNN lists).
 // What made narrow features slow was everything AROUND the rows: the inverse index was a separate launch of one
 // workgroup per sample with 256-step dependent LDS chains (21-59 us), and every scatter workgroup then rebuilt its
 // tables from that index (flags, two block scans per 256 targets, 32 list entries per thread) -- ~67 us of fixed cost
@@ -387,126 +387,144 @@ __global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_bal_kernel(
 // first run end; per target (rank among non-empty targets | first chunk | last chunk).  A scatter workgroup loads that
 // image (E / 2 + 2 words per thread, n words through LDS) and starts streaming rows.  Same order of additions as
 // group_points_grad_bal_kernel: deterministic, bit-reproducible.
+//
+// The plan kernel is a stable counting sort of the row's entries by target, without atomics and without per-row serial loops
+// (round 4; the first form gave a thread one idx row and walked it with dependent LDS read-modify-writes against a dense
+// rows x targets count matrix: 17 us per call on 4 waves, 37 % of the C = 64 call of (64,256,32)).  16 waves; a wave owns
+// E / 4 consecutive 64-entry chunks and keeps its entries in registers through all phases:
+//   A  per chunk, the lanes holding the same target find each other with one ballot per key bit; a lane's rank among them is a
+//      population count, the wave's running count per target (run[wave][target], LDS) gives its rank inside the wave;
+//   B  a thread per target turns the 16 per-wave counts into exclusive prefixes, a block scan of the totals gives offs[];
+//   C  every entry goes to offs[target] + run[wave][target] + rank, tagged (bit 15) if it is the last of its target;
+//   D  the scatter threads' register image is read off the sorted row.
 // ---------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t gpg_plan_words(int E, int n) { return (size_t)GG_THREADS * (E / 2) + 2 * GG_THREADS + (size_t)n; }
+constexpr int GPL_THREADS = 1024;
+constexpr int GPL_WAVES = GPL_THREADS / 64;
+constexpr int GPL_MAX_N = 2048;              // targets the plan kernel keeps per-wave counts for (16 x n x 2 bytes of LDS)
+inline size_t gpg_plan_lds(int E, int n)
+{
+    return ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16 + (size_t)GG_THREADS * E * 2 + (size_t)(n + 1) * 4;
+}
+
+// inclusive prefix sum over the 1024 threads of the plan workgroup; wsum: 16 ints of LDS
+__device__ __forceinline__ int gp_block_scan(int v, int *wsum, int &block_total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    __syncthreads();                                                // previous users of wsum are done
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int add = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < GPL_WAVES; ++w) {
+        const int x = wsum[w];
+        if (w < wave) add += x;
+        tot += x;
+    }
+    block_total = tot;
+    return v + add;
+}
 
 template <int E>
-__global__ __launch_bounds__(GG_THREADS) void gpg_plan_kernel(int n, int P, int S, const int *__restrict__ idx, unsigned *__restrict__ plan_all)
+__global__ __launch_bounds__(GPL_THREADS) void gpg_plan_kernel(int n, int total, const int *__restrict__ idx, unsigned *__restrict__ plan_all)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-    __shared__ int scan[GG_THREADS / 64];
-    const int ld = n | 1;                                             // odd row stride: column walks spread over the banks
-    const int total = P * S;
-    unsigned short *cnt = reinterpret_cast<unsigned short *>(psm);    // [P][ld] multiplicities, then exclusive prefixes over p
-    size_t o = ((size_t)P * ld * 2 + 15) / 16 * 16;
-    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += ((size_t)total * 2 + 15) / 16 * 16;   // [total] positions by target
-    int *offs = reinterpret_cast<int *>(psm + o); o += ((size_t)(n + 1) * 4 + 15) / 16 * 16;                         // [n + 1]
-    unsigned char *rk = psm + o;                                      // [total] rank of an entry among its row's entries of the same target;
-    unsigned char *flags = rk;                                        //         later: 1 at the last sorted entry of every target
-    const int t = threadIdx.x, bs = blockIdx.x;
+    __shared__ int scan[GPL_WAVES];
+    constexpr int CH = E / 4;                                         // 64-entry chunks per wave
+    constexpr unsigned PAD = (unsigned)(GG_THREADS * E);              // padding reads the zero slot behind the row
+    unsigned short *run = reinterpret_cast<unsigned short *>(psm);    // [GPL_WAVES][n] per-wave counts, then exclusive prefixes over the waves
+    size_t o = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16;
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += (size_t)GG_THREADS * E * 2;   // positions by target | last-of-target << 15
+    int *offs = reinterpret_cast<int *>(psm + o);                     // [n + 1]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockIdx.x;
     const int *ix = idx + (size_t)bs * total;
     unsigned *plan = plan_all + (size_t)bs * gpg_plan_words(E, n);
-    for (int i = t; i < (int)(((size_t)P * ld * 2 + 15) / 16); i += GG_THREADS) reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-    // A: row p counts its targets; the running count is the entry's rank inside (row, target) -- one owner per row: no atomics.
-    // The row's indices come as 16-byte loads, the next four requested before the current four are counted: with one 4-byte
-    // load per step the loop was S dependent L2 round trips (and phase C the same again): 17-18 us per call, 37 % of the
-    // C = 64 call and 68 % of the C = 3 call of (64,256,32) (profiles/r04_op_kernels.txt).
-    const bool v4 = (S & 3) == 0 && (((uintptr_t)ix) & 15) == 0;
-    if (t < P) {
-        if (v4) {
-            int4 nx = *(const int4 *)(ix + t * S);
-            for (int sl = 0; sl < S; sl += 4) {
-                const int4 cur = nx;
-                if (sl + 4 < S) nx = *(const int4 *)(ix + t * S + sl + 4);
-                const int jj[4] = {cur.x, cur.y, cur.z, cur.w};
+    int key[CH];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned short c = cnt[t * ld + jj[u]];
-                    rk[t * S + sl + u] = (unsigned char)c;
-                    cnt[t * ld + jj[u]] = (unsigned short)(c + 1);
-                }
-            }
-        } else
-            for (int sl = 0; sl < S; ++sl) {
-                const int j = ix[t * S + sl];
-                const unsigned short c = cnt[t * ld + j];
-                rk[t * S + sl] = (unsigned char)c;
-                cnt[t * ld + j] = (unsigned short)(c + 1);
-            }
+    for (int c = 0; c < CH; ++c) {
+        const int e = (wave * CH + c) * 64 + lane;
+        key[c] = e < total ? ix[e] : -1;
+    }
+    for (int i = t; i < (int)(((size_t)GPL_WAVES * n * 2 + 15) / 16); i += GPL_THREADS) reinterpret_cast<uint4 *>(run)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // A
+    const int kb = 32 - __clz(max(n - 1, 1));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned short *myrun = run + (size_t)wave * n;
+    int rank[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const bool valid = key[c] >= 0;
+        unsigned long long peers = __ballot(valid);
+        for (int bit = 0; bit < kb; ++bit) {
+            const bool one = (key[c] >> bit) & 1;
+            const unsigned long long bm = __ballot(one);
+            peers &= one ? bm : ~bm;
+        }
+        rank[c] = 0;
+        if (valid) {
+            const int seen = myrun[key[c]];
+            rank[c] = seen + __popcll(peers & lt);
+            if ((peers >> lane) == 1ull) myrun[key[c]] = (unsigned short)(seen + __popcll(peers));   // the highest lane of the group
+        }
     }
     __syncthreads();
-    // B: column j -> exclusive prefix over the rows (8 loads in flight, then 8 stores: the loads of a serial read-modify-write
-    // loop cannot be overlapped by the compiler, it must assume the store aliases the next load); column totals -> offsets
+    // B
     int base = 0;
-    for (int j0 = 0; j0 < n; j0 += GG_THREADS) {
+    for (int j0 = 0; j0 < n; j0 += GPL_THREADS) {
         const int j = j0 + t;
-        int run = 0;
+        int tot_j = 0;
         if (j < n) {
-            int p0 = 0;
-            for (; p0 + 8 <= P; p0 += 8) {
-                unsigned short v[8];
+            unsigned short v[GPL_WAVES];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = cnt[(p0 + u) * ld + j];
+            for (int w = 0; w < GPL_WAVES; ++w) v[w] = run[(size_t)w * n + j];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { cnt[(p0 + u) * ld + j] = (unsigned short)run; run += v[u]; }
-            }
-            for (; p0 < P; ++p0) { const int c = cnt[p0 * ld + j]; cnt[p0 * ld + j] = (unsigned short)run; run += c; }
+            for (int w = 0; w < GPL_WAVES; ++w) { run[(size_t)w * n + j] = (unsigned short)tot_j; tot_j += v[w]; }
         }
         int tot;
-        const int incl = gg_block_scan(run, scan, tot);
-        if (j < n) offs[j] = base + incl - run;
+        const int incl = gp_block_scan(tot_j, scan, tot);
+        if (j < n) offs[j] = base + incl - tot_j;
         base += tot;
     }
     if (t == 0) offs[n] = base;
     __syncthreads();
-    // C: every entry to its slot: ascending (row, slot) order inside a target's list
-    if (t < P) {
-        if (v4) {
-            int4 nx = *(const int4 *)(ix + t * S);
-            for (int sl = 0; sl < S; sl += 4) {
-                const int4 cur = nx;
-                if (sl + 4 < S) nx = *(const int4 *)(ix + t * S + sl + 4);
-                const int jj[4] = {cur.x, cur.y, cur.z, cur.w};
-                int dst[4];
+    // C: ascending position inside a target's list (waves, chunks and lanes all ascend with the position)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) dst[u] = offs[jj[u]] + cnt[t * ld + jj[u]] + rk[t * S + sl + u];     // four independent chains
-#pragma unroll
-                for (int u = 0; u < 4; ++u) sorted[dst[u]] = (unsigned short)(t * S + sl + u);
-            }
-        } else
-            for (int sl = 0; sl < S; ++sl) {
-                const int j = ix[t * S + sl];
-                sorted[offs[j] + cnt[t * ld + j] + rk[t * S + sl]] = (unsigned short)(t * S + sl);
-            }
+    for (int c = 0; c < CH; ++c) {
+        const int e = (wave * CH + c) * 64 + lane;
+        if (key[c] >= 0) {
+            const int dst = offs[key[c]] + myrun[key[c]] + rank[c];
+            sorted[dst] = (unsigned short)(e | (dst + 1 == offs[key[c] + 1] ? 0x8000 : 0));
+        }
     }
+    for (int i = total + t; i < GG_THREADS * E; i += GPL_THREADS) sorted[i] = (unsigned short)PAD;
     __syncthreads();
     // D: the scatter workgroup's register image
-    for (int i = t; i < (total + 3) / 4; i += GG_THREADS) reinterpret_cast<unsigned *>(flags)[i] = 0u;
-    __syncthreads();
-    for (int j = t; j < n; j += GG_THREADS)
-        if (offs[j + 1] > offs[j]) flags[offs[j + 1] - 1] = 1;
-    __syncthreads();
+    const unsigned *sw = reinterpret_cast<const unsigned *>(sorted);
+    for (int i = t; i < GG_THREADS * (E / 2); i += GPL_THREADS) plan[i] = sw[i] & 0x7FFF7FFFu;
     unsigned mask = 0;
+    if (t < GG_THREADS) {
 #pragma unroll
-    for (int k = 0; k < E; k += 2) {
-        const int e = t * E + k;
-        const unsigned p0 = e < total ? sorted[e] : (unsigned)(GG_THREADS * E);       // padding reads the zero slot behind the row
-        const unsigned p1 = e + 1 < total ? sorted[e + 1] : (unsigned)(GG_THREADS * E);
-        plan[(size_t)t * (E / 2) + k / 2] = p0 | (p1 << 16);
-        if (e < total && flags[e]) mask |= 1u << k;
-        if (e + 1 < total && flags[e + 1]) mask |= 1u << (k + 1);
+        for (int k = 0; k < E / 2; ++k) {
+            const unsigned w = sw[t * (E / 2) + k];
+            mask |= ((w >> 15) & 1u) << (2 * k) | ((w >> 31) & 1u) << (2 * k + 1);
+        }
     }
     unsigned *pm = plan + (size_t)GG_THREADS * (E / 2);
     int tot;
-    const int rank0 = gg_block_scan(__popc(mask), scan, tot) - __popc(mask);
-    pm[t] = mask; pm[GG_THREADS + t] = (unsigned)rank0;
+    const int rank0 = gp_block_scan(__popc(mask), scan, tot) - __popc(mask);
+    if (t < GG_THREADS) { pm[t] = mask; pm[GG_THREADS + t] = (unsigned)rank0; }
     unsigned *pt = pm + 2 * GG_THREADS;                               // per target: rank (16) | first chunk (8) | last chunk (8); 0xFFFF....: empty
     base = 0;
-    for (int j0 = 0; j0 < n; j0 += GG_THREADS) {
+    for (int j0 = 0; j0 < n; j0 += GPL_THREADS) {
         const int j = j0 + t;
         const int ne = (j < n && offs[j + 1] > offs[j]) ? 1 : 0;
-        const int inc = gg_block_scan(ne, scan, tot);
+        const int inc = gp_block_scan(ne, scan, tot);
         if (j < n) pt[j] = ne ? ((unsigned)(base + inc - 1) | ((unsigned)(offs[j] / E) << 16) | ((unsigned)((offs[j + 1] - 1) / E) << 24)) : 0xFFFFFFFFu;
         base += tot;
     }
@@ -592,20 +610,20 @@ __global__ __launch_bounds__(GG_THREADS, 4) void group_points_grad_plan_kernel(
 }
 
 template <int E>
-static int launch_plan(int b, int c, int n, int P, int S, int ch_per_wg, size_t lds_plan, const float *grad_out, const int *idx,
+static int launch_plan(int b, int c, int n, int total, int ch_per_wg, const float *grad_out, const int *idx,
                        unsigned *plan, float *grad_points, hipStream_t st)
 {
     static CmfPerDevice attr_set;
     int attr_dev;
     if (attr_set.need(attr_dev)) {
-        (void)hipFuncSetAttribute((const void *)gpg_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        (void)hipFuncSetAttribute((const void *)gpg_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpg_plan_lds(E, GPL_MAX_N));
         (void)hipFuncSetAttribute((const void *)group_points_grad_plan_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   ((GG_THREADS * E + 4) + 2 * GG_MAX_N_BAL + GG_THREADS) * 4);
         attr_set.done(attr_dev);
     }
-    hipLaunchKernelGGL(gpg_plan_kernel<E>, dim3(b), dim3(GG_THREADS), lds_plan, st, n, P, S, idx, plan);
+    hipLaunchKernelGGL(gpg_plan_kernel<E>, dim3(b), dim3(GPL_THREADS), gpg_plan_lds(E, n), st, n, total, idx, plan);
     const size_t lds = (size_t)((GG_THREADS * E + 4) + 2 * n + GG_THREADS) * 4;
-    hipLaunchKernelGGL(group_points_grad_plan_kernel<E>, dim3(b, cmf_divup(c, ch_per_wg)), dim3(GG_THREADS), lds, st, c, n, P * S, ch_per_wg,
+    hipLaunchKernelGGL(group_points_grad_plan_kernel<E>, dim3(b, cmf_divup(c, ch_per_wg)), dim3(GG_THREADS), lds, st, c, n, total, ch_per_wg,
                        grad_out, plan, grad_points);
     return cmf_launch_status();
 }
@@ -688,18 +706,22 @@ __global__ __launch_bounds__(GA_THREADS) void group_points_grad_stream_kernel(
 // form that ADDS into LDS is bound by its atomic lanes.  This form only READS LDS.  Per call, an index kernel cuts a sample's row into tiles of 32768 entries and builds, per tile,
 // (a) a 64-bit mask per list marking the slots that repeat the list's first entry (the reference's padding, three quarters
 // of all entries on LiDAR-like clouds) and (b) a CSR index target -> positions over the remaining entries (counting sort
-// in LDS with integer atomics, every target's short segment then sorted by position: a fixed order).  The gather kernel
+// in LDS with integer atomics, every target's short segment then sorted by position: a fixed order).  [A stable counting sort
+// without atomics -- per-wave counts, the lanes of a 64-entry chunk that hold the same target matched with one ballot per key
+// bit, as gpg_plan_kernel does for 8-bit keys -- was measured slower here: 100 against 76 us at config 5; with 12-bit keys and
+// 512 chunks per tile the per-lane 64-bit mask arithmetic of the matching dominates.]  The gather kernel
 // owns (sample, a few channels): per channel and tile it stages the 128 KB of the row in LDS -- while a list passes
 // through the registers its padded slots are summed across the lanes (DPP) and folded into the list's first entry -- and
 // then a thread walks the segments of its targets and accumulates in registers.  No atomics, every sum in a fixed order:
 // bit-reproducible.  n <= 8192, lists of 16 / 32 / 64 slots.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int GC_THREADS = 512;
 #ifndef CMF_GC_SMALL
 #define CMF_GC_SMALL 0                                 // experiment: 16384-entry tiles, two 512-thread workgroups per CU
 #endif
+constexpr int GC_THREADS = 512;
 constexpr int GC_TILE = CMF_GC_SMALL ? 16384 : 32768;  // entries per tile
 constexpr int GC_MAX_N = 8192;
+constexpr int GC_UN = 8;                               // chunks of indices in flight per wave (index kernel)
 constexpr int GC_SHORT = 32;                           // longest segment a single thread sorts
 
 template <int CTRL>
@@ -738,15 +760,22 @@ __global__ __launch_bounds__(GC_THREADS) void gpg_csr_index_kernel(
     for (int i = tid; i < n; i += GC_THREADS) cur[i] = 0u;
     __syncthreads();
     const int seg0 = lane & ~(S - 1);
-    for (int e0 = wave * 64; e0 < len; e0 += GC_THREADS) {
-        const int e = e0 + lane;
-        const bool valid = e < len;
-        const int t = valid ? id[e] : -1;
-        const int t0 = __shfl(t, seg0, 64);
-        const bool pad = valid && lane != seg0 && t == t0;
-        const unsigned long long m = __ballot(pad);
-        if (valid && lane == seg0) pm[e / S] = S == 64 ? m : ((m >> seg0) & ((1ull << (S & 63)) - 1ull));
-        if (valid && !pad) atomicAdd(&cur[t], 1u);
+    // (the indices of GC_UN chunks are requested together: with one load per step both passes were 64 exposed global round trips)
+    for (int e0 = wave * 64; e0 < len; e0 += GC_THREADS * GC_UN) {
+        int tv[GC_UN];
+#pragma unroll
+        for (int u = 0; u < GC_UN; ++u) { const int e = e0 + u * GC_THREADS + lane; tv[u] = e < len ? id[e] : -1; }
+#pragma unroll
+        for (int u = 0; u < GC_UN; ++u) {
+            const int e = e0 + u * GC_THREADS + lane;
+            const bool valid = e < len;
+            const int t = tv[u];
+            const int t0 = __shfl(t, seg0, 64);
+            const bool pad = valid && lane != seg0 && t == t0;
+            const unsigned long long m = __ballot(pad);
+            if (valid && lane == seg0) pm[e / S] = S == 64 ? m : ((m >> seg0) & ((1ull << (S & 63)) - 1ull));
+            if (valid && !pad) atomicAdd(&cur[t], 1u);
+        }
     }
     __syncthreads();
     // exclusive scan of the counts (thread t owns the targets [t*nt, t*nt + nt))
@@ -768,13 +797,19 @@ __global__ __launch_bounds__(GC_THREADS) void gpg_csr_index_kernel(
     if (tid == GC_THREADS - 1) start[n] = run;
     __syncthreads();
     // placement (any order inside a target's segment), then every segment sorted by position
-    for (int e0 = wave * 64; e0 < len; e0 += GC_THREADS) {
-        const int e = e0 + lane;
-        const bool valid = e < len;
-        const int t = valid ? id[e] : -1;
-        const int t0 = __shfl(t, seg0, 64);
-        const bool pad = valid && lane != seg0 && t == t0;
-        if (valid && !pad) spos[atomicAdd(&cur[t], 1u)] = (unsigned short)e;
+    for (int e0 = wave * 64; e0 < len; e0 += GC_THREADS * GC_UN) {
+        int tv[GC_UN];
+#pragma unroll
+        for (int u = 0; u < GC_UN; ++u) { const int e = e0 + u * GC_THREADS + lane; tv[u] = e < len ? id[e] : -1; }
+#pragma unroll
+        for (int u = 0; u < GC_UN; ++u) {
+            const int e = e0 + u * GC_THREADS + lane;
+            const bool valid = e < len;
+            const int t = tv[u];
+            const int t0 = __shfl(t, seg0, 64);
+            const bool pad = valid && lane != seg0 && t == t0;
+            if (valid && !pad) spos[atomicAdd(&cur[t], 1u)] = (unsigned short)e;
+        }
     }
     __syncthreads();
     // short segments (the rule on neighbour lists): insertion sort by their thread; long ones (arbitrary idx can put a whole
@@ -817,17 +852,36 @@ __global__ __launch_bounds__(GC_THREADS) void gpg_csr_index_kernel(
 // LDS of the gather: the tile's floats | as many of its sorted positions as fit (the rest, if any, is read from global memory).
 // [16384-entry tiles with two 512-thread workgroups per CU were measured slower: 1633 against 1230-1270 us at config 5 --
 //  twice the per-(target, tile) segment overhead for half the staging latency.]
-constexpr int GCG_THREADS = CMF_GC_SMALL ? 512 : 1024;
+#ifndef CMF_GC_THREADS
+#define CMF_GC_THREADS 1024
+#endif
+constexpr int GCG_THREADS = CMF_GC_SMALL ? 512 : CMF_GC_THREADS;
 constexpr int GCG_EPT = GC_TILE / GCG_THREADS;         // entries per thread and tile (32 = 8 x float4)
 constexpr size_t GCG_LDS = CMF_GC_SMALL ? 80 * 1024 - 128 : 160 * 1024 - 256;
 constexpr int GCG_CAP = (int)((GCG_LDS - (size_t)GC_TILE * 4) / 2);
 
+typedef unsigned gc_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gc_rsrc(const void *q, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)q, 0, (int)bytes, 0x00020000);   // raw buffer: loads past `bytes` return 0
+}
+constexpr int GCG_PCH = (GCG_CAP / 8 + GCG_THREADS - 1) / GCG_THREADS;   // 16-byte chunks of staged positions per thread
+
+// Every stream of the tile loop is a buffer load (descriptor in SGPRs + one lane offset + a scalar offset): with plain pointers the
+// compiler keeps one 64-bit address per unrolled load (24 register pairs at 128 registers per thread: spills), and the range
+// check of the descriptor replaces the tail selects.  A tile's segment bounds and its sorted positions are requested together
+// with the tile, one tile ahead [before round 4 they were fetched behind the barriers: two exposed global latencies per tile].
 template <int S, int NT>                               // NT targets per thread: n <= NT * GCG_THREADS
-__global__ __launch_bounds__(GCG_THREADS, 4) void gpg_csr_gather_kernel(
+__global__ __launch_bounds__(GCG_THREADS, GCG_THREADS / 256) void gpg_csr_gather_kernel(
     int c, int n, int total, int tiles, int ch_per_wg, const float *__restrict__ grad_out,
     const unsigned long long *__restrict__ padmask, const unsigned short *__restrict__ off, const unsigned short *__restrict__ pos,
-    float *__restrict__ grad_points, int diag)
+    float *__restrict__ grad_points, int diag_arg)
 {
+#ifdef CMF_GC_EXPERIMENT
+    const int diag = diag_arg;                                       // timing ablations (experiment builds only): 1 no walk, 2 no index staging, 4 no tile staging
+#else
+    constexpr int diag = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) float gc_buf[];   // [GC_TILE]
     unsigned short *p_s = (unsigned short *)(gc_buf + GC_TILE);      // [GCG_CAP]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -835,61 +889,81 @@ __global__ __launch_bounds__(GCG_THREADS, 4) void gpg_csr_gather_kernel(
     const int c0 = blockIdx.y * ch_per_wg, c1 = min(c, c0 + ch_per_wg);
     constexpr int LPL = S / 4;                                       // lanes per list: a lane holds 4 consecutive slots
     const int l0 = lane & ~(LPL - 1);
-    const unsigned long long *pm_s = padmask + (size_t)bs * total / S;
+    // the byte of a list's 64-bit mask that holds this lane's four slots (slot 4 * (lane - l0) of the list)
+    const __amdgpu_buffer_rsrc_t r_pm = gc_rsrc(padmask + (size_t)bs * total / S, (unsigned)(total / S) * 8u);
+    const int vo_pm = (4 * tid / S) * 8 + ((lane - l0) >> 1);
+    const int pm_sh = 4 * ((lane - l0) & 1);
     auto lds_barrier = [&]() {                                       // __syncthreads() would drain the prefetches (vmcnt(0)) as well
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
     for (int ch = c0; ch < c1; ++ch) {
-        const float *g = grad_out + ((size_t)bs * c + ch) * total;
+        const __amdgpu_buffer_rsrc_t r_g = gc_rsrc(grad_out + ((size_t)bs * c + ch) * total, (unsigned)total * 4u);
         float acc[NT], acc2[NT];
 #pragma unroll
         for (int q = 0; q < NT; ++q) acc[q] = acc2[q] = 0.f;
-        float4 v[GCG_EPT / 4];
-        unsigned long long pmv[GCG_EPT / 4];
+        gc_u32x4 v[GCG_EPT / 4], psr[GCG_PCH];
+        unsigned pmv[GCG_EPT / 4];
+        unsigned ob[NT], oe[NT];                                     // segment bounds of this thread's targets in the requested tile
+        int nnz_req = 0;
         // a thread stages the entries 4 * (tid + i * GCG_THREADS) .. + 3 of a tile (total % 4 == 0: a float4 is in or out)
         auto load_tile = [&](int tile) {
-            const int base = tile * GC_TILE, len = min(GC_TILE, total - base);
+            const int base = tile * GC_TILE;
 #pragma unroll
             for (int i = 0; i < GCG_EPT / 4; ++i) {
-                const int e = 4 * (tid + i * GCG_THREADS);
-                const bool ok = e < len;
-                pmv[i] = ok ? pm_s[(base + e) / S] : 0ull;
-                v[i] = ok ? *(const float4 *)(g + base + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[i] = __builtin_amdgcn_raw_buffer_load_b128(r_g, 16 * tid, (base + 4 * i * GCG_THREADS) * 4, 0);
+                pmv[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(r_pm, vo_pm, ((base + 4 * i * GCG_THREADS) / S) * 8, 0);
             }
+            const unsigned short *o = off + ((size_t)bs * tiles + tile) * (n + 1);
+            const __amdgpu_buffer_rsrc_t r_o = gc_rsrc(o, (unsigned)(n + 1) * 2u);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                ob[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r_o, 2 * tid, q * GCG_THREADS * 2, 0);
+                oe[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(r_o, 2 * tid + 2, q * GCG_THREADS * 2, 0);
+            }
+            nnz_req = o[n];
+        };
+        auto load_positions = [&](int tile, int nnz) {               // behind load_tile of the same tile, once its nnz is known
+            const __amdgpu_buffer_rsrc_t r_p = gc_rsrc(pos + ((size_t)bs * tiles + tile) * GC_TILE, (unsigned)GCG_CAP * 2u);
+#pragma unroll
+            for (int k = 0; k < GCG_PCH; ++k)
+                if (8 * (tid + k * GCG_THREADS) < nnz && !(diag & 2))
+                    psr[k] = __builtin_amdgcn_raw_buffer_load_b128(r_p, 16 * tid, k * GCG_THREADS * 16, 0);
         };
         load_tile(0);
+        load_positions(0, nnz_req);
         for (int tile = 0; tile < tiles; ++tile) {
             const int len = min(GC_TILE, total - tile * GC_TILE);
-            const unsigned short *o = off + ((size_t)bs * tiles + tile) * (n + 1);
             const unsigned short *ps = pos + ((size_t)bs * tiles + tile) * GC_TILE;
-            // this thread's segments (needed behind the barrier: the loads fly under the staging)
+            const int nnz = nnz_req;
             int b0[NT], b1[NT];
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                const int j = tid + q * GCG_THREADS;
-                b0[q] = j < n ? o[j] : 0; b1[q] = j < n ? o[j + 1] : 0;
+                const bool in = tid + q * GCG_THREADS < n;
+                b0[q] = in ? (int)ob[q] : 0; b1[q] = in ? (int)oe[q] : 0;
             }
-            const int nnz = o[n];
             // fold every list's padded slots into its first entry (the lanes of a list are neighbours inside a DPP row), store
 #pragma unroll
             for (int i = 0; i < GCG_EPT / 4; ++i) {
                 const int e = 4 * (tid + i * GCG_THREADS);
-                const unsigned bits = (unsigned)(pmv[i] >> (4 * (lane - l0))) & 0xFu;
-                float part = ((bits & 1u) ? v[i].x : 0.f) + ((bits & 2u) ? v[i].y : 0.f) + ((bits & 4u) ? v[i].z : 0.f) + ((bits & 8u) ? v[i].w : 0.f);
+                const unsigned bits = (pmv[i] >> pm_sh) & 0xFu;
+                float4 w = __builtin_bit_cast(float4, v[i]);
+                float part = ((bits & 1u) ? w.x : 0.f) + ((bits & 2u) ? w.y : 0.f) + ((bits & 4u) ? w.z : 0.f) + ((bits & 8u) ? w.w : 0.f);
                 part += gc_dpp<0xB1>(part);                                         // 2 lanes
                 part += gc_dpp<0x4E>(part);                                         // 4 lanes = a list of 16 slots
                 if (S >= 32) part += gc_dpp<0x141>(part);                           // 8 lanes
                 if (S >= 64) part += gc_dpp<0x140>(part);                           // 16 lanes = a list of 64 slots
-                float4 w = v[i];
                 if (lane == l0) w.x += part;
-                if (e < len) *(float4 *)(gc_buf + e) = w;
+                if (e < len && !(diag & 4)) *(float4 *)(gc_buf + e) = w;
+                if (diag & 4) acc[0] += w.x + w.y + w.z + w.w;
             }
-            if (!(diag & 2))
-                for (int i = tid; i < min(nnz, GCG_CAP); i += GCG_THREADS) p_s[i] = ps[i];
+#pragma unroll
+            for (int k = 0; k < GCG_PCH; ++k)
+                if (8 * (tid + k * GCG_THREADS) < min(nnz, GCG_CAP) && !(diag & 2))
+                    *(gc_u32x4 *)(p_s + 8 * (tid + k * GCG_THREADS)) = psr[k];
             lds_barrier();
-            if (tile + 1 < tiles) load_tile(tile + 1);                              // in flight under the walk below
+            if (tile + 1 < tiles) { load_tile(tile + 1); load_positions(tile + 1, nnz_req); }   // in flight under the walk below
             int maxl = 0;
 #pragma unroll
             for (int q = 0; q < NT; ++q) maxl = max(maxl, b1[q] - b0[q]);
@@ -945,7 +1019,11 @@ static int launch_csr(int b, int c, int n, int total, const float *grad_out, con
     }
     const size_t lds_i = (size_t)(2 * n + 1) * sizeof(unsigned) + (size_t)GC_TILE * sizeof(unsigned short);
     hipLaunchKernelGGL(gpg_csr_index_kernel<S>, dim3(tiles, b), dim3(GC_THREADS), lds_i, st, n, total, tiles, idx, padmask, off, pos);
-    const int gdiag = 0;                                // (kernel argument of the timing ablations of round 3: 1 no walk, 2 no index staging)
+#ifdef CMF_GC_EXPERIMENT
+    const int gdiag = getenv("CMF_GC_DIAG") ? atoi(getenv("CMF_GC_DIAG")) : 0;   // timing ablations: 1 no walk, 2 no index staging, 4 no tile staging
+#else
+    const int gdiag = 0;
+#endif
     int ch_per_wg = 8;                                  // >= 2 workgroups per CU over the launch
     while (ch_per_wg > 1 && (long long)b * cmf_divup(c, ch_per_wg) < 512) ch_per_wg /= 2;
     const dim3 grid(b, cmf_divup(c, ch_per_wg));
@@ -1305,12 +1383,10 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
                            (size_t)GA_CH * n * sizeof(float), st, c, n, (int)total, grad_out, idx, grad_points);
         return cmf_launch_status();
     }
-    // rows x slots lists of the model's sizes: one plan kernel + the plan form of the balanced kernel (CMF_GROUP_GRAD_PLAN=0:
-    // the inverse index + balanced kernel below, diagnostics)
+    // rows of the model's sizes: one plan kernel + the plan form of the balanced kernel (CMF_GROUP_GRAD_PLAN=0: the inverse
+    // index + balanced kernel below, diagnostics)
     static const bool use_plan = !(getenv("CMF_GROUP_GRAD_PLAN") && getenv("CMF_GROUP_GRAD_PLAN")[0] == '0');
-    const size_t lds_plan = ((size_t)npoints * (n | 1) * 2 + 15) / 16 * 16 + ((size_t)total * 2 + 15) / 16 * 16 +
-                            ((size_t)(n + 1) * 4 + 15) / 16 * 16 + ((size_t)total + 15) / 16 * 16;
-    if (use_plan && balanced && npoints <= GG_THREADS && nsample <= 64 && n <= 65535 && lds_plan <= 160 * 1024 - 64) {
+    if (use_plan && balanced && n <= GPL_MAX_N) {
         int ch_per_wg = GG_CH;
         while (ch_per_wg > 2 && (long long)b * cmf_divup(c, ch_per_wg) < 1024) ch_per_wg /= 2;
         const int e_need = (int)cmf_divup(total, GG_THREADS);
@@ -1318,10 +1394,10 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         const CmfScratchLease lease = cmf_stream_scratch(st, 0, (size_t)b * gpg_plan_words(E, n) * sizeof(unsigned));
         unsigned *plan = (unsigned *)lease.ptr;
         if (!plan) return (int)hipErrorOutOfMemory;
-        if (E == 4) return launch_plan<4>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
-        if (E == 8) return launch_plan<8>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
-        if (E == 16) return launch_plan<16>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
-        return launch_plan<32>(b, c, n, npoints, nsample, ch_per_wg, lds_plan, grad_out, idx, plan, grad_points, st);
+        if (E == 4) return launch_plan<4>(b, c, n, (int)total, ch_per_wg, grad_out, idx, plan, grad_points, st);
+        if (E == 8) return launch_plan<8>(b, c, n, (int)total, ch_per_wg, grad_out, idx, plan, grad_points, st);
+        if (E == 16) return launch_plan<16>(b, c, n, (int)total, ch_per_wg, grad_out, idx, plan, grad_points, st);
+        return launch_plan<32>(b, c, n, (int)total, ch_per_wg, grad_out, idx, plan, grad_points, st);
     }
     // per-stream library scratch for the inverse index (cmf_common.h)
     const size_t n_off = (size_t)b * (n + 1), n_inv = (size_t)b * total;

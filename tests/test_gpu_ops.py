@@ -209,10 +209,11 @@ def test_config5_full_batch_matches_oracle(dev):
 
 
 @pytest.mark.parametrize("B,C,N,P,S", [(64, 3, 256, 256, 32), (8, 64, 256, 256, 32), (2, 70, 256, 128, 64), (3, 5, 100, 256, 8), (2, 9, 290, 256, 4),
-                                       (1, 130, 256, 256, 17), (2, 4, 600, 100, 50), (5, 1, 16, 3, 1)])
+                                       (1, 130, 256, 256, 17), (2, 4, 600, 100, 50), (5, 1, 16, 3, 1), (2, 6, 1500, 300, 20), (1, 3, 2048, 128, 64),
+                                       (2, 5, 1, 40, 9), (2, 3, 2049, 64, 32), (2, 7, 256, 256, 31)])
 def test_group_points_grad_plan_form(dev, B, C, N, P, S):
-    """Lists of <= 256 rows x <= 64 slots (the model's ball-query / kNN shapes) take the plan form: one kernel turns idx into
-    the register image of the scatter workgroups, no separate inverse index.  Real ball-query lists (first-hit padding: heavy
+    """Rows of <= 8192 entries over <= 2048 targets (the model's ball-query / kNN shapes) take the plan form: one kernel turns idx
+    into the register image of the scatter workgroups, no separate inverse index (2049 targets: the inverse-index form).  Real ball-query lists (first-hit padding: heavy
     low-numbered targets, empty targets) and uniform random ones; result within fp32 rounding of the oracle's scan-order sum,
     bit-reproducible run to run, accumulating into grad_points."""
     from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
@@ -603,3 +604,23 @@ def test_group_points_grad_long_rows_real_indices(dev):
         gp = torch.zeros(2, 5, 4096, device=dev)
         ext.group_points_grad_wrapper(2, 5, 4096, 4096, ns, go.to(dev), idx.to(dev), gp)
         np.testing.assert_allclose(gp.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,N,P,S,hi", [(2, 5, 2000, 1000, 16, 2000), (1, 3, 8192, 300, 32, 8192), (2, 4, 4096, 4100, 16, 4096), (1, 6, 4096, 1024, 64, 3),
+                                          (2, 3, 300, 2048, 32, 300), (1, 2, 5000, 700, 64, 1)])
+def test_group_points_grad_csr_index_variants(dev, B, C, N, P, S, hi):
+    """The pad-folded CSR gather on arbitrary (not ball-query) indices: every wave count of the index kernel (16 / 8 / 4 waves for
+    n <= 2048 / 4096 / 8192), ragged last tiles, and a handful of targets taking whole tiles (hi = 3, 1: segments of ~10 000 entries,
+    every list 'padded' by chance).  Against the oracle's scan-order sum, bit-reproducible."""
+    from cmflow_amd.pointnet2_utils import pointnet2_cuda as ext
+    g = torch.Generator().manual_seed(N + P + S + hi)
+    idx = torch.randint(0, hi, (B, P, S), generator=g, dtype=torch.int32)
+    go = torch.randn(B, C, P, S, generator=g)
+    ref = orc.group_points_grad(go, idx, N)
+    outs = []
+    for _ in range(2):
+        gp = torch.zeros(B, C, N, device=dev)
+        ext.group_points_grad_wrapper(B, C, N, P, S, go.to(dev), idx.to(dev), gp)
+        outs.append(gp.cpu())
+    assert torch.equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), rtol=2e-5, atol=1e-5 * float(ref.abs().max()) + 1e-6)
