@@ -872,7 +872,7 @@ constexpr int GCG_PCH = (GCG_CAP / 8 + GCG_THREADS - 1) / GCG_THREADS;   // 16-b
 // check of the descriptor replaces the tail selects.  A tile's segment bounds and its sorted positions are requested together
 // with the tile, one tile ahead [before round 4 they were fetched behind the barriers: two exposed global latencies per tile].
 template <int S, int NT>                               // NT targets per thread: n <= NT * GCG_THREADS
-__global__ __launch_bounds__(GCG_THREADS, GCG_THREADS / 256) void gpg_csr_gather_kernel(
+__global__ __launch_bounds__(GCG_THREADS, 4) void gpg_csr_gather_kernel(
     int c, int n, int total, int tiles, int ch_per_wg, const float *__restrict__ grad_out,
     const unsigned long long *__restrict__ padmask, const unsigned short *__restrict__ off, const unsigned short *__restrict__ pos,
     float *__restrict__ grad_points, int diag_arg)

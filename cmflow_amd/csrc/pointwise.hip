@@ -96,6 +96,87 @@ __device__ __forceinline__ void fin_reduce4(int tiles, int ncols, const int (&co
         for (int i = 0; i < 4; ++i) out[g][i] = ((sh[0][g][i] + sh[1][g][i]) + sh[2][g][i]) + sh[3][g][i];
 }
 
+// The same reduction for 16 adjacent columns per 1024-thread workgroup (round 4): 256 row slots x 4 lanes of float4, so a wave
+// reads 16 rows x 64 contiguous bytes (whole sectors) and 4096 tiles are ONE round of 16 loads per thread.  [The 4-column
+// form above reads 16 bytes of every row per workgroup -- neighbouring workgroups re-fetch the same sectors: 55 us for the
+// [4096][2560] matrix of a 524288-row data gradient, 760 GB/s; profiles/r04_finalize_probe.txt.]  Fixed order: per thread
+// ascending tiles, butterfly over the 16 row slots of a wave, the 16 waves in order.  Result in res[G][16] (LDS).
+constexpr int FIN16_THREADS = 1024;
+template <int G>
+__device__ __forceinline__ void fin_reduce16(int tiles, int ncols, const int (&col16)[G], const float *__restrict__ partial,
+                                             double (*sh)[G][16], double (*res)[16])
+{
+    const int rl = threadIdx.x >> 2, cl = threadIdx.x & 3;
+    double s[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[g][i] = 0.0;
+    constexpr int U = 16 / G;
+    constexpr int RS = FIN16_THREADS / 4;                            // row slots
+    int t = rl;
+    for (; t + (U - 1) * RS < tiles; t += U * RS) {
+        float4 v[U][G];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) v[u][g] = *(const float4 *)(partial + (size_t)(t + u * RS) * ncols + col16[g] + 4 * cl);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int g = 0; g < G; ++g) { s[g][0] += (double)v[u][g].x; s[g][1] += (double)v[u][g].y; s[g][2] += (double)v[u][g].z; s[g][3] += (double)v[u][g].w; }
+    }
+    for (; t < tiles; t += RS)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 v = *(const float4 *)(partial + (size_t)t * ncols + col16[g] + 4 * cl);
+            s[g][0] += (double)v.x; s[g][1] += (double)v.y; s[g][2] += (double)v.z; s[g][3] += (double)v.w;
+        }
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int off = 32; off >= 4; off >>= 1) s[g][i] += __shfl_xor(s[g][i], off, 64);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 4)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sh[wave][g][4 * cl + i] = s[g][i];
+    __syncthreads();
+    if (threadIdx.x < 16 * G) {
+        const int g = threadIdx.x >> 4, k = threadIdx.x & 15;
+        double r = 0.0;
+#pragma unroll
+        for (int w = 0; w < FIN16_THREADS / 64; ++w) r += sh[w][g][k];
+        res[g][k] = r;
+    }
+    __syncthreads();
+}
+
+// per-channel tail of bn_finalize from the channel's two sums
+__device__ __forceinline__ void bn_finalize_channel(
+    int ch, double s1, double s2, double count, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
+    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out)
+{
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+    }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double a = (gamma ? (double)gamma[ch] : 1.0) * invstd;
+    if (mean_out) mean_out[ch] = (float)mean;
+    if (invstd_out) invstd_out[ch] = (float)invstd;
+    a_out[ch] = (float)a;
+    c_out[ch] = (float)((beta ? (double)beta[ch] : 0.0) - mean * a);
+}
+
 // bn_finalize for C % 4 == 0: one workgroup per 4 channels, sums and sums of squares reduced together
 __device__ __forceinline__ void bn_finalize4_body(
     int tiles, int C, double count, const float *__restrict__ partial,
@@ -112,24 +193,47 @@ __device__ __forceinline__ void bn_finalize4_body(
     double r[2][4];
     fin_reduce4<2>(tiles, 2 * C, col4, partial, sh, r);
     if (threadIdx.x >= 4) return;
-    const int ch = c0 + threadIdx.x;
     const int i = threadIdx.x;
     const double s1 = i == 0 ? r[0][0] : i == 1 ? r[0][1] : i == 2 ? r[0][2] : r[0][3];
     const double s2 = i == 0 ? r[1][0] : i == 1 ? r[1][1] : i == 2 ? r[1][2] : r[1][3];
-    double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    if (running_mean) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
-        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
-    }
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double a = (gamma ? (double)gamma[ch] : 1.0) * invstd;
-    if (mean_out) mean_out[ch] = (float)mean;
-    if (invstd_out) invstd_out[ch] = (float)invstd;
-    a_out[ch] = (float)a;
-    c_out[ch] = (float)((beta ? (double)beta[ch] : 0.0) - mean * a);
+    bn_finalize_channel(c0 + i, s1, s2, count, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out);
+}
+
+// ... and for C % 16 == 0: one 1024-thread workgroup per 16 channels
+__device__ __forceinline__ void bn_finalize16_body(
+    int tiles, int C, double count, const float *__restrict__ partial,
+    const float *__restrict__ gamma, const float *__restrict__ beta,
+    float eps, float momentum, float *__restrict__ running_mean,
+    float *__restrict__ running_var, float *__restrict__ mean_out,
+    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out,
+    long long *__restrict__ num_batches_tracked, const int bx)
+{
+    __shared__ double sh[FIN16_THREADS / 64][2][16];
+    __shared__ double res[2][16];
+    if (num_batches_tracked && bx == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
+    const int c0 = bx * 16;
+    const int col16[2] = {c0, C + c0};
+    fin_reduce16<2>(tiles, 2 * C, col16, partial, sh, res);
+    if (threadIdx.x >= 16) return;
+    bn_finalize_channel(c0 + threadIdx.x, res[0][threadIdx.x], res[1][threadIdx.x], count, gamma, beta, eps, momentum, running_mean,
+                        running_var, mean_out, invstd_out, a_out, c_out);
+}
+
+__global__ __launch_bounds__(FIN16_THREADS) void bn_finalize16_kernel(
+    int tiles, int C, double count, const float *__restrict__ partial, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float eps, float momentum, float *__restrict__ running_mean, float *__restrict__ running_var, float *__restrict__ mean_out,
+    float *__restrict__ invstd_out, float *__restrict__ a_out, float *__restrict__ c_out, long long *__restrict__ num_batches_tracked)
+{
+    bn_finalize16_body(tiles, C, count, partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
+                       num_batches_tracked, blockIdx.x);
+}
+
+__global__ __launch_bounds__(FIN16_THREADS) void bn_finalize16_batch_kernel(const CmfBatch<CmfBnFinArgs> b)
+{
+    const CmfBnFinArgs &p = b.a[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= p.C) return;
+    bn_finalize16_body(p.tiles, p.C, p.count, p.partial, p.gamma, p.beta, p.eps, p.momentum, p.rmean, p.rvar, p.mean_out, p.invstd_out,
+                       p.a_out, p.c_out, p.nbt, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void bn_finalize4_kernel(
@@ -159,7 +263,10 @@ int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st)
         b.a[i] = a[i];
         cmax = std::max(cmax, a[i].C);
     }
-    hipLaunchKernelGGL(bn_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
+    bool wide = true;                                   // every item's channel count a multiple of 16: the coalesced 16-column form
+    for (int i = 0; i < n; ++i) wide = wide && a[i].C % 16 == 0;
+    if (wide) hipLaunchKernelGGL(bn_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
+    else hipLaunchKernelGGL(bn_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
     return cmf_launch_status();
 }
 
@@ -204,6 +311,12 @@ extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *part
                                float *c_out, long long *num_batches_tracked, void *stream)
 {
     CMF_CHECK_ARG(C > 0 && a_out && c_out && (tiles == 0 ? (running_mean && running_var) : partial != nullptr));
+    if (tiles > 0 && C % 16 == 0 && (uintptr_t)partial % 16 == 0) {
+        hipLaunchKernelGGL(bn_finalize16_kernel, dim3(C / 16), dim3(FIN16_THREADS), 0, (hipStream_t)stream, tiles, C, count,
+                           partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
+                           num_batches_tracked);
+        return cmf_launch_status();
+    }
     if (tiles > 0 && C % 4 == 0 && (uintptr_t)partial % 16 == 0) {
         hipLaunchKernelGGL(bn_finalize4_kernel, dim3(C / 4), dim3(256), 0, (hipStream_t)stream, tiles, C, count,
                            partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
@@ -247,6 +360,34 @@ __device__ __forceinline__ void colsum_finalize4_body(int tiles, int C2, const f
     if (acc1 && col >= C && col < 2 * C) acc1[col - C] = store ? (float)s : acc1[col - C] + (float)s;
 }
 
+__device__ __forceinline__ void colsum_finalize16_body(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
+                                                       int C, float *__restrict__ acc0, float *__restrict__ acc1, int store, const int bx)
+{
+    __shared__ double sh[FIN16_THREADS / 64][1][16];
+    __shared__ double res[1][16];
+    const int col16[1] = {bx * 16};
+    fin_reduce16<1>(tiles, C2, col16, partial, sh, res);
+    if (threadIdx.x >= 16) return;
+    const int col = col16[0] + threadIdx.x;
+    const double s = res[0][threadIdx.x];
+    out[col] = (float)s;
+    if (acc0 && col < C) acc0[col] = store ? (float)s : acc0[col] + (float)s;
+    if (acc1 && col >= C && col < 2 * C) acc1[col - C] = store ? (float)s : acc1[col - C] + (float)s;
+}
+
+__global__ __launch_bounds__(FIN16_THREADS) void colsum_finalize16_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
+                                                                          int C, float *__restrict__ acc0, float *__restrict__ acc1, int store)
+{
+    colsum_finalize16_body(tiles, C2, partial, out, C, acc0, acc1, store, blockIdx.x);
+}
+
+__global__ __launch_bounds__(FIN16_THREADS) void colsum_finalize16_batch_kernel(const CmfBatch<CmfColsumArgs> b)
+{
+    const CmfColsumArgs &p = b.a[blockIdx.y];
+    if ((int)blockIdx.x * 16 >= p.ncols) return;
+    colsum_finalize16_body(p.tiles, p.ncols, p.partial, p.out, p.C, p.acc0, p.acc1, p.store, blockIdx.x);
+}
+
 __global__ __launch_bounds__(256) void colsum_finalize4_kernel(int tiles, int C2, const float *__restrict__ partial, float *__restrict__ out,
                                                                int C, float *__restrict__ acc0, float *__restrict__ acc1, int store)
 {
@@ -270,13 +411,18 @@ int cmf_colsum_batch(int n, const CmfColsumArgs *a, hipStream_t st)
         b.a[i] = a[i];
         cmax = std::max(cmax, a[i].ncols);
     }
-    hipLaunchKernelGGL(colsum_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
+    bool wide = true;
+    for (int i = 0; i < n; ++i) wide = wide && a[i].ncols % 16 == 0;
+    if (wide) hipLaunchKernelGGL(colsum_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
+    else hipLaunchKernelGGL(colsum_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
     return cmf_launch_status();
 }
 
 static int launch_colsum(int tiles, int ncols, const float *partial, float *out, int C, float *a0, float *a1, int store, void *stream)
 {
-    if (ncols % 4 == 0 && (uintptr_t)partial % 16 == 0)
+    if (ncols % 16 == 0 && (uintptr_t)partial % 16 == 0)
+        hipLaunchKernelGGL(colsum_finalize16_kernel, dim3(ncols / 16), dim3(FIN16_THREADS), 0, (hipStream_t)stream, tiles, ncols, partial, out, C, a0, a1, store);
+    else if (ncols % 4 == 0 && (uintptr_t)partial % 16 == 0)
         hipLaunchKernelGGL(colsum_finalize4_kernel, dim3(ncols / 4), dim3(256), 0, (hipStream_t)stream, tiles, ncols, partial, out, C, a0, a1, store);
     else
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cmf_divup(ncols, FIN_COLS)), dim3(256), 0, (hipStream_t)stream,
