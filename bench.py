@@ -141,9 +141,9 @@ def hbm_op_rooflines(dev, iters=20):
     st = _lib.stream_ptr()
 
     def timed(fn):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
+        for _ in range(3):                  # synchronised warm-up calls: library scratch grown by the first call retires its old
+            fn()                            # buffer behind an event and a LATER call frees it (a multi-ms hipFree) -- that one-off
+            torch.cuda.synchronize()        # must happen here, not between the events below
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(iters):

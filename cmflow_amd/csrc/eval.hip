@@ -193,10 +193,11 @@ extern "C" int cmf_pseudo_labels(int b, int n, const float *pc1, const float *gt
     CMF_CHECK_ARG(b >= 0 && n > 0 && n <= 36000);
     if (b == 0) return 0;
     CMF_CHECK_ARG(pc1 && gt_trans && vel1 && interval && fg_mask && flow_label && dyn_mask && mseg_gt);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmfPerDevice attr_set;                       // the dynamic-LDS limit is per (function, device)
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
         (void)hipFuncSetAttribute((const void *)pseudo_label_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 36000 * 4);
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     hipLaunchKernelGGL(pseudo_label_kernel, dim3(b), dim3(EV_THREADS), (size_t)n * sizeof(float), (hipStream_t)stream,
                        n, pc1, gt_trans, vel1, interval, fg_mask, flow_label, vr_thres, dyn_mask, mseg_gt, residual);

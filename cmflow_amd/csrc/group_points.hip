@@ -715,11 +715,8 @@ __global__ __launch_bounds__(GA_THREADS) void group_points_grad_stream_kernel(
 // then a thread walks the segments of its targets and accumulates in registers.  No atomics, every sum in a fixed order:
 // bit-reproducible.  n <= 8192, lists of 16 / 32 / 64 slots.
 // ---------------------------------------------------------------------------------------------------------------
-#ifndef CMF_GC_SMALL
-#define CMF_GC_SMALL 0                                 // experiment: 16384-entry tiles, two 512-thread workgroups per CU
-#endif
 constexpr int GC_THREADS = 512;
-constexpr int GC_TILE = CMF_GC_SMALL ? 16384 : 32768;  // entries per tile
+constexpr int GC_TILE = 32768;                         // entries per tile
 constexpr int GC_MAX_N = 8192;
 constexpr int GC_UN = 8;                               // chunks of indices in flight per wave (index kernel)
 constexpr int GC_SHORT = 32;                           // longest segment a single thread sorts
@@ -850,14 +847,12 @@ __global__ __launch_bounds__(GC_THREADS) void gpg_csr_index_kernel(
 }
 
 // LDS of the gather: the tile's floats | as many of its sorted positions as fit (the rest, if any, is read from global memory).
-// [16384-entry tiles with two 512-thread workgroups per CU were measured slower: 1633 against 1230-1270 us at config 5 --
-//  twice the per-(target, tile) segment overhead for half the staging latency.]
-#ifndef CMF_GC_THREADS
-#define CMF_GC_THREADS 1024
-#endif
-constexpr int GCG_THREADS = CMF_GC_SMALL ? 512 : CMF_GC_THREADS;
+// [16384-entry tiles with two 512-thread workgroups per CU were measured slower, in round 3 (1633 against 1230-1270 us at config 5)
+//  and again in round 4 with the index prefetch below (708 against 626 us at C = 64): twice the per-(target, tile) segment
+//  overhead, and 8 targets per thread spill.]
+constexpr int GCG_THREADS = 1024;
 constexpr int GCG_EPT = GC_TILE / GCG_THREADS;         // entries per thread and tile (32 = 8 x float4)
-constexpr size_t GCG_LDS = CMF_GC_SMALL ? 80 * 1024 - 128 : 160 * 1024 - 256;
+constexpr size_t GCG_LDS = 160 * 1024 - 256;
 constexpr int GCG_CAP = (int)((GCG_LDS - (size_t)GC_TILE * 4) / 2);
 
 typedef unsigned gc_u32x4 __attribute__((ext_vector_type(4)));
@@ -1365,8 +1360,12 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
         int nch_wg = GT_CH;
         while (nch_wg > 1 && (size_t)nch_wg * n * sizeof(float) > 64 * 1024) nch_wg /= 2;
         const size_t lds = ((size_t)nch_wg * n + GT_TILE + 4 + GT_THREADS) * sizeof(float) + GT_TILE * sizeof(unsigned short);
-        static bool attr_t = false;
-        if (!attr_t) { (void)hipFuncSetAttribute((const void *)gpg_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_t = true; }
+        static CmfPerDevice attr_t;
+        int attr_dev;
+        if (attr_t.need(attr_dev)) {
+            (void)hipFuncSetAttribute((const void *)gpg_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_t.done(attr_dev);
+        }
         hipLaunchKernelGGL(gpg_tiled_kernel, dim3(b, cmf_divup(c, nch_wg)), dim3(GT_THREADS), lds, st, c, n, (int)total, tiles, nch_wg,
                            grad_out, rec, grad_points);
         return cmf_launch_status();

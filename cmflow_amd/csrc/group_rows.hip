@@ -218,8 +218,12 @@ int cmf_build_inverse_rows(int b, int n, int P, int S, const int *idx, int *offs
 {
     const size_t mat = (((size_t)P * (n | 1) + 7) / 8) * 16 + (size_t)P * S;         // count matrix (16-byte granules) + rank bytes
     if (P > 0 && P <= INVM_THREADS && S <= 64 && mat <= 150 * 1024) {
-        static bool set = false;
-        if (!set) { (void)hipFuncSetAttribute((const void *)inverse_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; }
+        static CmfPerDevice attr_set;                   // the dynamic-LDS limit is per (function, device)
+        int attr_dev;
+        if (attr_set.need(attr_dev)) {
+            (void)hipFuncSetAttribute((const void *)inverse_matrix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            attr_set.done(attr_dev);
+        }
         hipLaunchKernelGGL(inverse_matrix_kernel, dim3(b), dim3(INVM_THREADS), mat, (hipStream_t)stream, n, P, S, idx, offsets, inv);
         return cmf_launch_status();
     }

@@ -477,11 +477,12 @@ extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
                            d->workspace);
     a.use_inv = d->N <= LS_INV_MAX_N ? 1 : 0;
     const size_t lds = ((size_t)(LS_WORDS_PER_POINT + (a.use_inv ? LS_NB + 2 : 0)) * d->N + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CmfPerDevice attr_set;                       // the dynamic-LDS limit is per (function, device)
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
         (void)hipFuncSetAttribute((const void *)loss_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LS_WORDS_PER_POINT * LS_MAX_N * (int)sizeof(float));
-        attr_set = true;
+        attr_set.done(attr_dev);
     }
     hipLaunchKernelGGL(loss_sample_kernel, dim3(d->B), dim3(LS_THREADS), lds, st, a);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, d->items);

@@ -23,4 +23,6 @@ python tools/ball_query_probe.py 2>&1 | grep -v amdgpu.ids > $R/ball_query_probe
 python tools/gemm_vendor_compare.py 2>&1 | grep -v amdgpu.ids > $R/gemm_vendor_compare.txt
 python tools/host_time_probe.py 20 2>&1 | grep -v amdgpu.ids > $R/host_time_probe.txt
 python tools/phase_probe.py 2>&1 | grep -v amdgpu.ids > $R/phase_probe.txt
+python tools/finalize_probe.py 2>&1 | grep -v amdgpu.ids > $R/finalize_probe.txt
+bash tools/session.sh r op_pmc > /dev/null 2>&1
 ls -la $R
