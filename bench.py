@@ -31,7 +31,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_PROFILE = "r03_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
+TRAFFIC_PROFILE = "r04_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
 
 
@@ -384,7 +384,7 @@ def main():
             rec = json.load(open(tp))
             traffic = rec["traffic_bytes_per_launch"]
             traffic_source = ("NOT measured by this run: constant from the committed rocprofv3 PMC passes in profiles/%s (%s)"
-                              % (TRAFFIC_PROFILE, rec.get("measured_at", "round 3 build")))
+                              % (TRAFFIC_PROFILE, rec.get("measured_at", "earlier build")))
         if prof.get("shapes"):
             tot = sum(cnt * 4.0 * (M * K + K * N + M * N * (2 if kind >= 2 else 1))
                       for (M, N, K, layout, kind, split_k, bm, bn), (cnt, _) in prof["shapes"].items())

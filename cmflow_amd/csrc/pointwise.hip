@@ -263,9 +263,12 @@ int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st)
         b.a[i] = a[i];
         cmax = std::max(cmax, a[i].C);
     }
-    bool wide = true;                                   // every item's channel count a multiple of 16: the coalesced 16-column form
-    for (int i = 0; i < n; ++i) wide = wide && a[i].C % 16 == 0;
-    if (wide) hipLaunchKernelGGL(bn_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
+    // every item's channel count a multiple of 16 and a long partial matrix among them: the coalesced 16-column form (below
+    // 2048 partial rows the 4-column form is 1.5 us quicker: profiles/r04_finalize_probe.txt)
+    bool wide = true;
+    int tmax = 0;
+    for (int i = 0; i < n; ++i) { wide = wide && a[i].C % 16 == 0; tmax = std::max(tmax, a[i].tiles); }
+    if (wide && tmax >= 2048) hipLaunchKernelGGL(bn_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
     else hipLaunchKernelGGL(bn_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
     return cmf_launch_status();
 }
@@ -311,7 +314,7 @@ extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *part
                                float *c_out, long long *num_batches_tracked, void *stream)
 {
     CMF_CHECK_ARG(C > 0 && a_out && c_out && (tiles == 0 ? (running_mean && running_var) : partial != nullptr));
-    if (tiles > 0 && C % 16 == 0 && (uintptr_t)partial % 16 == 0) {
+    if (tiles >= 2048 && C % 16 == 0 && (uintptr_t)partial % 16 == 0) {
         hipLaunchKernelGGL(bn_finalize16_kernel, dim3(C / 16), dim3(FIN16_THREADS), 0, (hipStream_t)stream, tiles, C, count,
                            partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
                            num_batches_tracked);
