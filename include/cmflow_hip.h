@@ -46,7 +46,9 @@ int cmf_group_points(int b, int c, int n, int npoints, int nsample,
 
 /* Replaces group_points_grad_kernel_launcher_fast (lib/src/group_points_gpu.cu:27-28).
  * grad_out (b,c,npoints,nsample), idx -> grad_points (b,c,n) += scatter (caller zero-fills,
- * lib/pointnet2_utils.py:218). */
+ * lib/pointnet2_utils.py:218).  The reference adds with fp32 atomics (order varies run to run); here rows of <= 8192 entries
+ * over <= 2048 targets (plan form) and per-centre lists of 16 / 32 / 64 slots over <= 8192 targets (pad-folded CSR gather)
+ * are summed in a fixed order: bit-reproducible.  Other shapes use LDS atomics unless CMF_GROUP_GRAD_DETERMINISTIC=1. */
 int cmf_group_points_grad(int b, int c, int n, int npoints, int nsample,
                           const float *grad_out, const int *idx, float *grad_points, void *stream);
 
