@@ -58,7 +58,14 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
             for (int ch = 0; ch < nch; ++ch) rows[(size_t)ch * n + k] = src[(size_t)k * 3 + ch];
     }
     const bool vec_ok = (total % GP_VEC) == 0;
-    for (int tile = tile0; tile < tile1; ++tile) {
+    // Workgroups of different channel chunks walk their tiles in rotated order.  With every workgroup at tile t the launch wrote
+    // the same offset of up to 2048 planes that lie a power of two apart (n x nsample x 4 bytes = 1 MB at BASELINE config 5) at
+    // the same time, and those streams pile up on few HBM channels: 516-630 us against 436-460 us rotated, (32,4096,64,C = 64),
+    // four placements of the tensors each (tools/gp_probe.py).  [Also tried: rotation by sample, by sample and chunk, by a hash
+    // of the block index: equal or worse.]
+    const int rot = (int)blockIdx.y % (tile1 - tile0);
+    for (int ti = tile0; ti < tile1; ++ti) {
+    const int tile = tile0 + (ti - tile0 + rot) % (tile1 - tile0);
     const int e0 = tile * (TPB * GP_VEC * GP_STEPS);
     // this thread's idx entries, loaded once and reused for every channel
     int my[GP_STEPS][GP_VEC];
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(TPB) void group_points_kernel(
             for (int j = 0; j < GP_VEC; ++j) my[s][j] = (e + j < total) ? ix[e + j] : 0;
         }
     }
-    if (ROWS_IN_LDS && tile == tile0) __syncthreads();
+    if (ROWS_IN_LDS && ti == tile0) __syncthreads();
 
     if (!is_xyz) {                                      // feature planes: the plain gather
     for (int ch = 0; ch < nch; ++ch) {
@@ -926,6 +933,7 @@ __global__ __launch_bounds__(GCG_THREADS, 4) void gpg_csr_gather_kernel(
                 if (8 * (tid + k * GCG_THREADS) < nnz && !(diag & 2))
                     psr[k] = __builtin_amdgcn_raw_buffer_load_b128(r_p, 16 * tid, k * GCG_THREADS * 16, 0);
         };
+        // [a rotated tile order per (sample, channel), which helps the gather kernel of the forward op, changes nothing here]
         load_tile(0);
         load_positions(0, nnz_req);
         for (int tile = 0; tile < tiles; ++tile) {
