@@ -528,6 +528,59 @@ static inline size_t tile_lds(int C) { return (size_t)(PW_THREADS / (C / 4)) * 2
 // plus BN partial statistics of z, and the relative coordinates dxyz (B,P,S,4) (4th lane 0) that the
 // WeightNet and the weight-gradient GEMM consume.   (radarflow_util.py:148-151 / :207-214)
 // ---------------------------------------------------------------------------------------------
+// accumulators of one thread (its 4 columns over its rows of the tile)
+struct GaSums { float4 s1, s2, tz0, tz1, tz2; float ud0, ud1, ud2; };
+
+// The rows of a tile whose 128 rows all exist, specialised by what the call needs (CTR: centre rows added, ST: BN partial sums,
+// XS: the z * d_k sums of the set-conv dW_xyz).  No bounds checks, no 64-bit divisions and no branches in the loop: the generic
+// loop below (ragged last tile, narrow C) carried four `row / S` long divisions and four validity branches per step, and the
+// kernel was bound by instruction issue, not by its stores.
+template <bool CTR, bool ST, bool XS>
+__device__ __forceinline__ void ga_full_rows(const TileMap &tm, int C, const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr,
+                                             int ld_ctr, const float (&wx)[4][3], int act, float *__restrict__ zt /* z + row0 * C + col */,
+                                             const float4 *sd, const int *ssrc, const int *sctr, GaSums &a)
+{
+    const float *ys = ysrc + tm.col;
+    const float *yc = CTR ? yctr + tm.col : nullptr;
+    // [requesting the gathers of step i + 1 before the stores of step i (two register sets) was measured equal: 227-238 us against
+    //  234 us at 524288 rows; the kernel runs at 4.7 TB/s of stores next to 1 GB of gathers from L2, a plain fill at 6.8 TB/s]
+    for (int rb = tm.r0; rb < PW_ROWS; rb += 4 * tm.rl) {
+        float4 v[4], cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * tm.rl;
+            v[u] = *(const float4 *)(ys + (size_t)ssrc[r] * ld_src);
+            if (CTR) cc[u] = *(const float4 *)(yc + (size_t)sctr[r] * ld_ctr);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb + u * tm.rl;
+            const float4 d4 = sd[r];
+            const float dx = d4.x, dy = d4.y, dz = d4.z;
+            float4 o = v[u];
+            if (CTR) { o.x += cc[u].x; o.y += cc[u].y; o.z += cc[u].z; o.w += cc[u].w; }
+            o.x += fmaf(wx[0][2], dz, fmaf(wx[0][1], dy, wx[0][0] * dx));
+            o.y += fmaf(wx[1][2], dz, fmaf(wx[1][1], dy, wx[1][0] * dx));
+            o.z += fmaf(wx[2][2], dz, fmaf(wx[2][1], dy, wx[2][0] * dx));
+            o.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
+            if (act == 2) { o.x = o.x > 0.f ? o.x : 0.1f * o.x; o.y = o.y > 0.f ? o.y : 0.1f * o.y;
+                            o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
+            *(float4 *)(zt + (size_t)r * C) = o;
+            if (ST) {
+                a.s1.x += o.x; a.s1.y += o.y; a.s1.z += o.z; a.s1.w += o.w;
+                a.s2.x += o.x * o.x; a.s2.y += o.y * o.y; a.s2.z += o.z * o.z; a.s2.w += o.w * o.w;
+            }
+            if (XS) {
+                a.tz0.x += o.x * dx; a.tz0.y += o.y * dx; a.tz0.z += o.z * dx; a.tz0.w += o.w * dx;
+                a.tz1.x += o.x * dy; a.tz1.y += o.y * dy; a.tz1.z += o.z * dy; a.tz1.w += o.w * dy;
+                a.tz2.x += o.x * dz; a.tz2.y += o.y * dz; a.tz2.z += o.z * dz; a.tz2.w += o.w * dz;
+                a.ud0 += dx; a.ud1 += dy; a.ud2 += dz;
+            }
+        }
+    }
+}
+
+template <bool CTR, bool ST, bool XS>                    // centre rows added / BN partial sums / z * d_k sums (the call's NULL pointers)
 __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
     int n_src, int P, int S, int C, long long rows,
     const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr, int ld_ctr,
@@ -537,23 +590,23 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
 {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const TileMap tm = tile_map(C);
-    float4 tz0 = make_float4(0.f, 0.f, 0.f, 0.f), tz1 = tz0, tz2 = tz0;     // sum z*dx, z*dy, z*dz per channel
-    float ud0 = 0.f, ud1 = 0.f, ud2 = 0.f;                                   // sum dx, dy, dz (column group 0 only)
+    GaSums acc;
+    acc.s1 = acc.s2 = acc.tz0 = acc.tz1 = acc.tz2 = make_float4(0.f, 0.f, 0.f, 0.f);   // tz*: sum z*dx, z*dy, z*dz per channel
+    acc.ud0 = acc.ud1 = acc.ud2 = 0.f;                                                  // sum dx, dy, dz (column group 0 only)
     float wx[4][3];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k) wx[j][k] = Wx[(size_t)(tm.col + j) * ldw + k];
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     // tiles of one sample on one XCD: the sample's n_src x C source rows (512 KB at C = 512) are fetched from HBM by that
     // L2 only (round 2 counted 1.41x the algorithmic bytes: all eight XCDs pulled all sources)
     const long long tile = xcd_major_tile(blockIdx.x, gridDim.x);
     const long long row0 = tile * PW_ROWS;
-    // Per-row quantities (source row, relative xyz) are computed ONCE per tile into LDS: with C = 512 the 128 threads
+    // Per-row quantities (source row, centre row, relative xyz) are computed ONCE per tile into LDS: with C = 512 the 128 threads
     // that share a row used to issue the same idx load and six scalar xyz loads each -- nine memory instructions per
     // useful 16-byte gather, and the kernel was bound by their issue rate (2.5 TB/s of stores at C = 512).
     __shared__ float4 sd[PW_ROWS];
-    __shared__ long long ssrc[PW_ROWS];
+    __shared__ int ssrc[PW_ROWS], sctr[PW_ROWS];
     for (int r = threadIdx.x; r < PW_ROWS; r += PW_THREADS) {
         const long long row = row0 + r;
         if (row < rows) {
@@ -564,29 +617,31 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             const float *xc = xyz_ctr + (size_t)bp * 3;
             const float4 d4 = make_float4(xs[0] - xc[0], xs[1] - xc[1], xs[2] - xc[2], 0.f);
             sd[r] = d4;
-            ssrc[r] = (long long)b * n_src + j;
+            ssrc[r] = b * n_src + j;
+            sctr[r] = (int)bp;
             if (dxyz) *(float4 *)(dxyz + (size_t)row * 4) = d4;
         }
     }
     __syncthreads();
-    // 4 rows per step: the gathers of 4 rows are in flight together
+    if (row0 + PW_ROWS <= rows && 4 * tm.rl <= PW_ROWS)
+        ga_full_rows<CTR, ST, XS>(tm, C, ysrc, ld_src, yctr, ld_ctr, wx, act, z + (size_t)row0 * C + tm.col, sd, ssrc, sctr, acc);
+    else
+    // the generic loop (ragged last tile; C < 32: fewer than four row slots' worth of rows per step); 4 rows per step in flight
     for (int rb = tm.r0; rb < PW_ROWS; rb += 4 * tm.rl) {
-        long long rows4[4]; bool ok[4];
+        bool ok[4];
         float4 v[4], cc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = rb + u * tm.rl;
-            rows4[u] = row0 + r;
-            ok[u] = (r < PW_ROWS) && rows4[u] < rows;
-            const long long src = ok[u] ? ssrc[r] : 0;
-            const long long bp = (ok[u] ? rows4[u] : 0) / S;
-            v[u] = *(const float4 *)(ysrc + (size_t)src * ld_src + tm.col);
-            cc[u] = yctr ? *(const float4 *)(yctr + (size_t)bp * ld_ctr + tm.col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ok[u] = (r < PW_ROWS) && row0 + r < rows;
+            v[u] = *(const float4 *)(ysrc + (size_t)(ok[u] ? ssrc[r] : 0) * ld_src + tm.col);
+            cc[u] = CTR ? *(const float4 *)(yctr + (size_t)(ok[u] ? sctr[r] : 0) * ld_ctr + tm.col) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (!ok[u]) continue;
-            const float4 d4 = sd[rb + u * tm.rl];
+            const int r = rb + u * tm.rl;
+            const float4 d4 = sd[r];
             const float dx = d4.x, dy = d4.y, dz = d4.z;
             float4 o = v[u];
             o.x += cc[u].x; o.y += cc[u].y; o.z += cc[u].z; o.w += cc[u].w;
@@ -596,19 +651,23 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             o.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
             if (act == 2) { o.x = o.x > 0.f ? o.x : 0.1f * o.x; o.y = o.y > 0.f ? o.y : 0.1f * o.y;
                             o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
-            *(float4 *)(z + (size_t)rows4[u] * C + tm.col) = o;
-            s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
-            s2.x += o.x * o.x; s2.y += o.y * o.y; s2.z += o.z * o.z; s2.w += o.w * o.w;
-            if (partial_x) {
-                tz0.x += o.x * dx; tz0.y += o.y * dx; tz0.z += o.z * dx; tz0.w += o.w * dx;
-                tz1.x += o.x * dy; tz1.y += o.y * dy; tz1.z += o.z * dy; tz1.w += o.w * dy;
-                tz2.x += o.x * dz; tz2.y += o.y * dz; tz2.z += o.z * dz; tz2.w += o.w * dz;
-                ud0 += dx; ud1 += dy; ud2 += dz;
+            *(float4 *)(z + (size_t)(row0 + r) * C + tm.col) = o;
+            if (ST) {
+                acc.s1.x += o.x; acc.s1.y += o.y; acc.s1.z += o.z; acc.s1.w += o.w;
+                acc.s2.x += o.x * o.x; acc.s2.y += o.y * o.y; acc.s2.z += o.z * o.z; acc.s2.w += o.w * o.w;
+            }
+            if (XS) {
+                acc.tz0.x += o.x * dx; acc.tz0.y += o.y * dx; acc.tz0.z += o.z * dx; acc.tz0.w += o.w * dx;
+                acc.tz1.x += o.x * dy; acc.tz1.y += o.y * dy; acc.tz1.z += o.z * dy; acc.tz1.w += o.w * dy;
+                acc.tz2.x += o.x * dz; acc.tz2.y += o.y * dz; acc.tz2.z += o.z * dz; acc.tz2.w += o.w * dz;
+                acc.ud0 += dx; acc.ud1 += dy; acc.ud2 += dz;
             }
         }
     }
-    if (partial) tile_reduce_store(s1, s2, tm, C, partial, red, tile);
-    if (partial_x) {
+    const float4 s1 = acc.s1, s2 = acc.s2, tz0 = acc.tz0, tz1 = acc.tz1, tz2 = acc.tz2;
+    const float ud0 = acc.ud0, ud1 = acc.ud1, ud2 = acc.ud2;
+    if (ST) tile_reduce_store(s1, s2, tm, C, partial, red, tile);
+    if (XS) {
         // same tree as tile_reduce_store, for the 3 z*d_k column sums and the 3 scalar d_k sums: row
         // layout of partial_x is [tz0[C] | tz1[C] | tz2[C] | u0 u1 u2 0]
         __syncthreads();
@@ -644,8 +703,12 @@ extern "C" int cmf_group_affine(int b, int n_src, int P, int S, int C,
     CMF_CHECK_ARG(!partial_x || (partial && C >= 4));
     const long long rows = (long long)b * P * S;
     const int tiles = cmf_divup(rows, PW_ROWS);
-    hipLaunchKernelGGL(group_affine_kernel, dim3(tiles), dim3(PW_THREADS), partial ? tile_lds(C) : 0, (hipStream_t)stream,
-                       n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial, partial_x);
+#define CMF_GA_LAUNCH(CTR, ST, XS)                                                                                            \
+    hipLaunchKernelGGL((group_affine_kernel<CTR, ST, XS>), dim3(tiles), dim3(PW_THREADS), partial ? tile_lds(C) : 0, (hipStream_t)stream, \
+                       n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial, partial_x)
+    if (yctr) { if (partial_x) CMF_GA_LAUNCH(true, true, true); else if (partial) CMF_GA_LAUNCH(true, true, false); else CMF_GA_LAUNCH(true, false, false); }
+    else { if (partial_x) CMF_GA_LAUNCH(false, true, true); else if (partial) CMF_GA_LAUNCH(false, true, false); else CMF_GA_LAUNCH(false, false, false); }
+#undef CMF_GA_LAUNCH
     return cmf_launch_status();
 }
 
