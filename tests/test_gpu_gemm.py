@@ -706,3 +706,48 @@ def test_persistent_gemm_weight_gradient_matches_tiled_kernel(dev, rows, M, N, s
     g_eff = grid if grid else 512
     if min(split, g_eff // tiles) // 8 * 8 == split and not (prob and rows >= 32768):
         assert torch.equal(got, ref)             # same slabs, same loop arithmetic
+
+
+@pytest.mark.parametrize("tiles,C", [(4096, 256), (2048, 64), (2047, 32), (700, 512), (33, 48), (5000, 12), (9, 6), (1, 16)])
+def test_statistics_fold_kernels_match_fp64(dev, tiles, C):
+    """cmf_bn_finalize / cmf_colsum over a [tiles][2][C] partial matrix in every form the dispatch picks (16 columns per
+    1024-thread workgroup: C % 16 == 0, and for bn_finalize >= 2048 partial rows; 4 columns: C % 4 == 0; generic otherwise) against
+    an fp64 reduction: sums within 1e-6 of sum|terms| (fp64 accumulation inside, one rounding to fp32), the folded BatchNorm
+    (mean, invstd, a, c, running statistics, counter) as nn.BatchNorm1d computes them from the same sums; twice = bit-identical."""
+    from cmflow_amd import fused_blocks as FB
+    g = torch.Generator().manual_seed(tiles * 7 + C)
+    rows = tiles * 128
+    s1 = torch.randn(tiles, C, generator=g, dtype=torch.float64) * 40 + 3.0            # per-tile sums of ~N(0.02, 1) values
+    s2 = (torch.rand(tiles, C, generator=g, dtype=torch.float64) + 0.5) * 128 * 1.3 + s1 * s1 / 128
+    part = torch.stack((s1, s2), dim=1).float().to(dev).contiguous()
+    p64 = part.double()
+    want = p64.sum(dim=0)
+    # column sums, accumulated into / stored to gradient buffers
+    acc0 = torch.ones(C, device=dev); acc1 = torch.full((C,), 2.0, device=dev)
+    outs = [FB.colsum(part, acc0.clone(), acc1.clone()) for _ in range(2)]
+    assert torch.equal(outs[0], outs[1])
+    bound = 1e-6 * p64.abs().sum(dim=0) + 1e-6
+    assert bool(((outs[0].double() - want).abs() <= bound).all())
+    a0, a1 = acc0.clone(), acc1.clone()
+    FB.colsum(part, a0, a1)
+    assert bool(((a0.double() - 1.0 - want[0]).abs() <= bound[0] + 1e-6 * want[0].abs()).all())
+    assert bool(((a1.double() - 2.0 - want[1]).abs() <= bound[1] + 1e-6 * want[1].abs()).all())
+    outn = FB.colsum_n(part)
+    assert torch.equal(outn, outs[0])
+    # BatchNorm fold
+    bn = torch.nn.BatchNorm1d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=None); bn.bias.normal_(); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    rm0, rv0 = bn.running_mean.double().clone(), bn.running_var.double().clone()
+    st = FB.bn_fold(bn, part, rows)
+    mean = want[0] / rows
+    var = (want[1] / rows - mean * mean).clamp(min=0)
+    invstd = 1.0 / torch.sqrt(var + bn.eps)
+    np.testing.assert_allclose(st.mean.double().cpu().numpy(), mean.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(st.invstd.double().cpu().numpy(), invstd.cpu().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(st.a.double().cpu().numpy(), (bn.weight.detach().double() * invstd).cpu().numpy(), rtol=3e-6)
+    np.testing.assert_allclose(st.c.double().cpu().numpy(), (bn.bias.detach().double() - mean * bn.weight.detach().double() * invstd).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    unb = var * rows / (rows - 1)
+    np.testing.assert_allclose(bn.running_mean.double().cpu().numpy(), (0.9 * rm0 + 0.1 * mean).cpu().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(bn.running_var.double().cpu().numpy(), (0.9 * rv0 + 0.1 * unb).cpu().numpy(), rtol=2e-6)
+    assert int(bn.num_batches_tracked) == 1
