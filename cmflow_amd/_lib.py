@@ -63,6 +63,8 @@ SIGNATURES = {
     "cmf_bn_finalize": [_ci, _ci, ctypes.c_double, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_group_prep": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_gemm_gather_affine": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],
     "cmf_group_rows_grad_bn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _ci, _vp],
@@ -117,7 +119,8 @@ class SetConvDesc(ctypes.Structure):
                 ("gamma", _vp * 6), ("beta", _vp * 6), ("rmean", _vp * 6), ("rvar", _vp * 6), ("nbt", _vp * 6),
                 ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
                 ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("lddy", _ll), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
-                ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6)]
+                ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6),
+                ("inference", _ci)]
 
 
 class MlpDesc(ctypes.Structure):

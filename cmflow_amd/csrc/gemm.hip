@@ -107,9 +107,12 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 
 // EPI: the epilogue kind compiled into the fast path of this instantiation (the host picks the kernel by the call's
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
-template <int BM, int BN, bool A_T, bool B_T, int EPI = 0>
+// GATHER: the A rows are gathered from a per-point matrix and the set-conv first layer's coordinate term + BN + ReLU are applied
+// to the fragments (GemmArgs ga_*): LDS-direct loop only, full tiles only (the host checks).
+template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, bool GATHER = false>
 __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
 {
+    static_assert(!GATHER || (!A_T && B_T), "gathering A operand: A[M][K] W[N][K] layout");
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;     // wave tile
@@ -344,10 +347,20 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
     // ---- main loop, LDS-direct variant ----
     constexpr int D_ASLOTS = BM * (G_BK / 4), D_BSLOTS = BN * (G_BK / 4);     // 16-byte slots per operand chunk
     constexpr int D_ANI = D_ASLOTS / G_THREADS, D_BNI = D_BSLOTS / G_THREADS; // load instructions per thread
-    constexpr int D_STAGE = (D_ASLOTS + D_BSLOTS) * 4 + 32;                   // floats: A | B | pro_a[16] pro_c[16]
+    constexpr int D_STAGE = (D_ASLOTS + D_BSLOTS) * 4 + (GATHER ? 96 : 32);   // floats: A | B | pro_a[16] pro_c[16] (| wx0[16] wx1[16] wx2[16])
     const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && !p.no_direct && !bnbA;
     if (direct && kc_begin < kc_end) {
         const long long pro_delta = proA ? (long long)(p.pro_c - p.pro_a) : 0ll;
+        if (GATHER && !proA) __builtin_trap();
+        // gathering A: the source row of each of this lane's D_ANI staging slots (fixed for the tile), and the base of the
+        // constant block a lane of wave 0 requests per chunk (pro_a | pro_c | wx0 | wx1 | wx2, 16 floats each)
+        long long asrc[D_ANI];
+        const float *gconst = nullptr;
+        if (GATHER) {
+#pragma unroll
+            for (int q = 0; q < D_ANI; ++q) asrc[q] = (long long)p.ga_rows[m0 + (((q * 4 + wid) * 64 + lane) >> 2)] * p.lda;
+            gconst = (lane < 4 ? p.pro_a : lane < 8 ? p.pro_c : p.ga_wx + (long long)((lane >> 2) - 2) * p.K) + 4 * (lane & 3);
+        }
         // A plain s_barrier: __syncthreads() carries a workgroup fence, which makes the compiler drain EVERY outstanding
         // LDS-direct load (vmcnt(0)) -- the prefetch distance would collapse to zero.  Visibility of the stage that is
         // consumed next is established explicitly: each wave waits for its own loads of that stage (wait_prev), then
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             for (int q = 0; q < D_ANI; ++q) {
                 const int grp = q * 4 + wid, sl = grp * 64 + lane;
                 const float *g;
-                if (!A_T) { const int row = sl >> 2; g = p.A + (long long)(m0 + row) * p.lda + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
+                if (!A_T) { const int row = sl >> 2; g = p.A + (GATHER ? asrc[q] : (long long)(m0 + row) * p.lda) + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
                 else { const int k = sl / (BM / 4); g = p.A + (long long)(k0 + k) * p.lda + m0 + 4 * ((sl % (BM / 4)) ^ (((k >> 2) & 1) * 8)); }
                 __builtin_amdgcn_global_load_lds((g_gptr)g, (g_lptr)(sa + grp * 256), 16, 0, 0);
             }
@@ -371,13 +384,16 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 else { const int k = sl / (BN / 4); g = p.B + (long long)(k0 + k) * p.ldb + n0 + 4 * ((sl % (BN / 4)) ^ (((k >> 2) & 1) * 8)); }
                 __builtin_amdgcn_global_load_lds((g_gptr)g, (g_lptr)(sb + grp * 256), 16, 0, 0);
             }
+            if (GATHER) {
+                if (wid == 0 && lane < 20) __builtin_amdgcn_global_load_lds((g_gptr)(gconst + k0), (g_lptr)sp, 16, 0, 0);
+            } else
             if (proA && wid == 0 && lane < 8)                       // this chunk's 16 prologue scales and shifts
                 __builtin_amdgcn_global_load_lds((g_gptr)(p.pro_a + (lane < 4 ? 0ll : pro_delta) + k0 + 4 * (lane & 3)), (g_lptr)sp, 16, 0, 0);
         };
         // all but the newest issue() of this wave complete (vector-memory loads retire in order)
         auto wait_prev = [&](bool newest_outstanding) {
             if (!newest_outstanding) { CMF_WAIT_VMCNT(0); return; }
-            if (proA && wid == 0) { CMF_WAIT_VMCNT(D_ANI + D_BNI + 1); } else { CMF_WAIT_VMCNT(D_ANI + D_BNI); }
+            if (proA && wid == 0) { CMF_WAIT_VMCNT(D_ANI + D_BNI + 1); } else { CMF_WAIT_VMCNT(D_ANI + D_BNI); }   // (wave 0: + the constants' request)
         };
         const int nch = kc_end - kc_begin;
         issue(kc_begin, 0);
@@ -398,6 +414,13 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         }
         // fragment loader for one k8 step of stage (sa, sb, sp): issues the reads, does not wait
         f32x4 af[2][TM], bf[2][TN], pa4[2], pc4[2];
+        // gathering A: ONE set of per-k constants (both fragment sets pass through it: a set's prologue is applied as soon as the
+        // set has landed, before the other set's reads are requested) and the rows' relative coordinates
+        f32x4 gw0, gw1, gw2, gdq[TM];
+        if (GATHER) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) gdq[i] = *(const f32x4 *)(p.ga_dxyz + (long long)(m0 + arow[i]) * 4);
+        }
         auto read_frags = [&](const float *sa, const float *sb, const float *sp, int k8, int w) {
             const int kq = k8 / 4 + h;                                          // this lane's 4 consecutive k: 4*kq .. 4*kq+3
 #pragma unroll
@@ -418,6 +441,11 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                     bf[w][j].z = g_lds_read32<BN * 8>(q); bf[w][j].w = g_lds_read32<BN * 12>(q);
                 }
             }
+            if (GATHER) {
+                pa4[0] = g_lds_read128(g_lds_addr(sp + 4 * kq)); pc4[0] = g_lds_read128(g_lds_addr(sp + 16 + 4 * kq));
+                gw0 = g_lds_read128(g_lds_addr(sp + 32 + 4 * kq)); gw1 = g_lds_read128(g_lds_addr(sp + 48 + 4 * kq));
+                gw2 = g_lds_read128(g_lds_addr(sp + 64 + 4 * kq));
+            } else
             if (proA) { pa4[w] = g_lds_read128(g_lds_addr(sp + 4 * kq)); pc4[w] = g_lds_read128(g_lds_addr(sp + 16 + 4 * kq)); }
         };
         auto pin_frags = [&](int w) {
@@ -425,10 +453,24 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             for (int i = 0; i < TM; ++i) g_pin(af[w][i]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) g_pin(bf[w][j]);
-            if (proA) { g_pin(pa4[w]); g_pin(pc4[w]); }
+            if (GATHER) { g_pin(pa4[0]); g_pin(pc4[0]); g_pin(gw0); g_pin(gw1); g_pin(gw2); }
+            else if (proA) { g_pin(pa4[w]); g_pin(pc4[w]); }
+        };
+        // z = y + (wx0 dx + wx1 dy + wx2 dz), a = relu(pa z + pc): the operations of group_affine_kernel followed by the A prologue,
+        // in their order (bit-identical to the materialised path)
+        auto gather_prologue = [&](int w) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float dx = gdq[i].x, dy = gdq[i].y, dz = gdq[i].z;
+                f32x4 z = af[w][i];
+                z.x += fmaf(gw2.x, dz, fmaf(gw1.x, dy, gw0.x * dx)); z.y += fmaf(gw2.y, dz, fmaf(gw1.y, dy, gw0.y * dx));
+                z.z += fmaf(gw2.z, dz, fmaf(gw1.z, dy, gw0.z * dx)); z.w += fmaf(gw2.w, dz, fmaf(gw1.w, dy, gw0.w * dx));
+                af[w][i].x = fmaxf(fmaf(pa4[0].x, z.x, pc4[0].x), 0.f); af[w][i].y = fmaxf(fmaf(pa4[0].y, z.y, pc4[0].y), 0.f);
+                af[w][i].z = fmaxf(fmaf(pa4[0].z, z.z, pc4[0].z), 0.f); af[w][i].w = fmaxf(fmaf(pa4[0].w, z.w, pc4[0].w), 0.f);
+            }
         };
         auto prologue_step = [&](int w) {
-            if (proA) {                                                         // fused BN + ReLU of the producer layer
+            if (!GATHER && proA) {                                              // fused BN + ReLU of the producer layer
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     af[w][i].x = fmaxf(fmaf(pa4[w].x, af[w][i].x, pc4[w].x), 0.f); af[w][i].y = fmaxf(fmaf(pa4[w].y, af[w][i].y, pc4[w].y), 0.f);
@@ -466,6 +508,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 const float *sa = smem, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
                 read_frags(sa, sb, sp, 0, 0);
                 g_lds_wait(); pin_frags(0);
+                if (GATHER) gather_prologue(0);
             }
             for (int c = 0; c < nch; ++c) {
                 // the second fragment set of THIS chunk is requested here, not at the end of the previous iteration: the reads are
@@ -478,6 +521,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 }
                 mfma_step(0);
                 g_lds_wait(); pin_frags(1);                                         // every LDS read of chunk c by this wave is complete
+                if (GATHER) gather_prologue(1);
                 if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);   // (st + 2) % 3: the stage of chunk c - 1
                 const int sn = st == 2 ? 0 : st + 1;
                 const float *sa = smem + sn * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
@@ -487,13 +531,15 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                     read_frags(sa, sb, sp, 0, 0);                                   // in flight under the second half of chunk c
                 }
                 mfma_step(1);
-                if (c + 1 < nch) { g_lds_wait(); pin_frags(0); }
+                if (c + 1 < nch) { g_lds_wait(); pin_frags(0); if (GATHER) gather_prologue(0); }
                 st = sn;
             }
             __builtin_amdgcn_s_barrier();                                            // the epilogue reuses the staging buffers
         }
         __builtin_amdgcn_s_setprio(0);
     } else
+    if (GATHER) __builtin_trap();                           // (the host only sends shapes the LDS-direct loop takes)
+    else
     if (kc_begin < kc_end) {
         load_tiles(kc_begin);
         store_A(0); store_B(0);
@@ -1309,14 +1355,14 @@ extern "C" long long cmf_gemm_profile_records(cmf_gemm_launch_record *out, long 
     return (long long)g_gprof.used;
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EPI = 0>
+template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, bool GATHER = false>
 static int launch(const GemmArgs &a, hipStream_t st)
 {
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per = (tiles_m + 7) / 8;
     dim3 grid(a.split_k > 1 ? 8 * ((a.split_k + 7) / 8) * tiles_m * tiles_n : 8 * per * tiles_n);
     const size_t lds_reg = (size_t)2 * ((A_T ? G_BK * (BM + 4) : BM * G_LDS_LD) + (B_T ? BN * G_LDS_LD : G_BK * (BN + 4))) * sizeof(float);
-    const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + 32) * sizeof(float);
+    const size_t lds_dir = (size_t)G_STAGES * ((BM + BN) * (G_BK / 4) * 4 + (GATHER ? 96 : 32)) * sizeof(float);
     const size_t lds = lds_reg > lds_dir ? lds_reg : lds_dir;
     // the dynamic-LDS limit is a per-device attribute of the function: set once per (instantiation, device); cmf_gemm is
     // entered concurrently by the host threads of cmf_setconv_*_multi, hence the atomics
@@ -1325,7 +1371,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
     (void)hipGetDevice(&dev);
     const unsigned bit = 1u << (dev & 31);
     if (dev >= 128 || !(set_mask[dev >> 5].load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EPI, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return (int)hipGetLastError();
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
@@ -1333,11 +1379,11 @@ static int launch(const GemmArgs &a, hipStream_t st)
     if (unsigned long long *tb = trace_take(grid.x, st)) {
         GemmArgs t = a;
         t.trace = tb;
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, t);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI, GATHER>), grid, dim3(G_THREADS), lds, st, t);
         gprof_close(pe, st);
         return cmf_launch_status();
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI>), grid, dim3(G_THREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI, GATHER>), grid, dim3(G_THREADS), lds, st, a);
     gprof_close(pe, st);
     return cmf_launch_status();
 }
@@ -1411,6 +1457,27 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     if (err) return err;
     if (split_k > 1) return cmf_splitk_reduce(M, N, g.split_k, workspace, C, ldc, accumulate, st);     // (the persistent kernel may have lowered it)
     return 0;
+}
+
+// Forward GEMM of the set-conv layer BEHIND the hoisted first conv, with that first layer formed in the A-operand path instead of
+// being materialised (inference: nothing of it is needed afterwards):
+//   C[m][n] = sum_k relu( pro_a[k] * ( Y[rows[m]][k] + wx3[0][k] dx_m + wx3[1][k] dy_m + wx3[2][k] dz_m ) + pro_c[k] ) * W[n][k]
+// Y (.., K) per-point rows of pitch ldy, rows[M] the source row of every neighbour slot, dxyz (M,4) its relative coordinates,
+// wx3 (3,K) the coordinate columns of the first conv as planes.  The same operations, in the same order, as cmf_group_affine
+// followed by cmf_gemm with the A prologue: bit-identical output, without the (M,K) tensor (2 GB at the second encoder's scales)
+// written and read back.  M, N multiples of 128, K of 16; all pointers 16-byte aligned.
+extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long long ldy, const int *rows, const float *dxyz,
+                                      const float *wx3, const float *pro_a, const float *pro_c, const float *W, long long ldw,
+                                      float *C, long long ldc, void *stream)
+{
+    CMF_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && K % G_BK == 0);
+    CMF_CHECK_ARG(Y && rows && dxyz && wx3 && pro_a && pro_c && W && C && ldy % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0);
+    CMF_CHECK_ARG((((uintptr_t)Y | (uintptr_t)dxyz | (uintptr_t)wx3 | (uintptr_t)pro_a | (uintptr_t)pro_c | (uintptr_t)W | (uintptr_t)C) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.A = Y; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc;
+    g.pro_a = pro_a; g.pro_c = pro_c; g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
+    return launch<128, 128, false, true, 0, true>(g, st);
 }
 
 // Weight gradient of a layer whose output gradient still has to go through the train-mode BatchNorm backward:

@@ -33,6 +33,10 @@ struct GemmArgs {
     const float *bnb_a, *bnb_mean, *bnb_invstd, *bnb_sums;      // sums: [2][M] (s1 | s2)
     float bnb_ic;                                               // 1 / rows
     float *bnb_out; long long ldbo;
+    // gathering A operand (cmf_gemm_gather_affine, A[M][K] layout only): row m of A is
+    //   act( Y[ga_rows[m]][k] + wx0[k] dx_m + wx1[k] dy_m + wx2[k] dz_m )   -- the set-conv first layer, never materialised
+    // A points at Y (row pitch lda), ga_dxyz holds (dx, dy, dz, 0) per row, ga_wx the three planes [3][K]; act = pro_a / pro_c
+    const int *ga_rows; const float *ga_dxyz; const float *ga_wx;
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
     int no_direct;              // diagnostics (env CMF_GEMM_NO_DIRECT=1): register-staged main loop everywhere

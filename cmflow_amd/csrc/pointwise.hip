@@ -712,6 +712,39 @@ extern "C" int cmf_group_affine(int b, int n_src, int P, int S, int C,
     return cmf_launch_status();
 }
 
+// What the gathering GEMM (cmf_gemm_gather_affine, gemm.hip) needs of the neighbour lists: the source row and the relative
+// coordinates of every slot, and the coordinate columns of the first conv as planes.
+__global__ __launch_bounds__(PW_THREADS) void group_prep_kernel(int n_src, int P, int S, int C, long long rows, const float *__restrict__ xyz_src,
+                                                                const float *__restrict__ xyz_ctr, const float *__restrict__ Wx, int ldw,
+                                                                const int *__restrict__ idx, int *__restrict__ rows_out,
+                                                                float *__restrict__ dxyz, float *__restrict__ wx3)
+{
+    const long long gid = (long long)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (gid < 3 * C) { const int k = (int)(gid / C), c = (int)(gid - (long long)k * C); wx3[gid] = Wx[(size_t)c * ldw + k]; }
+    if (gid >= rows) return;
+    const int j = idx[gid];
+    const long long bp = gid / S;
+    const int b = (int)(bp / P);
+    const float *xs = xyz_src + ((size_t)b * n_src + j) * 3;
+    const float *xc = xyz_ctr + (size_t)bp * 3;
+    rows_out[gid] = b * n_src + j;
+    *(float4 *)(dxyz + (size_t)gid * 4) = make_float4(xs[0] - xc[0], xs[1] - xc[1], xs[2] - xc[2], 0.f);
+}
+
+extern "C" int cmf_group_prep(int b, int n_src, int P, int S, int C, const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
+                              const int *idx, int *rows, float *dxyz, float *wx3, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n_src > 0 && P > 0 && S > 0 && C > 0 && ldw >= 3);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(xyz_src && xyz_ctr && Wx && idx && rows && dxyz && wx3 && ((uintptr_t)dxyz & 15) == 0);
+    const long long n = (long long)b * P * S;
+    CMF_CHECK_ARG(n < (1ll << 31) && (long long)b * n_src < (1ll << 31));
+    const long long work = n > 3ll * C ? n : 3ll * C;
+    hipLaunchKernelGGL(group_prep_kernel, dim3((unsigned)cmf_divup(work, PW_THREADS)), dim3(PW_THREADS), 0, (hipStream_t)stream,
+                       n_src, P, S, C, n, xyz_src, xyz_ctr, Wx, ldw, idx, rows, dxyz, wx3);
+    return cmf_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[p, :] = max_s relu(a*z[p,s,:] + c)   (radarflow_util.py:151-155 fused: BN + ReLU + max over the ball)
 // argmax (uint8, first maximum) is kept for the backward pass.  out may be a column slice (ldo).

@@ -272,11 +272,24 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     // idx is pre-zeroed like the reference's BallQuery.forward (every point is its own neighbour here, but keep the contract)
     if (!d->training) CMF_TRY(fold_all_eval(d, L, st));
     CMF_TRY(cmf_ball_query_defined(d->B, d->N, d->N, d->radius, d->S, d->xyz, d->xyz, L.idx, st));
+    // inference (eval-mode BN and no backward call to follow): the grouped first-layer tensor z1 (M x O1: 1 GB at the largest scale of
+    // the second encoder) is never written -- the second layer's GEMM gathers the per-point rows and forms the layer in its A-operand
+    // path (cmf_gemm_gather_affine, bit-identical); the slot of z1 holds the M source-row indices and the coordinate planes of Wx
+    const bool gather = !d->training && d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
+                        (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31);
+    if (gather) {
+        int *rows = reinterpret_cast<int *>(L.z1);
+        float *wx3 = L.z1 + (M + 3) / 4 * 4;
+        CMF_TRY(cmf_group_prep(d->B, d->N, d->N, d->S, O1, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, rows, L.dxyz, wx3, st));
+        CMF_TRY(cmf_gemm_gather_affine((int)M, C2, O1, d->y, d->ldy, rows, L.dxyz, wx3, L.bn[0] + 2 * O1, L.bn[0] + 3 * O1, d->w[0], O1,
+                                       L.z2, C2, st));
+    } else {
     CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
                              L.z1, L.dxyz, d->training ? L.partial : nullptr, d->training ? L.partial_x : nullptr, st));
     if (d->training) CMF_TRY(cmf_colsum(tiles128(M), 3 * O1 + 4, L.partial_x, L.fwd_sums, 0, nullptr, nullptr, st));
     CMF_TRY(fold(d, L, 0, M, st));
     CMF_TRY(fwd_gemm(d, L, M, O1, C2, L.z1, 0, d->w[0], L.z2, st));
+    }
     CMF_TRY(fold(d, L, 1, M, st));
     CMF_TRY(fwd_gemm(d, L, M, C2, C3, L.z2, 1, d->w[1], L.z3, st));
     CMF_TRY(fold(d, L, 2, M, st));

@@ -737,7 +737,7 @@ class SetConvFn(Function):
                 g["b3"], g["w4"], g["g4"], g["b4"], g["w5"], g["g5"], g["b5"], g["w6"], g["g6"], g["b6"])
 
 
-def _block_forward(xyz_t, y, radius, nsample, bns, training, params, out=None):
+def _block_forward(xyz_t, y, radius, nsample, bns, training, params, out=None, inference=False):
     """Fill a cmf_setconv_desc, allocate saved/scratch/out on the CURRENT stream and issue
     cmf_setconv_forward there.  out: optional (B*N, 64) strided view to write into."""
     import ctypes
@@ -749,6 +749,7 @@ def _block_forward(xyz_t, y, radius, nsample, bns, training, params, out=None):
     xyz_t = xyz_t.contiguous()
     d = _lib.SetConvDesc()
     d.B, d.N, d.S, d.O1, d.radius, d.training = B, N, nsample, y.shape[2], radius, int(training)
+    d.inference = int(bool(inference) and not training)     # no backward call will follow: nothing is kept for one
     for i, w in enumerate(ws):
         d.C[i] = w.shape[0]
         d.w[i] = w.data_ptr()
@@ -830,7 +831,7 @@ class SetConvBlockFn(Function):
     @staticmethod
     def forward(ctx, xyz_t, y, radius, nsample, bns, training, *params):
         B, N, _ = xyz_t.shape
-        out, ctx.state = _block_forward(xyz_t, y, radius, nsample, bns, training, params)
+        out, ctx.state = _block_forward(xyz_t, y, radius, nsample, bns, training, params, inference=not any(ctx.needs_input_grad))
         return out.view(B, N, -1)
 
     @staticmethod
@@ -1030,11 +1031,13 @@ class MultiScaleBlockFn(Function):
         saved = torch.empty(plan.off_saved[-1], dtype=_f32, device=dev)
         scratch = torch.empty(plan.off_fwd[-1], dtype=_f32, device=dev)
         o1 = plan.descs[0].O1
+        inference = int(not any(ctx.needs_input_grad) and not plan.descs[0].training)   # no backward call will follow
         for i in range(n):
             d = plan.descs[i]
             d.xyz, d.y = xyz_t.data_ptr(), y_all.data_ptr() + 4 * i * o1
             d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_fwd[i]
             d.out, d.ldo = out_all.data_ptr() + 4 * i * co, n * co
+            d.inference = inference
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
         _multi_call(False, n, plan, sp, streams, main)
         ctx.plan, ctx.keep, ctx.streams, ctx.sink_mode = plan, (xyz_t, y_all, saved), streams, sink_mode

@@ -208,6 +208,19 @@ int cmf_group_affine(int b, int n_src, int P, int S, int C,
                      const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
                      const int *idx, int act, float *z, float *dxyz, float *partial, float *partial_x, void *stream);
 
+/* The same first layer WITHOUT the (b,P,S,C) tensor, for inference (nothing of it is needed afterwards): cmf_group_prep writes what
+ * depends on the neighbour lists only -- rows[b,p,s] = b*n_src + idx[b,p,s], dxyz (b,P,S,4) = xyz_src[idx] - xyz_ctr[p], wx3 (3,C) the
+ * coordinate columns of Wx as planes -- and cmf_gemm_gather_affine is the NEXT layer's GEMM
+ *   out[m,n] = sum_k relu( pro_a[k] * ( Y[rows[m],k] + wx3[0,k] dx_m + wx3[1,k] dy_m + wx3[2,k] dz_m ) + pro_c[k] ) * W[n,k]
+ * with that layer formed in its A-operand path (rows gathered by the LDS-direct loads, the coordinate term + BN + ReLU applied to
+ * the fragments).  Same operations in the same order as cmf_group_affine followed by cmf_gemm with the A prologue: bit-identical.
+ * M, N multiples of 128, K a multiple of 16, pointers 16-byte aligned. */
+int cmf_group_prep(int b, int n_src, int P, int S, int C, const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
+                   const int *idx, int *rows, float *dxyz, float *wx3, void *stream);
+int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long long ldy, const int *rows, const float *dxyz,
+                           const float *wx3, const float *pro_a, const float *pro_c, const float *W, long long ldw,
+                           float *C, long long ldc, void *stream);
+
 /* out[p,:] = max_s relu(a*z[p,s,:] + c): BN + ReLU + max over the ball (radarflow_util.py:151-155);
  * argmax (P,C) uint8 optional. */
 int cmf_bn_relu_maxpool(long long P, int S, int C, const float *z, const float *a, const float *c,
@@ -350,6 +363,8 @@ typedef struct cmf_setconv_desc {
     float *dwx; long long lddwx; int acc_wx;
     float *dw[5]; int acc_w[5];  /* weight gradients: written (0) or accumulated into (1) */
     float *dgamma[6], *dbeta[6]; int acc_bn[6];
+    int inference;               /* 1 (with training == 0): no backward call will follow -- the forward call may skip what only the
+                                    backward pass reads (the grouped first-layer tensor: cmf_gemm_gather_affine) */
 } cmf_setconv_desc;
 int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);

@@ -751,3 +751,38 @@ def test_statistics_fold_kernels_match_fp64(dev, tiles, C):
     np.testing.assert_allclose(bn.running_mean.double().cpu().numpy(), (0.9 * rm0 + 0.1 * mean).cpu().numpy(), rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(bn.running_var.double().cpu().numpy(), (0.9 * rv0 + 0.1 * unb).cpu().numpy(), rtol=2e-6)
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("B,N,S,K,NO,r", [(4, 256, 8, 512, 256, 4.0), (2, 256, 32, 64, 128, 16.0), (1, 128, 4, 16, 128, 2.0), (8, 256, 16, 512, 256, 8.0)])
+def test_gather_affine_gemm_is_bit_identical_to_the_materialised_path(dev, B, N, S, K, NO, r):
+    """cmf_group_prep + cmf_gemm_gather_affine (the set-conv first layer formed in the A-operand path of the next layer's GEMM,
+    inference) against cmf_group_affine followed by cmf_gemm with the A prologue: the same operations in the same order, so the
+    outputs must be equal bit for bit; twice = reproducible."""
+    from cmflow_amd import _lib, synth, fused_blocks as FB, pointnet2_utils as pu
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    torch.manual_seed(B * 100 + S)
+    xyz = synth.make_batch(B, N=N, seed=7)["pc1"].to(dev).transpose(1, 2).contiguous()
+    idx = pu.ball_query(r, S, xyz, xyz)
+    M = B * N * S
+    ybig = torch.randn(B, N, K + 48, device=dev)
+    y = ybig[:, :, 16:16 + K]                               # a column slice of a wider per-point matrix, as the encoder passes it
+    wx = torch.randn(K, 3, device=dev)
+    pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+    W = torch.randn(NO, K, device=dev)
+    z, dxyz, _ = FB.group_affine(y, None, xyz, xyz, wx, idx, act=0, stats=False)
+    want = gemm(z.view(M, K), W, pro=(pa, pc))
+    rows = torch.empty(M, dtype=torch.int32, device=dev); dq = torch.empty(M, 4, device=dev); wx3 = torch.empty(3, K, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(L.cmf_group_prep(B, N, N, S, K, xyz.data_ptr(), xyz.data_ptr(), wx.data_ptr(), 3, idx.data_ptr(), rows.data_ptr(),
+                                dq.data_ptr(), wx3.data_ptr(), st), "prep")
+    assert torch.equal(dq, dxyz.view(M, 4)) and torch.equal(wx3, wx.t().contiguous())
+    assert torch.equal(rows.view(B, N, S).long(), idx.long() + torch.arange(B, device=dev).view(B, 1, 1) * N)
+    outs = []
+    for _ in range(2):
+        out = torch.empty(M, NO, device=dev)
+        _lib.check(L.cmf_gemm_gather_affine(M, NO, K, y.data_ptr(), y.stride(1), rows.data_ptr(), dq.data_ptr(), wx3.data_ptr(),
+                                            pa.data_ptr(), pc.data_ptr(), W.data_ptr(), K, out.data_ptr(), NO, st), "gather gemm")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], want), float((outs[0] - want).abs().max())

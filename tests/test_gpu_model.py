@@ -326,6 +326,19 @@ def test_full_size_forward_matches_oracle(dev):
           % (float(epe.mean()), float(epe.max()), float((cls - want[1]).abs().max()), int(flips.sum()), ang, dt))
 
 
+def test_inference_forward_equals_eval_forward_with_autograd(dev):
+    """Under torch.no_grad() the second encoder's blocks skip the grouped first-layer tensor (cmf_gemm_gather_affine: the layer is
+    formed in the A-operand path of the next GEMM); with autograd recording (eval-mode BN, a backward pass may follow) they
+    materialise it.  Same operations in the same order: every output of the model must be equal bit for bit (B = 64, bench.py's batch)."""
+    ref, net, b, bd = _bench_setup(dev, train=False)
+    with torch.no_grad():
+        a = net(bd["pc1"], bd["pc2"], bd["ft1"], bd["ft2"], None, "test")
+    g = net(bd["pc1"], bd["pc2"], bd["ft1"], bd["ft2"], None, "test")
+    assert g[0].requires_grad and not a[0].requires_grad
+    for x, y in zip(a, g):
+        assert torch.equal(x, y.detach())
+
+
 def test_full_size_train_step_matches_oracle(dev):
     """BASELINE config 3 (the headline) at its own size: one training step of bench.py's batch and weights, train-mode
     BN, 7 losses -- loss within 2e-4, every loss item within 2e-4, labels bit-equal, outputs as in the forward test,
