@@ -109,10 +109,14 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // kind, epilogue_kind()); tiles the fast path does not take (edges, unaligned rows, C += ...) use the generic loop.
 // GATHER: the A rows are gathered from a per-point matrix and the set-conv first layer's coordinate term + BN + ReLU are applied
 // to the fragments (GemmArgs ga_*): LDS-direct loop only, full tiles only (the host checks).
-template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, bool GATHER = false>
+// GMODE 2: the same for the B operand of the weight gradient (B[K][N] = the activated first layer, K = neighbour slots): register-staged
+// loop only, the rows' source indices requested one chunk ahead.
+template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
 __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
 {
+    constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2;
     static_assert(!GATHER || (!A_T && B_T), "gathering A operand: A[M][K] W[N][K] layout");
+    static_assert(!GATHER_B || (A_T && !B_T), "gathering B operand: A[K][M] B[K][N] layout");
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
     constexpr int WARPS_N = 4 / WARPS_M;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;     // wave tile
@@ -171,6 +175,10 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
     constexpr int A_IT = A_T ? (G_BK / A_RPI) : (BM / G_RP);
     constexpr int B_IT = B_T ? (BN / G_RP) : (G_BK / B_RPI);
     float4 ra[A_IT], rb[B_IT];
+    // gathering B (GMODE 2): source rows of this thread's B rows of the chunk requested next, their relative coordinates, and the
+    // three coordinate weights of the thread's four columns
+    int gbrow[GATHER_B ? B_IT : 1];
+    float4 gbd[GATHER_B ? B_IT : 1], gbw[3];
     // BN backward fused into the A staging of the weight-gradient layout (GemmArgs::bnb_*): interior tiles only, the host
     // checks the shape.  A thread stages 4 fixed columns m of every chunk, so its coefficients are loop constants.
     float4 rz[A_T ? A_IT : 1];
@@ -227,6 +235,14 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 const float *src = p.B + (long long)(n0 + (tid / G_KT)) * p.ldb + k0 + (tid % G_KT) * 4;
 #pragma unroll
                 for (int i = 0; i < B_IT; ++i) rb[i] = *(const float4 *)(src + (long long)G_RP * i * p.ldb);
+            } else if (GATHER_B) {
+#pragma unroll
+                for (int i = 0; i < B_IT; ++i) {
+                    const int k = k0 + tid / B_TPR + B_RPI * i;
+                    rb[GATHER_B ? i : 0] = *(const float4 *)(p.B + (long long)gbrow[GATHER_B ? i : 0] * p.ldb + n0 + (tid % B_TPR) * 4);
+                    gbd[GATHER_B ? i : 0] = *(const float4 *)(p.ga_dxyz + (long long)k * 4);
+                    gbrow[GATHER_B ? i : 0] = k + G_BK < p.K ? p.ga_rows[k + G_BK] : 0;      // for the next chunk: a chunk's MFMAs ahead of its use
+                }
             } else {
                 const float *src = p.B + (long long)(k0 + tid / B_TPR) * p.ldb + n0 + (tid % B_TPR) * 4;
 #pragma unroll
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             kmask = 0xF;
             return;
         }
+        if (GATHER_B) __builtin_trap();                         // (the host only sends full tiles and whole chunks)
         // ---- edge path: bounds-checked, zero-filled ----
         auto ld4 = [&](const float *src, int valid) {
             float t[4] = {0.f, 0.f, 0.f, 0.f};
@@ -325,6 +342,11 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             for (int i = 0; i < B_IT; ++i) {
                 const int k = tid / B_TPR + B_RPI * i, n = (tid % B_TPR) * 4;
                 float4 v = rb[i];
+                if (GATHER_B) {                                     // z = y + (wx0 dx + wx1 dy + wx2 dz): group_affine_kernel's operations, in its order
+                    const float4 d = gbd[GATHER_B ? i : 0];
+                    v.x += fmaf(gbw[2].x, d.z, fmaf(gbw[1].x, d.y, gbw[0].x * d.x)); v.y += fmaf(gbw[2].y, d.z, fmaf(gbw[1].y, d.y, gbw[0].y * d.x));
+                    v.z += fmaf(gbw[2].z, d.z, fmaf(gbw[1].z, d.y, gbw[0].z * d.x)); v.w += fmaf(gbw[2].w, d.z, fmaf(gbw[1].w, d.y, gbw[0].w * d.x));
+                }
                 if (proB) {
                     const bool dead = v.x != v.x;
                     v = pro4(v, qsa, qsc);
@@ -348,7 +370,13 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
     constexpr int D_ASLOTS = BM * (G_BK / 4), D_BSLOTS = BN * (G_BK / 4);     // 16-byte slots per operand chunk
     constexpr int D_ANI = D_ASLOTS / G_THREADS, D_BNI = D_BSLOTS / G_THREADS; // load instructions per thread
     constexpr int D_STAGE = (D_ASLOTS + D_BSLOTS) * 4 + (GATHER ? 96 : 32);   // floats: A | B | pro_a[16] pro_c[16] (| wx0[16] wx1[16] wx2[16])
-    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && !p.no_direct && !bnbA;
+    const bool direct = G_BK == 16 && !edge_mn && (p.K % G_BK == 0) && !p.no_direct && !bnbA && !GATHER_B;
+    if (GATHER_B) {
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) gbrow[GATHER_B ? i : 0] = p.ga_rows[kc_begin * G_BK + tid / B_TPR + B_RPI * i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gbw[c] = *(const float4 *)(p.ga_wx + (long long)c * p.N + n0 + (tid % B_TPR) * 4);
+    }
     if (direct && kc_begin < kc_end) {
         const long long pro_delta = proA ? (long long)(p.pro_c - p.pro_a) : 0ll;
         if (GATHER && !proA) __builtin_trap();
@@ -1355,9 +1383,10 @@ extern "C" long long cmf_gemm_profile_records(cmf_gemm_launch_record *out, long 
     return (long long)g_gprof.used;
 }
 
-template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, bool GATHER = false>
+template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
 static int launch(const GemmArgs &a, hipStream_t st)
 {
+    constexpr bool GATHER = GMODE == 1;
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int per = (tiles_m + 7) / 8;
     dim3 grid(a.split_k > 1 ? 8 * ((a.split_k + 7) / 8) * tiles_m * tiles_n : 8 * per * tiles_n);
@@ -1371,7 +1400,7 @@ static int launch(const GemmArgs &a, hipStream_t st)
     (void)hipGetDevice(&dev);
     const unsigned bit = 1u << (dev & 31);
     if (dev >= 128 || !(set_mask[dev >> 5].load(std::memory_order_acquire) & bit)) {
-        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EPI, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)gemm_kernel<BM, BN, A_T, B_T, EPI, GMODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) return (int)hipGetLastError();
         if (dev < 128) set_mask[dev >> 5].fetch_or(bit, std::memory_order_release);
     }
@@ -1379,11 +1408,11 @@ static int launch(const GemmArgs &a, hipStream_t st)
     if (unsigned long long *tb = trace_take(grid.x, st)) {
         GemmArgs t = a;
         t.trace = tb;
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI, GATHER>), grid, dim3(G_THREADS), lds, st, t);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI, GMODE>), grid, dim3(G_THREADS), lds, st, t);
         gprof_close(pe, st);
         return cmf_launch_status();
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI, GATHER>), grid, dim3(G_THREADS), lds, st, a);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, A_T, B_T, EPI, GMODE>), grid, dim3(G_THREADS), lds, st, a);
     gprof_close(pe, st);
     return cmf_launch_status();
 }
@@ -1477,7 +1506,32 @@ extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long 
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.A = Y; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
-    return launch<128, 128, false, true, 0, true>(g, st);
+    return launch<128, 128, false, true, 0, 1>(g, st);
+}
+
+// Weight gradient of the set-conv layer behind the hoisted first conv with that first layer formed in the B-operand staging instead
+// of being read back:   dW[cout][cin] (+)= sum_r dZ[r][cout] * relu( prob_a[k] * ( Y[rows[r]][k] + wx3[:,k] . dxyz[r] ) + prob_c[k] )
+// -- the same operations in the same order as cmf_gemm(a_t = 1, b_t = 0, prob) on the materialised tensor in the register-staged
+// loop (bit-identical).  cout, cin multiples of 128, nrows a multiple of 16.
+extern "C" int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const float *dZ, long long ldz, const float *Y, long long ldy,
+                                  const int *rows, const float *dxyz, const float *wx3, const float *prob_a, const float *prob_c,
+                                  float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream)
+{
+    CMF_CHECK_ARG(cout > 0 && cin > 0 && nrows > 0 && nrows < (1ll << 31) && split_k >= 1);
+    CMF_CHECK_ARG(cout % 128 == 0 && cin % 128 == 0 && nrows % G_BK == 0);
+    CMF_CHECK_ARG(dZ && Y && rows && dxyz && wx3 && prob_a && prob_c && dW && (split_k == 1 || workspace));
+    CMF_CHECK_ARG(ldz % 4 == 0 && ldy % 4 == 0 && lddw % 4 == 0);
+    CMF_CHECK_ARG((((uintptr_t)dZ | (uintptr_t)Y | (uintptr_t)dxyz | (uintptr_t)wx3 | (uintptr_t)dW) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{};
+    g.M = cout; g.N = cin; g.K = (int)nrows; g.A = dZ; g.lda = ldz; g.B = Y; g.ldb = ldy;
+    g.C = split_k > 1 ? workspace : dW; g.ldc = split_k > 1 ? cin : lddw;
+    g.prob_a = prob_a; g.prob_c = prob_c; g.split_k = split_k; g.accumulate = split_k > 1 ? 0 : accumulate;
+    g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.no_direct = 1;
+    const int err = launch<128, 128, true, false, 0, 2>(g, st);
+    if (err) return err;
+    if (split_k > 1) return cmf_splitk_reduce(cout, cin, split_k, workspace, dW, lddw, accumulate, st);
+    return 0;
 }
 
 // Weight gradient of a layer whose output gradient still has to go through the train-mode BatchNorm backward:

@@ -535,7 +535,7 @@ struct GaSums { float4 s1, s2, tz0, tz1, tz2; float ud0, ud1, ud2; };
 // XS: the z * d_k sums of the set-conv dW_xyz).  No bounds checks, no 64-bit divisions and no branches in the loop: the generic
 // loop below (ragged last tile, narrow C) carried four `row / S` long divisions and four validity branches per step, and the
 // kernel was bound by instruction issue, not by its stores.
-template <bool CTR, bool ST, bool XS>
+template <bool CTR, bool ST, bool XS, bool WR>
 __device__ __forceinline__ void ga_full_rows(const TileMap &tm, int C, const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr,
                                              int ld_ctr, const float (&wx)[4][3], int act, float *__restrict__ zt /* z + row0 * C + col */,
                                              const float4 *sd, const int *ssrc, const int *sctr, GaSums &a)
@@ -565,7 +565,7 @@ __device__ __forceinline__ void ga_full_rows(const TileMap &tm, int C, const flo
             o.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
             if (act == 2) { o.x = o.x > 0.f ? o.x : 0.1f * o.x; o.y = o.y > 0.f ? o.y : 0.1f * o.y;
                             o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
-            *(float4 *)(zt + (size_t)r * C) = o;
+            if (WR) *(float4 *)(zt + (size_t)r * C) = o;
             if (ST) {
                 a.s1.x += o.x; a.s1.y += o.y; a.s1.z += o.z; a.s1.w += o.w;
                 a.s2.x += o.x * o.x; a.s2.y += o.y * o.y; a.s2.z += o.z * o.z; a.s2.w += o.w * o.w;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void ga_full_rows(const TileMap &tm, int C, const flo
     }
 }
 
-template <bool CTR, bool ST, bool XS>                    // centre rows added / BN partial sums / z * d_k sums (the call's NULL pointers)
+template <bool CTR, bool ST, bool XS, bool WR = true>   // centre rows added / BN partial sums / z * d_k sums / z written (the call's NULL pointers)
 __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
     int n_src, int P, int S, int C, long long rows,
     const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr, int ld_ctr,
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
     }
     __syncthreads();
     if (row0 + PW_ROWS <= rows && 4 * tm.rl <= PW_ROWS)
-        ga_full_rows<CTR, ST, XS>(tm, C, ysrc, ld_src, yctr, ld_ctr, wx, act, z + (size_t)row0 * C + tm.col, sd, ssrc, sctr, acc);
+        ga_full_rows<CTR, ST, XS, WR>(tm, C, ysrc, ld_src, yctr, ld_ctr, wx, act, z + (size_t)row0 * C + tm.col, sd, ssrc, sctr, acc);
     else
     // the generic loop (ragged last tile; C < 32: fewer than four row slots' worth of rows per step); 4 rows per step in flight
     for (int rb = tm.r0; rb < PW_ROWS; rb += 4 * tm.rl) {
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             o.w += fmaf(wx[3][2], dz, fmaf(wx[3][1], dy, wx[3][0] * dx));
             if (act == 2) { o.x = o.x > 0.f ? o.x : 0.1f * o.x; o.y = o.y > 0.f ? o.y : 0.1f * o.y;
                             o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
-            *(float4 *)(z + (size_t)(row0 + r) * C + tm.col) = o;
+            if (WR) *(float4 *)(z + (size_t)(row0 + r) * C + tm.col) = o;
             if (ST) {
                 acc.s1.x += o.x; acc.s1.y += o.y; acc.s1.z += o.z; acc.s1.w += o.w;
                 acc.s2.x += o.x * o.x; acc.s2.y += o.y * o.y; acc.s2.z += o.z * o.z; acc.s2.w += o.w * o.w;
@@ -699,13 +699,21 @@ extern "C" int cmf_group_affine(int b, int n_src, int P, int S, int C,
 {
     CMF_CHECK_ARG(b >= 0 && n_src > 0 && P > 0 && S > 0 && tile_ok(C));
     if (b == 0) return 0;
-    CMF_CHECK_ARG(ysrc && xyz_src && xyz_ctr && Wx && idx && z && ld_src % 4 == 0 && (!yctr || ld_ctr % 4 == 0));
+    // z == NULL (with partial): the statistics only -- the tensor itself is formed again where it is consumed (cmf_gemm_gather_affine)
+    CMF_CHECK_ARG(ysrc && xyz_src && xyz_ctr && Wx && idx && (z || (partial && !yctr)) && ld_src % 4 == 0 && (!yctr || ld_ctr % 4 == 0));
     CMF_CHECK_ARG(!partial_x || (partial && C >= 4));
     const long long rows = (long long)b * P * S;
     const int tiles = cmf_divup(rows, PW_ROWS);
 #define CMF_GA_LAUNCH(CTR, ST, XS)                                                                                            \
     hipLaunchKernelGGL((group_affine_kernel<CTR, ST, XS>), dim3(tiles), dim3(PW_THREADS), partial ? tile_lds(C) : 0, (hipStream_t)stream, \
                        n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial, partial_x)
+    if (!z) {
+        if (partial_x) hipLaunchKernelGGL((group_affine_kernel<false, true, true, false>), dim3(tiles), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
+                                          n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial, partial_x);
+        else hipLaunchKernelGGL((group_affine_kernel<false, true, false, false>), dim3(tiles), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
+                                n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial, partial_x);
+        return cmf_launch_status();
+    }
     if (yctr) { if (partial_x) CMF_GA_LAUNCH(true, true, true); else if (partial) CMF_GA_LAUNCH(true, true, false); else CMF_GA_LAUNCH(true, false, false); }
     else { if (partial_x) CMF_GA_LAUNCH(false, true, true); else if (partial) CMF_GA_LAUNCH(false, true, false); else CMF_GA_LAUNCH(false, false, false); }
 #undef CMF_GA_LAUNCH

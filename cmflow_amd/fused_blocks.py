@@ -211,13 +211,14 @@ def colsum(partial, acc_beta=None, acc_gamma=None):
     return out
 
 
-def group_affine(ysrc, yctr, xyz_src, xyz_ctr, wx, idx, act=0, stats=True, want_dxyz=True, extra=False):
-    """-> z (B,P,S,C), dxyz (B,P,S,4) or None, partial or None[, partial_x].  ysrc (B,n_src,C) row-strided view."""
+def group_affine(ysrc, yctr, xyz_src, xyz_ctr, wx, idx, act=0, stats=True, want_dxyz=True, extra=False, write_z=True):
+    """-> z (B,P,S,C), dxyz (B,P,S,4) or None, partial or None[, partial_x].  ysrc (B,n_src,C) row-strided view.
+    write_z=False (with stats): the statistics only, z is None."""
     B, n_src, C = ysrc.shape
     _, P, S = idx.shape
     assert ysrc.stride(2) == 1 and ysrc.stride(0) == n_src * ysrc.stride(1)
     dev = ysrc.device
-    z = torch.empty(B, P, S, C, dtype=_f32, device=dev)
+    z = torch.empty(B, P, S, C, dtype=_f32, device=dev) if write_z else None
     dxyz = torch.empty(B, P, S, 4, dtype=_f32, device=dev) if want_dxyz else None
     part = torch.empty(_tiles(B * P * S), 2, C, dtype=_f32, device=dev) if stats else None
     part_x = torch.empty(_tiles(B * P * S), 3 * C + 4, dtype=_f32, device=dev) if (stats and extra) else None

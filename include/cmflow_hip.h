@@ -202,7 +202,8 @@ int cmf_colsum(int tiles, int ncols, const float *partial, float *out, int C, fl
  * ysrc (b,n_src,ld_src), yctr (b,P,ld_ctr) or NULL, Wx (C,3) with row stride ldw, idx (b,P,S);
  * act 0 none / 2 leaky(0.1); z (b,P,S,C); dxyz (b,P,S,4) relative coordinates (optional);
  * partial: BN statistics of z (optional); partial_x (optional, with partial): [tiles][3*C+4] extra sums
- * sum z*d_k (k=0..2, per channel) and sum d_k, used by cmf_setconv_dwx in the backward pass. */
+ * sum z*d_k (k=0..2, per channel) and sum d_k, used by cmf_setconv_dwx in the backward pass.
+ * z == NULL (yctr == NULL, partial given): the statistics only, bit-identical to the writing form's. */
 int cmf_group_affine(int b, int n_src, int P, int S, int C,
                      const float *ysrc, int ld_src, const float *yctr, int ld_ctr,
                      const float *xyz_src, const float *xyz_ctr, const float *Wx, int ldw,
@@ -220,6 +221,14 @@ int cmf_group_prep(int b, int n_src, int P, int S, int C, const float *xyz_src, 
 int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long long ldy, const int *rows, const float *dxyz,
                            const float *wx3, const float *pro_a, const float *pro_c, const float *W, long long ldw,
                            float *C, long long ldc, void *stream);
+/* ... and the weight gradient of that next layer with the first layer formed in its B-operand staging (register-staged loop, the
+ * rows' source indices requested one chunk ahead):
+ *   dW[cout,cin] (+)= sum_r dZ[r,cout] * relu( prob_a[k] * ( Y[rows[r],k] + wx3[:,k] . dxyz[r] ) + prob_c[k] )
+ * bit-identical to cmf_gemm(a_t = 1, b_t = 0, prob_a, prob_c) on the materialised tensor.  cout, cin multiples of 128, nrows of 16;
+ * split_k > 1: deterministic slabs in `workspace` (split_k * cout * cin floats). */
+int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const float *dZ, long long ldz, const float *Y, long long ldy,
+                       const int *rows, const float *dxyz, const float *wx3, const float *prob_a, const float *prob_c,
+                       float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream);
 
 /* out[p,:] = max_s relu(a*z[p,s,:] + c): BN + ReLU + max over the ball (radarflow_util.py:151-155);
  * argmax (P,C) uint8 optional. */

@@ -786,3 +786,38 @@ def test_gather_affine_gemm_is_bit_identical_to_the_materialised_path(dev, B, N,
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], want), float((outs[0] - want).abs().max())
+
+
+@pytest.mark.parametrize("B,N,S,K,NO,r,split", [(8, 256, 16, 512, 256, 8.0, 8), (4, 256, 32, 128, 128, 16.0, 1), (2, 256, 4, 256, 128, 2.0, 4)])
+def test_gather_weight_gradient_is_bit_identical_to_the_materialised_path(dev, B, N, S, K, NO, r, split):
+    """cmf_gemm_dw_gather (the set-conv first layer formed in the B-operand staging of the next layer's weight gradient) against
+    cmf_gemm(a_t, prob) on the tensor cmf_group_affine writes, both in the register-staged loop: bit for bit, with and without
+    split-K, written and accumulated."""
+    from cmflow_amd import _lib, synth, fused_blocks as FB, pointnet2_utils as pu
+    L = _lib.lib()
+    torch.manual_seed(B * 10 + S)
+    xyz = synth.make_batch(B, N=N, seed=11)["pc1"].to(dev).transpose(1, 2).contiguous()
+    idx = pu.ball_query(r, S, xyz, xyz)
+    M = B * N * S
+    y = torch.randn(B, N, 2 * K, device=dev)[:, :, :K]
+    wx = torch.randn(K, 3, device=dev)
+    pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+    dZ = torch.randn(M, NO, device=dev)
+    z, dxyz, _ = FB.group_affine(y, None, xyz, xyz, wx, idx, act=0, stats=False)
+    st = _lib.stream_ptr()
+    rows = torch.empty(M, dtype=torch.int32, device=dev); dq = torch.empty(M, 4, device=dev); wx3 = torch.empty(3, K, device=dev)
+    _lib.check(L.cmf_group_prep(B, N, N, S, K, xyz.data_ptr(), xyz.data_ptr(), wx.data_ptr(), 3, idx.data_ptr(), rows.data_ptr(),
+                                dq.data_ptr(), wx3.data_ptr(), st), "prep")
+    ws = torch.empty(max(split, 1) * NO * K, device=dev)
+    for acc in (0, 1):
+        want = torch.full((NO, K), 0.5, device=dev); got = want.clone()
+        # the materialised form, forced onto the register-staged loop like the model's long weight gradients (cmf_gemm picks it for K >= 32768)
+        g_no_direct = M >= 32768
+        _lib.check(L.cmf_gemm(NO, K, M, 1, 0, dZ.data_ptr(), NO, z.data_ptr(), K, want.data_ptr(), K, None, None, pa.data_ptr(), pc.data_ptr(),
+                              None, 0, None, 0, None, 0, None, None, None, None, None, split, ws.data_ptr() if split > 1 else None, acc, st), "dw")
+        _lib.check(L.cmf_gemm_dw_gather(NO, K, M, dZ.data_ptr(), NO, y.data_ptr(), y.stride(1), rows.data_ptr(), dq.data_ptr(), wx3.data_ptr(),
+                                        pa.data_ptr(), pc.data_ptr(), got.data_ptr(), K, split, ws.data_ptr() if split > 1 else None, acc, st), "dwg")
+        if g_no_direct:
+            assert torch.equal(got, want), float((got - want).abs().max())
+        else:                                               # the LDS-direct loop applies the prologue to fragments: same values, same order
+            assert torch.equal(got, want) or float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) * 50

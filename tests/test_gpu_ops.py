@@ -624,3 +624,20 @@ def test_group_points_grad_csr_index_variants(dev, B, C, N, P, S, hi):
         outs.append(gp.cpu())
     assert torch.equal(outs[0], outs[1])
     np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), rtol=2e-5, atol=1e-5 * float(ref.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("B,N,S,C,r", [(4, 256, 16, 512, 8.0), (2, 256, 32, 64, 16.0), (3, 100, 8, 32, 4.0)])
+def test_group_affine_statistics_only_form(dev, B, N, S, C, r):
+    """cmf_group_affine with z == NULL (the tensor is formed again where it is consumed): the BN partial sums, the z * d_k sums and
+    dxyz must be bit-identical to the writing form's."""
+    from cmflow_amd import fused_blocks as FB, pointnet2_utils as pu
+    xyz, _ = clouds(B, N, seed=S + C)
+    xyz = xyz.to(dev)
+    idx = pu.ball_query(r, S, xyz, xyz)
+    g = torch.Generator(device="cpu").manual_seed(C)
+    y = torch.randn(B, N, C, generator=g).to(dev); wx = torch.randn(C, 3, generator=g).to(dev)
+    z, d, p, px = FB.group_affine(y, None, xyz, xyz, wx, idx, extra=True)
+    z0, d0, p0, px0 = FB.group_affine(y, None, xyz, xyz, wx, idx, extra=True, write_z=False)
+    assert z0 is None and torch.equal(d, d0) and torch.equal(p, p0) and torch.equal(px, px0)
+    z1, d1, p1 = FB.group_affine(y, None, xyz, xyz, wx, idx, write_z=False)
+    assert z1 is None and torch.equal(d, d1) and torch.equal(p, p1)
