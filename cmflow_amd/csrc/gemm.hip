@@ -110,11 +110,13 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // GATHER: the A rows are gathered from a per-point matrix and the set-conv first layer's coordinate term + BN + ReLU are applied
 // to the fragments (GemmArgs ga_*): LDS-direct loop only, full tiles only (the host checks).
 // GMODE 2: the same for the B operand of the weight gradient (B[K][N] = the activated first layer, K = neighbour slots): register-staged
-// loop only, the rows' source indices requested one chunk ahead.
+// loop only, the rows' source indices requested one chunk ahead.  GMODE 3: the producer's Z rows of the kind-4 backward epilogue
+// (p.Z = the per-point matrix, rows through ga_rows, + the coordinate term).
 template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
 __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
 {
-    constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2;
+    constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2, GATHER_Z = GMODE == 3;
+    static_assert(!GATHER_Z || (!A_T && !B_T && EPI == 4 && BM == 128 && BN == 128), "gathered Z rows: the kind-4 data gradient");
     static_assert(!GATHER || (!A_T && B_T), "gathering A operand: A[M][K] W[N][K] layout");
     static_assert(!GATHER_B || (A_T && !B_T), "gathering B operand: A[K][M] B[K][N] layout");
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         static_assert(WN == 64 && TN == 2, "wave tile 64 columns wide");
         constexpr int W_LD = WN;                                      // 64 floats = one pass over the 64 banks: the 32 lanes of a ds_write_b32 group
                                                                       // write one row, the 16 lanes of a ds_read_b128 group read whole rows -- no padding needed
-        constexpr int W_TILE = 32 * W_LD, W_SZ = W_TILE + WM * 4 + 4 * WN;     // per wave: transposition tile | dxyz rows | column constants
+        constexpr int W_TILE = 32 * W_LD, W_SZ = W_TILE + WM * 4 + (GATHER_Z ? 7 : 4) * WN;   // per wave: transposition tile | dxyz rows | column constants (| wx planes)
         float *wt = smem + wid * W_SZ, *wdq = wt + W_TILE;
         const int rl = lane >> 4, c4 = (lane & 15) * 4;               // row inside a group of 4, first of the lane's 4 columns
         const int cb = wn * WN + c4;                                  // tile-local column; global: n0 + cb
@@ -905,19 +907,27 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         // of 4 and its columns): per-lane 64-bit addresses for 16 rows x 2 matrices would take 64 registers
         const int wms = __builtin_amdgcn_readfirstlane(wm), wns = __builtin_amdgcn_readfirstlane(wn);
         const int rbase = m0 + wms * WM;
-        const float *zbase = p.Z + (long long)rbase * p.ldz + n0 + wns * WN;
+        const float *zbase = GATHER_Z ? p.Z + n0 + wns * WN : p.Z + (long long)rbase * p.ldz + n0 + wns * WN;
         float *cbase = Cout + (long long)rbase * p.ldc + n0 + wns * WN;
         const unsigned lane_z = (unsigned)((rl * (int)p.ldz + c4) * 4), lane_c = (unsigned)((rl * (int)p.ldc + c4) * 4);
         // Z rows of ONE half block row (16 rows: 4 per lane) at a time, requested one half ahead: the next half's loads are
         // issued after this half's arithmetic and BEFORE its stores, so no load is ever waited on behind a store
         f32x4 zp[4];
+        int zi[GATHER_Z ? 4 : 1];                                    // gathered Z: the source rows of the half requested next (one half ahead of their use)
+        auto load_zi = [&](int g) {
+#pragma unroll
+            for (int u = 0; u < (GATHER_Z ? 4 : 0); ++u) zi[GATHER_Z ? u : 0] = p.ga_rows[rbase + g * 16 + u * 4 + rl];
+        };
         auto load_z = [&](int g) {                                    // g = 2 * block row + half
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (p.diag & 32) { zp[u] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }            // timing diagnostic: no Z loads
-                zp[u] = *(const f32x4 *)((const char *)(zbase + (long long)(g * 16 + u * 4) * p.ldz) + lane_z);
+                if (GATHER_Z) zp[u] = *(const f32x4 *)(zbase + (long long)zi[GATHER_Z ? u : 0] * p.ldz + c4);
+                else zp[u] = *(const f32x4 *)((const char *)(zbase + (long long)(g * 16 + u * 4) * p.ldz) + lane_z);
             }
+            if (GATHER_Z && g + 1 < 2 * TM) load_zi(g + 1);
         };
+        if (GATHER_Z) load_zi(0);
         if (USE_Z) load_z(0);
         // per-column constants and the wave's dxyz rows: wave-private LDS (re-read per half: 16 registers less)
         float *wk = wdq + WM * 4;                                     // [4][WN]
@@ -929,6 +939,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         if (BNR) {
             const int c = n0 + wns * WN + lane;
             wk[lane] = p.ea[c]; wk[WN + lane] = p.ec[c]; wk[2 * WN + lane] = p.emean[c]; wk[3 * WN + lane] = p.einvstd[c];
+            if (GATHER_Z) { wk[4 * WN + lane] = p.ga_wx[c]; wk[5 * WN + lane] = p.ga_wx[(long long)p.N + c]; wk[6 * WN + lane] = p.ga_wx[2ll * p.N + c]; }
         }
         const float slope = KIND == 1 ? (p.act == 1 ? 0.f : (p.act == 2 ? 0.1f : 1.f)) : (p.bwd_mode == 2 ? 0.1f : 0.f);
         // compiler fences (no instructions): without them the scheduler hoists the LDS reads and Z loads of later halves above
@@ -952,6 +963,8 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                     f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, k2 = k0, k3 = k0;
                     if (KIND == 1 || BNR) k0 = *(const f32x4 *)(wk + c4);
                     if (BNR) { k1 = *(const f32x4 *)(wk + WN + c4); k2 = *(const f32x4 *)(wk + 2 * WN + c4); k3 = *(const f32x4 *)(wk + 3 * WN + c4); }
+                    f32x4 g0 = k0, g1 = k0, g2 = k0;
+                    if (GATHER_Z) { g0 = *(const f32x4 *)(wk + 4 * WN + c4); g1 = *(const f32x4 *)(wk + 5 * WN + c4); g2 = *(const f32x4 *)(wk + 6 * WN + c4); }
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
@@ -964,7 +977,8 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                                 x = x > 0.f ? x : (slope == 0.f ? 0.f : slope * x);
                                 s1[q] += x; s2[q] += x * x;
                             } else if (BNR) {
-                                const float z = zp[u][q];
+                                // (gathered: z = y + (wx0 dx + wx1 dy + wx2 dz), group_affine_kernel's operations in its order)
+                                const float z = GATHER_Z ? zp[u][q] + fmaf(g2[q], d4.z, fmaf(g1[q], d4.y, g0[q] * d4.x)) : zp[u][q];
                                 x = (fmaf(k0[q], z, k1[q]) > 0.f) ? x : 0.f;
                                 s1[q] += x; s2[q] += x * ((z - k2[q]) * k3[q]);
                             } else {
@@ -1507,6 +1521,28 @@ extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long 
     g.M = M; g.N = N; g.K = K; g.A = Y; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
     return launch<128, 128, false, true, 0, 1>(g, st);
+}
+
+// Data gradient through the layer behind the hoisted first conv, masked by the first layer's BN + ReLU and with its BN-backward and
+// dxyz partial sums (cmf_gemm's backward kind with dxyz), where the first layer's pre-activations are formed from the per-point rows
+// in the epilogue instead of being read back:   dU[m][k] = (dZ @ W)[m][k] * [ea[k] z + ec[k] > 0],  z = Y[rows[m]][k] + wx3[:,k] . dxyz[m]
+// -- bit-identical to cmf_gemm(bwd_mode 1, Z = the materialised tensor, dxyz) with the non-persistent kernel; statistics
+// [tiles_m][5][cin].  M, cin multiples of 128, cout of 16.
+extern "C" int cmf_gemm_dx_gather(int M, int cin, int cout, const float *dZ, long long ldz, const float *W, long long ldw,
+                                  float *dU, long long ldu, const float *Y, long long ldy, const int *rows, const float *dxyz,
+                                  const float *wx3, const float *ea, const float *ec, const float *emean, const float *einvstd,
+                                  float *stats, void *stream)
+{
+    CMF_CHECK_ARG(M > 0 && cin > 0 && cout > 0 && M % 128 == 0 && cin % 128 == 0 && cout % G_BK == 0);
+    CMF_CHECK_ARG(dZ && W && dU && Y && rows && dxyz && wx3 && ea && ec && emean && einvstd && stats);
+    CMF_CHECK_ARG(ldz % 4 == 0 && ldw % 4 == 0 && ldu % 4 == 0 && ldy % 4 == 0);
+    CMF_CHECK_ARG((((uintptr_t)dZ | (uintptr_t)W | (uintptr_t)dU | (uintptr_t)Y | (uintptr_t)dxyz) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{};
+    g.M = M; g.N = cin; g.K = cout; g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dU; g.ldc = ldu;
+    g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz;
+    g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
+    return launch<128, 128, false, false, 4, 3>(g, st);
 }
 
 // Weight gradient of the set-conv layer behind the hoisted first conv with that first layer formed in the B-operand staging instead

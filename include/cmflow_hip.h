@@ -226,6 +226,14 @@ int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long long ldy, c
  *   dW[cout,cin] (+)= sum_r dZ[r,cout] * relu( prob_a[k] * ( Y[rows[r],k] + wx3[:,k] . dxyz[r] ) + prob_c[k] )
  * bit-identical to cmf_gemm(a_t = 1, b_t = 0, prob_a, prob_c) on the materialised tensor.  cout, cin multiples of 128, nrows of 16;
  * split_k > 1: deterministic slabs in `workspace` (split_k * cout * cin floats). */
+/* ... and the data gradient INTO that first layer (cmf_gemm's backward kind with dxyz: mask by the first layer's BN + ReLU, BN-backward
+ * and dxyz partial sums [tiles_m][5][cin]) with the first layer's pre-activations formed from the per-point rows in the epilogue:
+ *   dU[m,k] = (dZ @ W)[m,k] * [ea[k] z + ec[k] > 0],   z = Y[rows[m],k] + wx3[:,k] . dxyz[m]
+ * bit-identical to cmf_gemm(bwd_mode = 1, Z = the materialised tensor, dxyz) in the non-persistent kernel.  M, cin multiples of 128. */
+int cmf_gemm_dx_gather(int M, int cin, int cout, const float *dZ, long long ldz, const float *W, long long ldw,
+                       float *dU, long long ldu, const float *Y, long long ldy, const int *rows, const float *dxyz,
+                       const float *wx3, const float *ea, const float *ec, const float *emean, const float *einvstd,
+                       float *stats, void *stream);
 int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const float *dZ, long long ldz, const float *Y, long long ldy,
                        const int *rows, const float *dxyz, const float *wx3, const float *prob_a, const float *prob_c,
                        float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream);

@@ -821,3 +821,39 @@ def test_gather_weight_gradient_is_bit_identical_to_the_materialised_path(dev, B
             assert torch.equal(got, want), float((got - want).abs().max())
         else:                                               # the LDS-direct loop applies the prologue to fragments: same values, same order
             assert torch.equal(got, want) or float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) * 50
+
+
+@pytest.mark.parametrize("B,N,S,K,NO,r", [(4, 256, 8, 512, 256, 4.0), (2, 256, 32, 128, 64, 16.0), (1, 128, 4, 256, 16, 2.0)])
+def test_gather_data_gradient_is_bit_identical_to_the_materialised_path(dev, B, N, S, K, NO, r):
+    """cmf_gemm_dx_gather (the first layer's pre-activations formed from the per-point rows in the backward epilogue) against
+    cmf_gemm(bwd_mode 1, Z = the tensor cmf_group_affine writes, dxyz) in the non-persistent kernel: dU and the five partial sums
+    bit for bit."""
+    from cmflow_amd import _lib, synth, fused_blocks as FB, pointnet2_utils as pu
+    L = _lib.lib()
+    torch.manual_seed(B * 10 + S)
+    xyz = synth.make_batch(B, N=N, seed=13)["pc1"].to(dev).transpose(1, 2).contiguous()
+    idx = pu.ball_query(r, S, xyz, xyz)
+    M = B * N * S
+    y = torch.randn(B, N, 2 * K, device=dev)[:, :, :K]
+    wx = torch.randn(K, 3, device=dev)
+    ea, ec, em, ei = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3, torch.randn(K, device=dev), torch.rand(K, device=dev) + 0.5
+    dZ = torch.randn(M, NO, device=dev); W = torch.randn(NO, K, device=dev)
+    z, dxyz, _ = FB.group_affine(y, None, xyz, xyz, wx, idx, act=0, stats=False)
+    st = _lib.stream_ptr()
+    rows = torch.empty(M, dtype=torch.int32, device=dev); dq = torch.empty(M, 4, device=dev); wx3 = torch.empty(3, K, device=dev)
+    _lib.check(L.cmf_group_prep(B, N, N, S, K, xyz.data_ptr(), xyz.data_ptr(), wx.data_ptr(), 3, idx.data_ptr(), rows.data_ptr(),
+                                dq.data_ptr(), wx3.data_ptr(), st), "prep")
+    tiles = M // 128
+    want, ws = torch.empty(M, K, device=dev), torch.empty(tiles, 5, K, device=dev)
+    got, gs = torch.empty(M, K, device=dev), torch.empty(tiles, 5, K, device=dev)
+    L.cmf_gemm_persist_config(0, 0)
+    try:
+        _lib.check(L.cmf_gemm(M, K, NO, 0, 0, dZ.data_ptr(), NO, W.data_ptr(), K, want.data_ptr(), K, None, None, None, None, None, 0,
+                              ws.data_ptr(), 1, z.data_ptr(), K, ea.data_ptr(), ec.data_ptr(), em.data_ptr(), ei.data_ptr(), dq.data_ptr(),
+                              1, None, 0, st), "dx")
+    finally:
+        L.cmf_gemm_persist_config(1, 0)
+    _lib.check(L.cmf_gemm_dx_gather(M, K, NO, dZ.data_ptr(), NO, W.data_ptr(), K, got.data_ptr(), K, y.data_ptr(), y.stride(1), rows.data_ptr(),
+                                    dq.data_ptr(), wx3.data_ptr(), ea.data_ptr(), ec.data_ptr(), em.data_ptr(), ei.data_ptr(), gs.data_ptr(), st), "dxg")
+    assert torch.equal(got, want), float((got - want).abs().max())
+    assert torch.equal(gs, ws)
