@@ -64,7 +64,7 @@ SIGNATURES = {
     "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_prep": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
-    "cmf_gemm_gather_affine": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp],
+    "cmf_gemm_gather_affine": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp],
     "cmf_gemm_dx_gather": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_gemm_dw_gather": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ci, _vp, _ci, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],

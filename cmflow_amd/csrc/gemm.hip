@@ -1508,10 +1508,11 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
 // Y (.., K) per-point rows of pitch ldy, rows[M] the source row of every neighbour slot, dxyz (M,4) its relative coordinates,
 // wx3 (3,K) the coordinate columns of the first conv as planes.  The same operations, in the same order, as cmf_group_affine
 // followed by cmf_gemm with the A prologue: bit-identical output, without the (M,K) tensor (2 GB at the second encoder's scales)
-// written and read back.  M, N multiples of 128, K of 16; all pointers 16-byte aligned.
+// written and read back.  stats (optional): the output's BN partial sums like cmf_gemm's.  M, N multiples of 128, K of 16; all
+// pointers 16-byte aligned.
 extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long long ldy, const int *rows, const float *dxyz,
                                       const float *wx3, const float *pro_a, const float *pro_c, const float *W, long long ldw,
-                                      float *C, long long ldc, void *stream)
+                                      float *C, long long ldc, float *stats, void *stream)
 {
     CMF_CHECK_ARG(M > 0 && N > 0 && K > 0 && M % 128 == 0 && N % 128 == 0 && K % G_BK == 0);
     CMF_CHECK_ARG(Y && rows && dxyz && wx3 && pro_a && pro_c && W && C && ldy % 4 == 0 && ldw % 4 == 0 && ldc % 4 == 0);
@@ -1520,7 +1521,8 @@ extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long 
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.A = Y; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
-    return launch<128, 128, false, true, 0, 1>(g, st);
+    g.stats = stats;                                    // train mode: [M / 128][2][N] partial sums of the output
+    return stats ? launch<128, 128, false, true, 1, 1>(g, st) : launch<128, 128, false, true, 0, 1>(g, st);
 }
 
 // Data gradient through the layer behind the hoisted first conv, masked by the first layer's BN + ReLU and with its BN-backward and

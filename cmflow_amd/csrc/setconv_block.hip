@@ -249,6 +249,37 @@ int bwd_layer(const cmf_setconv_desc *d, const Layout &L, int l_out, long long r
     return dx_gemm(d, L, rows, cout, cin, dU, w, x, l_in, dU_in, dxyz, st);
 }
 
+// Training without the grouped first-layer tensor (CMF_TRAIN_GATHER=1, second-encoder shapes): the forward pass takes the layer's
+// statistics from cmf_group_affine's statistics-only form and the three GEMMs that read the tensor form it from the per-point rows
+// (cmf_gemm_gather_affine / cmf_gemm_dx_gather / cmf_gemm_dw_gather: each bit-identical to its materialised counterpart); the
+// tensor's slot in `saved` holds the row indices and the coordinate planes of Wx.
+bool train_gather(const cmf_setconv_desc *d)
+{
+    static const bool on = getenv("CMF_TRAIN_GATHER") && getenv("CMF_TRAIN_GATHER")[0] == '1';
+    const long long M = (long long)d->B * d->N * d->S;
+    return on && d->training && M % 128 == 0 && M < (1ll << 31) && d->C[0] % 128 == 0 && d->O1 % 128 == 0 && d->ldy % 4 == 0 &&
+           (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0;
+}
+int *gather_rows(const Layout &L) { return reinterpret_cast<int *>(L.z1); }
+float *gather_wx3(const Layout &L, long long M) { return L.z1 + (M + 3) / 4 * 4; }
+
+// bwd_layer for the layer behind the gathered first layer: BN-backward sums, BN backward in place, weight gradient and masked data
+// gradient with the first layer formed in their operand / epilogue paths
+int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, int C2, int O1, void *st)
+{
+    const float *b = L.bn[1], *b0 = L.bn[0];
+    if (d->acc_bn[1]) CMF_TRY(cmf_colsum_finalize(tiles128(M), C2, L.partial, L.sums, d->dbeta[1], d->dgamma[1], st));
+    else CMF_TRY(cmf_colsum_store(tiles128(M), 2 * C2, L.partial, L.sums, C2, d->dbeta[1], d->dgamma[1], st));
+    CMF_TRY(cmf_bn_bwd_apply(M, C2, L.dU2, L.z2, C2, b + 2 * C2, b, b + C2, L.sums, st));
+    if (d->dw[0]) {
+        const int split = dw_split(M, C2, O1);
+        CMF_TRY(cmf_gemm_dw_gather(C2, O1, M, L.dU2, C2, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M), b0 + 2 * O1, b0 + 3 * O1,
+                                   d->dw[0], O1, split, split > 1 ? L.splitk : nullptr, d->acc_w[0], st));
+    }
+    return cmf_gemm_dx_gather((int)M, O1, C2, L.dU2, C2, d->w[0], O1, L.dU1, O1, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M),
+                              b0 + 2 * O1, b0 + 3 * O1, b0, b0 + O1, L.partial, st);
+}
+
 }  // namespace
 
 extern "C" int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd)
@@ -277,12 +308,22 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     // path (cmf_gemm_gather_affine, bit-identical); the slot of z1 holds the M source-row indices and the coordinate planes of Wx
     const bool gather = !d->training && d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
                         (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31);
+    if (train_gather(d)) {
+        CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
+                                 nullptr, L.dxyz, L.partial, L.partial_x, st));
+        CMF_TRY(cmf_colsum(tiles128(M), 3 * O1 + 4, L.partial_x, L.fwd_sums, 0, nullptr, nullptr, st));
+        CMF_TRY(fold(d, L, 0, M, st));
+        CMF_TRY(cmf_group_prep(d->B, d->N, d->N, d->S, O1, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, gather_rows(L), L.dxyz,
+                               gather_wx3(L, M), st));
+        CMF_TRY(cmf_gemm_gather_affine((int)M, C2, O1, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M), L.bn[0] + 2 * O1,
+                                       L.bn[0] + 3 * O1, d->w[0], O1, L.z2, C2, L.partial, st));
+    } else
     if (gather) {
         int *rows = reinterpret_cast<int *>(L.z1);
         float *wx3 = L.z1 + (M + 3) / 4 * 4;
         CMF_TRY(cmf_group_prep(d->B, d->N, d->N, d->S, O1, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, rows, L.dxyz, wx3, st));
         CMF_TRY(cmf_gemm_gather_affine((int)M, C2, O1, d->y, d->ldy, rows, L.dxyz, wx3, L.bn[0] + 2 * O1, L.bn[0] + 3 * O1, d->w[0], O1,
-                                       L.z2, C2, st));
+                                       L.z2, C2, nullptr, st));
     } else {
     CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
                              L.z1, L.dxyz, d->training ? L.partial : nullptr, d->training ? L.partial_x : nullptr, st));
@@ -496,6 +537,8 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
         CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
         CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));
     }
+    if (train_gather(d)) CMF_TRY(bwd_layer1_gather(d, L, M, C2, O1, st));
+    else
     CMF_TRY(bwd_layer(d, L, 1, M, C2, O1, L.dU2, L.z2, d->w[0], L.z1, 0, L.dU1, L.dxyz, d->dw[0], d->acc_w[0], st, L.dZ2));
     // first layer: sums {s1,s2,q0,q1,q2}; dgamma/dbeta; dW_xyz from sums; BN backward folded into the scatter
     const float *b0 = L.bn[0];

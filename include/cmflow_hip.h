@@ -220,7 +220,7 @@ int cmf_group_prep(int b, int n_src, int P, int S, int C, const float *xyz_src, 
                    const int *idx, int *rows, float *dxyz, float *wx3, void *stream);
 int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long long ldy, const int *rows, const float *dxyz,
                            const float *wx3, const float *pro_a, const float *pro_c, const float *W, long long ldw,
-                           float *C, long long ldc, void *stream);
+                           float *C, long long ldc, float *stats /* [M/128][2][N] partial sums of the output, or NULL */, void *stream);
 /* ... and the weight gradient of that next layer with the first layer formed in its B-operand staging (register-staged loop, the
  * rows' source indices requested one chunk ahead):
  *   dW[cout,cin] (+)= sum_r dZ[r,cout] * relu( prob_a[k] * ( Y[rows[r],k] + wx3[:,k] . dxyz[r] ) + prob_c[k] )

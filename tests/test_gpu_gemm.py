@@ -782,7 +782,7 @@ def test_gather_affine_gemm_is_bit_identical_to_the_materialised_path(dev, B, N,
     for _ in range(2):
         out = torch.empty(M, NO, device=dev)
         _lib.check(L.cmf_gemm_gather_affine(M, NO, K, y.data_ptr(), y.stride(1), rows.data_ptr(), dq.data_ptr(), wx3.data_ptr(),
-                                            pa.data_ptr(), pc.data_ptr(), W.data_ptr(), K, out.data_ptr(), NO, st), "gather gemm")
+                                            pa.data_ptr(), pc.data_ptr(), W.data_ptr(), K, out.data_ptr(), NO, None, st), "gather gemm")
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], want), float((outs[0] - want).abs().max())

@@ -339,6 +339,26 @@ def test_inference_forward_equals_eval_forward_with_autograd(dev):
         assert torch.equal(x, y.detach())
 
 
+def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, tmp_path):
+    """CMF_TRAIN_GATHER=1: the second encoder's grouped first-layer tensor is never written in training either -- its statistics come
+    from cmf_group_affine's statistics-only form and the three GEMMs that read it form it from the per-point rows.  Every one of
+    them is bit-identical to its materialised counterpart in the non-persistent kernel, so against CMF_GEMM_PERSIST=0 the loss,
+    every gradient and every BN buffer of a whole training step (B = 64) must be equal bit for bit.  (Child processes: the
+    library reads its switches once.)"""
+    import subprocess, sys
+    outs = []
+    for i, env in enumerate((dict(CMF_GEMM_PERSIST="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1"))):
+        f = str(tmp_path / ("step%d.pt" % i))
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"], env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(f))
+    a, b = outs
+    assert a.keys() == b.keys() and len(a) > 300
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, bad[:10]
+
+
 def test_full_size_train_step_matches_oracle(dev):
     """BASELINE config 3 (the headline) at its own size: one training step of bench.py's batch and weights, train-mode
     BN, 7 losses -- loss within 2e-4, every loss item within 2e-4, labels bit-equal, outputs as in the forward test,

@@ -42,7 +42,7 @@ for S, r in ((32, 16.0), (16, 8.0), (8, 4.0), (4, 2.0)):
         _lib.check(L.cmf_group_prep(B, N, N, S, K, xyz.data_ptr(), xyz.data_ptr(), wx.data_ptr(), 3, idx.data_ptr(), rows.data_ptr(),
                                     dq.data_ptr(), wx3.data_ptr(), st), "prep")
         _lib.check(L.cmf_gemm_gather_affine(M, NO, K, y.data_ptr(), y.stride(1), rows.data_ptr(), dq.data_ptr(), wx3.data_ptr(),
-                                            pa.data_ptr(), pc.data_ptr(), W.data_ptr(), K, out.data_ptr(), NO, st), "gg")
+                                            pa.data_ptr(), pc.data_ptr(), W.data_ptr(), K, out.data_ptr(), NO, None, st), "gg")
 
     def gemm_only():
         gemm(z.view(M, K), W, pro=(pa, pc), out=out)
