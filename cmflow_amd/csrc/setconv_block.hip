@@ -249,13 +249,13 @@ int bwd_layer(const cmf_setconv_desc *d, const Layout &L, int l_out, long long r
     return dx_gemm(d, L, rows, cout, cin, dU, w, x, l_in, dU_in, dxyz, st);
 }
 
-// Training without the grouped first-layer tensor (CMF_TRAIN_GATHER=1, second-encoder shapes): the forward pass takes the layer's
+// Training without the grouped first-layer tensor (second-encoder shapes; CMF_TRAIN_GATHER=0 keeps the tensor: A/B): the forward pass takes the layer's
 // statistics from cmf_group_affine's statistics-only form and the three GEMMs that read the tensor form it from the per-point rows
 // (cmf_gemm_gather_affine / cmf_gemm_dx_gather / cmf_gemm_dw_gather: each bit-identical to its materialised counterpart); the
 // tensor's slot in `saved` holds the row indices and the coordinate planes of Wx.
 bool train_gather(const cmf_setconv_desc *d)
 {
-    static const bool on = getenv("CMF_TRAIN_GATHER") && getenv("CMF_TRAIN_GATHER")[0] == '1';
+    static const bool on = !(getenv("CMF_TRAIN_GATHER") && getenv("CMF_TRAIN_GATHER")[0] == '0');
     const long long M = (long long)d->B * d->N * d->S;
     return on && d->training && M % 128 == 0 && M < (1ll << 31) && d->C[0] % 128 == 0 && d->O1 % 128 == 0 && d->ldy % 4 == 0 &&
            (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0;

@@ -340,14 +340,14 @@ def test_inference_forward_equals_eval_forward_with_autograd(dev):
 
 
 def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, tmp_path):
-    """CMF_TRAIN_GATHER=1: the second encoder's grouped first-layer tensor is never written in training either -- its statistics come
+    """Default (CMF_TRAIN_GATHER=0 switches it off): the second encoder's grouped first-layer tensor is never written in training either -- its statistics come
     from cmf_group_affine's statistics-only form and the three GEMMs that read it form it from the per-point rows.  Every one of
     them is bit-identical to its materialised counterpart in the non-persistent kernel, so against CMF_GEMM_PERSIST=0 the loss,
     every gradient and every BN buffer of a whole training step (B = 64) must be equal bit for bit.  (Child processes: the
     library reads its switches once.)"""
     import subprocess, sys
     outs = []
-    for i, env in enumerate((dict(CMF_GEMM_PERSIST="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1"))):
+    for i, env in enumerate((dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1"))):
         f = str(tmp_path / ("step%d.pt" % i))
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=900)
