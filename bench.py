@@ -392,6 +392,9 @@ def main():
         out = {"kernel": prof["kernel"], "bound": prof["bound"], "achieved": round(achieved, 2), "peak": peak,
                "unit": unit, "frac": round(achieved / peak, 4), "traffic": traffic,
                "traffic_source": traffic_source, "traffic_profile": "profiles/" + TRAFFIC_PROFILE, "algorithmic_bytes_per_launch": alg_bytes,
+               "algorithmic_bytes_note": "A + B + C once (+ the Z operand of the backward epilogues) at their materialised sizes; the "
+                                         "gathering GEMMs of the second encoder read per-point rows (L2-resident) instead of an M x K operand, "
+                                         "so the counted traffic can be below this figure",
                "launches": prof["launches"], "avg_us": round(avg_ms * 1e3, 2),
                "algorithmic_per_launch": per_launch,
                "launch_filter": "every tiled-kernel launch >= %.0e flop, bracketed inside libcmflow_hip.so (block-internal "
