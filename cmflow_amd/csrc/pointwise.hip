@@ -155,6 +155,20 @@ __device__ __forceinline__ void fin_reduce16(int tiles, int ncols, const int (&c
     __syncthreads();
 }
 
+// Which fold form a call takes.  The 16-column form reads whole sectors and needs one round of loads, but it has only ncols / 16
+// (fat, 1024-thread) workgroups: it wins from about 2^20 partial sums up (4096 tiles x 256 columns: 4.1 against 5.4 us; 4096 x 2560:
+// 16 against 55 us), below that the two are equal in isolation (tools/fin_sweep.py) and inside the step, next to other streams'
+// kernels, the few fat workgroups of a narrow matrix (the first encoder's 32-64 channels) ran 2-3x slower than the 4-column form.
+static inline bool fin_wide(long long tiles, long long ncols)
+{
+#ifdef CMF_FIN_EXPERIMENT
+    if (const char *e = getenv("CMF_FIN_WIDE")) return atoi(e) != 0;
+#endif
+    return tiles * ncols >= (1ll << 20);
+}
+static inline bool fin_wide_bn(int tiles, int C) { return fin_wide(tiles, 2ll * C); }
+static inline bool fin_wide_cs(int tiles, int ncols) { return fin_wide(tiles, ncols); }
+
 // per-channel tail of bn_finalize from the channel's two sums
 __device__ __forceinline__ void bn_finalize_channel(
     int ch, double s1, double s2, double count, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -263,12 +277,11 @@ int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st)
         b.a[i] = a[i];
         cmax = std::max(cmax, a[i].C);
     }
-    // every item's channel count a multiple of 16 and a long partial matrix among them: the coalesced 16-column form (below
-    // 2048 partial rows the 4-column form is 1.5 us quicker: profiles/r04_finalize_probe.txt)
+    // every item's channel count a multiple of 16 and a large partial matrix among them: the coalesced 16-column form (fin_wide)
     bool wide = true;
     int tmax = 0;
     for (int i = 0; i < n; ++i) { wide = wide && a[i].C % 16 == 0; tmax = std::max(tmax, a[i].tiles); }
-    if (wide && tmax >= 2048) hipLaunchKernelGGL(bn_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
+    if (wide && fin_wide_bn(tmax, cmax)) hipLaunchKernelGGL(bn_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
     else hipLaunchKernelGGL(bn_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
     return cmf_launch_status();
 }
@@ -314,7 +327,7 @@ extern "C" int cmf_bn_finalize(int tiles, int C, double count, const float *part
                                float *c_out, long long *num_batches_tracked, void *stream)
 {
     CMF_CHECK_ARG(C > 0 && a_out && c_out && (tiles == 0 ? (running_mean && running_var) : partial != nullptr));
-    if (tiles >= 2048 && C % 16 == 0 && (uintptr_t)partial % 16 == 0) {
+    if (fin_wide_bn(tiles, C) && C % 16 == 0 && (uintptr_t)partial % 16 == 0) {
         hipLaunchKernelGGL(bn_finalize16_kernel, dim3(C / 16), dim3(FIN16_THREADS), 0, (hipStream_t)stream, tiles, C, count,
                            partial, gamma, beta, eps, momentum, running_mean, running_var, mean_out, invstd_out, a_out, c_out,
                            num_batches_tracked);
@@ -415,15 +428,16 @@ int cmf_colsum_batch(int n, const CmfColsumArgs *a, hipStream_t st)
         cmax = std::max(cmax, a[i].ncols);
     }
     bool wide = true;
-    for (int i = 0; i < n; ++i) wide = wide && a[i].ncols % 16 == 0;
-    if (wide) hipLaunchKernelGGL(colsum_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
+    int tmax = 0;
+    for (int i = 0; i < n; ++i) { wide = wide && a[i].ncols % 16 == 0; tmax = std::max(tmax, a[i].tiles); }
+    if (wide && fin_wide_cs(tmax, cmax)) hipLaunchKernelGGL(colsum_finalize16_batch_kernel, dim3(cmax / 16, n), dim3(FIN16_THREADS), 0, st, b);
     else hipLaunchKernelGGL(colsum_finalize4_batch_kernel, dim3(cmax / 4, n), dim3(256), 0, st, b);
     return cmf_launch_status();
 }
 
 static int launch_colsum(int tiles, int ncols, const float *partial, float *out, int C, float *a0, float *a1, int store, void *stream)
 {
-    if (ncols % 16 == 0 && (uintptr_t)partial % 16 == 0)
+    if (fin_wide_cs(tiles, ncols) && ncols % 16 == 0 && (uintptr_t)partial % 16 == 0)
         hipLaunchKernelGGL(colsum_finalize16_kernel, dim3(ncols / 16), dim3(FIN16_THREADS), 0, (hipStream_t)stream, tiles, ncols, partial, out, C, a0, a1, store);
     else if (ncols % 4 == 0 && (uintptr_t)partial % 16 == 0)
         hipLaunchKernelGGL(colsum_finalize4_kernel, dim3(ncols / 4), dim3(256), 0, (hipStream_t)stream, tiles, ncols, partial, out, C, a0, a1, store);

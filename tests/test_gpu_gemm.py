@@ -711,7 +711,7 @@ def test_persistent_gemm_weight_gradient_matches_tiled_kernel(dev, rows, M, N, s
 @pytest.mark.parametrize("tiles,C", [(4096, 256), (2048, 64), (2047, 32), (700, 512), (33, 48), (5000, 12), (9, 6), (1, 16)])
 def test_statistics_fold_kernels_match_fp64(dev, tiles, C):
     """cmf_bn_finalize / cmf_colsum over a [tiles][2][C] partial matrix in every form the dispatch picks (16 columns per
-    1024-thread workgroup: C % 16 == 0, and for bn_finalize >= 2048 partial rows; 4 columns: C % 4 == 0; generic otherwise) against
+    1024-thread workgroup: columns % 16 == 0 and >= 2^20 partial sums; 4 columns: C % 4 == 0; generic otherwise) against
     an fp64 reduction: sums within 1e-6 of sum|terms| (fp64 accumulation inside, one rounding to fp32), the folded BatchNorm
     (mean, invstd, a, c, running statistics, counter) as nn.BatchNorm1d computes them from the same sums; twice = bit-identical."""
     from cmflow_amd import fused_blocks as FB
