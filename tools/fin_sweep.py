@@ -1,6 +1,8 @@
+"""The two forms of the statistics fold kernels (4 columns per 256-thread workgroup / 16 columns per 1024-thread workgroup) over
+partial-matrix sizes.  CMF_FIN_WIDE=0|1 forces the form only in an experiment build (make GROUP_DEFS=-DCMF_FIN_EXPERIMENT
+OUT=../../tools/diag/libcmflow_fin.so, CMF_LIB=...); the product dispatches by size (pointwise.hip fin_wide)."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cmflow_amd import _lib
 dev = torch.device("cuda:0"); L = _lib.lib(); st = _lib.stream_ptr()
 def timed(fn, n=20):
