@@ -66,6 +66,10 @@ SIGNATURES = {
     "cmf_group_prep": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_gemm_gather_affine": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp],
     "cmf_gemm_dx_gather": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_group_perm": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_gemm_dx_gather_sum": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_group_rows_grad_bn_cf_pieces": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp,
+                                         _ci, _vp],
     "cmf_gemm_dw_gather": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ci, _vp, _ci, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],

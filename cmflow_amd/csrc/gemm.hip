@@ -111,11 +111,12 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // to the fragments (GemmArgs ga_*): LDS-direct loop only, full tiles only (the host checks).
 // GMODE 2: the same for the B operand of the weight gradient (B[K][N] = the activated first layer, K = neighbour slots): register-staged
 // loop only, the rows' source indices requested one chunk ahead.  GMODE 3: the producer's Z rows of the kind-4 backward epilogue
-// (p.Z = the per-point matrix, rows through ga_rows, + the coordinate term).
+// (p.Z = the per-point matrix, rows through ga_rows, + the coordinate term).  GMODE 4: the same data gradient over rows in
+// inverse-index order, reduced over runs of equal source points in the epilogue instead of stored (seg_epilogue).
 template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
 __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
 {
-    constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2, GATHER_Z = GMODE == 3;
+    constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2, GATHER_Z = GMODE == 3 || GMODE == 4, GATHER_S = GMODE == 4;
     static_assert(!GATHER_Z || (!A_T && !B_T && EPI == 4 && BM == 128 && BN == 128), "gathered Z rows: the kind-4 data gradient");
     static_assert(!GATHER || (!A_T && B_T), "gathering A operand: A[M][K] W[N][K] layout");
     static_assert(!GATHER_B || (A_T && !B_T), "gathering B operand: A[K][M] B[K][N] layout");
@@ -391,6 +392,10 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             for (int q = 0; q < D_ANI; ++q) asrc[q] = (long long)p.ga_rows[m0 + (((q * 4 + wid) * 64 + lane) >> 2)] * p.lda;
             gconst = (lane < 4 ? p.pro_a : lane < 8 ? p.pro_c : p.ga_wx + (long long)((lane >> 2) - 2) * p.K) + 4 * (lane & 3);
         }
+        if (GATHER_S) {
+#pragma unroll
+            for (int q = 0; q < D_ANI; ++q) asrc[q] = (long long)p.ga_arows[m0 + (((q * 4 + wid) * 64 + lane) >> 2)] * p.lda;
+        }
         // A plain s_barrier: __syncthreads() carries a workgroup fence, which makes the compiler drain EVERY outstanding
         // LDS-direct load (vmcnt(0)) -- the prefetch distance would collapse to zero.  Visibility of the stage that is
         // consumed next is established explicitly: each wave waits for its own loads of that stage (wait_prev), then
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             for (int q = 0; q < D_ANI; ++q) {
                 const int grp = q * 4 + wid, sl = grp * 64 + lane;
                 const float *g;
-                if (!A_T) { const int row = sl >> 2; g = p.A + (GATHER ? asrc[q] : (long long)(m0 + row) * p.lda) + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
+                if (!A_T) { const int row = sl >> 2; g = p.A + ((GATHER || GATHER_S) ? asrc[q] : (long long)(m0 + row) * p.lda) + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
                 else { const int k = sl / (BM / 4); g = p.A + (long long)(k0 + k) * p.lda + m0 + 4 * ((sl % (BM / 4)) ^ (((k >> 2) & 1) * 8)); }
                 __builtin_amdgcn_global_load_lds((g_gptr)g, (g_lptr)(sa + grp * 256), 16, 0, 0);
             }
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         }
         __builtin_amdgcn_s_setprio(0);
     } else
-    if (GATHER) __builtin_trap();                           // (the host only sends shapes the LDS-direct loop takes)
+    if (GATHER || GATHER_S) __builtin_trap();               // (the host only sends shapes the LDS-direct loop takes)
     else
     if (kc_begin < kc_end) {
         load_tiles(kc_begin);
@@ -1037,6 +1042,95 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         }
         stats_done = true;
     };
+    // ---- segmented form of the kind-4 epilogue (GMODE 4): the output rows are neighbour slots sorted by source point, and what the
+    // model needs of this data gradient is only its sum per source point (the scatter of the grouping's backward pass) and the five
+    // column statistics.  A lane owns ONE column of the wave's 64 x 64 tile and walks its 64 rows: mask and statistics per element as
+    // in wave_epilogue, a running sum that is stored to ga_pieces[(point + range)] and reset whenever the source point changes --
+    // (point, range) pairs are monotone along the rows, so point + range numbers the pieces uniquely and the consumer adds the pieces
+    // of a point in range order (deterministic).  The 1 GB the M x N gradient took at the largest scale is neither written nor read.
+    auto seg_epilogue = [&](auto only_when_called) {
+        static_assert(WM == 64 && WN == 64 && TM == 2 && TN == 2, "wave tile 64 x 64");
+        constexpr int S_SZ = 32 * 64 + 64 * 4 + 64;                   // per wave: transposition tile | dxyz rows | source points
+        float *wt = smem + wid * S_SZ, *wdq = wt + 32 * 64;
+        int *wpt = reinterpret_cast<int *>(wdq + 64 * 4);
+        const int wms = __builtin_amdgcn_readfirstlane(wm), wns = __builtin_amdgcn_readfirstlane(wn);
+        const int rbase = m0 + wms * WM;
+        const int c = n0 + wns * WN + lane;                           // this lane's column
+        *(f32x4 *)(wdq + lane * 4) = *(const f32x4 *)(p.dxyz + (long long)(rbase + lane) * 4);
+        wpt[lane] = p.ga_rows[rbase + lane];
+        const float k0 = p.ea[c], k1 = p.ec[c], k2 = p.emean[c], k3 = p.einvstd[c];
+        const float g0 = p.ga_wx[c], g1 = p.ga_wx[(long long)p.N + c], g2 = p.ga_wx[2ll * p.N + c];
+        const long long range = rbase / 64;
+        const float *ycol = p.Z + c;
+        float *pcol = p.ga_pieces + c;
+        float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, seg = 0.f;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (wave-private LDS: the wave's own writes above, in order)
+        int pt_prev = -1;
+        // the per-point rows of 8 output rows at a time, requested one group ahead (rows of one run re-read the same 256 bytes)
+        float ya[8], yb[8];
+        auto load_y = [&](int row0, float (&y)[8]) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) y[u] = ycol[(long long)wpt[row0 + u] * p.ldz];
+        };
+        auto rows8 = [&](int i, int row0, const float (&y)[8]) {       // rows row0 .. row0 + 7 of the wave tile (block row i)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = row0 + u;
+                const int pt = __builtin_amdgcn_readfirstlane(wpt[row]);
+                if (pt != pt_prev) {
+                    if (pt_prev >= 0) pcol[((long long)pt_prev + range) * p.N] = seg;
+                    seg = 0.f; pt_prev = pt;
+                }
+                const f32x4 d4 = *(const f32x4 *)(wdq + row * 4);
+                float x = wt[(row - i * 32) * 64 + lane];
+                const float z = y[u] + fmaf(g2, d4.z, fmaf(g1, d4.y, g0 * d4.x));
+                x = (fmaf(k0, z, k1) > 0.f) ? x : 0.f;
+                t1 += x; t2 += x * ((z - k2) * k3);
+                q0 += x * d4.x; q1 += x * d4.y; q2 += x * d4.z;
+                seg += x;
+            }
+        };
+        load_y(0, ya);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // (a real loop with compiler fences: unrolled, the scheduler hoists every LDS read and per-point load of the block row above
+            //  the arithmetic -- 235 spilled registers)
+#pragma unroll 1
+            for (int g = 0; g < 2; ++g) {
+                const int r0 = i * 32 + g * 16;
+                load_y(r0 + 8, yb);
+                asm volatile("" ::: "memory");
+                rows8(i, r0, ya);
+                asm volatile("" ::: "memory");
+                if (r0 + 16 < 64) load_y(r0 + 16, ya);
+                asm volatile("" ::: "memory");
+                rows8(i, r0 + 8, yb);
+                asm volatile("" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is read before the next block row overwrites it
+        }
+        pcol[((long long)pt_prev + range) * p.N] = seg;
+        // statistics: the two wave rows through LDS, one partial row per 128-row tile like the other epilogues
+        lds_barrier();
+        float *red = smem;                                            // [WARPS_M][5][BN]
+        const int cc = wns * WN + lane;
+        red[(wms * 5 + 0) * BN + cc] = t1; red[(wms * 5 + 1) * BN + cc] = t2;
+        red[(wms * 5 + 2) * BN + cc] = q0; red[(wms * 5 + 3) * BN + cc] = q1; red[(wms * 5 + 4) * BN + cc] = q2;
+        lds_barrier();
+        for (int e = tid; e < 5 * BN; e += G_THREADS) {
+            const int which = e / BN, col = e % BN;
+            p.stats[((long long)tm * 5 + which) * p.N + n0 + col] = red[(0 * 5 + which) * BN + col] + red[(1 * 5 + which) * BN + col];
+        }
+        stats_done = true;
+    };
+    if constexpr (GATHER_S) seg_epilogue(0);
+    else
     if (fast_epi && epilogue_kind(p) == EPI) {
         if constexpr (BM == 128 && EPI <= 1) direct_epilogue(std::integral_constant<int, EPI>{});
         else if constexpr (BM == 128 && BN == 128) wave_epilogue(std::integral_constant<int, EPI>{});
@@ -1545,6 +1639,29 @@ extern "C" int cmf_gemm_dx_gather(int M, int cin, int cout, const float *dZ, lon
     g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz;
     g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
     return launch<128, 128, false, false, 4, 3>(g, st);
+}
+
+// The same data gradient when only its per-source-point sums are needed (the grouping's backward pass sums it over the slots that
+// reference a point): the rows walk the slots in inverse-index order -- arows[m] = the slot (row of dZ) at position m, pts[m] = its
+// source point (row of Y), dxyz2 (M,4) its relative coordinates, all three in that order -- and instead of dU the kernel writes, for
+// every run of equal source points inside a 64-row range, the run's column sums to pieces[(point + m / 64)][cin]
+// (P + M / 64 rows suffice).  The sum of a point's pieces, in range order, equals the sum of cmf_gemm_dx_gather's rows over its slots
+// up to fp32 association; the five statistics are the same sums in another order.
+extern "C" int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ, long long ldz, const float *W, long long ldw,
+                                      const float *Y, long long ldy, const int *arows, const int *pts, const float *dxyz2,
+                                      const float *wx3, const float *ea, const float *ec, const float *emean, const float *einvstd,
+                                      float *pieces, float *stats, void *stream)
+{
+    CMF_CHECK_ARG(M > 0 && cin > 0 && cout > 0 && M % 128 == 0 && cin % 128 == 0 && cout % G_BK == 0);
+    CMF_CHECK_ARG(dZ && W && Y && arows && pts && dxyz2 && wx3 && ea && ec && emean && einvstd && pieces && stats);
+    CMF_CHECK_ARG(ldz % 4 == 0 && ldw % 4 == 0 && ldy % 4 == 0);
+    CMF_CHECK_ARG((((uintptr_t)dZ | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)dxyz2) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{};
+    g.M = M; g.N = cin; g.K = cout; g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = pieces; g.ldc = cin;
+    g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz2;
+    g.ga_rows = pts; g.ga_dxyz = dxyz2; g.ga_wx = wx3; g.ga_arows = arows; g.ga_pieces = pieces; g.split_k = 1;
+    return launch<128, 128, false, false, 4, 4>(g, st);
 }
 
 // Weight gradient of the set-conv layer behind the hoisted first conv with that first layer formed in the B-operand staging instead

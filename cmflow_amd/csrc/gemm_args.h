@@ -37,6 +37,10 @@ struct GemmArgs {
     //   act( Y[ga_rows[m]][k] + wx0[k] dx_m + wx1[k] dy_m + wx2[k] dz_m )   -- the set-conv first layer, never materialised
     // A points at Y (row pitch lda), ga_dxyz holds (dx, dy, dz, 0) per row, ga_wx the three planes [3][K]; act = pro_a / pro_c
     const int *ga_rows; const float *ga_dxyz; const float *ga_wx;
+    // GMODE 4 (cmf_gemm_dx_gather_sum): the rows of the data gradient walk the neighbour slots in inverse-index order (sorted by source
+    // point): ga_arows[m] = the row of A for output row m, ga_rows[m] = its source point; nothing of C is stored -- the sums over runs of
+    // equal source points inside a 64-row range go to ga_pieces[(point + range)][N]
+    const int *ga_arows; float *ga_pieces;
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
     int no_direct;              // diagnostics (env CMF_GEMM_NO_DIRECT=1): register-staged main loop everywhere

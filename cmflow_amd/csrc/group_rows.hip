@@ -377,7 +377,7 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
     const float *__restrict__ wx, long long ldw, const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
     const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
     const float *__restrict__ sums, float inv_count,
-    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg)
+    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg, const float *__restrict__ pieces)
 {
     // a wave owns (source point, block of 256 columns): the inverse lists are skewed (first-hit padding: some are 10x the
     // mean), and one wave walking a long list once per column block set the pace of the launch's tail
@@ -409,6 +409,18 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
     for (int col = cb * CMF_WAVE * 4 + lane * 4; col < min(c, (cb + 1) * CMF_WAVE * 4); col += CMF_WAVE * 4) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         int t = beg;
+        if (pieces) {
+            // the sums over the point's slots were formed by the data-gradient GEMM itself (cmf_gemm_dx_gather_sum), one piece per 64-row
+            // range of the inverse-ordered slots the list touches: rows (point + range) of `pieces`, added in range order
+            if (end > beg) {
+                const long long o0 = (long long)bs * entries + beg, o1 = (long long)bs * entries + end, pt = (long long)bs * n + j;
+                for (long long R = o0 / 64; R <= (o1 - 1) / 64; ++R) {
+                    const float4 u0 = *(const float4 *)(pieces + (size_t)(pt + R) * c + col);
+                    acc.x += u0.x; acc.y += u0.y; acc.z += u0.z; acc.w += u0.w;
+                }
+            }
+            t = end;
+        }
         for (; DEEP && t + 16 <= end; t += 16) {            // 16 rows in flight; the sum keeps ascending entry order
             int e[16];
             float4 u[16];
@@ -461,10 +473,35 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
     }
 }
 
+int cmf_group_rows_grad_bn_cf_impl(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,
+                                   const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
+                                   const float *a, const float *mean, const float *invstd, const float *sums,
+                                   float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, const float *pieces, void *stream);
+
 extern "C" int cmf_group_rows_grad_bn_cf(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,
                                          const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
                                          const float *a, const float *mean, const float *invstd, const float *sums,
                                          float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream)
+{
+    return cmf_group_rows_grad_bn_cf_impl(b, n, c, entries, S, dU, y, ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets, inv,
+                                          grad_feat, ldg, nullptr, stream);
+}
+
+// ... with the per-point sums of dU already formed by cmf_gemm_dx_gather_sum (pieces, see there): dU is not read
+extern "C" int cmf_group_rows_grad_bn_cf_pieces(int b, int n, int c, int entries, int S, const float *pieces, const float *y, long long ldy,
+                                                const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
+                                                const float *a, const float *mean, const float *invstd, const float *sums,
+                                                float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream)
+{
+    CMF_CHECK_ARG(pieces && ((uintptr_t)pieces & 15) == 0);
+    return cmf_group_rows_grad_bn_cf_impl(b, n, c, entries, S, pieces, y, ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets, inv,
+                                          grad_feat, ldg, pieces, stream);
+}
+
+int cmf_group_rows_grad_bn_cf_impl(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,
+                                   const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
+                                   const float *a, const float *mean, const float *invstd, const float *sums,
+                                   float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, const float *pieces, void *stream)
 {
     CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && c % 4 == 0 && entries >= 0 && S > 0 && entries % S == 0 && ldg >= c && ldg % 4 == 0);
     if (b == 0) return 0;
@@ -477,11 +514,11 @@ extern "C" int cmf_group_rows_grad_bn_cf(int b, int n, int c, int entries, int S
     if (S >= 32)
         hipLaunchKernelGGL(group_rows_grad_bn_cf_kernel<true>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
                            n, c, entries, S, (int)waves, dU, y, ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets, inv,
-                           grad_feat, ldg);
+                           grad_feat, ldg, pieces);
     else
         hipLaunchKernelGGL(group_rows_grad_bn_cf_kernel<false>, dim3(grid), dim3(GR_THREADS), 0, (hipStream_t)stream,
                            n, c, entries, S, (int)waves, dU, y, ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets, inv,
-                           grad_feat, ldg);
+                           grad_feat, ldg, pieces);
     return cmf_launch_status();
 }
 

@@ -767,6 +767,33 @@ extern "C" int cmf_group_prep(int b, int n_src, int P, int S, int C, const float
     return cmf_launch_status();
 }
 
+// The neighbour slots in inverse-index order (sorted by source point, ascending slot inside a point's list) for
+// cmf_gemm_dx_gather_sum: position m = sample * entries + t holds slot perm[m] = sample * entries + inv[sample][t], its source point
+// and its relative coordinates.
+__global__ __launch_bounds__(PW_THREADS) void group_perm_kernel(long long total, int entries, const int *__restrict__ inv, const int *__restrict__ rows,
+                                                                const float *__restrict__ dxyz, int *__restrict__ perm, int *__restrict__ pts,
+                                                                float *__restrict__ dxyz2)
+{
+    const long long m = (long long)blockIdx.x * PW_THREADS + threadIdx.x;
+    if (m >= total) return;
+    const long long r = m / entries * entries + inv[m];
+    perm[m] = (int)r;
+    pts[m] = rows[r];
+    *(float4 *)(dxyz2 + (size_t)m * 4) = *(const float4 *)(dxyz + (size_t)r * 4);
+}
+
+extern "C" int cmf_group_perm(int b, int entries, const int *inv, const int *rows, const float *dxyz, int *perm, int *pts, float *dxyz2, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && entries > 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(inv && rows && dxyz && perm && pts && dxyz2 && (((uintptr_t)dxyz | (uintptr_t)dxyz2) & 15) == 0);
+    const long long total = (long long)b * entries;
+    CMF_CHECK_ARG(total < (1ll << 31));
+    hipLaunchKernelGGL(group_perm_kernel, dim3((unsigned)cmf_divup(total, PW_THREADS)), dim3(PW_THREADS), 0, (hipStream_t)stream, total, entries, inv, rows,
+                       dxyz, perm, pts, dxyz2);
+    return cmf_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // out[p, :] = max_s relu(a*z[p,s,:] + c)   (radarflow_util.py:151-155 fused: BN + ReLU + max over the ball)
 // argmax (uint8, first maximum) is kept for the backward pass.  out may be a column slice (ldo).

@@ -234,6 +234,15 @@ int cmf_gemm_dx_gather(int M, int cin, int cout, const float *dZ, long long ldz,
                        float *dU, long long ldu, const float *Y, long long ldy, const int *rows, const float *dxyz,
                        const float *wx3, const float *ea, const float *ec, const float *emean, const float *einvstd,
                        float *stats, void *stream);
+/* ... and the same data gradient when only its sums per source point are needed (the grouping's backward pass): the rows walk the
+ * slots in inverse-index order (cmf_group_perm: arows[m] the slot at position m, pts[m] its source point, dxyz2 its relative
+ * coordinates) and the kernel stores no dU -- for every run of equal source points inside a 64-row range it writes the run's column
+ * sums to pieces[(point + m / 64)][cin] (P + M / 64 rows), which cmf_group_rows_grad_bn_cf_pieces adds per point in range order. */
+int cmf_group_perm(int b, int entries, const int *inv, const int *rows, const float *dxyz, int *perm, int *pts, float *dxyz2, void *stream);
+int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ, long long ldz, const float *W, long long ldw,
+                           const float *Y, long long ldy, const int *arows, const int *pts, const float *dxyz2,
+                           const float *wx3, const float *ea, const float *ec, const float *emean, const float *einvstd,
+                           float *pieces, float *stats, void *stream);
 int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const float *dZ, long long ldz, const float *Y, long long ldy,
                        const int *rows, const float *dxyz, const float *wx3, const float *prob_a, const float *prob_c,
                        float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream);
@@ -321,6 +330,11 @@ int cmf_group_rows_grad_bn_cf(int b, int n, int c, int entries, int S, const flo
                               const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
                               const float *a, const float *mean, const float *invstd, const float *sums,
                               float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream);
+/* ... with the sums of dU over every point's slots already formed by cmf_gemm_dx_gather_sum (`pieces`): dU is not read */
+int cmf_group_rows_grad_bn_cf_pieces(int b, int n, int c, int entries, int S, const float *pieces, const float *y, long long ldy,
+                                     const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
+                                     const float *a, const float *mean, const float *invstd, const float *sums,
+                                     float inv_count, const int *offsets, const int *inv, float *grad_feat, int ldg, void *stream);
 
 /* dW_xyz of the set-conv's first conv from column sums only (no pass over the grouped tensor):
  *   dWx[c,k] = a_c*( q_k[c] - (s1_c/M)*u_k - (s2_c/M)*invstd_c*(tz_k[c] - mean_c*u_k) )

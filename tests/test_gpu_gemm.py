@@ -857,3 +857,65 @@ def test_gather_data_gradient_is_bit_identical_to_the_materialised_path(dev, B, 
                                     dq.data_ptr(), wx3.data_ptr(), ea.data_ptr(), ec.data_ptr(), em.data_ptr(), ei.data_ptr(), gs.data_ptr(), st), "dxg")
     assert torch.equal(got, want), float((got - want).abs().max())
     assert torch.equal(gs, ws)
+
+
+@pytest.mark.parametrize("B,N,S,K,NO,r", [(4, 256, 8, 512, 256, 4.0), (2, 256, 32, 128, 64, 16.0), (8, 256, 16, 256, 128, 8.0), (1, 128, 4, 128, 16, 2.0)])
+def test_gather_data_gradient_summed_per_source_point(dev, B, N, S, K, NO, r):
+    """cmf_group_perm + cmf_gemm_dx_gather_sum + cmf_group_rows_grad_bn_cf_pieces (the data gradient into the first layer never
+    stored: rows in inverse-index order, runs of equal source points reduced in the GEMM's epilogue) against cmf_gemm_dx_gather +
+    cmf_group_rows_grad_bn_cf: the five statistics and the per-point result agree up to fp32 association (1e-5 of the column's
+    absolute sums), twice = bit-reproducible."""
+    from cmflow_amd import _lib, synth, fused_blocks as FB, pointnet2_utils as pu
+    from cmflow_amd.fused import Neighbors
+    L = _lib.lib()
+    torch.manual_seed(B * 10 + S)
+    xyz = synth.make_batch(B, N=N, seed=17)["pc1"].to(dev).transpose(1, 2).contiguous()
+    idx = pu.ball_query(r, S, xyz, xyz)
+    off, inv = Neighbors(idx, N).inverse()
+    M, P, E = B * N * S, B * N, N * S
+    y = torch.randn(B, N, 2 * K, device=dev)[:, :, :K]
+    wx = torch.randn(K, 3, device=dev)
+    ea, ec, em, ei = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3, torch.randn(K, device=dev), torch.rand(K, device=dev) + 0.5
+    dZ = torch.randn(M, NO, device=dev); W = torch.randn(NO, K, device=dev)
+    st = _lib.stream_ptr()
+    rows = torch.empty(M, dtype=torch.int32, device=dev); dq = torch.empty(M, 4, device=dev); wx3 = torch.empty(3, K, device=dev)
+    _lib.check(L.cmf_group_prep(B, N, N, S, K, xyz.data_ptr(), xyz.data_ptr(), wx.data_ptr(), 3, idx.data_ptr(), rows.data_ptr(),
+                                dq.data_ptr(), wx3.data_ptr(), st), "prep")
+    tiles = M // 128
+    dU, s_ref = torch.empty(M, K, device=dev), torch.empty(tiles, 5, K, device=dev)
+    _lib.check(L.cmf_gemm_dx_gather(M, K, NO, dZ.data_ptr(), NO, W.data_ptr(), K, dU.data_ptr(), K, y.data_ptr(), y.stride(1), rows.data_ptr(),
+                                    dq.data_ptr(), wx3.data_ptr(), ea.data_ptr(), ec.data_ptr(), em.data_ptr(), ei.data_ptr(), s_ref.data_ptr(), st), "dxg")
+    sums = s_ref.double().sum(0).float().contiguous()
+    want = torch.empty(B, N, K, device=dev)
+    args = (y.data_ptr(), y.stride(1), wx.data_ptr(), 3, xyz.data_ptr(), xyz.data_ptr(), ea.data_ptr(), em.data_ptr(), ei.data_ptr(), sums.data_ptr(),
+            1.0 / M, off.data_ptr(), inv.data_ptr())
+    _lib.check(L.cmf_group_rows_grad_bn_cf(B, N, K, E, S, dU.data_ptr(), *args, want.data_ptr(), K, st), "cf")
+    perm = torch.empty(M, dtype=torch.int32, device=dev); pts = torch.empty(M, dtype=torch.int32, device=dev); dq2 = torch.empty(M, 4, device=dev)
+    _lib.check(L.cmf_group_perm(B, E, inv.data_ptr(), rows.data_ptr(), dq.data_ptr(), perm.data_ptr(), pts.data_ptr(), dq2.data_ptr(), st), "perm")
+    assert torch.equal(pts, rows[perm.long()]) and torch.equal(dq2, dq[perm.long()]) and bool((pts[1:] >= pts[:-1]).all())
+    outs = []
+    for _ in range(2):
+        pieces = torch.full((P + M // 64, K), float("nan"), device=dev)
+        s_got = torch.empty(tiles, 5, K, device=dev)
+        _lib.check(L.cmf_gemm_dx_gather_sum(M, K, NO, dZ.data_ptr(), NO, W.data_ptr(), K, y.data_ptr(), y.stride(1), perm.data_ptr(), pts.data_ptr(),
+                                            dq2.data_ptr(), wx3.data_ptr(), ea.data_ptr(), ec.data_ptr(), em.data_ptr(), ei.data_ptr(),
+                                            pieces.data_ptr(), s_got.data_ptr(), st), "dxs")
+        got = torch.empty(B, N, K, device=dev)
+        _lib.check(L.cmf_group_rows_grad_bn_cf_pieces(B, N, K, E, S, pieces.data_ptr(), *args, got.data_ptr(), K, st), "cfp")
+        outs.append((got, s_got))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    got, s_got = outs[0]
+    assert not bool(torch.isnan(got).any())
+    # statistics: the same terms in another order
+    absum = torch.zeros(5, K, dtype=torch.float64, device=dev)
+    d64 = dU.double()
+    zhat = ((FB.group_affine(y, None, xyz, xyz, wx, idx, act=0, stats=False)[0].view(M, K).double() - em.double()) * ei.double())
+    terms = [d64, d64 * zhat, d64 * dq[:, 0:1].double(), d64 * dq[:, 1:2].double(), d64 * dq[:, 2:3].double()]
+    for k in range(5):
+        absum[k] = terms[k].abs().sum(0)
+        assert bool(((s_got[:, k].double().sum(0) - terms[k].sum(0)).abs() <= 2e-6 * absum[k] + 1e-5).all()), k
+    # the per-point result: against the materialised form, scaled by the absolute sums that go into a point
+    scale = torch.zeros(P, K, dtype=torch.float64, device=dev).index_add_(0, rows.long(), d64.abs())
+    err = (got.view(P, K).double() - want.view(P, K).double()).abs()
+    bound = 1e-5 * (scale * ea.double().abs() + 1.0) + 1e-4 * want.view(P, K).double().abs().clamp(max=1.0)
+    assert bool((err <= bound).all()), float((err / bound).max())
