@@ -1050,14 +1050,16 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
     // of a point in range order (deterministic).  The 1 GB the M x N gradient took at the largest scale is neither written nor read.
     auto seg_epilogue = [&](auto only_when_called) {
         static_assert(WM == 64 && WN == 64 && TM == 2 && TN == 2, "wave tile 64 x 64");
-        constexpr int S_SZ = 32 * 64 + 64 * 4 + 64;                   // per wave: transposition tile | dxyz rows | source points
+        constexpr int S_SZ = 32 * 64 + 64 * 4;                        // per wave: transposition tile | dxyz rows
         float *wt = smem + wid * S_SZ, *wdq = wt + 32 * 64;
-        int *wpt = reinterpret_cast<int *>(wdq + 64 * 4);
         const int wms = __builtin_amdgcn_readfirstlane(wm), wns = __builtin_amdgcn_readfirstlane(wn);
         const int rbase = m0 + wms * WM;
         const int c = n0 + wns * WN + lane;                           // this lane's column
         *(f32x4 *)(wdq + lane * 4) = *(const f32x4 *)(p.dxyz + (long long)(rbase + lane) * 4);
-        wpt[lane] = p.ga_rows[rbase + lane];
+        // the source point of row `lane` stays in the lane (read per row with v_readlane); the rows where it changes as a wave mask
+        const int ptv = p.ga_rows[rbase + lane];
+        const int ptb = __shfl_up(ptv, 1, 64);
+        const unsigned long long starts = __ballot(lane == 0 || ptv != ptb);
         const float k0 = p.ea[c], k1 = p.ec[c], k2 = p.emean[c], k3 = p.einvstd[c];
         const float g0 = p.ga_wx[c], g1 = p.ga_wx[(long long)p.N + c], g2 = p.ga_wx[2ll * p.N + c];
         const long long range = rbase / 64;
@@ -1065,27 +1067,26 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         float *pcol = p.ga_pieces + c;
         float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, seg = 0.f;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (wave-private LDS: the wave's own writes above, in order)
-        int pt_prev = -1;
+        int pt_cur = 0;
         // the per-point rows of 8 output rows at a time, requested one group ahead (rows of one run re-read the same 256 bytes)
         float ya[8], yb[8];
         auto load_y = [&](int row0, float (&y)[8]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) y[u] = ycol[(long long)wpt[row0 + u] * p.ldz];
+            for (int u = 0; u < 8; ++u) y[u] = ycol[(long long)__builtin_amdgcn_readlane(ptv, row0 + u) * p.ldz];
         };
         auto rows8 = [&](int i, int row0, const float (&y)[8]) {       // rows row0 .. row0 + 7 of the wave tile (block row i)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = row0 + u;
-                const int pt = __builtin_amdgcn_readfirstlane(wpt[row]);
-                if (pt != pt_prev) {
-                    if (pt_prev >= 0) pcol[((long long)pt_prev + range) * p.N] = seg;
-                    seg = 0.f; pt_prev = pt;
+                if ((starts >> row) & 1ull) {                        // wave-uniform: a run of equal source points begins
+                    if (row > 0) { pcol[((long long)pt_cur + range) * p.N] = seg; t1 += seg; }
+                    seg = 0.f; pt_cur = __builtin_amdgcn_readlane(ptv, row);
                 }
                 const f32x4 d4 = *(const f32x4 *)(wdq + row * 4);
                 float x = wt[(row - i * 32) * 64 + lane];
                 const float z = y[u] + fmaf(g2, d4.z, fmaf(g1, d4.y, g0 * d4.x));
                 x = (fmaf(k0, z, k1) > 0.f) ? x : 0.f;
-                t1 += x; t2 += x * ((z - k2) * k3);
+                t2 += x * ((z - k2) * k3);
                 q0 += x * d4.x; q1 += x * d4.y; q2 += x * d4.z;
                 seg += x;
             }
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is read before the next block row overwrites it
         }
-        pcol[((long long)pt_prev + range) * p.N] = seg;
+        pcol[((long long)pt_cur + range) * p.N] = seg; t1 += seg;    // (s1 = the sum of the runs' sums)
         // statistics: the two wave rows through LDS, one partial row per 128-row tile like the other epilogues
         lds_barrier();
         float *red = smem;                                            // [WARPS_M][5][BN]

@@ -265,6 +265,27 @@ float *gather_wx3(const Layout &L, long long M) { return L.z1 + (M + 3) / 4 * 4;
 
 // bwd_layer for the layer behind the gathered first layer: BN-backward sums, BN backward in place, weight gradient and masked data
 // gradient with the first layer formed in their operand / epilogue paths
+// ... and, when the input gradient is wanted, without the data gradient into the first layer either (M x O1 again): the GEMM walks the
+// slots in inverse-index order and reduces runs of equal source points in its epilogue (cmf_gemm_dx_gather_sum); the scatter at the end
+// of the block adds a point's pieces.  CMF_TRAIN_GATHER_SUM=0 keeps the stored gradient (A/B).  The slot of dU1 holds the pieces, the
+// permutation, the permuted source points and relative coordinates.
+bool train_gather_sum(const cmf_setconv_desc *d)
+{
+    static const bool on = !(getenv("CMF_TRAIN_GATHER_SUM") && getenv("CMF_TRAIN_GATHER_SUM")[0] == '0');
+    return on && train_gather(d) && d->dy != nullptr && d->S >= 2;
+}
+struct SumSlots { float *pieces; int *perm, *pts; float *dq2; };
+SumSlots sum_slots(const cmf_setconv_desc *d, const Layout &L)
+{
+    const long long P = (long long)d->B * d->N, M = P * d->S;
+    SumSlots s;
+    s.pieces = L.dU1;
+    s.perm = reinterpret_cast<int *>(L.dU1 + (P + M / 64) * d->O1);
+    s.pts = s.perm + M;
+    s.dq2 = reinterpret_cast<float *>(s.pts + M);
+    return s;
+}
+
 int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, int C2, int O1, void *st)
 {
     const float *b = L.bn[1], *b0 = L.bn[0];
@@ -275,6 +296,12 @@ int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, i
         const int split = dw_split(M, C2, O1);
         CMF_TRY(cmf_gemm_dw_gather(C2, O1, M, L.dU2, C2, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M), b0 + 2 * O1, b0 + 3 * O1,
                                    d->dw[0], O1, split, split > 1 ? L.splitk : nullptr, d->acc_w[0], st));
+    }
+    if (train_gather_sum(d)) {
+        const SumSlots q = sum_slots(d, L);
+        CMF_TRY(cmf_group_perm(d->B, d->N * d->S, L.inv, gather_rows(L), L.dxyz, q.perm, q.pts, q.dq2, st));
+        return cmf_gemm_dx_gather_sum((int)M, O1, C2, L.dU2, C2, d->w[0], O1, d->y, d->ldy, q.perm, q.pts, q.dq2, gather_wx3(L, M),
+                                      b0 + 2 * O1, b0 + 3 * O1, b0, b0 + O1, q.pieces, L.partial, st);
     }
     return cmf_gemm_dx_gather((int)M, O1, C2, L.dU2, C2, d->w[0], O1, L.dU1, O1, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M),
                               b0 + 2 * O1, b0 + 3 * O1, b0, b0 + O1, L.partial, st);
@@ -550,6 +577,11 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
     if (d->dy) {
         // z1 rows of one source point differ only by wx . dxyz: the BN-backward part of the scatter has a closed form,
         // so only dU1 is streamed (csrc/group_rows.hip)
+        if (train_gather_sum(d))
+            CMF_TRY(cmf_group_rows_grad_bn_cf_pieces(d->B, d->N, O1, d->N * d->S, d->S, sum_slots(d, L).pieces, d->y, d->ldy, d->wx, d->ldwx, d->xyz,
+                                                     d->xyz, b0 + 2 * O1, b0, b0 + O1, L.sums, (float)(1.0 / (double)M), L.offsets, L.inv, d->dy,
+                                                     d->lddy ? (int)d->lddy : O1, st));
+        else
         CMF_TRY(cmf_group_rows_grad_bn_cf(d->B, d->N, O1, d->N * d->S, d->S, L.dU1, d->y, d->ldy, d->wx, d->ldwx, d->xyz, d->xyz,
                                           b0 + 2 * O1, b0, b0 + O1, d->training ? L.sums : nullptr, (float)(1.0 / (double)M),
                                           L.offsets, L.inv, d->dy, d->lddy ? (int)d->lddy : O1, st));

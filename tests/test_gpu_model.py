@@ -347,7 +347,7 @@ def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, t
     library reads its switches once.)"""
     import subprocess, sys
     outs = []
-    for i, env in enumerate((dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1"))):
+    for i, env in enumerate((dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1", CMF_TRAIN_GATHER_SUM="0"))):
         f = str(tmp_path / ("step%d.pt" % i))
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"], env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=900)
@@ -357,6 +357,32 @@ def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, t
     assert a.keys() == b.keys() and len(a) > 300
     bad = [k for k in a if not torch.equal(a[k], b[k])]
     assert not bad, bad[:10]
+
+
+def test_summed_data_gradient_changes_nothing_but_the_association(dev, tmp_path):
+    """Default (CMF_TRAIN_GATHER_SUM=0 switches it off): the data gradient into the second encoder's first layer is not stored either --
+    the GEMM reduces it over runs of equal source points (cmf_gemm_dx_gather_sum).  Same terms, another association: against the
+    stored form the loss and everything computed in the forward pass are bit-identical, every gradient within 2e-5 of its norm
+    (the oracle comparison at this size, test_full_size_train_step_matches_oracle, runs the default)."""
+    import subprocess, sys
+    outs = []
+    for i, env in enumerate((dict(CMF_TRAIN_GATHER_SUM="0"), dict(CMF_TRAIN_GATHER_SUM="1"))):
+        f = str(tmp_path / ("step%d.pt" % i))
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(f))
+    a, b = outs
+    assert a.keys() == b.keys() and torch.equal(a["loss"], b["loss"])
+    worst = 0.0
+    for k in a:
+        if k.startswith("b."):
+            assert torch.equal(a[k], b[k]), k                          # BN buffers: forward only
+        elif k.startswith("g."):
+            rel = float((a[k].double() - b[k].double()).norm() / (a[k].double().norm() + 1e-30))
+            worst = max(worst, rel)
+            assert rel <= 2e-5, (k, rel)
+    print("summed data gradient: worst relative gradient difference %.3g" % worst)
 
 
 def test_full_size_train_step_matches_oracle(dev):
