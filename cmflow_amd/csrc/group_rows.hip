@@ -473,6 +473,76 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
     }
 }
 
+// Narrow rows (c = 16 .. 128: the first encoder's 32 channels): LPP = c / 4 lanes own a source point and a wave walks 64 / LPP lists at
+// once -- the kernel above gives a wave one point and 256 columns, which left 56 of 64 lanes idle at c = 32 (0.5 TB/s).  Same order
+// of the row sums (ascending entries); D_j is reduced over the LPP lanes of the point.
+template <int LPP>
+__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_narrow_kernel(
+    int n, int entries, int S, long long points, const float *__restrict__ dU, const float *__restrict__ y, long long ldy,
+    const float *__restrict__ wx, long long ldw, const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
+    const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ sums, float inv_count,
+    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg)
+{
+    constexpr int PPW = CMF_WAVE / LPP, c = LPP * 4;
+    const long long gwave = ((long long)blockIdx.x * GR_THREADS + threadIdx.x) / CMF_WAVE;
+    const int lane = threadIdx.x % CMF_WAVE, sub = lane / LPP, sl = lane % LPP;
+    const long long pt = gwave * PPW + sub;
+    const bool live = pt < points;
+    const int bs = live ? (int)(pt / n) : 0, j = live ? (int)(pt - (long long)bs * n) : 0;
+    const int *off = offsets + (size_t)bs * (n + 1);
+    const int beg = live ? off[j] : 0, end = live ? off[j + 1] : 0;
+    const int *lst = inv + (size_t)bs * entries;
+    const float *gu = dU + (size_t)bs * entries * c;
+    const int col = sl * 4;
+    float Dx = 0.f, Dy = 0.f, Dz = 0.f;
+    if (sums) {
+        const float *xs = xyz_src + ((size_t)bs * n + j) * 3;
+        const float sx = xs[0], sy = xs[1], sz = xs[2];
+        const float *xc = xyz_ctr + (size_t)bs * (entries / S) * 3;
+        for (int t = beg + sl; t < end; t += LPP) {
+            const int p = lst[t] / S;
+            Dx += sx - xc[p * 3]; Dy += sy - xc[p * 3 + 1]; Dz += sz - xc[p * 3 + 2];
+        }
+#pragma unroll
+        for (int m = LPP / 2; m > 0; m >>= 1) { Dx += __shfl_xor(Dx, m, CMF_WAVE); Dy += __shfl_xor(Dy, m, CMF_WAVE); Dz += __shfl_xor(Dz, m, CMF_WAVE); }
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int t = beg;
+    for (; t + 8 <= end; t += 8) {                          // 8 rows in flight, ascending entry order
+        int e[8];
+        float4 u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = lst[t + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = *(const float4 *)(gu + (size_t)e[q] * c + col);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { acc.x += u[q].x; acc.y += u[q].y; acc.z += u[q].z; acc.w += u[q].w; }
+    }
+    for (; t < end; ++t) {
+        const float4 u0 = *(const float4 *)(gu + (size_t)lst[t] * c + col);
+        acc.x += u0.x; acc.y += u0.y; acc.z += u0.z; acc.w += u0.w;
+    }
+    if (!live) return;
+    const float cnt = (float)(end - beg);
+    const float4 sa = *(const float4 *)(a + col);
+    float r[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (sums) {
+        const float4 t1 = *(const float4 *)(sums + col), t2 = *(const float4 *)(sums + c + col);
+        const float4 is = *(const float4 *)(invstd + col), mu = *(const float4 *)(mean + col);
+        const float4 yv = *(const float4 *)(y + ((size_t)bs * n + j) * ldy + col);
+        const float s1[4] = {t1.x, t1.y, t1.z, t1.w}, s2[4] = {t2.x, t2.y, t2.z, t2.w}, iv[4] = {is.x, is.y, is.z, is.w};
+        const float ym[4] = {yv.x - mu.x, yv.y - mu.y, yv.z - mu.z, yv.w - mu.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *w = wx + (size_t)(col + i) * ldw;
+            const float zsum = cnt * ym[i] + (w[0] * Dx + w[1] * Dy + w[2] * Dz);
+            r[i] = r[i] - cnt * (s1[i] * inv_count) - (iv[i] * s2[i] * inv_count) * zsum;
+        }
+    }
+    *(float4 *)(grad_feat + ((size_t)bs * n + j) * ldg + col) = make_float4(sa.x * r[0], sa.y * r[1], sa.z * r[2], sa.w * r[3]);
+}
+
 int cmf_group_rows_grad_bn_cf_impl(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,
                                    const float *wx, long long ldw, const float *xyz_src, const float *xyz_ctr,
                                    const float *a, const float *mean, const float *invstd, const float *sums,
@@ -508,6 +578,16 @@ int cmf_group_rows_grad_bn_cf_impl(int b, int n, int c, int entries, int S, cons
     CMF_CHECK_ARG(dU && a && offsets && inv && grad_feat);
     CMF_CHECK_ARG(!sums || (y && wx && xyz_src && xyz_ctr && mean && invstd && ldy >= c && ldy % 4 == 0 && ldw >= 3));
     CMF_CHECK_ARG((((uintptr_t)dU | (uintptr_t)y | (uintptr_t)grad_feat | (uintptr_t)a) & 15) == 0);
+    if (!pieces && (c == 16 || c == 32 || c == 64 || c == 128)) {
+        const int lpp = c / 4;
+        const long long points = (long long)b * n, nw = (points * lpp + CMF_WAVE - 1) / CMF_WAVE;
+        const dim3 grid((unsigned)((nw * CMF_WAVE + GR_THREADS - 1) / GR_THREADS));
+#define CMF_GRN(L) hipLaunchKernelGGL(group_rows_grad_bn_cf_narrow_kernel<L>, grid, dim3(GR_THREADS), 0, (hipStream_t)stream, n, entries, S, points, dU, y, \
+                                      ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets, inv, grad_feat, ldg)
+        if (lpp == 4) CMF_GRN(4); else if (lpp == 8) CMF_GRN(8); else if (lpp == 16) CMF_GRN(16); else CMF_GRN(32);
+#undef CMF_GRN
+        return cmf_launch_status();
+    }
     const long long waves = (long long)b * n * ((c + CMF_WAVE * 4 - 1) / (CMF_WAVE * 4));
     CMF_CHECK_ARG(waves * CMF_WAVE < (1ll << 31));
     const int grid = (int)((waves * CMF_WAVE + GR_THREADS - 1) / GR_THREADS);

@@ -342,7 +342,8 @@ def test_product_refuses_cpu_tensors():
         ball_query(1.0, 2, x, x)
 
 
-@pytest.mark.parametrize("B,N,S,C,r", [(4, 256, 16, 64, 6.0), (2, 100, 8, 32, 3.0), (3, 64, 32, 512, 50.0), (1, 50, 4, 8, 0.01)])
+@pytest.mark.parametrize("B,N,S,C,r", [(4, 256, 16, 64, 6.0), (2, 100, 8, 32, 3.0), (3, 64, 32, 512, 50.0), (1, 50, 4, 8, 0.01),
+                                        (8, 256, 32, 32, 16.0), (3, 77, 16, 16, 4.0), (2, 256, 4, 128, 2.0), (5, 33, 8, 32, 100.0)])
 def test_group_rows_grad_bn_closed_form(dev, B, N, S, C, r):
     """Set-conv first-layer backward (radarflow_util.py:148-151): the scatter with the BN backward folded in, once
     reading z (cmf_group_rows_grad_bn) and once from the closed form over per-point rows (cmf_group_rows_grad_bn_cf),
