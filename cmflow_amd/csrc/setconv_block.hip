@@ -257,7 +257,9 @@ bool train_gather(const cmf_setconv_desc *d)
 {
     static const bool on = !(getenv("CMF_TRAIN_GATHER") && getenv("CMF_TRAIN_GATHER")[0] == '0');
     const long long M = (long long)d->B * d->N * d->S;
-    return on && d->training && M % 128 == 0 && M < (1ll << 31) && d->C[0] % 128 == 0 && d->O1 % 128 == 0 && d->ldy % 4 == 0 &&
+    // (train-mode or eval-mode BatchNorm alike: with eval-mode statistics -- the regime of every epoch after the first in the reference's
+    //  training loop -- the forward pass is the inference form and the backward pass the same two gathering GEMMs)
+    return on && M % 128 == 0 && M < (1ll << 31) && d->C[0] % 128 == 0 && d->O1 % 128 == 0 && d->ldy % 4 == 0 &&
            (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0;
 }
 int *gather_rows(const Layout &L) { return reinterpret_cast<int *>(L.z1); }
@@ -291,7 +293,7 @@ int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, i
     const float *b = L.bn[1], *b0 = L.bn[0];
     if (d->acc_bn[1]) CMF_TRY(cmf_colsum_finalize(tiles128(M), C2, L.partial, L.sums, d->dbeta[1], d->dgamma[1], st));
     else CMF_TRY(cmf_colsum_store(tiles128(M), 2 * C2, L.partial, L.sums, C2, d->dbeta[1], d->dgamma[1], st));
-    CMF_TRY(cmf_bn_bwd_apply(M, C2, L.dU2, L.z2, C2, b + 2 * C2, b, b + C2, L.sums, st));
+    CMF_TRY(cmf_bn_bwd_apply(M, C2, L.dU2, L.z2, C2, b + 2 * C2, b, b + C2, d->training ? L.sums : nullptr, st));
     if (d->dw[0]) {
         const int split = dw_split(M, C2, O1);
         CMF_TRY(cmf_gemm_dw_gather(C2, O1, M, L.dU2, C2, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M), b0 + 2 * O1, b0 + 3 * O1,
@@ -333,9 +335,9 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     // inference (eval-mode BN and no backward call to follow): the grouped first-layer tensor z1 (M x O1: 1 GB at the largest scale of
     // the second encoder) is never written -- the second layer's GEMM gathers the per-point rows and forms the layer in its A-operand
     // path (cmf_gemm_gather_affine, bit-identical); the slot of z1 holds the M source-row indices and the coordinate planes of Wx
-    const bool gather = !d->training && d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
-                        (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31);
-    if (train_gather(d)) {
+    const bool gather = !d->training && ((d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
+                                          (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31)) || train_gather(d));
+    if (d->training && train_gather(d)) {
         CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
                                  nullptr, L.dxyz, L.partial, L.partial_x, st));
         CMF_TRY(cmf_colsum(tiles128(M), 3 * O1 + 4, L.partial_x, L.fwd_sums, 0, nullptr, nullptr, st));
@@ -579,7 +581,7 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
         // so only dU1 is streamed (csrc/group_rows.hip)
         if (train_gather_sum(d))
             CMF_TRY(cmf_group_rows_grad_bn_cf_pieces(d->B, d->N, O1, d->N * d->S, d->S, sum_slots(d, L).pieces, d->y, d->ldy, d->wx, d->ldwx, d->xyz,
-                                                     d->xyz, b0 + 2 * O1, b0, b0 + O1, L.sums, (float)(1.0 / (double)M), L.offsets, L.inv, d->dy,
+                                                     d->xyz, b0 + 2 * O1, b0, b0 + O1, d->training ? L.sums : nullptr, (float)(1.0 / (double)M), L.offsets, L.inv, d->dy,
                                                      d->lddy ? (int)d->lddy : O1, st));
         else
         CMF_TRY(cmf_group_rows_grad_bn_cf(d->B, d->N, O1, d->N * d->S, d->S, L.dU1, d->y, d->ldy, d->wx, d->ldwx, d->xyz, d->xyz,

@@ -346,17 +346,18 @@ def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, t
     every gradient and every BN buffer of a whole training step (B = 64) must be equal bit for bit.  (Child processes: the
     library reads its switches once.)"""
     import subprocess, sys
-    outs = []
-    for i, env in enumerate((dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1", CMF_TRAIN_GATHER_SUM="0"))):
-        f = str(tmp_path / ("step%d.pt" % i))
-        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"], env=dict(os.environ, **env),
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        outs.append(torch.load(f))
-    a, b = outs
-    assert a.keys() == b.keys() and len(a) > 300
-    bad = [k for k in a if not torch.equal(a[k], b[k])]
-    assert not bad, bad[:10]
+    for bn_mode in ("train", "eval"):                   # eval-mode BatchNorm with gradients: the same path with folded running statistics
+        outs = []
+        for i, env in enumerate((dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="0"), dict(CMF_GEMM_PERSIST="0", CMF_TRAIN_GATHER="1", CMF_TRAIN_GATHER_SUM="0"))):
+            f = str(tmp_path / ("step_%s%d.pt" % (bn_mode, i)))
+            r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64", bn_mode],
+                               env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            outs.append(torch.load(f))
+        a, b = outs
+        assert a.keys() == b.keys() and len(a) > 300
+        bad = [k for k in a if not torch.equal(a[k], b[k])]
+        assert not bad, (bn_mode, bad[:10])
 
 
 def test_summed_data_gradient_changes_nothing_but_the_association(dev, tmp_path):
