@@ -62,6 +62,73 @@ class FlatGradBucket:
         return lo, hi - lo
 
 
+class FlatAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (L2 weight decay, no amsgrad: the reference's optimizer, main.py:107) over a FlatGradBucket as ONE kernel
+    launch (cmf_adam_step): the gradients already lie contiguously in the bucket, the moments are two flat arrays in the same order, and
+    the parameters stay where the module holds them (a device table of their addresses).  torch's fused Adam needs six multi-tensor
+    launches for the model's 182 tensors at the very end of a step.  A torch Optimizer all the same: lr schedulers act on
+    param_groups[0]['lr'] (the reference steps a StepLR per epoch, main.py:108,151)."""
+
+    def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(bucket.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.bucket = bucket
+        self.exp_avg = torch.zeros_like(bucket.flat)
+        self.exp_avg_sq = torch.zeros_like(bucket.flat)
+        self.steps = 0
+        self._ptrs = None
+        self._tables()
+
+    def _tables(self):
+        ps = self.bucket.params
+        ptrs = tuple(p.data_ptr() for p in ps)
+        if ptrs == self._ptrs:
+            return
+        for p in ps:
+            if not (p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda):
+                raise RuntimeError("FlatAdam: parameters must be contiguous fp32 device tensors")
+        offs, o = [], 0
+        for p in ps:
+            offs.append(o)
+            o += p.numel()
+        offs.append(o)
+        dev = self.bucket.flat.device
+        self._offs = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._pt = torch.tensor(ptrs, dtype=torch.int64, device=dev)
+        self._ptrs = ptrs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        loss = closure() if closure is not None else None
+        b = self.bucket
+        for p, v in zip(b.params, b.views):
+            if p.grad is not v:
+                raise RuntimeError("a gradient left the flat bucket (zero_grad(set_to_none=True)?)")
+        self._tables()                                       # a parameter whose storage was replaced gets its new address
+        g = self.param_groups[0]
+        self.steps += 1
+        _lib.check(_lib.lib().cmf_adam_step(len(b.params), self._offs.data_ptr(), self._pt.data_ptr(), b.numel, b.flat.data_ptr(),
+                                            self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), float(g["lr"]), float(g["betas"][0]),
+                                            float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.steps,
+                                            _lib.stream_ptr()), "cmf_adam_step")
+        return loss
+
+    def zero_grad(self, set_to_none=False):
+        self.bucket.zero()
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["flat"] = dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, steps=self.steps)
+        return d
+
+    def load_state_dict(self, d):
+        d = dict(d)
+        flat = d.pop("flat", None)
+        super().load_state_dict(d)
+        if flat is not None:
+            self.exp_avg.copy_(flat["exp_avg"]); self.exp_avg_sq.copy_(flat["exp_avg_sq"]); self.steps = int(flat["steps"])
+
+
 class SegmentedReducer:
     """The gradient all-reduce of a step, cut into segments that are launched as soon as their part of the backward pass
     has been enqueued -- the counterpart of nn.DataParallel's reduction running inside backward (models/model.py:40-42).

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import synth
-from .dp import FlatGradBucket, SegmentedReducer
+from .dp import FlatAdam, FlatGradBucket, SegmentedReducer
 from .fused_blocks import join_side_streams
 from .losses import RadarFlowLoss, make_labels
 
@@ -24,8 +24,10 @@ class TrainStep:
         self.loss_obj = RadarFlowLoss(camera_projection or synth.CAMERA_PROJECTION,
                                       t_camera_radar or synth.T_CAMERA_RADAR).to(dev)
         self.bucket = FlatGradBucket(net)
-        # fused=True: one multi-tensor kernel per step instead of ~10 foreach launches (same update rule)
-        self.opt = torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay, fused=dev.type == "cuda")
+        # the reference's Adam (main.py:107) as one launch over the flat bucket (dp.FlatAdam; torch's fused Adam: six launches at the
+        # tail of the step); on a CPU model torch's own
+        self.opt = (FlatAdam(self.bucket, lr=lr, weight_decay=weight_decay) if dev.type == "cuda"
+                    else torch.optim.Adam(self.bucket.params, lr=lr, weight_decay=weight_decay))
         self.recurrent = hasattr(net, "gru")
         self.self_supervised = hasattr(net, "fd_layer")
         # the scales of an encoder run on side streams while the gradient bucket lives on the main stream

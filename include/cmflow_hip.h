@@ -400,6 +400,13 @@ typedef struct cmf_setconv_desc {
 int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
 int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
+/* The optimizer step of the reference's loop (main.py:107: torch.optim.Adam with L2 weight decay) over a flat gradient bucket in ONE
+ * launch: grad / m / v are flat arrays of `total` floats in bucket order, params[t] the address of tensor t and offsets[t] its first
+ * element in the bucket (offsets[n_tensors] = total; both tables in device memory).  step >= 1 is the count INCLUDING this update.
+ *   g' = g + wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps) */
+int cmf_adam_step(int n_tensors, const long long *offsets, float *const *params, long long total, const float *grad, float *m, float *v,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void *stream);
+
 /* Float offsets, inside `saved`, of the six per-layer BatchNorm blocks (mean | invstd | a | c, 4*C_l floats each). */
 int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6);
 

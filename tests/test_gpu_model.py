@@ -957,3 +957,33 @@ def test_two_rank_cmflow_t_clip_matches_single_rank_shards(dev, tmp_path):
     for f in range(2):
         mean = (ranks[0]["_locals"][f] + ranks[1]["_locals"][f]) / 2
         assert float((ranks[0]["frames"][f]["averaged"].double() - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
+
+
+def test_flat_adam_matches_torch_adam(dev):
+    """dp.FlatAdam (cmf_adam_step: one launch over the flat gradient bucket) against torch.optim.Adam with the reference's settings
+    (lr 1e-3, L2 weight decay 1e-4, main.py:107) on a module with odd tensor sizes: parameters within 2e-6 relative after each of 5
+    steps (same update rule; torch forms its bias corrections in double as well), a StepLR acts on it like on torch's, and a
+    parameter whose storage is replaced is followed."""
+    from cmflow_amd.dp import FlatAdam, FlatGradBucket
+    torch.manual_seed(3)
+    # (no bias in front of the BatchNorm: its true gradient is zero, and Adam normalises the rounding noise it gets instead into steps of lr)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(37, 129, bias=False), torch.nn.BatchNorm1d(129), torch.nn.ReLU(), torch.nn.Linear(129, 5)).to(dev)
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    bucket = FlatGradBucket(a)
+    oa = FlatAdam(bucket, lr=1e-3, weight_decay=1e-4)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3, weight_decay=1e-4)
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, 2, gamma=0.5), torch.optim.lr_scheduler.StepLR(ob, 2, gamma=0.5)
+    for it in range(5):
+        x = torch.randn(64, 37, device=dev)
+        for net, opt in ((a, oa), (b, ob)):
+            opt.zero_grad() if net is b else bucket.zero()
+            net(x).square().mean().backward()
+            opt.step()
+        sa.step(); sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+        for (k, p), q in zip(a.named_parameters(), b.parameters()):
+            np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=2e-7, err_msg="%s step %d" % (k, it))
+        if it == 2:                                         # a replaced storage (same values) must be picked up
+            p0 = next(a.parameters())
+            p0.data = p0.data.clone()
