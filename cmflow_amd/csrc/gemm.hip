@@ -42,6 +42,13 @@ constexpr int G_RP = 256 / G_KT;          // rows staged per pass by the 256 thr
 constexpr int G_LDS_LD = G_BK + 4;      // 20 floats (BK=16) / 36 (BK=32): row strides whose 16-B slots tile all 64 banks -> conflict-free b128 reads
 
 #include "gemm_args.h"
+// timing diagnostics (GemmArgs::diag) are compiled in only with -DCMF_GEMM_DIAG (tools/diag builds): in the shipped kernels the
+// main loop carries no run-time switches
+#ifdef CMF_GEMM_DIAG
+#define GDIAG(p) ((p).diag)
+#else
+#define GDIAG(p) 0
+#endif
 
 __device__ __forceinline__ float act_fn(float v, int act)
 {
@@ -114,7 +121,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // (p.Z = the per-point matrix, rows through ga_rows, + the coordinate term).  GMODE 4: the same data gradient over rows in
 // inverse-index order, reduced over runs of equal source points in the epilogue instead of stored (seg_epilogue).
 template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
-__global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const GemmArgs p)
 {
     constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2, GATHER_Z = GMODE == 3 || GMODE == 4, GATHER_S = GMODE == 4;
     static_assert(!GATHER_Z || (!A_T && !B_T && EPI == 4 && BM == 128 && BN == 128), "gathered Z rows: the kind-4 data gradient");
@@ -533,7 +540,9 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 }
         };
         int st = 0;
+#ifndef CMF_NO_SETPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         // Software-pipelined form: the barrier sits in the MIDDLE of a chunk's MFMAs.  When a wave arrives there it has read
         // all of chunk c (its second fragment set was awaited just before), so the barrier still means "stage c is free and
         // chunk c + 1 is visible" -- but the first fragment reads of chunk c + 1 are issued right behind it and land under
@@ -557,12 +566,12 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 mfma_step(0);
                 g_lds_wait(); pin_frags(1);                                         // every LDS read of chunk c by this wave is complete
                 if (GATHER) gather_prologue(1);
-                if (c + 2 < nch && !(p.diag & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);   // (st + 2) % 3: the stage of chunk c - 1
+                if (c + 2 < nch && !(GDIAG(p) & 1)) issue(kc_begin + c + 2, st == 0 ? 2 : st - 1);   // (st + 2) % 3: the stage of chunk c - 1
                 const int sn = st == 2 ? 0 : st + 1;
                 const float *sa = smem + sn * D_STAGE, *sb = sa + D_ASLOTS * 4, *sp = sb + D_BSLOTS * 4;
                 if (c + 1 < nch) {
-                    if (!(p.diag & 3)) wait_prev(c + 2 < nch);
-                    if (!(p.diag & 4)) __builtin_amdgcn_s_barrier();
+                    if (!(GDIAG(p) & 3)) wait_prev(c + 2 < nch);
+                    if (!(GDIAG(p) & 4)) __builtin_amdgcn_s_barrier();
                     read_frags(sa, sb, sp, 0, 0);                                   // in flight under the second half of chunk c
                 }
                 mfma_step(1);
@@ -626,7 +635,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
 
     const unsigned long long t_main = p.trace ? wall_clock64() : 0ull;
     unsigned long long t_e[3] = {0ull, 0ull, 0ull};     // trace: first transposition visible, band-0 stores issued, last band done
-    if (p.diag & 8) {                                   // timing diagnostic: no epilogue at all (accumulators kept live)
+    if (GDIAG(p) & 8) {                                   // timing diagnostic: no epilogue at all (accumulators kept live)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -881,12 +890,14 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 }
             }
             lds_barrier();
-            for (int c = tid; c < nstat * BN; c += G_THREADS) {
-                const int which = c / BN, cc = c % BN;
+            // (partial sums are consumed per 128-row tile, cmf_gemm_tiles_m: a 256-row tile's two wave rows are one partial row each)
+            constexpr int SPT = BM > 128 ? BM / 128 : 1, WPS = WARPS_M / SPT;
+            for (int c = tid; c < SPT * nstat * BN; c += G_THREADS) {
+                const int sp = c / (nstat * BN), which = (c / BN) % nstat, cc = c % BN;
                 float sum = 0.f;
 #pragma unroll
-                for (int g = 0; g < WARPS_M; ++g) sum += red[(g * nstat + which) * BN + cc];
-                p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
+                for (int g = 0; g < WPS; ++g) sum += red[((sp * WPS + g) * nstat + which) * BN + cc];
+                p.stats[(((long long)tm * SPT + sp) * nstat + which) * p.N + n0 + cc] = sum;
             }
         }
         stats_done = true;
@@ -926,7 +937,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
         auto load_z = [&](int g) {                                    // g = 2 * block row + half
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                if (p.diag & 32) { zp[u] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }            // timing diagnostic: no Z loads
+                if (GDIAG(p) & 32) { zp[u] = f32x4{1.f, 1.f, 1.f, 1.f}; continue; }            // timing diagnostic: no Z loads
                 if (GATHER_Z) zp[u] = *(const f32x4 *)(zbase + (long long)zi[GATHER_Z ? u : 0] * p.ldz + c4);
                 else zp[u] = *(const f32x4 *)((const char *)(zbase + (long long)(g * 16 + u * 4) * p.ldz) + lane_z);
             }
@@ -1009,7 +1020,7 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 if (USE_Z && 2 * i + hf + 1 < 2 * TM) load_z(2 * i + hf + 1);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (p.diag & 16) { asm volatile("" :: "v"(t4[u])); continue; }                // timing diagnostic: no C stores
+                    if (GDIAG(p) & 16) { asm volatile("" :: "v"(t4[u])); continue; }                // timing diagnostic: no C stores
                     *(f32x4 *)((char *)(cbase + (long long)(i * 32 + (hf * 4 + u) * 4) * p.ldc) + lane_c) = t4[u];
                 }
                 fence();
@@ -1032,12 +1043,13 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
                 }
             }
             lds_barrier();
-            for (int c = tid; c < nstat * BN; c += G_THREADS) {
-                const int which = c / BN, cc = c % BN;
+            constexpr int SPT = BM > 128 ? BM / 128 : 1, WPS = WARPS_M / SPT;
+            for (int c = tid; c < SPT * nstat * BN; c += G_THREADS) {
+                const int sp = c / (nstat * BN), which = (c / BN) % nstat, cc = c % BN;
                 float sum = 0.f;
 #pragma unroll
-                for (int g = 0; g < WARPS_M; ++g) sum += red[(g * nstat + which) * BN + cc];
-                p.stats[((long long)tm * nstat + which) * p.N + n0 + cc] = sum;
+                for (int g = 0; g < WPS; ++g) sum += red[((sp * WPS + g) * nstat + which) * BN + cc];
+                p.stats[(((long long)tm * SPT + sp) * nstat + which) * p.N + n0 + cc] = sum;
             }
         }
         stats_done = true;
@@ -1133,8 +1145,8 @@ __global__ __launch_bounds__(G_THREADS, 3) void gemm_kernel(const GemmArgs p)
     if constexpr (GATHER_S) seg_epilogue(0);
     else
     if (fast_epi && epilogue_kind(p) == EPI) {
-        if constexpr (BM == 128 && EPI <= 1) direct_epilogue(std::integral_constant<int, EPI>{});
-        else if constexpr (BM == 128 && BN == 128) wave_epilogue(std::integral_constant<int, EPI>{});
+        if constexpr (BM >= 128 && EPI <= 1) direct_epilogue(std::integral_constant<int, EPI>{});
+        else if constexpr (BM >= 128 && BN == 128) wave_epilogue(std::integral_constant<int, EPI>{});
         else fast_epilogue(std::integral_constant<int, EPI>{});
     } else {
     if (p.split_k == 1)
@@ -1526,6 +1538,13 @@ static int launch(const GemmArgs &a, hipStream_t st)
     return cmf_launch_status();
 }
 
+// 256 x 128 tiles for tall interior shapes (env CMF_GEMM_TALL=0: the 128 x 128 tiles everywhere, A/B)
+static int gemm_tall_mode()
+{
+    static const int mode = getenv("CMF_GEMM_TALL") ? atoi(getenv("CMF_GEMM_TALL")) : 1;
+    return mode;
+}
+
 extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
                         const float *A, long long lda, const float *B, long long ldb, float *C, long long ldc,
                         const float *pro_a, const float *pro_c, const float *prob_a, const float *prob_c,
@@ -1572,13 +1591,18 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
     // kind 0 / 2 / 3, weight gradients and the rest kind 0; any other pairing runs the kind-0 kernel, whose generic loop
     // handles every epilogue
     const int kind = epilogue_kind(g);
-    // [256 x 128 tiles at 2 workgroups per CU (wave tile 128 x 64) were measured against this: 107 vs 118 TF on
-    //  524288 x 256 x 512, 26.2 vs 24.6 ms per training step -- two waves per SIMD do not cover each other's stalls.]
+    // 256 x 128 tiles (wave tile 128 x 64, 2 workgroups per CU): half the operand bytes per flop through L2 and LDS-direct, a quarter
+    // fewer LDS fragment reads, tiles twice as long against the same prologue / epilogue (round 5; tools/lab/gemm_lab.hip: + 5-20 % on the
+    // model's plain shapes).  Interior shapes only (the LDS-direct loop); enough tiles to fill 2 workgroups per CU.
+    const int tall_mode = gemm_tall_mode();
+    const long long work_tiles = (long long)(M / 256) * ((N + 127) / 128) * g.split_k;
 #define CMF_PICK(AT, BT, EP)                                                                               \
-    (tall ? (wide ? launch<128, 128, AT, BT, EP>(g, st) : launch<128, 64, AT, BT, EP>(g, st)) \
+    (big ? launch<256, 128, AT, BT, EP>(g, st) :                                                          \
+     tall ? (wide ? launch<128, 128, AT, BT, EP>(g, st) : launch<128, 64, AT, BT, EP>(g, st)) \
           : (wide ? launch<64, 128, AT, BT, EP>(g, st) : launch<64, 64, AT, BT, EP>(g, st)))
     const int pgrid = thin_done ? 0 : cmf_pgemm_grid(g, a_t, b_t, kind);
     if (!pgrid && staged_dw) g.no_direct = 1;
+    const bool big = tall_mode && !a_t && M % 256 == 0 && N % 128 == 0 && K % G_BK == 0 && work_tiles >= 384 && !g.no_direct && !(accumulate && g.split_k == 1);
     if (thin_done)         err = 0;
     else if (pgrid) {
         const long long pe = gprof_open(2.0 * M * N * K, st, &g, (a_t ? 2 : 0) | (b_t ? 1 : 0) | 4, 128, 128);      // layout bit 2: persistent kernel
@@ -1617,6 +1641,10 @@ extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long 
     g.M = M; g.N = N; g.K = K; g.A = Y; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
     g.stats = stats;                                    // train mode: [M / 128][2][N] partial sums of the output
+    // (256 x 128 tiles measured here, round 5: 111 against 118 TF -- the per-row state of the gathering loads and the fragment prologue
+    //  do not fit 256 registers beside a 128 x 64 wave tile; CMF_GEMM_TALL=2 keeps that form reachable)
+    if (gemm_tall_mode() == 2 && M % 256 == 0 && (long long)(M / 256) * (N / 128) >= 384)
+        return stats ? launch<256, 128, false, true, 1, 1>(g, st) : launch<256, 128, false, true, 0, 1>(g, st);
     return stats ? launch<128, 128, false, true, 1, 1>(g, st) : launch<128, 128, false, true, 0, 1>(g, st);
 }
 
