@@ -228,6 +228,30 @@ def hbm_op_rooflines(dev, iters=20):
             "rows": rows}
 
 
+def clip_from_loader(batch, clip_len, rank, dev):
+    """`batch` synthetic mini-clips of `clip_len` frames written as sample files (ragged clouds of 200-340 points), read back through
+    cmflow_amd.dataset.vodClipDataset + a DataLoader, one resident batch dict per frame."""
+    import shutil
+    import tempfile
+    import numpy as np
+    from cmflow_amd import dataset as D
+
+    class A:
+        num_points, eval, mini_clip_len, update_len = 256, False, clip_len, 1
+
+    tmp = tempfile.mkdtemp(prefix="cmf_bench_clip_")
+    try:
+        clips = tuple(("train", "delft_%d" % c, tuple(200 + (37 * c + 53 * f) % 141 for f in range(clip_len))) for c in range(batch))
+        D.write_synthetic_split(tmp, seed=1234 + 100003 * rank, clips=clips)
+        ds = D.vodClipDataset(A(), root=tmp + "/", partition="train")
+        assert len(ds) == batch, (len(ds), batch)
+        np.random.seed(1234 + rank)
+        data = next(iter(torch.utils.data.DataLoader(ds, batch_size=batch, shuffle=False)))
+        return [D.as_batch_dict(D.extract_data_info_clip(data, j, device=dev)) for j in range(clip_len)]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,8 +325,12 @@ def main():
     # CMFlow-T trains on mini-clips (clip_util.py:34-62): `--clip` consecutive frames, the GRU state handed from frame to
     # frame as gfeat.detach() (:54), one optimizer step per frame, gfeat = None at the first frame of a clip (:51-52).
     # A bench "step" is one frame; the clip's frames are distinct resident batches.
-    clip = [batch] + [{k: v.to(dev) for k, v in synth.make_batch(a.batch, seed=1234 + rank + 1000 * f, train_extras=True).items()}
-                      for f in range(1, a.clip if (a.model == "cmflow_t" and a.mode == "train") else 1)]
+    # The clip comes through the reference's own input path (dataset/vod_clip.py vodClipDataset -> DataLoader -> extract_data_info_clip,
+    # clip_util.py:81-96): `batch` mini-clips of `--clip` ragged synthetic sample files, resampled to 256 points by the loader.
+    if a.model == "cmflow_t" and a.mode == "train":
+        clip = clip_from_loader(a.batch, a.clip, rank, dev)
+    else:
+        clip = [batch]
     frame = [0]
 
     if a.mode == "train":

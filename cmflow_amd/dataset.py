@@ -1,6 +1,7 @@
-"""Sample I/O: the View-of-Delft scene-flow sample format and its Dataset -- mirror of ``dataset/vod.py``
-(vodDataset :14-137; format described in src/GETTING_STARTED.md:97-106) and of ``extract_data_info``
-(main_util.py:21-36).
+"""Sample I/O: the View-of-Delft scene-flow sample format and its Datasets -- mirror of ``dataset/vod.py``
+(vodDataset :14-137; format described in src/GETTING_STARTED.md:97-106), of ``dataset/vod_clip.py`` (vodClipDataset
+:14-198, the mini-clip loader CMFlow-T trains on) and of ``extract_data_info`` / ``extract_data_info_clip``
+(main_util.py:21-36, clip_util.py:81-96).
 
 One sample = one JSON file ``<root>/<partition>/<clip>/<k>_*.json`` with
     pc1, pc2          [n][5]  x, y, z, RCS, v_r          (features fed to the net: [v_r, RCS, RCS], vod.py:62-63)
@@ -49,41 +50,115 @@ class vodDataset(Dataset):
     def __len__(self):
         return len(self.samples)
 
-    def _resample(self, n):
-        """vod.py:99-111: keep all n points and pad with random duplicates, or draw a random subset."""
-        if n < self.npoints:
-            return np.append(np.arange(0, n), np.random.choice(n, self.npoints - n, replace=True))
-        return np.random.choice(n, self.npoints, replace=False)
-
     def __getitem__(self, index):
         with open(self.samples[index], 'rb') as fp:
             data = json.load(fp)
-        d1 = np.array(data["pc1"]).astype('float32')
-        d2 = np.array(data["pc2"]).astype('float32')
-        pos_1, pos_2 = d1[:, 0:3], d2[:, 0:3]
-        feature_1, feature_2 = d1[:, [4, 3, 3]], d2[:, [4, 3, 3]]
-        if self.partition in ('test', 'val', 'train_anno'):          # ground truth for evaluation
-            labels = np.array(data["gt_labels"]).astype('float32')
-            mask = np.array(data["gt_mask"])
-            n1 = pos_1.shape[0]
-            opt_flow = np.zeros((n1, 2)).astype('float32')
-            radar_u, radar_v = np.zeros(n1).astype('float32'), np.zeros(n1).astype('float32')
-        else:                                                         # pseudo labels + optical flow for training
-            labels = np.array(data["pse_labels"]).astype('float32')
-            mask = np.array(data["pse_mask"])
-            info = data["opt_info"]
-            opt_flow = np.array(info["opt_flow"]).astype('float32')
-            radar_u = np.array(info["radar_u"]).astype('float32')
-            radar_v = np.array(info["radar_v"]).astype('float32')
-        trans = np.linalg.inv(np.array(data["trans"])).astype('float32')
+        return _sample_item(self, data)
+
+
+def _resample(npoints, n):
+    """vod.py:99-111 / vod_clip.py:183-191: keep all n points and pad with random duplicates, or draw a random subset."""
+    if n < npoints:
+        return np.append(np.arange(0, n), np.random.choice(n, npoints - n, replace=True))
+    return np.random.choice(n, npoints, replace=False)
+
+
+def _sample_item(ds, data):
+    """One decoded sample -> the reference's 11-tuple (vod.py:54-124 = vod_clip.py:77-127: the two loaders share this body).
+    Training (``not ds.eval``): both clouds resampled to ``ds.npoints`` -- cloud 1's index draw first, then cloud 2's, the numpy RNG
+    call order of ``sample_points`` (vod_clip.py:181-193)."""
+    d1 = np.array(data["pc1"]).astype('float32')
+    d2 = np.array(data["pc2"]).astype('float32')
+    pos_1, pos_2 = d1[:, 0:3], d2[:, 0:3]
+    feature_1, feature_2 = d1[:, [4, 3, 3]], d2[:, [4, 3, 3]]
+    if ds.partition in ('test', 'val', 'train_anno'):            # ground truth for evaluation
+        labels = np.array(data["gt_labels"]).astype('float32')
+        mask = np.array(data["gt_mask"])
+        n1 = pos_1.shape[0]
+        opt_flow = np.zeros((n1, 2)).astype('float32')
+        radar_u, radar_v = np.zeros(n1).astype('float32'), np.zeros(n1).astype('float32')
+    else:                                                         # pseudo labels + optical flow for training
+        labels = np.array(data["pse_labels"]).astype('float32')
+        mask = np.array(data["pse_mask"])
+        info = data["opt_info"]
+        opt_flow = np.array(info["opt_flow"]).astype('float32')
+        radar_u = np.array(info["radar_u"]).astype('float32')
+        radar_v = np.array(info["radar_v"]).astype('float32')
+    trans = np.linalg.inv(np.array(data["trans"])).astype('float32')
+    if not ds.eval:
+        i1 = _resample(ds.npoints, pos_1.shape[0])
+        i2 = _resample(ds.npoints, pos_2.shape[0])
+        pos_1, pos_2 = pos_1[i1, :], pos_2[i2, :]
+        feature_1, feature_2 = feature_1[i1, :], feature_2[i2, :]
+        radar_u, radar_v, opt_flow = radar_u[i1], radar_v[i1], opt_flow[i1, :]
+        labels, mask = labels[i1, :], mask[i1]
+    return pos_1, pos_2, feature_1, feature_2, trans, labels, mask, ds.interval, radar_u, radar_v, opt_flow
+
+
+class vodClipDataset(Dataset):
+    """``dataset/vod_clip.py:14-198``.  Training (``args.eval`` false): item i is the i-th MINI-CLIP -- ``args.mini_clip_len``
+    consecutive samples of one clip (clips cut into floor(len / mini_clip_len) mini-clips, the remainder dropped, :40-50) -- as
+    eleven arrays with a leading ``(mini_clip_len, ...)`` axis (:131-170); every frame is resampled to ``args.num_points`` in
+    file order (one numpy RNG stream).  Evaluation: item i is ONE frame (:69-74), ragged, in clip order, with ``clips_info``
+    giving each clip's [first, last) frame range (:34-39)."""
+
+    def __init__(self, args, root, partition='train', textio=None):
+        self.npoints = args.num_points
+        self.textio = textio
+        self.res = {'r_res': 0.2, 'theta_res': 1.5 * np.pi / 180, 'phi_res': 1.5 * np.pi / 180}
+        self.camera_projection_matrix = np.array(synth.CAMERA_PROJECTION, dtype=np.float32)
+        self.t_camera_radar = np.array(synth.T_CAMERA_RADAR, dtype=np.float32)
+        self.eval = args.eval
+        self.partition = partition
+        self.root = os.path.join(root, self.partition)
+        self.interval = 0.10
+        self.mini_clip_len = args.mini_clip_len
+        self.update_len = args.update_len
+        self.clips = sorted(os.listdir(self.root), key=lambda x: int(x.split("_")[1]))
+        self.mini_samples = []
+        self.samples = []
+        self.clips_info = []
+        self.mini_clips_info = []
+        for clip in self.clips:
+            clip_path = os.path.join(self.root, clip)
+            files = sorted(os.listdir(clip_path), key=lambda x: int(x.split("/")[-1].split("_")[0]))
+            if self.eval:
+                self.clips_info.append({'clip_name': clip, 'index': [len(self.samples), len(self.samples) + len(files)]})
+                self.samples.extend(os.path.join(clip_path, f) for f in files)
+            else:
+                for i in range(int(np.floor(len(files) / self.mini_clip_len))):
+                    mini = [os.path.join(clip_path, files[i * self.mini_clip_len + j]) for j in range(self.mini_clip_len)]
+                    self.samples.extend(mini)
+                    self.mini_samples.append(mini)
+        if self.textio is not None:
+            if self.eval:
+                self.textio.cprint(self.partition + ' : ' + str(len(self.samples)) + ' frames')
+            else:
+                self.textio.cprint(self.partition + ' : ' + str(len(self.mini_samples)) + ' mini_clips')
+
+    def __len__(self):
+        return len(self.samples) if self.eval else len(self.mini_samples)
+
+    def get_sample_item(self, data):
+        return _sample_item(self, data)
+
+    def get_clip_item(self, index):
+        mini = self.mini_samples[index]
+        L, n = self.mini_clip_len, self.npoints
+        z = lambda *shape: np.zeros(shape).astype('float32')
+        out = (z(L, n, 3), z(L, n, 3), z(L, n, 3), z(L, n, 3), z(L, 4, 4), z(L, n, 3), z(L, n), z(L), z(L, n), z(L, n), z(L, n, 2))
+        for i, path in enumerate(mini):
+            with open(path, 'rb') as fp:
+                item = _sample_item(self, json.load(fp))
+            for dst, v in zip(out, item):
+                dst[i] = v
+        return out
+
+    def __getitem__(self, index):
         if not self.eval:
-            i1 = self._resample(pos_1.shape[0])
-            i2 = self._resample(pos_2.shape[0])
-            pos_1, pos_2 = pos_1[i1, :], pos_2[i2, :]
-            feature_1, feature_2 = feature_1[i1, :], feature_2[i2, :]
-            radar_u, radar_v, opt_flow = radar_u[i1], radar_v[i1], opt_flow[i1, :]
-            labels, mask = labels[i1, :], mask[i1]
-        return pos_1, pos_2, feature_1, feature_2, trans, labels, mask, self.interval, radar_u, radar_v, opt_flow
+            return self.get_clip_item(index)
+        with open(self.samples[index], 'rb') as fp:
+            return _sample_item(self, json.load(fp))
 
 
 def extract_data_info(data, device="cuda"):
@@ -94,6 +169,11 @@ def extract_data_info(data, device="cuda"):
     fl = lambda t: torch.as_tensor(t).to(device).float()
     return (cm(pc1), cm(pc2), cm(ft1), cm(ft2), fl(trans), fl(gt), fl(mask), fl(interval), fl(radar_u), fl(radar_v),
             fl(opt_flow))
+
+
+def extract_data_info_clip(seq_data, idx, device="cuda"):
+    """clip_util.py:81-96: frame ``idx`` of a collated mini-clip batch -> the tuple of extract_data_info."""
+    return extract_data_info(tuple(t[:, idx] for t in seq_data), device=device)
 
 
 def as_batch_dict(info):

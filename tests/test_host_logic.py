@@ -126,6 +126,67 @@ def test_vod_dataset_matches_reference_loader(golden_dir, tmp_path):
     assert set(D.as_batch_dict(info)) >= {"pc1", "ft1", "gt_trans", "flow_label", "fg_mask", "interval", "opt_flow"}
 
 
+def test_vod_clip_dataset_matches_reference_loader(golden_dir, tmp_path):
+    """cmflow_amd.dataset.vodClipDataset against what the reference's dataset/vod_clip.py produced from the same
+    sample files (tests/golden/make_golden_clip.py): mini-clip tuples of the training partition under the same numpy seed (same RNG
+    call order), per-frame tuples and clips_info of the evaluation partition, the file lists, the textio lines."""
+    import json
+    import numpy as np
+    from cmflow_amd import dataset as D
+    g = np.load(os.path.join(golden_dir, "vod_clip_kat.npz"))
+    files = [k[6:] for k in g.files if k.startswith("file::")]
+    assert len(files) == 13
+    for rel in files:
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_text(str(g["file::" + rel]))
+
+    class A:
+        num_points = 96
+        eval = False
+        mini_clip_len = 2
+        update_len = 1
+
+    class Textio:
+        def __init__(self):
+            self.lines = []
+
+        def cprint(self, s):
+            self.lines.append(s)
+
+    for part, ev in (("train", False), ("test", True)):
+        a = A()
+        a.eval = ev
+        tio = Textio()
+        ds = D.vodClipDataset(a, root=str(tmp_path) + "/", partition=part, textio=tio)
+        assert len(ds) == int(g["%s/len" % part])
+        assert tio.lines == json.loads(str(g["%s/textio" % part]))
+        assert [os.path.relpath(q, str(tmp_path)) for q in ds.samples] == json.loads(str(g["%s/samples" % part]))
+        assert ds.mini_clip_len == 2 and ds.update_len == 1
+        if ev:
+            assert ds.clips_info == json.loads(str(g["%s/clips_info" % part]))
+        else:
+            assert [[os.path.relpath(q, str(tmp_path)) for q in m] for m in ds.mini_samples] == json.loads(str(g["%s/mini_samples" % part]))
+        np.random.seed(23)
+        for i in range(len(ds)):
+            item = ds[i]
+            assert len(item) == 11
+            for j, v in enumerate(item):
+                ref = g["%s/%d/%d" % (part, i, j)]
+                v = np.asarray(v)
+                assert v.shape == ref.shape and v.dtype == ref.dtype, (part, i, j, v.shape, ref.shape, v.dtype, ref.dtype)
+                np.testing.assert_array_equal(v, ref)
+    # a collated mini-clip batch, frame by frame (clip_util.py:81-96), on CPU here
+    ds = D.vodClipDataset(A(), root=str(tmp_path) + "/", partition="train")
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)))
+    assert batch[0].shape == (2, 2, 96, 3) and batch[4].shape == (2, 2, 4, 4) and batch[7].shape == (2, 2)
+    for j in range(ds.mini_clip_len):
+        info = D.extract_data_info_clip(batch, j, device="cpu")
+        assert info[0].shape == (2, 3, 96) and info[3].shape == (2, 3, 96) and info[4].shape == (2, 4, 4) and info[7].shape == (2,)
+        assert info[5].shape == (2, 96, 3) and info[10].shape == (2, 96, 2) and all(t.dtype == torch.float32 for t in info)
+        assert torch.equal(info[0], batch[0][:, j].transpose(2, 1))
+
+
 def test_raflow_checkpoint_layout(golden_dir):
     """RaFlow mirror: the reference's 355 state tensors in the reference's order."""
     import json
