@@ -1,12 +1,13 @@
 """GPU: the fused loss kernel cmf_radar_loss against the oracle's restatement of
 losses/radar_loss.py (values: fp32 oracle; gradients: fp64 autograd of the oracle) and against the torch-op
-terms of cmflow_amd.losses on the same device."""
+terms of tests/loss_torch.py (a test fixture) on the same device."""
 import numpy as np
 import pytest
 import torch
 
 from cmflow_amd import synth
 from cmflow_amd.losses import ITEM_KEYS, RadarFlowLoss, make_labels
+from loss_torch import TorchRadarFlowLoss
 from oracle import train_oracle as TO
 
 pytestmark = pytest.mark.gpu
@@ -110,7 +111,7 @@ def test_fused_loss_matches_torch_terms_and_is_reproducible(dev):
     dyn, mseg = make_labels(bd, 0.3)
     out = []
     for native in (True, False, True):
-        crit = RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR, native=native).to(dev)
+        crit = (RadarFlowLoss if native else TorchRadarFlowLoss)(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR).to(dev)
         pf, pt, pm = (x.to(dev).requires_grad_(True) for x in (pred_f, pre_trans, mseg_pre))
         total, items = crit(bd["pc1"], bd["pc2"], pf, bd["ft1"][:, 0], bd["flow_label"].transpose(2, 1), pt, pm,
                             bd["gt_trans"], mseg, dyn, bd["radar_u"], bd["radar_v"], bd["opt_flow"])
@@ -144,3 +145,12 @@ def test_fused_loss_forward_only_and_bounds(dev):
     assert _lib.lib().cmf_radar_loss(ctypes.addressof(d), None) != 0
     d.N = 8
     assert _lib.lib().cmf_radar_loss(ctypes.addressof(d), None) != 0
+    # ... and so does the module: one loss path, no torch-op fallback (larger clouds, another neighbour count, CPU tensors)
+    big = synth.make_batch(1, 720, seed=5, train_extras=True)
+    with pytest.raises(RuntimeError, match="keeps a sample in LDS"):
+        crit(big["pc1"].to(dev), big["pc2"].to(dev), torch.zeros(1, 3, 720, device=dev), big["ft1"][:, 0].to(dev))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        crit(batch["pc1"], batch["pc2"], pred_f, batch["ft1"][:, 0])
+    with pytest.raises(RuntimeError, match="num_nb = 8"):
+        RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR, num_nb=4).to(dev)(
+            bd["pc1"], bd["pc2"], pred_f.to(dev), bd["ft1"][:, 0])

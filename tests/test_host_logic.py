@@ -71,7 +71,7 @@ def test_label_prep_matches_reference_golden(golden_dir):
     """main_util.py:209-265 label prep (the torch-op form, device-agnostic) against the reference's output; the
     HIP form (make_labels -> cmf_pseudo_labels) is checked against the same golden in tests/test_gpu_eval.py."""
     import numpy as np
-    from cmflow_amd.losses import make_labels_torch as make_labels
+    from loss_torch import make_labels_torch as make_labels                 # test fixture (tests/loss_torch.py)
     with np.load(os.path.join(golden_dir, "cmflow_train_synth_b4.npz")) as z:
         g = {k: z[k] for k in z.files}
     batch = {k: torch.from_numpy(g[k]) for k in ("pc1", "ft1", "gt_trans", "flow_label", "fg_mask", "interval")}

@@ -61,3 +61,13 @@ def test_product_has_no_torch_math_path():
     for f in ("radarflow_util.py", "cmflow.py", "raflow.py", "fused.py", "fused_blocks.py"):
         text = open(os.path.join(REPO, "cmflow_amd", f)).read()
         assert "F.linear" not in text and "batch_norm" not in text and "use_blocks" not in text and '"pm_torch"' not in text, f
+
+
+def test_product_has_one_loss_path():
+    """cmflow_amd/losses.py runs the fused kernels only (cmf_radar_loss, cmf_pseudo_labels) and raises outside their range: the
+    torch-op restatement of losses/radar_loss.py is a test fixture (tests/loss_torch.py), not a fallback inside the product."""
+    text = open(os.path.join(REPO, "cmflow_amd", "losses.py")).read()
+    for needle in ("torch.topk", "square_distance", "F.relu", "binary_cross_entropy", "torch.softmax", "native=", "index_points_group"):
+        assert needle not in text, needle
+    assert "raise RuntimeError" in text and "cmf_radar_loss" in text
+    assert os.path.exists(os.path.join(REPO, "tests", "loss_torch.py"))
