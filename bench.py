@@ -8,12 +8,13 @@ Adam) on synthetic N=256 radar clouds at B=64 per GPU (BASELINE.json metric / co
 
 One process per GPU; batches shard over ranks (weak scaling: 64 pairs per GPU); the only
 collective is one RCCL all-reduce of the flat gradient bucket per step.  Rank 0 prints ONE
-JSON line.  `roofline` is measured live with HIP events around every launch >= 1 GFLOP of the dominant
-hand-written kernel (cmf_gemm, the fp32 MFMA GEMM behind every 1x1 conv) inside the timed region --
-the events are recorded INSIDE the library on the launch stream, so the GEMMs of the set-conv block
-calls count too; `flop_share` is the share of all cmf_gemm FLOPs the bracketed launches carry:
-achieved = sum of 2*M*N*K over those launches / sum of their durations, peak = 157.3 TFLOP/s dense
-fp32 MFMA.  `roofline_hbm` (N=1 only, after the timed region): the drop-in ball_query + group_points
+JSON line.  The dominant hand-written kernel is cmf_gemm (the fp32 MFMA GEMM behind every 1x1 conv); every launch
+>= 1 GFLOP is bracketed live with HIP events recorded INSIDE the library on the launch stream (the GEMMs of the
+set-conv block calls count too).  `roofline` = what the STEP extracts from the MFMA pipe: sum of 2*M*N*K over the
+bracketed launches of the timed region / the region's wall time (chains run on four streams, so per-launch
+durations overlap and their sum exceeds the wall time: that contended per-launch figure is kept under `extra`);
+`roofline_isolated` = the kernel's own rate (the same launches with every chain on one stream: flops / sum of
+durations); peak = 157.3 TFLOP/s dense fp32 MFMA; `flop_share` = share of all cmf_gemm FLOPs the bracketed launches carry.  `roofline_hbm` (N=1 only, after the timed region): the drop-in ball_query + group_points
 (+ group_points_grad) kernels at the op shapes of SURVEY 8d against the 8 TB/s HBM peak.
 `cpu_baseline` is the CPU oracle ("port") timed on this box's host cores on a bounded sample of the
 same workload; `cpu_baseline_config1` is BASELINE config 1 (B=1 forward, eval mode) on the same oracle.
@@ -31,8 +32,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_PROFILE = "r04_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
+TRAFFIC_PROFILE = "r05_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+OP_TRAFFIC_PROFILE = "r05_op_hbm_pmc.json"        # committed PMC passes over the drop-in calls (tools/session.sh op_pmc)
 
 
 class Args:
@@ -213,16 +215,20 @@ def hbm_op_rooflines(dev, iters=20):
             del feats, out, gp
     # counted HBM bytes per call from the committed PMC passes over the same calls (tools/session.sh op_pmc): constants of a
     # profiled build, NOT measured by this run
-    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_op_hbm_pmc.json")
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", OP_TRAFFIC_PROFILE)
+    src_ok = None
     if os.path.exists(tj):
-        table = {(r["op"], tuple(r["shape_BNKC"])): r["traffic_bytes"] for r in json.load(open(tj))["rows"]}
+        rec = json.load(open(tj))
+        src_ok = rec.get("source_id") == _lib.source_id()       # constants of another build of the kernels are not reported
+        table = {(r["op"], tuple(r["shape_BNKC"])): (r["traffic_bytes"] if src_ok else None) for r in rec["rows"]}
         for row in rows:
             key = tuple(row["shape_BNKC"])
             row["query_and_group"]["traffic_committed"] = table.get(("query_and_group", key))
             row["group_grad"]["traffic_committed"] = table.get(("group_points_grad", key))
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-            "traffic_source": "per-row traffic_committed: constants from the committed rocprofv3 PMC passes (profiles/r04_op_hbm_pmc.md), not measured by this run",
-            "traffic_profile": "profiles/r04_op_hbm_pmc.md",
+            "traffic_source": ("per-row traffic_committed: constants from the committed rocprofv3 PMC passes (profiles/%s), not measured by "
+                               "this run; null when the profile was taken on other kernel sources" % OP_TRAFFIC_PROFILE),
+            "traffic_profile": "profiles/" + OP_TRAFFIC_PROFILE, "traffic_profile_matches_sources": src_ok, "source_id": _lib.source_id(),
             "kernels": ["ball_query_ballot_kernel / bq_grid_*", "group_points_kernel", "query_and_group_kernel", "group_points_grad_*_kernel"],
             "method": "%d back-to-back launches per op between one HIP event pair; bytes = SURVEY 8d algorithmic bytes" % iters,
             "rows": rows}
@@ -269,9 +275,25 @@ def main():
     ap.add_argument("--no-op-rooflines", action="store_true", help="skip the roofline_hbm op benchmarks after the timed region")
     ap.add_argument("--clip", type=int, default=5, help="cmflow_t: frames per mini-clip (clip_util.py:34-62)")
     ap.add_argument("--gemm-table", default=None, help="write a markdown table of the bracketed cmf_gemm launches by shape to this file")
+    ap.add_argument("--host-cores", type=int, default=0,
+                    help="restrict this process (and the library's chain threads) to K host cores: the budget a rank has when N ranks "
+                         "share one host (nproc / N); applied with sched_setaffinity before anything touches the GPU")
+    ap.add_argument("--watchdog", type=float, default=0.0,
+                    help="seconds after which a rank that has not finished exits non-zero (default: 600 at world > 1, off at world 1)")
     a = ap.parse_args()
     if a.steps is None:
         a.steps = 100
+    host_cores = None
+    if a.host_cores > 0:
+        # in-process, before any HIP call (never a re-exec): the cores are taken from the allowed set in order, offset by the local
+        # rank so that ranks sharing a host get disjoint sets
+        allowed = sorted(os.sched_getaffinity(0))
+        k = min(a.host_cores, len(allowed))
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        first = (lr * k) % max(1, len(allowed) - k + 1)
+        os.sched_setaffinity(0, set(allowed[first:first + k]))
+        host_cores = {"requested": a.host_cores, "granted": len(os.sched_getaffinity(0)), "of": len(allowed)}
+        torch.set_num_threads(max(1, min(torch.get_num_threads(), k)))
 
     # stdout carries exactly ONE line (the JSON record): libraries that print to the C-level stdout (RCCL's version banner
     # at communicator creation) are sent to stderr, and the record is written to the saved descriptor at the end.  Done
@@ -308,6 +330,31 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
+    # a rank stuck in a collective (a peer died, a link is down) must not hang the launcher: a daemon thread ends the process
+    # with a non-zero code after the limit -- a fresh exit, nothing is re-executed
+    wd_limit = a.watchdog if a.watchdog > 0 else (600.0 if world > 1 else 0.0)
+    if wd_limit > 0:
+        import threading
+
+        def _watchdog():
+            time.sleep(wd_limit)
+            print("bench.py watchdog: rank %d still running after %.0f s, exiting 3" % (rank, wd_limit), file=sys.stderr, flush=True)
+            os._exit(3)
+        threading.Thread(target=_watchdog, daemon=True).start()
+    # who takes part: every rank's (host, device) identity gathered over the process group the step uses -- evidence a driver can
+    # check that RCCL saw `world` ranks on `world` distinct devices
+    ranks_seen, devices, backend = 1, None, None
+    props = torch.cuda.get_device_properties(dev)
+    me = "%s/%s/%s" % (os.uname().nodename, getattr(props, "uuid", "?"), getattr(props, "pci_bus_id", "?"))
+    if dist.is_initialized():
+        backend = dist.get_backend()
+        got = [None] * dist.get_world_size()
+        dist.all_gather_object(got, me)
+        ranks_seen, devices = len(got), got
+        if world > 1 and not one_gpu:
+            assert len(set(got)) == world, "ranks share a device: %s" % got
+    else:
+        devices = [me]
 
     from cmflow_amd import _lib, synth
     from cmflow_amd.cmflow import CMFlow, CMFlow_T
@@ -410,9 +457,13 @@ def main():
         tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", TRAFFIC_PROFILE)
         if prof["bound"] == "mfma" and a.mode == "train" and a.model == "cmflow" and os.path.exists(tp):
             rec = json.load(open(tp))
-            traffic = rec["traffic_bytes_per_launch"]
-            traffic_source = ("NOT measured by this run: constant from the committed rocprofv3 PMC passes in profiles/%s (%s)"
-                              % (TRAFFIC_PROFILE, rec.get("measured_at", "earlier build")))
+            if rec.get("source_id") == _lib.source_id():
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_source = ("NOT measured by this run: constant from the committed rocprofv3 PMC passes in profiles/%s over this same "
+                                  "command, taken on the same kernel sources (source_id %s)" % (TRAFFIC_PROFILE, rec.get("source_id")))
+            else:
+                traffic_source = ("null: profiles/%s was taken on other kernel sources (source_id %s, this library %s)"
+                                  % (TRAFFIC_PROFILE, rec.get("source_id"), _lib.source_id()))
         if prof.get("shapes"):
             tot = sum(cnt * 4.0 * (M * K + K * N + M * N * (2 if kind >= 2 else 1))
                       for (M, N, K, layout, kind, split_k, bm, bn), (cnt, _) in prof["shapes"].items())
@@ -450,12 +501,39 @@ def main():
         if iso:
             iso["note"] = "3 extra steps with every chain on one stream (outside the timed region): the kernel's own rate"
 
+    # the gradient all-reduce alone (world > 1, or forced at world 1): 20 back-to-back all-reduces of the flat bucket between one
+    # event pair on the current stream -- every rank enters them
+    allreduce_ms = None
+    if a.mode == "train" and dist.is_initialized() and not one_gpu:
+        bucket = step.bucket.flat if hasattr(step, "bucket") and hasattr(step.bucket, "flat") else None
+        if bucket is not None:
+            scratch = torch.zeros_like(bucket)
+            for _ in range(3):
+                dist.all_reduce(scratch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dist.all_reduce(scratch)
+            e1.record(); torch.cuda.synchronize()
+            allreduce_ms = round(e0.elapsed_time(e1) / 20, 4)
+            del scratch
+
     if rank == 0:
         pairs = a.batch * world * a.steps
-        roof = roofline_of(prof)
-        if roof:
-            roof["note"] = ("independent chains run on 3 side streams next to the caller's: a bracketed launch shares the chip with "
-                            "kernels (often other cmf_gemm launches) of the other streams, so its duration is a contended one")
+        contended = roofline_of(prof)
+        roof = None
+        if contended:
+            # the step figure: flops of the bracketed launches / wall time of the timed region (rank 0's launches over the
+            # max-over-ranks wall time)
+            tf = prof["units"] / dt / 1e12
+            roof = dict(contended)
+            roof.update({"achieved": round(tf, 2), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                         "avg_us": round(dt / prof["launches"] * 1e6, 2),
+                         "definition": "sum of 2*M*N*K over the bracketed launches of the timed region / the region's wall time: what the "
+                                       "step extracts from the MFMA pipe (avg_us = wall time per bracketed launch); the kernel's own rate "
+                                       "is roofline_isolated"})
+            roof.pop("note", None)
         cpu = cpu1 = hbm = None
         if world == 1 and not a.no_op_rooflines:
             hbm = hbm_op_rooflines(dev)
@@ -488,7 +566,13 @@ def main():
             # x3 for fwd+bwd) -- the build's hoisted first convs execute fewer FLOPs than that
             "algorithmic_model_tflops": round(pairs / dt * 25.52e9 * (3.0 if a.mode == "train" else 1.0) / 1e12, 2),
             # ms per step of three back-to-back timed regions of `steps` steps each (the first one is `value`): rank 0's clock
-            "extra": {"ms_per_step_regions": [round(v, 3) for v in spread]},
+            "extra": {"ms_per_step_regions": [round(v, 3) for v in spread],
+                      # per-launch durations bracketed inside the timed region: launches on four streams overlap, so their sum exceeds
+                      # the wall time -- a concurrency artefact, not a roofline figure
+                      "contended_per_launch": ({k: contended[k] for k in ("achieved", "frac", "avg_us", "launches")} if contended else None),
+                      "host_cores": host_cores},
+            "ranks_seen": ranks_seen, "devices": devices, "backend": backend, "allreduce_ms": allreduce_ms,
+            "source_id": _lib.source_id(),
         }
         if a.gemm_table:
             with open(a.gemm_table, "w") as f:

@@ -221,6 +221,22 @@ def check(err, what):
 # Only launches of at least this many flops are bracketed: an event pair costs a few microseconds of stream time, which
 # would distort the step if the ~150 thin / small GEMM launches of a step were bracketed too.  The share of the FLOPs
 # the bracketed launches carry is reported next to the result (`flop_share`).
+def source_id():
+    """Identity of the kernel SOURCES the in-tree library was built from (sha256 over csrc/*.hip, *.h and include/*.h, first 16
+    hex digits): profiles that carry PMC constants record it, and bench.py only reports such a constant next to a library of the
+    same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    for d in (csrc, inc):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".h")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 TRACK_MIN_UNITS = {"cmf_gemm": 1.0e9}
 _prof_open = False
 

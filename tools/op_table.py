@@ -3,6 +3,9 @@ table per (op, shape): kernels of one call, duration, algorithmic bytes (SURVEY 
 HBM bytes (FETCH_SIZE x 2: gfx950 counts 64 B per 128-B request; both counters are reported in KB) and counted / algorithmic.
     python tools/op_table.py <kernel_trace.csv> <fetch counter_collection.csv> <write counter_collection.csv> <probe stdout> [out.json]"""
 import csv, json, sys, collections
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from cmflow_amd import _lib
 trace, fetch, write, probe = sys.argv[1:5]
 json_out = sys.argv[5] if len(sys.argv) > 5 else None
 records = []
@@ -48,4 +51,4 @@ for ph, d, f, w in zip(phases, D, F, W):
                     "fetch_bytes_x2": round(fmb * 1e6), "write_bytes": round(wmb * 1e6), "traffic_bytes": round((fmb + wmb) * 1e6)})
 if json_out:
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/op_probe.py; FETCH_SIZE x 2 "
-                       "(gfx950 counts 64 B per 128-B request); per call (mean of 3)", "rows": records}, open(json_out, "w"), indent=1)
+                       "(gfx950 counts 64 B per 128-B request); per call (mean of 3)", "source_id": _lib.source_id(), "rows": records}, open(json_out, "w"), indent=1)
