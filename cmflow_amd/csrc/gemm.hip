@@ -124,7 +124,7 @@ template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
 __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const GemmArgs p)
 {
     constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2, GATHER_Z = GMODE == 3 || GMODE == 4, GATHER_S = GMODE == 4;
-    static_assert(!GATHER_Z || (!A_T && !B_T && EPI == 4 && BM == 128 && BN == 128), "gathered Z rows: the kind-4 data gradient");
+    static_assert(!GATHER_Z || (!A_T && !B_T && EPI == 4 && (BM == 128 || (BM == 256 && GMODE == 4)) && BN == 128), "gathered Z rows: the kind-4 data gradient");
     static_assert(!GATHER || (!A_T && B_T), "gathering A operand: A[M][K] W[N][K] layout");
     static_assert(!GATHER_B || (A_T && !B_T), "gathering B operand: A[K][M] B[K][N] layout");
     constexpr int WARPS_M = (BM == 64) ? 2 : ((BN >= 128) ? 2 : 4);
@@ -1061,23 +1061,28 @@ __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const
     // (point, range) pairs are monotone along the rows, so point + range numbers the pieces uniquely and the consumer adds the pieces
     // of a point in range order (deterministic).  The 1 GB the M x N gradient took at the largest scale is neither written nor read.
     auto seg_epilogue = [&](auto only_when_called) {
-        static_assert(WM == 64 && WN == 64 && TM == 2 && TN == 2, "wave tile 64 x 64");
-        constexpr int S_SZ = 32 * 64 + 64 * 4;                        // per wave: transposition tile | dxyz rows
+        static_assert(WM % 64 == 0 && WN == 64 && TN == 2, "wave tile 64 h x 64");
+        constexpr int S_SZ = 32 * 64 + 64 * 4;                        // per wave: transposition tile | dxyz rows (of one 64-row half)
         float *wt = smem + wid * S_SZ, *wdq = wt + 32 * 64;
         const int wms = __builtin_amdgcn_readfirstlane(wm), wns = __builtin_amdgcn_readfirstlane(wn);
-        const int rbase = m0 + wms * WM;
         const int c = n0 + wns * WN + lane;                           // this lane's column
+        const float k0 = p.ea[c], k1 = p.ec[c], k2 = p.emean[c], k3 = p.einvstd[c];
+        const float g0 = p.ga_wx[c], g1 = p.ga_wx[(long long)p.N + c], g2 = p.ga_wx[2ll * p.N + c];
+        const float *ycol = p.Z + c;
+        float *pcol = p.ga_pieces + c;
+        float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f;
+        // a wave tile of 128 rows (256-row workgroup tiles) is two 64-row halves, each a range of its own in `pieces`
+#pragma unroll
+        for (int hv = 0; hv < WM / 64; ++hv) {
+        const int rbase = m0 + wms * WM + hv * 64;
+        if (hv > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous half's reads of wdq are complete
         *(f32x4 *)(wdq + lane * 4) = *(const f32x4 *)(p.dxyz + (long long)(rbase + lane) * 4);
         // the source point of row `lane` stays in the lane (read per row with v_readlane); the rows where it changes as a wave mask
         const int ptv = p.ga_rows[rbase + lane];
         const int ptb = __shfl_up(ptv, 1, 64);
         const unsigned long long starts = __ballot(lane == 0 || ptv != ptb);
-        const float k0 = p.ea[c], k1 = p.ec[c], k2 = p.emean[c], k3 = p.einvstd[c];
-        const float g0 = p.ga_wx[c], g1 = p.ga_wx[(long long)p.N + c], g2 = p.ga_wx[2ll * p.N + c];
         const long long range = rbase / 64;
-        const float *ycol = p.Z + c;
-        float *pcol = p.ga_pieces + c;
-        float t1 = 0.f, t2 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, seg = 0.f;
+        float seg = 0.f;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (wave-private LDS: the wave's own writes above, in order)
         int pt_cur = 0;
         // the per-point rows of 8 output rows at a time, requested one group ahead (rows of one run re-read the same 256 bytes)
@@ -1086,7 +1091,7 @@ __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const
 #pragma unroll
             for (int u = 0; u < 8; ++u) y[u] = ycol[(long long)__builtin_amdgcn_readlane(ptv, row0 + u) * p.ldz];
         };
-        auto rows8 = [&](int i, int row0, const float (&y)[8]) {       // rows row0 .. row0 + 7 of the wave tile (block row i)
+        auto rows8 = [&](int i, int row0, const float (&y)[8]) {       // rows row0 .. row0 + 7 of the half (block row i of it)
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = row0 + u;
@@ -1105,12 +1110,12 @@ __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const
         };
         load_y(0, ya);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    wt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+                    wt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[(2 * hv + i) % TM][j][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // (a real loop with compiler fences: unrolled, the scheduler hoists every LDS read and per-point load of the block row above
             //  the arithmetic -- 235 spilled registers)
@@ -1129,16 +1134,21 @@ __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is read before the next block row overwrites it
         }
         pcol[((long long)pt_cur + range) * p.N] = seg; t1 += seg;    // (s1 = the sum of the runs' sums)
-        // statistics: the two wave rows through LDS, one partial row per 128-row tile like the other epilogues
+        }
+        // statistics: one partial row per 128 rows like the other epilogues -- the wave rows of a 128-row slice through LDS
         lds_barrier();
         float *red = smem;                                            // [WARPS_M][5][BN]
         const int cc = wns * WN + lane;
         red[(wms * 5 + 0) * BN + cc] = t1; red[(wms * 5 + 1) * BN + cc] = t2;
         red[(wms * 5 + 2) * BN + cc] = q0; red[(wms * 5 + 3) * BN + cc] = q1; red[(wms * 5 + 4) * BN + cc] = q2;
         lds_barrier();
-        for (int e = tid; e < 5 * BN; e += G_THREADS) {
-            const int which = e / BN, col = e % BN;
-            p.stats[((long long)tm * 5 + which) * p.N + n0 + col] = red[(0 * 5 + which) * BN + col] + red[(1 * 5 + which) * BN + col];
+        constexpr int SPT = BM > 128 ? BM / 128 : 1, WPS = WARPS_M / SPT;
+        for (int e = tid; e < SPT * 5 * BN; e += G_THREADS) {
+            const int sp = e / (5 * BN), which = (e / BN) % 5, col = e % BN;
+            float sum = red[((sp * WPS) * 5 + which) * BN + col];
+#pragma unroll
+            for (int g = 1; g < WPS; ++g) sum += red[((sp * WPS + g) * 5 + which) * BN + col];
+            p.stats[(((long long)tm * SPT + sp) * 5 + which) * p.N + n0 + col] = sum;
         }
         stats_done = true;
     };
@@ -1690,6 +1700,9 @@ extern "C" int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ,
     g.M = M; g.N = cin; g.K = cout; g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = pieces; g.ldc = cin;
     g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz2;
     g.ga_rows = pts; g.ga_dxyz = dxyz2; g.ga_wx = wx3; g.ga_arows = arows; g.ga_pieces = pieces; g.split_k = 1;
+    // (256-row tiles -- wave tile 128 x 64 = two 64-row ranges of `pieces` -- measured here, round 5: 99.7 against 105 TF at 524288 rows:
+    //  the serial row walk of the epilogue doubles per wave while only two workgroups per CU are left to cover it; CMF_GEMM_TALL=2: A/B)
+    if (gemm_tall_mode() == 2 && M % 256 == 0 && (long long)(M / 256) * (cin / 128) >= 384) return launch<256, 128, false, false, 4, 4>(g, st);
     return launch<128, 128, false, false, 4, 4>(g, st);
 }
 
