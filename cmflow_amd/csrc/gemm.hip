@@ -1612,7 +1612,7 @@ extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
           : (wide ? launch<64, 128, AT, BT, EP>(g, st) : launch<64, 64, AT, BT, EP>(g, st)))
     const int pgrid = thin_done ? 0 : cmf_pgemm_grid(g, a_t, b_t, kind);
     if (!pgrid && staged_dw) g.no_direct = 1;
-    const bool big = tall_mode && !a_t && M % 256 == 0 && N % 128 == 0 && K % G_BK == 0 && work_tiles >= 384 && !g.no_direct && !(accumulate && g.split_k == 1);
+    const bool big = tall_mode && (!a_t || tall_mode == 3) && M % 256 == 0 && N % 128 == 0 && K % G_BK == 0 && work_tiles >= 384 && !g.no_direct && !(accumulate && g.split_k == 1);
     if (thin_done)         err = 0;
     else if (pgrid) {
         const long long pe = gprof_open(2.0 * M * N * K, st, &g, (a_t ? 2 : 0) | (b_t ? 1 : 0) | 4, 128, 128);      // layout bit 2: persistent kernel

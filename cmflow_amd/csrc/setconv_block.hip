@@ -140,6 +140,11 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
 #define CMF_TRY(call) do { int e_ = (call); if (e_) return e_; } while (0)
 
 }  // namespace
+// csrc/setconv_chain.hip (internal)
+bool cmf_setconv_chain_supported(int N, int S, int O1, int C2, int C3, long long M);
+int cmf_setconv_chain_infer(long long M, int N, int S, const int *idx, const float *xyz, const float *y, long long ldy, const float *wx,
+                            long long ldwx, const float *bn0, const float *bn1, const float *bn2, const float *w2, const float *w3, float *out,
+                            long long ldo, void *stream);
 // csrc/pointwise.hip (internal): cmf_colsum with the first 2*C columns stored to dst0 / dst1
 int cmf_colsum_store(int tiles, int ncols, const float *partial, float *out, int C, float *dst0, float *dst1, void *stream);
 namespace {
@@ -335,6 +340,17 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     // inference (eval-mode BN and no backward call to follow): the grouped first-layer tensor z1 (M x O1: 1 GB at the largest scale of
     // the second encoder) is never written -- the second layer's GEMM gathers the per-point rows and forms the layer in its A-operand
     // path (cmf_gemm_gather_affine, bit-identical); the slot of z1 holds the M source-row indices and the coordinate planes of Wx
+    // inference of the narrow block (first encoder): layers 1-3 and the max over the ball as ONE register-chain kernel
+    // (csrc/setconv_chain.hip; every layer bit-identical to the per-layer kernels) -- nothing but the pooled rows is written
+    if (!d->training && d->inference && cmf_setconv_chain_supported(d->N, d->S, O1, C2, C3, M) && d->ldy % 4 == 0 && ((uintptr_t)d->y & 15) == 0) {
+        CMF_TRY(cmf_setconv_chain_infer(M, d->N, d->S, L.idx, d->xyz, d->y, d->ldy, d->wx, d->ldwx, L.bn[0], L.bn[1], L.bn[2], d->w[0], d->w[1],
+                                        L.x, C3, st));
+        if (part == 1) return 0;
+        CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, st));
+        CMF_TRY(fwd_gemm(d, L, P, C4, C5, L.z4, 3, d->w[3], L.z5, st));
+        CMF_TRY(fwd_gemm(d, L, P, C5, C6, L.z5, 4, d->w[4], L.z6, st));
+        return cmf_affine_relu(P, C6, L.z6, C6, L.bn[5] + 2 * C6, L.bn[5] + 3 * C6, d->out, d->ldo, st);
+    }
     const bool gather = !d->training && ((d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
                                           (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31)) || train_gather(d));
     if (d->training && train_gather(d)) {

@@ -328,8 +328,10 @@ def test_full_size_forward_matches_oracle(dev):
 
 def test_inference_forward_equals_eval_forward_with_autograd(dev):
     """Under torch.no_grad() the second encoder's blocks skip the grouped first-layer tensor (cmf_gemm_gather_affine: the layer is
-    formed in the A-operand path of the next GEMM); with autograd recording (eval-mode BN, a backward pass may follow) they
-    materialise it.  Same operations in the same order: every output of the model must be equal bit for bit (B = 64, bench.py's batch)."""
+    formed in the A-operand path of the next GEMM) and the first encoder's blocks run layers 1-3 + the max over the ball as ONE
+    register-chain kernel (csrc/setconv_chain.hip: no activation is written between the layers); with autograd recording (eval-mode
+    BN, a backward pass may follow) both materialise their layers with the per-layer kernels.  Same operations in the same order:
+    every output of the model must be equal bit for bit (B = 64, bench.py's batch)."""
     ref, net, b, bd = _bench_setup(dev, train=False)
     with torch.no_grad():
         a = net(bd["pc1"], bd["pc2"], bd["ft1"], bd["ft2"], None, "test")
