@@ -891,7 +891,7 @@ __global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_kernel(
     long long P, int S, int C, const float *__restrict__ dout, long long ldd, const float *__restrict__ z,
     const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
     const float *__restrict__ invstd, const unsigned char *__restrict__ argmax, float *__restrict__ g,
-    float *__restrict__ partial)
+    float *__restrict__ partial, int sel)
 {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const TileMap tm = tile_map(C);
@@ -902,10 +902,16 @@ __global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_kernel(
     for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
         const long long p = p0 + r;
         if (p >= P) break;
-        const uchar4 am = *(const uchar4 *)(argmax + (size_t)p * C + tm.col);
         const float4 gi = *(const float4 *)(dout + (size_t)p * ldd + tm.col);
-        const float *zp = z + (size_t)p * S * C + tm.col;
-        const float vx = zp[(size_t)am.x * C], vy = zp[(size_t)am.y * C + 1], vz = zp[(size_t)am.z * C + 2], vw = zp[(size_t)am.w * C + 3];
+        float vx, vy, vz, vw;
+        if (sel) {                                       // z = the selected pre-activations per point (P, C): the set-conv chain keeps only those
+            const float4 zs = *(const float4 *)(z + (size_t)p * C + tm.col);
+            vx = zs.x; vy = zs.y; vz = zs.z; vw = zs.w;
+        } else {
+            const uchar4 am = *(const uchar4 *)(argmax + (size_t)p * C + tm.col);
+            const float *zp = z + (size_t)p * S * C + tm.col;
+            vx = zp[(size_t)am.x * C]; vy = zp[(size_t)am.y * C + 1]; vz = zp[(size_t)am.z * C + 2]; vw = zp[(size_t)am.w * C + 3];
+        }
         float4 d;
         d.x = fmaf(sa.x, vx, sc.x) > 0.f ? gi.x : 0.f;
         d.y = fmaf(sa.y, vy, sc.y) > 0.f ? gi.y : 0.f;
@@ -927,7 +933,19 @@ extern "C" int cmf_maxpool_bwd_point(long long P, int S, int C, const float *dou
     if (P == 0) return 0;
     CMF_CHECK_ARG(dout && z && a && c && mean && invstd && argmax && g && partial);
     hipLaunchKernelGGL(maxpool_bwd_point_kernel, dim3(cmf_divup(P, PW_ROWS)), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
-                       P, S, C, dout, ldd, z, a, c, mean, invstd, argmax, g, partial);
+                       P, S, C, dout, ldd, z, a, c, mean, invstd, argmax, g, partial, 0);
+    return cmf_launch_status();
+}
+
+// internal (setconv_block.hip): the same with the pre-activation of every point's argmax slot given directly (zsel: P x C)
+int cmf_maxpool_bwd_point_sel(long long P, int C, const float *dout, long long ldd, const float *zsel, const float *a, const float *c,
+                              const float *mean, const float *invstd, float *g, float *partial, void *stream)
+{
+    CMF_CHECK_ARG(P >= 0 && tile_ok(C) && ldd % 4 == 0);
+    if (P == 0) return 0;
+    CMF_CHECK_ARG(dout && zsel && a && c && mean && invstd && g && partial);
+    hipLaunchKernelGGL(maxpool_bwd_point_kernel, dim3(cmf_divup(P, PW_ROWS)), dim3(PW_THREADS), tile_lds(C), (hipStream_t)stream,
+                       P, 1, C, dout, ldd, zsel, a, c, mean, invstd, nullptr, g, partial, 1);
     return cmf_launch_status();
 }
 

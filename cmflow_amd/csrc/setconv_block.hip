@@ -13,7 +13,25 @@
 #include "gemm_args.h"
 #include "../../include/cmflow_hip.h"
 
+bool cmf_setconv_chain_supported(int N, int S, int O1, int C2, int C3, long long M);
+long long cmf_setconv_chain_waves(long long M, int backward);
+
 namespace {
+
+// training through the register chain (csrc/setconv_chain.hip): the narrow block's slot-level activations z1 / z2 / z3 are never stored
+// -- every pass recomputes them from the gathered per-point rows; z3's slot of `saved` holds the selected pre-activations (P x C3).
+// OPT-IN (CMF_CHAIN_TRAIN=1), measured round 5 on the training step's first encoder (both clouds, four scales, isolated kernel
+// time): five chain passes 1.64 ms against 1.50 ms for the per-layer kernels they replace -- at 64 K .. 512 K rows per launch the
+// passes' fixed costs (constants and weights into LDS per workgroup, a statistics row per wave, the re-gather per pass) eat what
+// the 3x lower HBM traffic saves; the step is equal within noise (20.15 vs 20.20 ms).  Inference (one pass, nothing else to
+// amortise) is where the chain pays: forward 5.91 -> 5.56 ms.
+inline bool chain_train(const cmf_setconv_desc *d)
+{
+    static const bool on = getenv("CMF_CHAIN_TRAIN") && getenv("CMF_CHAIN_TRAIN")[0] == '1';
+    const long long M = (long long)d->B * d->N * d->S;
+    return on && !d->inference && cmf_setconv_chain_supported(d->N, d->S, d->O1, d->C[0], d->C[1], M) && M % 128 == 0 && d->ldy % 4 == 0 &&
+           ((uintptr_t)d->y & 15) == 0;
+}
 
 struct Bump {
     float *base;
@@ -129,6 +147,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         for (const auto &l : lay)
             if (cmf_thin_bwd_supported(l.cout, l.cin)) sk = std::max(sk, (size_t)cmf_thin_bwd_slabs(l.rows, nullptr) * l.cout * l.cin);
         if (cmf_thin_bwd_wide_supported(C3, C2)) sk = std::max(sk, (size_t)cmf_thin_bwd_wide_slabs(M, C2, nullptr) * 64 * C2);
+        if (cmf_setconv_chain_supported(d->N, d->S, O1, C2, C3, M)) sk = std::max(sk, (size_t)(cmf_setconv_chain_waves(M, 1) / 4) * C3 * C2);
         L.splitk = t.take(sk);
     } else {
         L.t6 = L.t5 = L.t4 = L.dx = L.dU3 = L.dU2 = L.dU1 = L.splitk = L.dZ2 = nullptr;
@@ -140,8 +159,17 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
 #define CMF_TRY(call) do { int e_ = (call); if (e_) return e_; } while (0)
 
 }  // namespace
-// csrc/setconv_chain.hip (internal)
+// csrc/setconv_chain.hip (internal): the narrow block's neighbour-slot layers as register-chain passes
+// (mode: 0 inference, 1 / 2 statistics of z2 / z3, 3 max over the ball + argmax + selected pre-activations, 4 / 5 backward of layers 3 / 2)
 bool cmf_setconv_chain_supported(int N, int S, int O1, int C2, int C3, long long M);
+long long cmf_setconv_chain_waves(long long M, int backward);
+int cmf_setconv_chain_pass(int mode, long long M, int N, int S, const int *idx, const float *xyz, const float *dxyz, const float *y, long long ldy, const float *wx,
+                           long long ldwx, const float *bn0, const float *bn1, const float *bn2, const float *w2, const float *w3, float *out,
+                           long long ldo, float *zsel, unsigned char *argmax, float *partial, const float *g, const float *sums,
+                           const float *dU_in, float *dU_out, float *slabs, void *stream);
+// csrc/pointwise.hip (internal)
+int cmf_maxpool_bwd_point_sel(long long P, int C, const float *dout, long long ldd, const float *zsel, const float *a, const float *c,
+                              const float *mean, const float *invstd, float *g, float *partial, void *stream);
 int cmf_setconv_chain_infer(long long M, int N, int S, const int *idx, const float *xyz, const float *y, long long ldy, const float *wx,
                             long long ldwx, const float *bn0, const float *bn1, const float *bn2, const float *w2, const float *w3, float *out,
                             long long ldo, void *stream);
@@ -351,6 +379,37 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
         CMF_TRY(fwd_gemm(d, L, P, C5, C6, L.z5, 4, d->w[4], L.z6, st));
         return cmf_affine_relu(P, C6, L.z6, C6, L.bn[5] + 2 * C6, L.bn[5] + 3 * C6, d->out, d->ldo, st);
     }
+    if (chain_train(d)) {
+        // training (batch statistics: a pass per BatchNorm layer, each recomputing the layers below it) or eval-mode BN with a backward
+        // pass to follow (one pass): nothing but the pooled rows, their argmax slots and the selected pre-activations is stored
+        const int wv = (int)cmf_setconv_chain_waves(M, 0);
+        auto pass = [&](int mode) {
+            return cmf_setconv_chain_pass(mode, M, d->N, d->S, L.idx, d->xyz, d->training ? L.dxyz : nullptr, d->y, d->ldy, d->wx, d->ldwx, L.bn[0], L.bn[1], L.bn[2], d->w[0],
+                                          d->w[1], L.x, C3, L.z3, L.argmax, L.partial, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+        };
+        if (d->training) {
+            CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
+                                     nullptr, L.dxyz, L.partial, L.partial_x, st));
+            CMF_TRY(cmf_colsum(tiles128(M), 3 * O1 + 4, L.partial_x, L.fwd_sums, 0, nullptr, nullptr, st));
+            CMF_TRY(fold(d, L, 0, M, st));
+            for (int l = 1; l <= 2; ++l) {
+                CMF_TRY(pass(l));
+                const int C = chan(d, l);
+                float *b = L.bn[l];
+                CMF_TRY(cmf_bn_finalize(wv, C, (double)M, L.partial, d->gamma[l], d->beta[l], d->eps[l], d->momentum[l], d->rmean[l], d->rvar[l],
+                                        b, b + C, b + 2 * C, b + 3 * C, d->nbt[l], st));
+            }
+        }
+        CMF_TRY(pass(3));
+        if (part == 1) return 0;
+        CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, st));
+        CMF_TRY(fold(d, L, 3, P, st));
+        CMF_TRY(fwd_gemm(d, L, P, C4, C5, L.z4, 3, d->w[3], L.z5, st));
+        CMF_TRY(fold(d, L, 4, P, st));
+        CMF_TRY(fwd_gemm(d, L, P, C5, C6, L.z5, 4, d->w[4], L.z6, st));
+        CMF_TRY(fold(d, L, 5, P, st));
+        return cmf_affine_relu(P, C6, L.z6, C6, L.bn[5] + 2 * C6, L.bn[5] + 3 * C6, d->out, d->ldo, st);
+    }
     const bool gather = !d->training && ((d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
                                           (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31)) || train_gather(d));
     if (d->training && train_gather(d)) {
@@ -557,6 +616,23 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
     // the wide-input form of the fused layer (64 <- 256 channels, second encoder): CMF_THIN_WIDE=0 keeps max-pool backward, BN
     // backward and the two tiled GEMMs (A/B: 22.6 vs 22.9 ms per step)
     static const bool wide = !(getenv("CMF_THIN_WIDE") && getenv("CMF_THIN_WIDE")[0] == '0');
+    if (chain_train(d)) {
+        // the chain's backward: the pooled gradient per point with layer 3's BN-backward sums from the selected pre-activations, then two
+        // passes that recompute the layers they differentiate (weight-gradient slabs per workgroup, statistics rows per wave)
+        float *g = L.dU3;
+        const int wv = (int)cmf_setconv_chain_waves(M, 1), nslab = wv / 4;
+        CMF_TRY(cmf_maxpool_bwd_point_sel(P, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, g, L.partial, st));
+        if (d->acc_bn[2]) CMF_TRY(cmf_colsum_finalize(tiles128(P), C3, L.partial, L.sums, d->dbeta[2], d->dgamma[2], st));
+        else CMF_TRY(cmf_colsum_store(tiles128(P), 2 * C3, L.partial, L.sums, C3, d->dbeta[2], d->dgamma[2], st));
+        CMF_TRY(cmf_setconv_chain_pass(4, M, d->N, d->S, L.idx, d->xyz, d->training ? L.dxyz : nullptr, d->y, d->ldy, d->wx, d->ldwx, L.bn[0], L.bn[1], L.bn[2], d->w[0], d->w[1],
+                                       nullptr, 0, nullptr, L.argmax, L.partial, g, d->training ? L.sums : nullptr, nullptr, L.dU2, L.splitk, st));
+        if (d->dw[1]) CMF_TRY(cmf_splitk_reduce(C3, C2, nslab, L.splitk, d->dw[1], C2, d->acc_w[1], (hipStream_t)st));
+        if (d->acc_bn[1]) CMF_TRY(cmf_colsum_finalize(wv, C2, L.partial, L.sums, d->dbeta[1], d->dgamma[1], st));
+        else CMF_TRY(cmf_colsum_store(wv, 2 * C2, L.partial, L.sums, C2, d->dbeta[1], d->dgamma[1], st));
+        CMF_TRY(cmf_setconv_chain_pass(5, M, d->N, d->S, L.idx, d->xyz, d->training ? L.dxyz : nullptr, d->y, d->ldy, d->wx, d->ldwx, L.bn[0], L.bn[1], L.bn[2], d->w[0], d->w[1],
+                                       nullptr, 0, nullptr, nullptr, L.partial, nullptr, d->training ? L.sums : nullptr, L.dU2, L.dU1, L.splitk, st));
+        if (d->dw[0]) CMF_TRY(cmf_splitk_reduce(C2, O1, nslab, L.splitk, d->dw[0], O1, d->acc_w[0], (hipStream_t)st));
+    } else
     if (fused && cmf_thin_bwd_supported(C3, C2) && M % 128 == 0 && C3 % 32 == 0 && C2 % 32 == 0 && d->dw[1]) {
         // narrow layers: the gradient of the pooled tensor is kept per POINT (g, in L.dx's neighbour L.dU3) and expanded
         // by the fused layer kernel on the fly -- the [M, C3] matrix is neither written nor read
@@ -582,13 +658,16 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
         CMF_TRY(cmf_maxpool_bwd(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, L.dU3, L.partial, st));
         CMF_TRY(bwd_layer(d, L, 2, M, C3, C2, L.dU3, L.z3, d->w[1], L.z2, 1, L.dU2, nullptr, d->dw[1], d->acc_w[1], st));
     }
-    if (train_gather(d)) CMF_TRY(bwd_layer1_gather(d, L, M, C2, O1, st));
+    const bool chain = chain_train(d);
+    if (chain) {}
+    else if (train_gather(d)) CMF_TRY(bwd_layer1_gather(d, L, M, C2, O1, st));
     else
     CMF_TRY(bwd_layer(d, L, 1, M, C2, O1, L.dU2, L.z2, d->w[0], L.z1, 0, L.dU1, L.dxyz, d->dw[0], d->acc_w[0], st, L.dZ2));
     // first layer: sums {s1,s2,q0,q1,q2}; dgamma/dbeta; dW_xyz from sums; BN backward folded into the scatter
     const float *b0 = L.bn[0];
-    if (d->acc_bn[0]) CMF_TRY(cmf_colsum(tiles128(M), 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));
-    else CMF_TRY(cmf_colsum_store(tiles128(M), 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));
+    const int rows0 = chain ? (int)cmf_setconv_chain_waves(M, 1) : tiles128(M);      // statistics rows of the pass that formed dU1
+    if (d->acc_bn[0]) CMF_TRY(cmf_colsum(rows0, 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));
+    else CMF_TRY(cmf_colsum_store(rows0, 5 * O1, L.partial, L.sums, O1, d->dbeta[0], d->dgamma[0], st));
     if (d->dwx)
         CMF_TRY(cmf_setconv_dwx(O1, (float)(1.0 / (double)M), d->training, L.sums, L.fwd_sums, b0 + 2 * O1, b0, b0 + O1, d->dwx,
                                 (int)d->lddwx, d->acc_wx, st));

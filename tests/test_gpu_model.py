@@ -365,6 +365,38 @@ def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, t
         assert not bad, (bn_mode, bad[:10])
 
 
+def test_chain_training_matches_the_per_layer_kernels(dev, tmp_path):
+    """CMF_CHAIN_TRAIN=1 (opt-in): the first encoder's blocks train through the register chain (csrc/setconv_chain.hip: slot-level
+    activations never stored, every pass recomputes them; statistics rows per wave instead of per 128 rows).  Same terms as the
+    per-layer kernels in another association -- but already in the FORWARD pass (the batch statistics are summed in another order, so
+    every activation moves in its last bits and a few ReLU / arg-max decisions flip): the loss agrees to 1e-6 relative and the BN
+    buffers to 1e-5, the gradients only to fp32's own noise floor at this size (tests/grad_noise_floor.py: 6e-4 of the norm for the
+    whole model, up to 1e-2 for cancellation-prone BN biases) -- the bound of test_full_size_train_step_matches_oracle."""
+    import subprocess, sys
+    outs = []
+    for i, env in enumerate((dict(CMF_CHAIN_TRAIN="0"), dict(CMF_CHAIN_TRAIN="1"))):
+        f = str(tmp_path / ("chain%d.pt" % i))
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(f))
+    a, b = outs
+    assert a.keys() == b.keys()
+    assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-6 * abs(float(a["loss"]))
+    worst = 0.0
+    for k in a:
+        if k.startswith("b.") and a[k].is_floating_point():
+            assert torch.allclose(a[k], b[k], rtol=1e-5, atol=1e-6), k
+        elif k.startswith("g."):
+            rel = float((a[k].double() - b[k].double()).norm() / (a[k].double().norm() + 1e-30))
+            worst = max(worst, rel)
+            assert rel <= 2e-2, (k, rel)
+    ga = torch.cat([a[k].flatten().double() for k in a if k.startswith("g.")]); gb = torch.cat([b[k].flatten().double() for k in a if k.startswith("g.")])
+    whole = float((ga - gb).norm() / ga.norm())
+    assert whole <= 2e-3, whole
+    print("chain training: worst per-tensor relative gradient difference %.3g, whole gradient %.3g" % (worst, whole))
+
+
 def test_summed_data_gradient_changes_nothing_but_the_association(dev, tmp_path):
     """Default (CMF_TRAIN_GATHER_SUM=0 switches it off): the data gradient into the second encoder's first layer is not stored either --
     the GEMM reduces it over runs of equal source points (cmf_gemm_dx_gather_sum).  Same terms, another association: against the

@@ -1,4 +1,5 @@
-"""Kernel-time breakdown of the first encoder alone (both clouds, forward + backward, train-mode BN) at B=64, N=256."""
+"""Kernel-time breakdown of the first encoder alone (both clouds, forward + backward, train-mode BN) at B=64, N=256.
+ENC1_SERIAL=1: every chain on one stream (isolated kernel durations)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -8,6 +9,9 @@ from cmflow_amd.train import TrainStep
 dev = torch.device("cuda:0")
 net = CMFlow(bench.Args()); net.load_state_dict(bench.load_weights("cmflow")); net = net.to(dev).train()
 step = TrainStep(net)                     # gradient sinks in place, as in training
+if os.environ.get("ENC1_SERIAL") == "1":
+    from cmflow_amd import fused_blocks as _FB
+    _FB.set_serial(net, True)
 b = {k: v.to(dev) for k, v in synth.make_batch(64, seed=1).items()}
 x1, x2 = b["pc1"].transpose(1, 2).contiguous(), b["pc2"].transpose(1, 2).contiguous()
 a1 = torch.nn.functional.pad(b["ft1"].transpose(1, 2).contiguous(), (0, 1))
