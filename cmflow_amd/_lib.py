@@ -63,7 +63,7 @@ SIGNATURES = {
     "cmf_bn_finalize": [_ci, _ci, ctypes.c_double, _vp, _vp, _vp, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_colsum_finalize": [_ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_affine": [_ci, _ci, _ci, _ci, _ci, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _ci, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
-    "cmf_adam_step": [_ci, _vp, _vp, _ll, _vp, _vp, _vp, _cf, _cf, _cf, _cf, _cf, _ll, _vp],
+    "cmf_adam_step": [_ci, _vp, _vp, _ll, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _ll, _vp],
     "cmf_group_prep": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_gemm_gather_affine": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp],
     "cmf_gemm_dx_gather": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

@@ -638,7 +638,9 @@ static int *sched_block(hipStream_t st)
     std::lock_guard<std::mutex> lock(mu);
     int *&e = (*table)[std::make_pair(dev, st)];
     if (!e) {
-        if (hipMalloc((void **)&e, 64) != hipSuccess || hipMemset(e, 0, 64) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
+        // zeroed IN STREAM ORDER on the stream whose launches use the block (side streams are non-blocking: nothing orders them behind a
+        // null-stream hipMemset), once, ahead of that stream's first persistent launch
+        if (hipMalloc((void **)&e, 64) != hipSuccess || hipMemsetAsync(e, 0, 64, st) != hipSuccess) { (void)hipGetLastError(); e = nullptr; }
     }
     return e;
 }

@@ -41,12 +41,15 @@ __global__ __launch_bounds__(AD_THREADS) void adam_flat_kernel(int n_tensors, co
     }
 }
 
+// The hyper-parameters arrive as doubles (Python floats) and every derived scalar is formed in double before it is rounded to fp32
+// once, as torch does: 1 - beta is (float)(1.0 - beta), not 1.f - (float)beta (those differ by 1e-5 relative for beta2 = 0.999).
 extern "C" int cmf_adam_step(int n_tensors, const long long *offsets, float *const *params, long long total, const float *grad, float *m,
-                             float *v, float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void *stream)
+                             float *v, double lr, double beta1, double beta2, double eps, double weight_decay, long long step, void *stream)
 {
-    CMF_CHECK_ARG(n_tensors > 0 && offsets && params && total > 0 && grad && m && v && step >= 1 && lr >= 0.f);
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    CMF_CHECK_ARG(n_tensors > 0 && offsets && params && total > 0 && grad && m && v && step >= 1 && lr >= 0.0);
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)cmf_divup(total, AD_CHUNK)), dim3(AD_THREADS), 0, (hipStream_t)stream, n_tensors, offsets,
-                       params, total, grad, m, v, weight_decay, 1.f - beta1, beta2, 1.f - beta2, (float)((double)lr / bc1), (float)sqrt(bc2), eps);
+                       params, total, grad, m, v, (float)weight_decay, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1),
+                       (float)sqrt(bc2), (float)eps);
     return cmf_launch_status();
 }

@@ -71,6 +71,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     def __init__(self, bucket, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(bucket.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam: one parameter group (the bucket's parameters) -- per-group options are not supported")
         self.bucket = bucket
         self.exp_avg = torch.zeros_like(bucket.flat)
         self.exp_avg_sq = torch.zeros_like(bucket.flat)
@@ -105,12 +107,19 @@ class FlatAdam(torch.optim.Optimizer):
             if p.grad is not v:
                 raise RuntimeError("a gradient left the flat bucket (zero_grad(set_to_none=True)?)")
         self._tables()                                       # a parameter whose storage was replaced gets its new address
+        if len(self.param_groups) != 1:
+            raise RuntimeError("FlatAdam: add_param_group is not supported (one group: the bucket's parameters)")
         g = self.param_groups[0]
         self.steps += 1
         _lib.check(_lib.lib().cmf_adam_step(len(b.params), self._offs.data_ptr(), self._pt.data_ptr(), b.numel, b.flat.data_ptr(),
                                             self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), float(g["lr"]), float(g["betas"][0]),
                                             float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self.steps,
                                             _lib.stream_ptr()), "cmf_adam_step")
+        # the kernel writes the parameters through raw pointers: bump their autograd version counters like an in-place torch op would,
+        # so that a backward pass through a graph recorded BEFORE this step raises instead of silently using the updated weights
+        bump = getattr(torch.autograd.graph, "increment_version", None)
+        if bump is not None:
+            bump(b.params)
         return loss
 
     def zero_grad(self, set_to_none=False):
@@ -122,11 +131,36 @@ class FlatAdam(torch.optim.Optimizer):
         return d
 
     def load_state_dict(self, d):
+        """Accepts this class's own format (`flat`) and a torch.optim.Adam checkpoint over the same parameters in the same order (per-
+        parameter `state` with exp_avg / exp_avg_sq / step -- what the previous TrainStep or a CPU run saved): the moments are scattered
+        into the flat arrays.  Anything else raises: restarting the moments silently would change the training run."""
         d = dict(d)
         flat = d.pop("flat", None)
-        super().load_state_dict(d)
+        per_param = d.get("state") or {}
+        super().load_state_dict(dict(d, state={}))
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam: the checkpoint has %d parameter groups, one is supported" % len(self.param_groups))
         if flat is not None:
             self.exp_avg.copy_(flat["exp_avg"]); self.exp_avg_sq.copy_(flat["exp_avg_sq"]); self.steps = int(flat["steps"])
+            return
+        if not per_param:
+            return                                           # a fresh optimizer's checkpoint: nothing to restore
+        ps = self.bucket.params
+        if sorted(per_param.keys()) != list(range(len(ps))):
+            raise ValueError("FlatAdam: the checkpoint's per-parameter state does not cover the bucket's %d parameters" % len(ps))
+        steps = set()
+        off = 0
+        for i, p in enumerate(ps):
+            st = per_param[i]
+            n = p.numel()
+            if st["exp_avg"].numel() != n:
+                raise ValueError("FlatAdam: state %d has %d elements, the parameter %d" % (i, st["exp_avg"].numel(), n))
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1)); self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+            off += n
+        if len(steps) != 1:
+            raise ValueError("FlatAdam: the checkpoint's parameters are at different step counts %s" % sorted(steps))
+        self.steps = steps.pop()
 
 
 class SegmentedReducer:

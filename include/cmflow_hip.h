@@ -405,7 +405,7 @@ int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
  * element in the bucket (offsets[n_tensors] = total; both tables in device memory).  step >= 1 is the count INCLUDING this update.
  *   g' = g + wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g'^2;  p -= lr / (1 - b1^step) * m / (sqrt(v) / sqrt(1 - b2^step) + eps) */
 int cmf_adam_step(int n_tensors, const long long *offsets, float *const *params, long long total, const float *grad, float *m, float *v,
-                  float lr, float beta1, float beta2, float eps, float weight_decay, long long step, void *stream);
+                  double lr, double beta1, double beta2, double eps, double weight_decay, long long step, void *stream);
 
 /* Float offsets, inside `saved`, of the six per-layer BatchNorm blocks (mean | invstd | a | c, 4*C_l floats each). */
 int cmf_setconv_bn_offsets(const cmf_setconv_desc *d, long long *offsets6);

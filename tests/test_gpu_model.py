@@ -1024,3 +1024,21 @@ def test_flat_adam_matches_torch_adam(dev):
         if it == 2:                                         # a replaced storage (same values) must be picked up
             p0 = next(a.parameters())
             p0.data = p0.data.clone()
+    # a torch.optim.Adam checkpoint over the same parameters is accepted: its moments and step count land in the flat arrays, and the
+    # next step from it equals torch's next step
+    oa2 = FlatAdam(bucket, lr=1e-3, weight_decay=1e-4)
+    oa2.load_state_dict(ob.state_dict())
+    assert oa2.steps == 5 and float(oa2.exp_avg.abs().sum()) > 0
+    off = 0
+    for q in b.parameters():
+        st = ob.state[q]
+        assert torch.equal(oa2.exp_avg[off:off + q.numel()], st["exp_avg"].reshape(-1)) and torch.equal(oa2.exp_avg_sq[off:off + q.numel()], st["exp_avg_sq"].reshape(-1))
+        off += q.numel()
+    with pytest.raises(ValueError):
+        bad = ob.state_dict(); bad["state"] = {k: v for k, v in bad["state"].items() if k != 0}
+        FlatAdam(bucket).load_state_dict(bad)
+    # the raw-pointer update bumps the parameters' version counters like an in-place torch op
+    p0 = next(a.parameters())
+    v0 = p0._version
+    bucket.zero(); a(torch.randn(8, 37, device=dev)).square().mean().backward(); oa.step()
+    assert p0._version > v0
