@@ -652,6 +652,18 @@ def mlp_chain(x, layers, training):
     return y.view(*shp[:-1], y.shape[-1])
 
 
+def mlp_chain_w(x, layers, training):
+    """mlp_chain with the weights given as (out, in) matrices: layers = [(weight2d, bn)]."""
+    shp = x.shape
+    params = []
+    for w, bn in layers:
+        params += [w, bn.weight, bn.bias]
+    block = USE_BLOCK_CALLS and len(layers) <= 4 and shp[-1] % 4 == 0 and all(w.shape[0] % 4 == 0 for w, _ in layers)
+    fn = MLPChainBlockFn if block else MLPChainFn
+    y = fn.apply(x.reshape(-1, shp[-1]), [bn for _, bn in layers], training, *params)
+    return y.view(*shp[:-1], y.shape[-1])
+
+
 # ---- the set-conv block (PointLocalFeature) -------------------------------------------------------
 class SetConvFn(Function):
     """utils/model_utils/radarflow_util.py:144-162 in one fused forward/backward.

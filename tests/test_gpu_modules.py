@@ -69,3 +69,45 @@ def test_modules_backward_runs_through_hip_ops(dev):
     up.square().mean().backward()
     assert feats.grad is not None and torch.isfinite(feats.grad).all() and feats.grad.abs().sum() > 0
     assert all(p.grad is not None for p in mods["fp"].parameters())
+
+
+@pytest.mark.parametrize("spec,shape,bn", [([6, 16, 32], (2, 6, 64, 8), True), ([83, 64, 64], (2, 83, 16, 8), True),
+                                           ([144, 64, 32], (3, 144, 40, 1), True), ([8, 16, 32, 64, 64, 128], (2, 8, 32, 4), True),
+                                           ([12, 32, 16], (2, 12, 24, 4), False)])
+def test_shared_mlp_native_path_matches_torch_modules(dev, spec, shape, bn):
+    """pytorch_utils.SharedMLP on device tensors runs cmf_mlp_forward / _backward (BatchNorm layers, up to four per call) or cmf_gemm
+    with the bias / ReLU epilogue (no BatchNorm) instead of nn.Conv2d / nn.BatchNorm2d: outputs, input gradient, every parameter
+    gradient and the BatchNorm running statistics against the same module run through torch (its own nn.Sequential.forward), train and
+    eval mode."""
+    from cmflow_amd import pytorch_utils as P
+    torch.manual_seed(5)
+    m = P.SharedMLP(list(spec), bn=bn).to(dev)
+    assert m._native
+    for p in m.parameters():
+        p.data.add_(0.1 * torch.randn_like(p))
+    x0 = torch.randn(*shape, device=dev)
+    res = {}
+    for native in (True, False):
+        mm = P.SharedMLP(list(spec), bn=bn).to(dev)
+        mm.load_state_dict(m.state_dict())
+        mm._native = native
+        out = {}
+        for mode in ("train", "eval"):
+            mm.train(mode == "train")
+            x = x0.clone().requires_grad_(True)
+            y = mm(x)
+            (y * torch.linspace(0.5, 1.5, y.numel(), device=dev).view_as(y)).sum().backward()
+            out[mode] = (y.detach(), x.grad.detach(), [p.grad.detach().clone() for p in mm.parameters()])
+            mm.zero_grad()
+        out["state"] = {k: v.clone() for k, v in mm.state_dict().items()}
+        res[native] = out
+    for mode in ("train", "eval"):
+        (ya, ga, pa), (yb, gb, pb) = res[True][mode], res[False][mode]
+        assert ya.shape == yb.shape
+        tol = lambda r: dict(rtol=2e-4, atol=2e-5 * float(r.abs().max()) + 1e-7)
+        assert torch.allclose(ya, yb, **tol(yb)), (mode, float((ya - yb).abs().max()))
+        assert torch.allclose(ga, gb, **tol(gb)), (mode, float((ga - gb).abs().max()))
+        for u, v in zip(pa, pb):
+            assert torch.allclose(u, v, rtol=5e-4, atol=5e-5 * float(v.abs().max()) + 1e-6), (mode, float((u - v).abs().max()), float(v.abs().max()))
+    for k, v in res[False]["state"].items():
+        assert torch.allclose(res[True]["state"][k].float(), v.float(), rtol=1e-4, atol=1e-6), k
