@@ -1023,6 +1023,22 @@ def _multi_call(backward, n, plan, sp, streams, main):
         _lib.check(L().cmf_setconv_tail_forward(n, descs, main.cuda_stream), "cmf_setconv_tail_forward")
 
 
+# Debug tap for tests: when a list, every multi-scale / dual-cloud forward call appends, per block, the ball-query indices the LIBRARY
+# issued (cmf_setconv_forward's first kernel; they sit at the head of the block's `saved` arena as int32 (B, N, S)):
+# (radius, nsample, idx clone).  None (default): nothing is copied.
+IDX_TAP = None
+
+
+def _tap_indices(plan, saved, blocks):
+    if IDX_TAP is None:
+        return
+    for i in blocks:
+        d = plan.descs[i]
+        m = d.B * d.N * d.S
+        idx = saved[plan.off_saved[i]:plan.off_saved[i] + m].view(torch.int32).view(d.B, d.N, d.S)
+        IDX_TAP.append((float(d.radius), int(d.S), idx.clone()))
+
+
 class MultiScaleBlockFn(Function):
     """The four set-conv scales of a MultiScaleEncoder (radarflow_util.py:101-118) as one autograd node and ONE
     C-ABI call per direction (cmf_setconv_forward_multi / _backward_multi: each scale is issued on its own HIP
@@ -1053,6 +1069,7 @@ class MultiScaleBlockFn(Function):
             d.inference = inference
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
         _multi_call(False, n, plan, sp, streams, main)
+        _tap_indices(plan, saved, range(n))
         ctx.plan, ctx.keep, ctx.streams, ctx.sink_mode = plan, (xyz_t, y_all, saved), streams, sink_mode
         return out_all.view(B, N, n * co)
 
@@ -1142,6 +1159,7 @@ class DualCloudBlockFn(Function):
             d.out, d.ldo = outs[c].data_ptr() + 4 * sc * co, ns * co
         sp = (ctypes.c_void_p * n)(*[st.cuda_stream for st in streams])
         _multi_call(False, n, plan, sp, streams, main)
+        _tap_indices(plan, saved, range(n))
         if plan.update_table is not None:                           # running statistics: first call, then second call
             _lib.check(L().cmf_bn_running_update(plan.n_update, plan.update_table.data_ptr(), 2, saved.data_ptr(),
                                                  saved.data_ptr() + 4 * plan.saved_per_cloud, _lib.stream_ptr()),

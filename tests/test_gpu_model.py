@@ -70,14 +70,28 @@ def test_forward_matches_reference_golden(case, path, dev, manifest, golden_dir,
     bq0, knn0 = pu.ball_query, ru.knn_point
     pu.ball_query = lambda *a: (bq.append(bq0(*a)) or bq[-1])
     ru.knn_point = lambda *a, **k: (knn.append(knn0(*a, **k)) or knn[-1])
+    from cmflow_amd import fused_blocks as FB
+    FB.IDX_TAP = tap = []   # "pm" issues its ball queries from C++ (csrc/setconv_block.hip): the debug tap reads them back from the blocks' arenas
     try:
         t = lambda k: torch.from_numpy(g[k]).to(dev)
         with torch.no_grad():
             sf, cls, trans, mask = net(t("pc1"), t("pc2"), t("ft1"), t("ft2"), None, "test")
     finally:
         pu.ball_query, ru.knn_point = bq0, knn0
+        FB.IDX_TAP = None
     keys = sorted(k for k in g if k.startswith("bq"))
-    if path != "pm":        # "pm" issues the ball queries from C++ (csrc/setconv_block.hip): not observable here
+    if path == "pm":
+        # the tap lists, per encoder call, the four scales of every cloud it handled: first encoder (both clouds in ONE call of 2B samples
+        # in eval mode, or a dual-cloud call), then the second encoder -- reorder to the reference's call order
+        # (pc1 x 4 scales, pc2 x 4 scales, embedding x 4 scales) and compare bit for bit
+        nb = g["pc1"].shape[0]
+        idx = [x for _, _, x in tap]
+        assert len(idx) in (8, 12), len(idx)
+        if len(idx) == 8:
+            idx = [x[:nb] for x in idx[:4]] + [x[nb:] for x in idx[:4]] + idx[4:]
+        for k, x in zip(keys, idx):
+            assert np.array_equal(g[k], x.cpu().numpy()), k                 # a1 bit-exact, as issued by the library
+    if path != "pm":
         if len(bq) == 8:    # eval mode on the fused path: both clouds go through the first encoder in ONE call (2B samples)
             nb = g["pc1"].shape[0]
             bq = [x[:nb] for x in bq[:4]] + [x[nb:] for x in bq[:4]] + bq[4:]
