@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BQG_THREADS) void bq_grid_build_kernel(int n, float
 // one wave per centre (4 per workgroup)
 __global__ __launch_bounds__(256) void bq_grid_query_kernel(int n, int m, float radius2, int nsample, const float *__restrict__ new_xyz,
                                                             const BqGridHeader *__restrict__ hdr, const int *__restrict__ cell_start,
-                                                            const float4 *__restrict__ spts, int *__restrict__ idx)
+                                                            const float4 *__restrict__ spts, int *__restrict__ idx, int zero_empty)
 {
     __shared__ unsigned bits[4][BQG_MAX_N / 32];
     const int bs = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -382,6 +382,8 @@ __global__ __launch_bounds__(256) void bq_grid_query_kernel(int n, int m, float 
     }
     if (total > 0 && total < nsample)
         for (int l = total + lane; l < nsample; l += 64) out[l] = first;           // ball_query_gpu.cu:37-41
+    if (total == 0 && zero_empty)                                                  // idx not pre-zeroed by the caller (cmf_query_and_group)
+        for (int l = lane; l < nsample; l += 64) out[l] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -551,7 +553,7 @@ static int bqb_group(int b, int m, int nsample)
 }
 
 static int ball_query_grid(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int *idx,
-                           hipStream_t st)
+                           hipStream_t st, int zero_empty = 0)
 {
     const size_t ncs = (size_t)BQG_CELLS + 1;
     const size_t off_cs = ((size_t)b * sizeof(BqGridHeader) + 255) / 256 * 256;
@@ -568,8 +570,15 @@ static int ball_query_grid(int b, int n, int m, float radius, int nsample, const
     float4 *sp = (float4 *)(scratch + off_sp);
     hipLaunchKernelGGL(bq_grid_build_kernel, dim3(b), dim3(BQG_THREADS), 0, st, n, radius, xyz, hdr, cs, sp);
     hipLaunchKernelGGL(bq_grid_query_kernel, dim3(cmf_divup(m, 4), b), dim3(256), 0, st, n, m, radius * radius, nsample, new_xyz,
-                       hdr, cs, sp, idx);
+                       hdr, cs, sp, idx, zero_empty);
     return cmf_launch_status();
+}
+// large clouds: cell grid + index-ordered read-back (CMF_BALL_QUERY_GRID=0 keeps the scan: diagnostics).  A radius that is not a
+// positive finite number has no grid; the scan handles it like the reference.
+static bool ball_query_grid_takes(int n, float radius)
+{
+    static const bool use_grid = !(getenv("CMF_BALL_QUERY_GRID") && getenv("CMF_BALL_QUERY_GRID")[0] == '0');
+    return use_grid && n >= 4096 && n <= BQG_MAX_N && radius > 0.f && radius < 3.0e38f;
 }
 
 static int ball_query_ballot(int b, int n, int m, float radius, int nsample, int zero_empty, const float *new_xyz, const float *xyz,
@@ -595,6 +604,7 @@ int cmf_ball_query_defined(int b, int n, int m, float radius, int nsample, const
     static const bool use_ballot = !(getenv("CMF_BALL_QUERY_BALLOT") && getenv("CMF_BALL_QUERY_BALLOT")[0] == '0');
     if (use_ballot && n > 0 && n <= BQB_MAX_N && nsample <= 256)
         return ball_query_ballot(b, n, m, radius, nsample, 1, new_xyz, xyz, idx, (hipStream_t)stream);
+    if (ball_query_grid_takes(n, radius)) return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream, 1);
     if (hipMemsetAsync(idx, 0, (size_t)b * m * nsample * sizeof(int), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
     return cmf_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
 }
@@ -605,11 +615,7 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     CMF_CHECK_ARG(b >= 0 && n >= 0 && m >= 0 && nsample > 0);
     if (b == 0 || m == 0 || n == 0) return 0;
     CMF_CHECK_ARG(new_xyz && xyz && idx);
-    // large clouds: cell grid + index-ordered read-back (CMF_BALL_QUERY_GRID=0 keeps the scan: diagnostics).  A radius that
-    // is not a positive finite number has no grid; the scan handles it like the reference.
-    static const bool use_grid = !(getenv("CMF_BALL_QUERY_GRID") && getenv("CMF_BALL_QUERY_GRID")[0] == '0');
-    if (use_grid && n >= 4096 && n <= BQG_MAX_N && radius > 0.f && radius < 3.0e38f)
-        return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
+    if (ball_query_grid_takes(n, radius)) return ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, idx, (hipStream_t)stream);
     // small clouds: the ballot kernel (CMF_BALL_QUERY_BALLOT=0 keeps the scan kernels: diagnostics)
     static const bool use_ballot = !(getenv("CMF_BALL_QUERY_BALLOT") && getenv("CMF_BALL_QUERY_BALLOT")[0] == '0');
     if (use_ballot && n <= BQB_MAX_N && nsample <= 256)
@@ -678,6 +684,7 @@ extern "C" int cmf_query_and_group(int b, int n, int m, float radius, int nsampl
     }
     int err;
     if (n <= BQB_MAX_N && nsample <= 256) err = ball_query_ballot(b, n, m, radius, nsample, 1, new_xyz, xyz, ix, st);
+    else if (ball_query_grid_takes(n, radius)) err = ball_query_grid(b, n, m, radius, nsample, new_xyz, xyz, ix, st, 1);     // (the query writes empty balls' zeros: no memset launch)
     else {
         if (hipMemsetAsync(ix, 0, (size_t)b * plane * sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
         err = cmf_ball_query(b, n, m, radius, nsample, new_xyz, xyz, ix, stream);

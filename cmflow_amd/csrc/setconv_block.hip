@@ -25,9 +25,13 @@ namespace {
 // passes' fixed costs (constants and weights into LDS per workgroup, a statistics row per wave, the re-gather per pass) eat what
 // the 3x lower HBM traffic saves; the step is equal within noise (20.15 vs 20.20 ms).  Inference (one pass, nothing else to
 // amortise) is where the chain pays: forward 5.91 -> 5.56 ms.
+// With eval-mode BatchNorm and a backward pass to follow (the regime of every epoch after the first in the reference's loop: no
+// statistics passes) the chain is three passes against seven per-layer kernels -- 1.25 against 1.50 ms -- and is the DEFAULT there
+// (CMF_CHAIN_TRAIN=0: the per-layer kernels everywhere).
 inline bool chain_train(const cmf_setconv_desc *d)
 {
-    static const bool on = getenv("CMF_CHAIN_TRAIN") && getenv("CMF_CHAIN_TRAIN")[0] == '1';
+    static const int mode = getenv("CMF_CHAIN_TRAIN") ? atoi(getenv("CMF_CHAIN_TRAIN")) : -1;     // -1: eval-mode BN only, 0: never, 1: always
+    const bool on = mode == 1 || (mode == -1 && !d->training);
     const long long M = (long long)d->B * d->N * d->S;
     return on && !d->inference && cmf_setconv_chain_supported(d->N, d->S, d->O1, d->C[0], d->C[1], M) && M % 128 == 0 && d->ldy % 4 == 0 &&
            ((uintptr_t)d->y & 15) == 0;
