@@ -18,6 +18,8 @@ _vp, _ci, _cf, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_lon
 # name -> argtypes (restype is int = hipError_t unless noted); mirrors include/cmflow_hip.h
 SIGNATURES = {
     "cmf_ball_query": [_ci, _ci, _ci, _cf, _ci, _vp, _vp, _vp, _vp],
+    "cmf_ball_query_multi": [_ci, _ci, _ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp, _ci, _vp],
+    "cmf_setconv_queries": [_ci, _vp, _vp],
     "cmf_group_points": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_group_points_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_query_and_group": [_ci, _ci, _ci, _cf, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -127,7 +129,7 @@ class SetConvDesc(ctypes.Structure):
                 ("saved", _vp), ("scratch", _vp), ("out", _vp), ("ldo", _ll),
                 ("dout", _vp), ("lddout", _ll), ("dy", _vp), ("lddy", _ll), ("dwx", _vp), ("lddwx", _ll), ("acc_wx", _ci),
                 ("dw", _vp * 5), ("acc_w", _ci * 5), ("dgamma", _vp * 6), ("dbeta", _vp * 6), ("acc_bn", _ci * 6),
-                ("inference", _ci)]
+                ("inference", _ci), ("idx_ready", _ci)]
 
 
 class MlpDesc(ctypes.Structure):

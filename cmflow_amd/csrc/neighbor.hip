@@ -7,6 +7,7 @@
 // with -ffp-contract=off and the pragma below; tests/test_build.py checks the ISA.
 #include <cstdlib>
 #include <mutex>
+#include <algorithm>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 
@@ -491,6 +492,51 @@ __global__ __launch_bounds__(BQB_WAVES *CMF_WAVE) void ball_query_ballot_kernel(
     }
 }
 
+// The ball queries of ONE MultiScaleEncoder call (radarflow_util.py:111-118: four scales (r, nsample) over the same centres and
+// cloud; models/cmflow.py:21-22: (2,4) (4,8) (8,16) (16,32)) in ONE launch: a wave loads the cloud and its G centres once and runs
+// the hit-list construction per scale -- the same bqb_centre as the single-scale kernel, so every list is bit-identical to a
+// cmf_ball_query call of its own.  blockIdx.z selects one of up to two (centres, cloud) pairs (the two clouds of the first encoder).
+struct BqMultiArgs {
+    int n, m, nq, G, zero_empty;
+    float r2[4];
+    int ns[4], lst_off[5];                // per scale: nsample, offset of its lists inside a wave's LDS block (in units of G ints)
+    const float *new_xyz[2], *xyz[2];
+    int *idx[2][4];
+};
+
+template <int NCH>
+__global__ __launch_bounds__(BQB_WAVES *CMF_WAVE) void ball_query_multi_ballot_kernel(const BqMultiArgs a)
+{
+    extern __shared__ int bqb_lds[];                          // [BQB_WAVES][G * sum(nsample)]
+    const int bs = blockIdx.y, cl = blockIdx.z, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pt0 = (blockIdx.x * BQB_WAVES + w) * a.G;
+    if (pt0 >= a.m) return;                                   // wave-uniform; no workgroup barrier anywhere
+    BqbCloud<NCH> cloud;
+    bqb_load_cloud<NCH>(a.xyz[cl] + (size_t)bs * a.n * 3, a.n, lane, cloud);
+    int *lst = bqb_lds + w * a.G * a.lst_off[a.nq];
+    const int gv = min(a.G, a.m - pt0);
+    unsigned empty[4] = {0u, 0u, 0u, 0u};
+    for (int g = 0; g < gv; ++g) {
+        const float *cc = a.new_xyz[cl] + ((size_t)bs * a.m + pt0 + g) * 3;
+        const float cx = cc[0], cy = cc[1], cz = cc[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q < a.nq && bqb_centre<NCH>(cloud, cx, cy, cz, a.r2[q], a.ns[q], lane, lst + a.G * a.lst_off[q] + g * a.ns[q]) == 0) empty[q] |= 1u << g;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q >= a.nq) break;
+        const int ns = a.ns[q];
+        int *out = a.idx[cl][q] + ((size_t)bs * a.m + pt0) * ns;
+        const int *src = lst + a.G * a.lst_off[q];
+        for (int e = lane; e < gv * ns; e += CMF_WAVE) {
+            if (!((empty[q] >> (e / ns)) & 1u)) out[e] = src[e];
+            else if (a.zero_empty) out[e] = 0;
+        }
+    }
+}
+
 // QueryAndGroup.forward (lib/pointnet2_utils.py:269-292) in ONE launch: ball query + grouped xyz relative to the centre
 // + grouped features, written in the reference's (B, 3 + C, M, nsample) layout.  The wave that found the G lists
 // gathers them: entry e of its G x nsample block is contiguous in every channel plane, so each channel is one (or a
@@ -643,6 +689,39 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     else
         hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(CMF_WAVE), 0, (hipStream_t)stream,
                            n, m, radius * radius, nsample, new_xyz, xyz, idx);
+    return cmf_launch_status();
+}
+
+// nq <= 4 ball queries (radii[q], nsamples[q]) -> idx[c][q] (B, M, nsamples[q]) over the same centres and cloud, for nclouds <= 2
+// (centres, cloud) pairs of equal geometry, in ONE launch; every list equals cmf_ball_query's for that scale.  zero_empty != 0: the
+// rows of empty balls are written as zeros (a caller that does not pre-zero idx).  Clouds of up to 1024 points (the ballot kernel).
+extern "C" int cmf_ball_query_multi(int b, int n, int m, int nq, const float *radii, const int *nsamples, int nclouds,
+                                    const float *const *new_xyz, const float *const *xyz, int *const *idx, int zero_empty, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && n <= BQB_MAX_N && m >= 0 && nq >= 1 && nq <= 4 && nclouds >= 1 && nclouds <= 2 && radii && nsamples &&
+                  new_xyz && xyz && idx);
+    if (b == 0 || m == 0) return 0;
+    BqMultiArgs a{};
+    a.n = n; a.m = m; a.nq = nq; a.zero_empty = zero_empty;
+    int nsmax = 0, tot = 0;
+    for (int q = 0; q < nq; ++q) {
+        CMF_CHECK_ARG(nsamples[q] > 0 && nsamples[q] <= 256);
+        a.r2[q] = radii[q] * radii[q]; a.ns[q] = nsamples[q]; a.lst_off[q] = tot;
+        tot += nsamples[q]; nsmax = std::max(nsmax, nsamples[q]);
+    }
+    for (int q = nq; q <= 4; ++q) a.lst_off[q] = tot;
+    for (int c = 0; c < nclouds; ++c) {
+        CMF_CHECK_ARG(new_xyz[c] && xyz[c]);
+        a.new_xyz[c] = new_xyz[c]; a.xyz[c] = xyz[c];
+        for (int q = 0; q < nq; ++q) { CMF_CHECK_ARG(idx[c * nq + q]); a.idx[c][q] = idx[c * nq + q]; }
+    }
+    a.G = bqb_group(b * nclouds, m, nsmax);
+    const dim3 grid(cmf_divup(m, a.G * BQB_WAVES), b, nclouds), block(BQB_WAVES * CMF_WAVE);
+    const size_t lds = (size_t)BQB_WAVES * a.G * tot * sizeof(int);
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 256) hipLaunchKernelGGL(ball_query_multi_ballot_kernel<1>, grid, block, lds, st, a);
+    else if (n <= 512) hipLaunchKernelGGL(ball_query_multi_ballot_kernel<2>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(ball_query_multi_ballot_kernel<4>, grid, block, lds, st, a);
     return cmf_launch_status();
 }
 

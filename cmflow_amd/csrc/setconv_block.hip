@@ -368,7 +368,7 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     const int O1 = d->O1, C2 = d->C[0], C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
     // idx is pre-zeroed like the reference's BallQuery.forward (every point is its own neighbour here, but keep the contract)
     if (!d->training) CMF_TRY(fold_all_eval(d, L, st));
-    CMF_TRY(cmf_ball_query_defined(d->B, d->N, d->N, d->radius, d->S, d->xyz, d->xyz, L.idx, st));
+    if (!d->idx_ready) CMF_TRY(cmf_ball_query_defined(d->B, d->N, d->N, d->radius, d->S, d->xyz, d->xyz, L.idx, st));
     // inference (eval-mode BN and no backward call to follow): the grouped first-layer tensor z1 (M x O1: 1 GB at the largest scale of
     // the second encoder) is never written -- the second layer's GEMM gathers the per-point rows and forms the layer in its A-operand
     // path (cmf_gemm_gather_affine, bit-identical); the slot of z1 holds the M source-row indices and the coordinate planes of Wx
@@ -455,6 +455,52 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
 }
 
 extern "C" int cmf_setconv_forward(const cmf_setconv_desc *d, void *st) { return setconv_forward_part(d, st, 0); }
+
+extern "C" int cmf_setconv_queries(int n, const cmf_setconv_desc *descs, void *stream)
+{
+    CMF_CHECK_ARG(n >= 0 && (n == 0 || descs));
+    int i = 0;
+    while (i < n) {
+        // a run of blocks over the same cloud (the scales of one encoder call), then -- if the next run has the same shape -- a second cloud
+        const cmf_setconv_desc &d0 = descs[i];
+        CMF_CHECK_ARG(d0.xyz && d0.saved);
+        int nq = 1;
+        while (i + nq < n && nq < 4 && descs[i + nq].xyz == d0.xyz && descs[i + nq].B == d0.B && descs[i + nq].N == d0.N) ++nq;
+        int nclouds = 1;
+        if (i + 2 * nq <= n && descs[i + nq].xyz != d0.xyz && descs[i + nq].B == d0.B && descs[i + nq].N == d0.N) {
+            bool same = true;
+            for (int q = 0; q < nq && same; ++q) {
+                const cmf_setconv_desc &u = descs[i + q], &v = descs[i + nq + q];
+                same = v.xyz == descs[i + nq].xyz && v.radius == u.radius && v.S == u.S && v.B == u.B && v.N == u.N;
+            }
+            if (same) nclouds = 2;
+        }
+        if (d0.N > 1024) {                                    // large clouds: the single-scale queries (cell grid)
+            for (int q = 0; q < nq * nclouds; ++q) {
+                const cmf_setconv_desc &d = descs[i + q];
+                const Layout L = make_layout(&d, d.saved, nullptr, false);
+                CMF_TRY(cmf_ball_query_defined(d.B, d.N, d.N, d.radius, d.S, d.xyz, d.xyz, L.idx, stream));
+            }
+        } else {
+            float radii[4];
+            int ns[4];
+            const float *ctr[2], *cloud[2];
+            int *idx[8];
+            for (int c = 0; c < nclouds; ++c) {
+                ctr[c] = cloud[c] = descs[i + c * nq].xyz;
+                for (int q = 0; q < nq; ++q) {
+                    const cmf_setconv_desc &d = descs[i + c * nq + q];
+                    CMF_CHECK_ARG(d.saved);
+                    idx[c * nq + q] = make_layout(&d, d.saved, nullptr, false).idx;
+                    if (c == 0) { radii[q] = d.radius; ns[q] = d.S; }
+                }
+            }
+            CMF_TRY(cmf_ball_query_multi(d0.B, d0.N, d0.N, nq, radii, ns, nclouds, ctr, cloud, idx, 1, stream));
+        }
+        i += nq * nclouds;
+    }
+    return 0;
+}
 
 // ---- the per-point tails of n blocks in batched launches (cmf_common.h "batched launches") ---------------------------
 // Layers 4-6 of a block work on B*N rows of <= 64 channels: 128 workgroups of latency per kernel.  The blocks of an

@@ -1011,6 +1011,12 @@ def _multi_call(backward, n, plan, sp, streams, main):
     if backward:
         _lib.check(L().cmf_setconv_tail_backward(n, descs, main.cuda_stream), "cmf_setconv_tail_backward")
         stress_point([main])                    # (tests) between the tails and the bodies that consume their gradients
+    elif NESTED_QUERIES:
+        # the ball queries of all n blocks as ONE launch per encoder call (nested radii over the same centres; both clouds of the first
+        # encoder), on the caller's stream in front of the fork -- the chains then start at their first layer
+        _lib.check(L().cmf_setconv_queries(n, descs, main.cuda_stream), "cmf_setconv_queries")
+        for i in range(n):
+            plan.descs[i].idx_ready = 1
     for st in streams:
         st.wait_stream(main)
     stress_point(streams)
@@ -1027,6 +1033,7 @@ def _multi_call(backward, n, plan, sp, streams, main):
 # issued (cmf_setconv_forward's first kernel; they sit at the head of the block's `saved` arena as int32 (B, N, S)):
 # (radius, nsample, idx clone).  None (default): nothing is copied.
 IDX_TAP = None
+NESTED_QUERIES = os.environ.get("CMF_NESTED_QUERIES", "1") != "0"       # 0: every block issues its own ball query (A/B)
 
 
 def _tap_indices(plan, saved, blocks):

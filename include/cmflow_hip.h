@@ -38,6 +38,13 @@ extern "C" {
  * idx is left untouched for an empty ball (caller pre-zeroes it, lib/pointnet2_utils.py:246). */
 int cmf_ball_query(int b, int n, int m, float radius, int nsample,
                    const float *new_xyz, const float *xyz, int *idx, void *stream);
+/* The nq <= 4 ball queries of one multi-scale grouping call (utils/model_utils/radarflow_util.py:111-118; models/cmflow.py:21-22:
+ * (r, nsample) = (2,4) (4,8) (8,16) (16,32)) over the same centres and cloud in ONE launch, optionally for nclouds <= 2 (centres,
+ * cloud) pairs of equal geometry: idx[c * nq + q] is (B, M, nsamples[q]) and equals cmf_ball_query(radii[q], nsamples[q]) bit for
+ * bit; zero_empty != 0 writes the rows of empty balls as zeros (callers that do not pre-zero idx).  n <= 1024.  radii / nsamples /
+ * the pointer tables are HOST arrays. */
+int cmf_ball_query_multi(int b, int n, int m, int nq, const float *radii, const int *nsamples, int nclouds,
+                         const float *const *new_xyz, const float *const *xyz, int *const *idx, int zero_empty, void *stream);
 
 /* Replaces group_points_kernel_launcher_fast (lib/src/group_points_gpu.cu:69-70).
  * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
@@ -396,8 +403,15 @@ typedef struct cmf_setconv_desc {
     float *dgamma[6], *dbeta[6]; int acc_bn[6];
     int inference;               /* 1 (with training == 0): no backward call will follow -- the forward call may skip what only the
                                     backward pass reads (the grouped first-layer tensor: cmf_gemm_gather_affine) */
+    int idx_ready;               /* 1: this block's ball query has been issued already (cmf_setconv_queries wrote the indices into
+                                    `saved`); the forward call does not launch its own */
 } cmf_setconv_desc;
 int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
+/* The ball queries of n blocks, issued ahead of their forward calls on ONE stream: blocks that share centres and cloud (the scales of
+ * a MultiScaleEncoder call, radarflow_util.py:111-118) are served by one cmf_ball_query_multi launch, two clouds of equal geometry
+ * (the weight-shared first encoder, models/cmflow.py:72-73) by the same launch -- 12 launches per CMFlow forward become 2.  The
+ * indices land where cmf_setconv_forward keeps them (head of `saved`); the caller then sets idx_ready in the descriptors. */
+int cmf_setconv_queries(int n, const cmf_setconv_desc *descs, void *stream);
 int cmf_setconv_forward(const cmf_setconv_desc *d, void *stream);
 int cmf_setconv_backward(const cmf_setconv_desc *d, void *stream);
 /* The optimizer step of the reference's loop (main.py:107: torch.optim.Adam with L2 weight decay) over a flat gradient bucket in ONE

@@ -37,6 +37,46 @@ def test_ball_query_bit_exact(dev, B, N, r, ns):
     assert got.dtype == torch.int32 and torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("B,N,M,scales,nclouds", [(4, 256, 256, ((2.0, 4), (4.0, 8), (8.0, 16), (16.0, 32)), 2), (3, 256, 256, ((2.0, 4), (4.0, 8), (8.0, 16), (16.0, 32)), 1),
+                                                  (2, 700, 123, ((0.01, 4), (3.0, 9), (1000.0, 64)), 1), (1, 1024, 1024, ((1.5, 32),), 2),
+                                                  (2, 300, 300, ((4.0, 8), (0.0, 3)), 2)])
+def test_ball_query_multi_equals_the_single_queries(dev, B, N, M, scales, nclouds):
+    """cmf_ball_query_multi: the ball queries of one multi-scale grouping call (radarflow_util.py:111-118) over the same centres
+    and cloud -- and over two clouds of equal geometry -- in ONE launch.  Every index tensor must equal the oracle's (and so
+    cmf_ball_query's) bit for bit, empty balls included (zero rows with zero_empty, untouched rows without)."""
+    import ctypes
+    from cmflow_amd import _lib
+    L = _lib.lib()
+    nq = len(scales)
+    radii = (ctypes.c_float * nq)(*[r for r, _ in scales])
+    ns = (ctypes.c_int * nq)(*[k for _, k in scales])
+    cl, ctrs = [], []
+    for c in range(nclouds):
+        xyz, other = clouds(B, N, seed=31 * B + N + c)
+        cl.append(xyz)
+        ctrs.append(xyz if M == N else (other[:, :M] + 0.5).contiguous())
+    dcl, dct = [x.to(dev) for x in cl], [x.to(dev) for x in ctrs]
+    for zero_empty in (1, 0):
+        out = [[torch.full((B, M, k), -7, dtype=torch.int32, device=dev) for _, k in scales] for _ in range(nclouds)]
+        pc = (ctypes.c_void_p * nclouds)(*[x.data_ptr() for x in dct])
+        px = (ctypes.c_void_p * nclouds)(*[x.data_ptr() for x in dcl])
+        pi = (ctypes.c_void_p * (nclouds * nq))(*[t.data_ptr() for row in out for t in row])
+        _lib.check(L.cmf_ball_query_multi(B, N, M, nq, ctypes.addressof(radii), ctypes.addressof(ns), nclouds, ctypes.addressof(pc),
+                                          ctypes.addressof(px), ctypes.addressof(pi), zero_empty, _lib.stream_ptr()), "cmf_ball_query_multi")
+        for c in range(nclouds):
+            for q, (r, k) in enumerate(scales):
+                ref = orc.ball_query(r, k, cl[c], ctrs[c])                   # (empty balls: zero rows, the pre-zeroed idx of the reference)
+                got = out[c][q].cpu()
+                d2 = ((ctrs[c][:, :, None, :] - cl[c][:, None, :, :]) ** 2).sum(-1)
+                empty = ~(d2 < r * r).any(-1)                                # (robust: rows the oracle left at zero AND that have no hit at all)
+                empty &= (ref == 0).all(-1)
+                if zero_empty:
+                    assert torch.equal(got, ref), (c, q)
+                else:
+                    assert torch.equal(got[~empty], ref[~empty]), (c, q)
+                    assert bool((got[empty] == -7).all()), (c, q)
+
+
 @pytest.mark.parametrize("B,N,M,r,ns,kind", [(2, 4096, 4096, 2.0, 64, "lidar"), (1, 8192, 300, 1.0, 32, "lidar"), (2, 4096, 777, 0.05, 8, "lidar"),
                                              (1, 4096, 4096, 1.0e4, 16, "lidar"), (1, 5000, 64, 3.0, 5, "line"), (1, 4096, 100, 0.5, 4, "dup"),
                                              (1, 6000, 50, 2.0, 7, "far")])
