@@ -36,6 +36,7 @@ SIGNATURES = {
                            _ci, _vp],
     "cmf_gemm_tiles_m": [_ci],
     "cmf_gemm_persist_config": [_ci, _ci],
+    "cmf_thin_general": [_ci],
     "cmf_gemm_trace_arm": [],
     "cmf_gemm_trace_read": [_vp, _ll],
     "cmf_gemm_profile_begin": [ctypes.c_double],
@@ -73,6 +74,7 @@ SIGNATURES = {
     "cmf_gemm_dx_gather_sum": [_ci, _ci, _ci, _vp, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_rows_grad_bn_cf_pieces": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp,
                                          _ci, _vp],
+    "cmf_gemm_dw_gather_split": [_ci, _ci, _ll],
     "cmf_gemm_dw_gather": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ci, _vp, _ci, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],

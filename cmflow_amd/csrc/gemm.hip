@@ -121,7 +121,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmArgs &p)
 // (p.Z = the per-point matrix, rows through ga_rows, + the coordinate term).  GMODE 4: the same data gradient over rows in
 // inverse-index order, reduced over runs of equal source points in the epilogue instead of stored (seg_epilogue).
 template <int BM, int BN, bool A_T, bool B_T, int EPI = 0, int GMODE = 0>
-__global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const GemmArgs p)
+__global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gemm_kernel(const GemmArgs p)
 {
     constexpr bool GATHER = GMODE == 1, GATHER_B = GMODE == 2, GATHER_Z = GMODE == 3 || GMODE == 4, GATHER_S = GMODE == 4;
     static_assert(!GATHER_Z || (!A_T && !B_T && EPI == 4 && (BM == 128 || (BM == 256 && GMODE == 4)) && BN == 128), "gathered Z rows: the kind-4 data gradient");
@@ -397,12 +397,16 @@ __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const
         if (GATHER) {
 #pragma unroll
             for (int q = 0; q < D_ANI; ++q) asrc[q] = (long long)p.ga_rows[m0 + (((q * 4 + wid) * 64 + lane) >> 2)] * p.lda;
-            gconst = (lane < 4 ? p.pro_a : lane < 8 ? p.pro_c : p.ga_wx + (long long)((lane >> 2) - 2) * p.K) + 4 * (lane & 3);
+            if (!(B_T && BN > 128)) gconst = (lane < 4 ? p.pro_a : lane < 8 ? p.pro_c : p.ga_wx + (long long)((lane >> 2) - 2) * p.K) + 4 * (lane & 3);
         }
         if (GATHER_S) {
 #pragma unroll
             for (int q = 0; q < D_ANI; ++q) asrc[q] = (long long)p.ga_arows[m0 + (((q * 4 + wid) * 64 + lane) >> 2)] * p.lda;
         }
+        // 256-column tiles of the gathering forward GEMM: the W rows through a buffer descriptor
+        constexpr bool WIDE_B = GATHER && B_T && BN > 128;
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.B + (long long)n0 * p.ldb), 0, -1, 0x00020000);
+        const unsigned offB = (unsigned)((((wid * 64 + lane) >> 2) * (int)p.ldb + 4 * ((lane & 3) ^ g_swz((wid * 64 + lane) >> 2))) * 4);
         // A plain s_barrier: __syncthreads() carries a workgroup fence, which makes the compiler drain EVERY outstanding
         // LDS-direct load (vmcnt(0)) -- the prefetch distance would collapse to zero.  Visibility of the stage that is
         // consumed next is established explicitly: each wave waits for its own loads of that stage (wait_prev), then
@@ -421,12 +425,24 @@ __global__ __launch_bounds__(G_THREADS, BM > 128 ? 2 : 3) void gemm_kernel(const
 #pragma unroll
             for (int q = 0; q < D_BNI; ++q) {
                 const int grp = q * 4 + wid, sl = grp * 64 + lane;
+                if (WIDE_B) {                                       // one lane offset + scalar offsets (the rows of request q lie 64 rows below those of request 0, same swizzle)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (g_lptr)(sb + grp * 256), 16, offB, (unsigned)((q * 64 * (int)p.ldb + k0) * 4), 0, 0);
+                    continue;
+                }
                 const float *g;
                 if (B_T) { const int row = sl >> 2; g = p.B + (long long)(n0 + row) * p.ldb + k0 + 4 * ((sl & 3) ^ g_swz(row)); }
                 else { const int k = sl / (BN / 4); g = p.B + (long long)(k0 + k) * p.ldb + n0 + 4 * ((sl % (BN / 4)) ^ (((k >> 2) & 1) * 8)); }
                 __builtin_amdgcn_global_load_lds((g_gptr)g, (g_lptr)(sb + grp * 256), 16, 0, 0);
             }
             if (GATHER) {
+                if (WIDE_B) {                                       // (the lane's source formed here: a 64-bit pointer kept across the loop is two registers this form does not have)
+                    int l = lane;
+                    asm volatile("" : "+v"(l));
+                    if (wid == 0 && l < 20) {
+                        const float *gc = (l < 4 ? p.pro_a : l < 8 ? p.pro_c : p.ga_wx + (long long)((l >> 2) - 2) * p.K) + 4 * (l & 3);
+                        __builtin_amdgcn_global_load_lds((g_gptr)(gc + k0), (g_lptr)sp, 16, 0, 0);
+                    }
+                } else
                 if (wid == 0 && lane < 20) __builtin_amdgcn_global_load_lds((g_gptr)(gconst + k0), (g_lptr)sp, 16, 0, 0);
             } else
             if (proA && wid == 0 && lane < 8)                       // this chunk's 16 prologue scales and shifts
@@ -1555,6 +1571,13 @@ static int gemm_tall_mode()
     return mode;
 }
 
+// 128 x 256 tiles for the gathering forward GEMM (env CMF_GEMM_WIDE=0: 128 x 128, A/B; 2: also below two workgroups per CU, tests)
+static int gemm_wide_mode()
+{
+    static const int mode = getenv("CMF_GEMM_WIDE") ? atoi(getenv("CMF_GEMM_WIDE")) : 1;
+    return mode;
+}
+
 extern "C" int cmf_gemm(int M, int N, int K, int a_t, int b_t,
                         const float *A, long long lda, const float *B, long long ldb, float *C, long long ldc,
                         const float *pro_a, const float *pro_c, const float *prob_a, const float *prob_c,
@@ -1655,6 +1678,10 @@ extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long 
     //  do not fit 256 registers beside a 128 x 64 wave tile; CMF_GEMM_TALL=2 keeps that form reachable)
     if (gemm_tall_mode() == 2 && M % 256 == 0 && (long long)(M / 256) * (N / 128) >= 384)
         return stats ? launch<256, 128, false, true, 1, 1>(g, st) : launch<256, 128, false, true, 0, 1>(g, st);
+    // 128 x 256 tiles (wave tile 64 x 128): the fragment arithmetic of the gathered operand -- 16 elements per lane and chunk either
+    // way -- then sits beside 64 MFMAs instead of 32, and a row panel is gathered once for 256 output columns
+    if (gemm_wide_mode() && N % 256 == 0 && ((long long)(M / 128) * (N / 256) >= 512 || gemm_wide_mode() == 2))
+        return stats ? launch<128, 256, false, true, 1, 1>(g, st) : launch<128, 256, false, true, 0, 1>(g, st);
     return stats ? launch<128, 128, false, true, 1, 1>(g, st) : launch<128, 128, false, true, 0, 1>(g, st);
 }
 
@@ -1706,6 +1733,17 @@ extern "C" int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ,
     return launch<128, 128, false, false, 4, 4>(g, st);
 }
 
+// The split count that fills the chip with the 256 x 128 tiles of cmf_gemm_dw_gather (two workgroups per CU: 512 slabs x tiles, slabs
+// dealt to the 8 XCDs); 0 = no preference (shape not tileable that way, or CMF_GEMM_TALL=0): the caller's usual choice.
+extern "C" int cmf_gemm_dw_gather_split(int cout, int cin, long long nrows)
+{
+    if (!gemm_tall_mode() || cout <= 0 || cin <= 0 || cout % 256 || cin % 128 || nrows % G_BK) return 0;
+    const long long tiles = (long long)(cout / 256) * (cin / 128), chunks = nrows / G_BK;
+    int s = (int)(512 / tiles) / 8 * 8;
+    while (s >= 8 && chunks / s < 8) s -= 8;
+    return s >= 16 ? s : 0;
+}
+
 // Weight gradient of the set-conv layer behind the hoisted first conv with that first layer formed in the B-operand staging instead
 // of being read back:   dW[cout][cin] (+)= sum_r dZ[r][cout] * relu( prob_a[k] * ( Y[rows[r]][k] + wx3[:,k] . dxyz[r] ) + prob_c[k] )
 // -- the same operations in the same order as cmf_gemm(a_t = 1, b_t = 0, prob) on the materialised tensor in the register-staged
@@ -1725,7 +1763,11 @@ extern "C" int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const floa
     g.C = split_k > 1 ? workspace : dW; g.ldc = split_k > 1 ? cin : lddw;
     g.prob_a = prob_a; g.prob_c = prob_c; g.split_k = split_k; g.accumulate = split_k > 1 ? 0 : accumulate;
     g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.no_direct = 1;
-    const int err = launch<128, 128, true, false, 0, 2>(g, st);
+    // 256 x 128 tiles when the caller took the split count that goes with them (cmf_gemm_dw_gather_split): the gathered rows are
+    // formed once for 256 output rows and a staged element feeds 64 MFMAs per wave instead of 32 -- 110-114 TF against 100-108 at the
+    // second encoder's scales (tools/dwg_probe.py); the slab partition differs from the 128 x 128 form's, the sums inside a slab do not
+    const bool tall = split_k > 1 && split_k == cmf_gemm_dw_gather_split(cout, cin, nrows);
+    const int err = tall ? launch<256, 128, true, false, 0, 2>(g, st) : launch<128, 128, true, false, 0, 2>(g, st);
     if (err) return err;
     if (split_k > 1) return cmf_splitk_reduce(cout, cin, split_k, workspace, dW, lddw, accumulate, st);
     return 0;

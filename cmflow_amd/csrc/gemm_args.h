@@ -43,6 +43,7 @@ struct GemmArgs {
     const int *ga_arows; float *ga_pieces;
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
+    int thin_general;           // diagnostics (env CMF_THIN_GENERAL=1): the narrow forward layers take their general body on full tiles too (A/B)
     int no_direct;              // diagnostics (env CMF_GEMM_NO_DIRECT=1): register-staged main loop everywhere
     int diag;                   // timing diagnostics, results invalid (env CMF_GEMM_DIAG_RT bits: 1 no loads in the loop, 2 no vmcnt waits, 4 no barrier,
                                 // 8 no epilogue (nothing stored), 16 epilogue at raised wave priority)

@@ -49,6 +49,14 @@ struct Bump {
     }
 };
 
+inline int dw_split(long long M, int N, int K);
+// the gathering weight gradient's split: the count its 256-row tiles go with, else the usual choice
+inline int dwg_split(long long M, int N, int K)
+{
+    const int s = cmf_gemm_dw_gather_split(N, K, M);
+    return s ? s : dw_split(M, N, K);
+}
+
 inline int tiles128(long long rows) { return (int)((rows + 127) / 128); }
 
 // split-K choice of fused_blocks.gemm_dw (positions M contracted into an N x K weight gradient)
@@ -145,6 +153,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         sk = std::max(sk, (size_t)dw_split(P, C4, C3) * C4 * C3);
         sk = std::max(sk, (size_t)dw_split(M, C3, C2) * C3 * C2);
         sk = std::max(sk, (size_t)dw_split(M, C2, O1) * C2 * O1);
+        sk = std::max(sk, (size_t)dwg_split(M, C2, O1) * C2 * O1);
         // the fused single-pass layers write their own slab counts (one slab per workgroup): size for those as well --
         // the wide form's tiles128(M) slabs of 64 x C2 exceed the dw_split-based sizes for 128 <= M < 1024 rows
         const struct { long long rows; int cout, cin; } lay[5] = {{P, C6, C5}, {P, C5, C4}, {P, C4, C3}, {M, C3, C2}, {M, C2, O1}};
@@ -332,7 +341,7 @@ int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, i
     else CMF_TRY(cmf_colsum_store(tiles128(M), 2 * C2, L.partial, L.sums, C2, d->dbeta[1], d->dgamma[1], st));
     CMF_TRY(cmf_bn_bwd_apply(M, C2, L.dU2, L.z2, C2, b + 2 * C2, b, b + C2, d->training ? L.sums : nullptr, st));
     if (d->dw[0]) {
-        const int split = dw_split(M, C2, O1);
+        const int split = dwg_split(M, C2, O1);
         CMF_TRY(cmf_gemm_dw_gather(C2, O1, M, L.dU2, C2, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M), b0 + 2 * O1, b0 + 3 * O1,
                                    d->dw[0], O1, split, split > 1 ? L.splitk : nullptr, d->acc_w[0], st));
     }

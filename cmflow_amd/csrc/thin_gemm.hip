@@ -14,6 +14,8 @@
 // B: lane l holds B[k=l>>5][j=l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).  As in gemm.hip a lane
 // loads 4 consecutive k of its row at once (lanes 0-31: k0..k0+3, lanes 32-63: k0+4..k0+7) and feeds 4 MFMAs.
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include "cmf_common.h"
 #include "../../include/cmflow_hip.h"
 #include "gemm_args.h"
@@ -64,7 +66,7 @@ __device__ __forceinline__ void thin_epilogue(const GemmArgs &p, f32x16 (&acc)[N
                         if (want_stats) s1 += x;
                         if (want_q) { const float4 d = *(const float4 *)(p.dxyz + (long long)m * 4); q0 += x * d.x; q1 += x * d.y; q2 += x * d.z; }
                     }
-                } else if (want_stats) { s1 += x; s2 += x * x; }
+                } else if (want_stats) { s1 += x; s2 = fmaf(x, x, s2); }         // (explicit: the full-tile body must sum the same way)
                 float *dst = p.C + (long long)m * p.ldc + n;
                 *dst = p.accumulate ? *dst + x : x;
             }
@@ -111,12 +113,97 @@ __device__ __forceinline__ void thin_load_a(const GemmArgs &p, int m0, int lane,
     }
 }
 
+// Forward form, full tiles (the model's case): every load of the wave -- its 32 input rows, the whole weight matrix as fragments, the
+// prologue constants -- is issued before the first wait, and the NT accumulators advance side by side.  [The general body below
+// loads fragment by fragment behind bounds checks: a chain of 12+ dependent round trips per wave, 2.7 TB/s at 524288 rows.]  The
+// MFMA sequence per accumulator, the statistics' summation order and the stores are those of the general body: bit-identical.
+template <int KS, int NT>
+__device__ __forceinline__ void thin_fwd_fast(const GemmArgs &p, const int bx, float *red)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = bx * 128 + wave * 32;
+    const int h = lane >> 5, cl = lane & 31;
+    float4 a[KS], b[NT][KS], sa[KS], sc[KS];
+    const float *src = p.A + (long long)(m0 + cl) * p.lda + 4 * h;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) a[j] = *(const float4 *)(src + 8 * j);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float *w = p.B + (long long)(nt * 32 + cl) * p.ldb + 4 * h;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) b[nt][j] = *(const float4 *)(w + 8 * j);
+    }
+    const bool pro = p.pro_a != nullptr;
+    if (pro) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { sa[j] = *(const float4 *)(p.pro_a + 8 * j + 4 * h); sc[j] = *(const float4 *)(p.pro_c + 8 * j + 4 * h); }
+    }
+    float bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bias[nt] = p.bias ? p.bias[nt * 32 + cl] : 0.f;
+    if (pro) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            a[j].x = fmaxf(fmaf(sa[j].x, a[j].x, sc[j].x), 0.f); a[j].y = fmaxf(fmaf(sa[j].y, a[j].y, sc[j].y), 0.f);
+            a[j].z = fmaxf(fmaf(sa[j].z, a[j].z, sc[j].z), 0.f); a[j].w = fmaxf(fmaf(sa[j].w, a[j].w, sc[j].w), 0.f);
+        }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b[nt][j].x, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b[nt][j].y, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b[nt][j].z, acc[nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b[nt][j].w, acc[nt], 0, 0, 0);
+    }
+    const bool want_stats = p.stats != nullptr;
+    const float slope = p.act == 1 ? 0.f : 0.1f;                        // act 1 / 2 as one slope select (0 * x would turn -inf into NaN)
+    float *crow = p.C + (long long)(m0 + 4 * h) * p.ldc + cl;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = acc[nt][r] + bias[nt];
+            if (p.act == 1 || p.act == 2) x = x > 0.f ? x : (p.act == 1 ? 0.f : slope * x);
+            else if (p.act == 3) x = 1.0f / (1.0f + __expf(-x));
+            s1 += x; s2 = fmaf(x, x, s2);
+            crow[(long long)((r & 3) + 8 * (r >> 2)) * p.ldc + nt * 32] = x;
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) { float *r0 = red + (size_t)wave * 5 * 64 + nt * 32 + cl; r0[0] = s1; r0[64] = s2; }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * p.N; i += TG_THREADS) {
+            const int which = i / p.N, n = i - which * p.N;
+            const float s = red[(0 * 5 + which) * 64 + n] + red[(1 * 5 + which) * 64 + n] +
+                            red[(2 * 5 + which) * 64 + n] + red[(3 * 5 + which) * 64 + n];
+            p.stats[((long long)bx * 2 + which) * p.N + n] = s;
+        }
+    }
+}
+
 // C = epi(pro(A) @ W^T): K = 8*KS <= 64, N <= 32*NT
 // (body + single / batch entry: cmf_common.h "batched launches")
 template <int KS, int NT>
 __device__ __forceinline__ void thin_fwd_body(const GemmArgs &p, const int bx)
 {
     __shared__ float red[4 * 5 * 64];
+    if (p.N == 32 * NT && (long long)bx * 128 + 128 <= p.M && !p.bwd_mode && !p.accumulate && !p.thin_general) {     // (workgroup-uniform)
+        thin_fwd_fast<KS, NT>(p, bx, red);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m0 = bx * 128 + wave * 32;
     const int h = lane >> 5, cl = lane & 31;
@@ -298,6 +385,18 @@ static int launch_fwd_dx(const GemmArgs &g, bool dx, hipStream_t st)
     return cmf_launch_status();
 }
 
+static std::atomic<int> &thin_general_flag()
+{
+    static std::atomic<int> mode{(getenv("CMF_THIN_GENERAL") && getenv("CMF_THIN_GENERAL")[0] == '1') ? 1 : 0};
+    return mode;
+}
+static int thin_general_mode() { return thin_general_flag().load(std::memory_order_relaxed); }
+// diagnostics / tests: 1 = the narrow forward layers take their general body on full tiles too; returns the previous setting
+extern "C" int cmf_thin_general(int on)
+{
+    return thin_general_flag().exchange(on ? 1 : 0);
+}
+
 // n <= CMF_MAX_BATCH forward GEMMs C = epi(pro(A) W^T) with the SAME (N, K) in one launch (rows may differ)
 int cmf_thin_fwd_batch(int n, const GemmArgs *g, hipStream_t st)
 {
@@ -310,6 +409,7 @@ int cmf_thin_fwd_batch(int n, const GemmArgs *g, hipStream_t st)
                       !q.prob_a && q.lda % 4 == 0 && ((uintptr_t)q.A % 16 == 0) && q.ldb % 4 == 0 && ((uintptr_t)q.B % 16 == 0) &&
                       (!q.pro_a || (((uintptr_t)q.pro_a | (uintptr_t)q.pro_c) % 16 == 0)));
         b.a[i] = q;
+        b.a[i].thin_general = thin_general_mode();
         max_m = std::max(max_m, q.M);
     }
     const dim3 grid((max_m + 127) / 128, n), block(TG_THREADS);
@@ -329,8 +429,10 @@ int cmf_thin_fwd_batch(int n, const GemmArgs *g, hipStream_t st)
 }
 
 // returns -1 when the shape is not a thin one (the caller falls back to the tiled kernel)
-int cmf_thin_gemm(const GemmArgs &g, int a_t, int b_t, hipStream_t st)
+int cmf_thin_gemm(const GemmArgs &g_in, int a_t, int b_t, hipStream_t st)
 {
+    GemmArgs g = g_in;
+    g.thin_general = thin_general_mode();
     if (g.split_k == 1 && !a_t && g.K % 8 == 0 && g.K >= 8 && g.K <= 64 && g.N <= 64 && g.M >= 1 && !g.prob_a &&
         g.lda % 4 == 0 && ((uintptr_t)g.A % 16 == 0) && (b_t ? (g.ldb % 4 == 0 && (uintptr_t)g.B % 16 == 0) : true) &&
         (!g.pro_a || (((uintptr_t)g.pro_a | (uintptr_t)g.pro_c) % 16 == 0))) {

@@ -159,6 +159,10 @@ int cmf_gemm_tiles_m(int M);
  * Outputs are bit-identical to the non-persistent kernel's; the column statistics are summed in a different (fixed) order.
  * Returns 0, -1 on an invalid argument.  Process-wide. */
 int cmf_gemm_persist_config(int mode, int grid);
+/* Diagnostics / tests: the <= 64-channel forward layers (cmf_gemm's per-wave kernels) have a full-tile body that issues all of a
+ * wave's loads before its first wait; on = 1 sends full tiles through the general body as well (also CMF_THIN_GENERAL=1).  Outputs
+ * and statistics of the two bodies are bit-identical.  Returns the previous setting.  Process-wide. */
+int cmf_thin_general(int on);
 
 /* Live timing of the tiled GEMM kernel for bench.py's `roofline` object.  Between _begin and _end every launch of the
  * tiled kernel with 2*M*N*K >= min_flops is bracketed by a HIP event pair on the stream it is launched on -- inside
@@ -253,6 +257,8 @@ int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ, long long 
 int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const float *dZ, long long ldz, const float *Y, long long ldy,
                        const int *rows, const float *dxyz, const float *wx3, const float *prob_a, const float *prob_c,
                        float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream);
+/* The split count with which cmf_gemm_dw_gather takes its 256-row tiles (workspace: split * cout * cin floats); 0 = no preference. */
+int cmf_gemm_dw_gather_split(int cout, int cin, long long nrows);
 
 /* out[p,:] = max_s relu(a*z[p,s,:] + c): BN + ReLU + max over the ball (radarflow_util.py:151-155);
  * argmax (P,C) uint8 optional. */

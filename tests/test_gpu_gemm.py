@@ -753,7 +753,7 @@ def test_statistics_fold_kernels_match_fp64(dev, tiles, C):
     assert int(bn.num_batches_tracked) == 1
 
 
-@pytest.mark.parametrize("B,N,S,K,NO,r", [(4, 256, 8, 512, 256, 4.0), (2, 256, 32, 64, 128, 16.0), (1, 128, 4, 16, 128, 2.0), (8, 256, 16, 512, 256, 8.0)])
+@pytest.mark.parametrize("B,N,S,K,NO,r", [(4, 256, 8, 512, 256, 4.0), (2, 256, 32, 64, 128, 16.0), (1, 128, 4, 16, 128, 2.0), (8, 256, 16, 512, 256, 8.0), (16, 256, 16, 512, 256, 8.0), (32, 256, 8, 256, 512, 4.0)])
 def test_gather_affine_gemm_is_bit_identical_to_the_materialised_path(dev, B, N, S, K, NO, r):
     """cmf_group_prep + cmf_gemm_gather_affine (the set-conv first layer formed in the A-operand path of the next layer's GEMM,
     inference) against cmf_group_affine followed by cmf_gemm with the A prologue: the same operations in the same order, so the
@@ -788,7 +788,7 @@ def test_gather_affine_gemm_is_bit_identical_to_the_materialised_path(dev, B, N,
     assert torch.equal(outs[0], want), float((outs[0] - want).abs().max())
 
 
-@pytest.mark.parametrize("B,N,S,K,NO,r,split", [(8, 256, 16, 512, 256, 8.0, 8), (4, 256, 32, 128, 128, 16.0, 1), (2, 256, 4, 256, 128, 2.0, 4)])
+@pytest.mark.parametrize("B,N,S,K,NO,r,split", [(8, 256, 16, 512, 256, 8.0, 8), (8, 256, 16, 512, 256, 8.0, 128), (16, 256, 8, 256, 512, 4.0, 128), (4, 256, 32, 128, 128, 16.0, 1), (2, 256, 4, 256, 128, 2.0, 4)])
 def test_gather_weight_gradient_is_bit_identical_to_the_materialised_path(dev, B, N, S, K, NO, r, split):
     """cmf_gemm_dw_gather (the set-conv first layer formed in the B-operand staging of the next layer's weight gradient) against
     cmf_gemm(a_t, prob) on the tensor cmf_group_affine writes, both in the register-staged loop: bit for bit, with and without
@@ -919,3 +919,36 @@ def test_gather_data_gradient_summed_per_source_point(dev, B, N, S, K, NO, r):
     err = (got.view(P, K).double() - want.view(P, K).double()).abs()
     bound = 1e-5 * (scale * ea.double().abs() + 1.0) + 1e-4 * want.view(P, K).double().abs().clamp(max=1.0)
     assert bool((err <= bound).all()), float((err / bound).max())
+
+
+@pytest.mark.parametrize("M,K,N", [(1024, 32, 64), (4096, 32, 32), (640, 64, 64), (256, 8, 32), (384, 16, 64), (128 * 37, 64, 32)])
+@pytest.mark.parametrize("pro,stats,act,bias", [(True, True, 0, False), (False, True, 1, True), (True, False, 2, True), (False, False, 0, False)])
+def test_narrow_forward_full_tile_body_equals_the_general_body(dev, M, K, N, pro, stats, act, bias):
+    """The <= 64-channel forward layers have a full-tile body (all loads of a wave issued up front, accumulators side by side) beside
+    the general one (bounds-checked, fragment by fragment): same MFMA sequence per accumulator, same summation order of the
+    statistics -- outputs and partial sums must be equal bit for bit."""
+    from cmflow_amd import _lib
+    from cmflow_amd.fused import gemm
+    L = _lib.lib()
+    torch.manual_seed(M + K + N)
+    A = torch.randn(M, K + 8, device=dev)[:, :K]            # a row-strided view, as the blocks pass column slices
+    W = torch.randn(N, K, device=dev)
+    pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+    b = torch.randn(N, device=dev) if bias else None
+    outs = []
+    prev = L.cmf_thin_general(0)
+    try:
+        for general in (0, 1, 0):
+            L.cmf_thin_general(general)
+            r = gemm(A, W, pro=(pa, pc) if pro else None, bias=b, act=act, stats=stats)
+            outs.append(r if stats else (r, None))
+    finally:
+        L.cmf_thin_general(prev)
+    for o, s in outs[1:]:
+        assert torch.equal(o, outs[0][0]), float((o - outs[0][0]).abs().max())
+        if stats:
+            assert torch.equal(s, outs[0][1]), float((s - outs[0][1]).abs().max())
+    x = torch.relu(A * pa + pc) if pro else A
+    want = x.double() @ W.double().t() + (b.double() if bias else 0.0)
+    want = torch.relu(want) if act == 1 else torch.where(want > 0, want, 0.1 * want) if act == 2 else want
+    assert float((outs[0][0].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
