@@ -62,8 +62,9 @@ class CMFlow(nn.Module):
     @staticmethod
     def rigid_to_flow(pc, trans):
         """cmflow.py:51-55"""
-        h_pc = torch.cat((pc, torch.ones((pc.size(0), 1, pc.size(2)), dtype=pc.dtype, device=pc.device)), dim=1)
-        return torch.matmul(trans, h_pc)[:, :3] - pc
+        # R pc + t - pc as one batched multiply-add and a subtraction (the reference appends a row of ones and multiplies by the 4 x 4
+        # matrix: the same sum with t added last instead of first)
+        return torch.baddbmm(trans[:, :3, 3:4], trans[:, :3, :3], pc) - pc
 
     def _propagate(self, pc1, pc2, feature1, feature2):
         """cmflow.py:59-88: everything of Backbone up to prop_features."""
@@ -74,15 +75,16 @@ class CMFlow(nn.Module):
     def _propagate_pm(self, pc1, pc2, feature1, feature2):
         """Same computation in point-major layout; returns prop_features as (B,256,N)."""
         x1, x2 = pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous()       # (B,N,3)
-        a1, a2 = feature1.transpose(1, 2).contiguous(), feature2.transpose(1, 2).contiguous()
+        # the input channels with one zero column behind them (rows of 4 floats for the stacked first-conv GEMM); a1 / a2 are views of it
+        a1p, a2p = torch.nn.functional.pad(feature1.transpose(1, 2), (0, 1)), torch.nn.functional.pad(feature2.transpose(1, 2), (0, 1))
+        a1, a2 = a1p[:, :, :-1], a2p[:, :, :-1]
         if not self.mse_layer.training and x1.shape == x2.shape:
             # eval-mode BN has no batch statistics: the two clouds share one call of the (weight-shared) encoder
             B = x1.shape[0]
-            f12 = self.mse_layer.forward_pm(torch.cat((x1, x2), dim=0), torch.nn.functional.pad(torch.cat((a1, a2), dim=0), (0, 1)))
+            f12 = self.mse_layer.forward_pm(torch.cat((x1, x2), dim=0), torch.cat((a1p, a2p), dim=0))
             f1, f2 = f12[:B], f12[B:]
         else:                                                   # one zero column: rows of 4 floats for the stacked first-conv GEMM
-            f1, f2 = self.mse_layer.forward_pm_pair(x1, torch.nn.functional.pad(a1, (0, 1)),
-                                                    x2, torch.nn.functional.pad(a2, (0, 1)))   # (B,N,256) each
+            f1, f2 = self.mse_layer.forward_pm_pair(x1, a1p, x2, a2p)                      # (B,N,256) each
         # train.TrainStep reduces the gradient bucket in segments as backward completes them.  Every autograd node of the cost
         # volume, the second encoder and the heads is created AFTER the first encoder's node and depends only on gradients that
         # exist before that node becomes ready, so the engine (highest sequence number first among ready nodes, AccumulateGrad

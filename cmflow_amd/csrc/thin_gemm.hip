@@ -592,6 +592,9 @@ __device__ __forceinline__ void thin_bwd_tile(const ThinBwdArgs &p, ThinBwdLds<N
                 if (train) zv[ku] = tb_ld4(zt, oz + 32u * k8);
             }
         }
+        // (32 -> 32 channels: a compiler fence keeps the loads of all k steps in front of the arithmetic -- the scheduler otherwise sinks
+        //  each step's loads to their use: 35.4 -> 32.4 us.  The wider forms have no registers for that at their occupancy: 46 -> 47.5 us)
+        if (NTO == 1 && NTI == 1) asm volatile("" ::: "memory");
 #pragma unroll
         for (int ku = 0; ku < CH; ++ku) {
             const int k8 = kb + ku;

@@ -510,9 +510,7 @@ def _pad_k(t):
     (rows, K) view of it."""
     r, k = t.shape
     ld = (k + 3) // 4 * 4
-    buf = torch.zeros(r, ld, dtype=t.dtype, device=t.device)
-    buf[:, :k] = t
-    return buf[:, :k]
+    return torch.nn.functional.pad(t, (0, ld - k))[:, :k]            # one kernel (zeros + copy were two)
 
 
 def _pad_cols(t):
@@ -521,9 +519,7 @@ def _pad_cols(t):
     ld = (k + 3) // 4 * 4
     if ld == k and t.is_contiguous():
         return t
-    buf = torch.zeros(r, ld, dtype=t.dtype, device=t.device)
-    buf[:, :k] = t
-    return buf
+    return torch.nn.functional.pad(t, (0, ld - k))                   # one kernel (zeros + copy were two)
 
 
 def linear(x, w, bias=None, act=0, preact_grad=False, in_bias=None):
