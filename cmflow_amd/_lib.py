@@ -26,6 +26,8 @@ SIGNATURES = {
     "cmf_knn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch_grad": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_ego_refine": [_ci, _ci, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_ego_refine_grad": [_ci, _ci, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_group_rows": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_build_inverse": [_ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_build_inverse_ps": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],

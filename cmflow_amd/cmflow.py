@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import fused_blocks as FB
-from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScaleEncoder, weighted_kabsch)
+from .radarflow_util import (FeatureCorrelator, FlowHead, MotionHead, MultiScaleEncoder, ego_refine, weighted_kabsch)
 
 
 class CMFlow(nn.Module):
@@ -53,6 +53,7 @@ class CMFlow(nn.Module):
         pass
 
     head_streams = True
+    fused_tail = True                               # _heads: cmf_ego_refine instead of the torch ops around weighted_kabsch (A/B, tests)
     _head_stream = None
 
     def _second_encoder(self):
@@ -155,6 +156,10 @@ class CMFlow(nn.Module):
             scores = label_m.unsqueeze(1)
         else:
             scores = stat_cls
+        if self.fused_tail and output.is_cuda:
+            # cmflow.py:96-125 (ego-motion weights, weighted Kabsch, rigid refinement, select) as one native call per direction
+            pre_trans, sf_agg, mask = ego_refine(output, pc1, scores.squeeze(1), self.score_eps or 0.0, self.stat_thres)
+            return sf_agg, stat_cls, pre_trans, mask
         mask = (scores > self.stat_thres).squeeze(1)
         pre_trans = self.EgoMotionHead(output, pc1, scores)
         sf_agg = self.refine_with_transform(output, pc1, pre_trans, mask)

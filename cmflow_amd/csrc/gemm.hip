@@ -1432,7 +1432,11 @@ long long gprof_open(double flops, hipStream_t st, const GemmArgs *a = nullptr, 
     if (flops < g_gprof.min_flops) return -1;
     if (g_gprof.used * 2 == g_gprof.events.size()) {
         hipEvent_t a = nullptr, b = nullptr;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { (void)hipGetLastError(); return -1; }
+        // timing events without the system-scope release / acquire a default event carries: bracketing a launch must not flush caches
+        // around it (measured: the bracketed timed region ran 0.15-0.2 ms per step slower than the unbracketed regions behind it)
+        if (hipEventCreateWithFlags(&a, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableSystemFence) != hipSuccess) {
+            (void)hipGetLastError(); return -1;
+        }
         g_gprof.events.push_back(a); g_gprof.events.push_back(b);
     }
     const size_t i = g_gprof.used++;

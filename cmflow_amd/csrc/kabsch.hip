@@ -97,12 +97,9 @@ __device__ __forceinline__ double det3(const double *M)
            M[2] * (M[3] * M[7] - M[4] * M[6]);
 }
 
-__global__ __launch_bounds__(CMF_WAVE) void kabsch_fwd_kernel(
-    int n, const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ W,
-    float *__restrict__ trans, double *__restrict__ aux)
+// one sample (one wavefront): a, b (3,n), w (n) -> T (4,4) [lane 0 writes], x = the sample's aux record or null
+__device__ __forceinline__ void kabsch_fwd_sample(int n, const float *a, const float *b, const float *w, float *T, double *x, int lane)
 {
-    const int bs = blockIdx.x, lane = threadIdx.x;
-    const float *a = A + (size_t)bs * 3 * n, *b = Bm + (size_t)bs * 3 * n, *w = W + (size_t)bs * n;
     // pass 1: weighted centroids  (cmflow.py:138-139)
     double sw = 0, ca[3] = {0, 0, 0}, cb[3] = {0, 0, 0};
     for (int i = lane; i < n; i += CMF_WAVE) {
@@ -132,17 +129,60 @@ __global__ __launch_bounds__(CMF_WAVE) void kabsch_fwd_kernel(
     const double D = det3(Z) < 0 ? -1.0 : 1.0;     // reflection: row 2 of V (hence of Z) negated
     double R[9];
     for (int c = 0; c < 3; ++c) { R[c] = Z[c]; R[3 + c] = Z[3 + c]; R[6 + c] = D * Z[6 + c]; }
-    float *T = trans + (size_t)bs * 16;
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) T[r * 4 + c] = (float)R[r * 3 + c];
         T[r * 4 + 3] = (float)(-(R[r * 3 + 0] * ca[0] + R[r * 3 + 1] * ca[1] + R[r * 3 + 2] * ca[2]) + cb[r]);
     }
     T[12] = 0.f; T[13] = 0.f; T[14] = 0.f; T[15] = 1.f;
-    if (aux) {
-        double *x = aux + (size_t)bs * KB_AUX;
+    if (x) {
         for (int k = 0; k < 9; ++k) { x[k] = U[k]; x[12 + k] = V[k]; }
         for (int k = 0; k < 3; ++k) { x[9 + k] = S[k]; x[21 + k] = ca[k]; x[24 + k] = cb[k]; }
         x[27] = D; x[28] = sw;
+    }
+}
+
+__global__ __launch_bounds__(CMF_WAVE) void kabsch_fwd_kernel(
+    int n, const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ W,
+    float *__restrict__ trans, double *__restrict__ aux)
+{
+    const int bs = blockIdx.x;
+    kabsch_fwd_sample(n, A + (size_t)bs * 3 * n, Bm + (size_t)bs * 3 * n, W + (size_t)bs * n, trans + (size_t)bs * 16,
+                      aux ? aux + (size_t)bs * KB_AUX : nullptr, threadIdx.x);
+}
+
+// ---- the ego-motion head and the rigid refinement around the solve (cmflow.py:96-125) as ONE kernel per direction ----
+//   w = (score + eps) / sum(score + eps),  B = pc1 + flow,  T = kabsch(pc1, B, w),  mask = score > thres,
+//   sf = mask ? (R pc1 + t - pc1) : flow
+// One wavefront per sample as above.  w and B are written out (the backward pass reads them; a lane re-reads only what it wrote
+// itself).  As torch ops this was ~10 small kernels forward and ~15 backward on the main stream with nothing beside them.
+__global__ __launch_bounds__(CMF_WAVE) void ego_refine_fwd_kernel(
+    int n, float eps, float thres, const float *__restrict__ pc1, const float *__restrict__ flow, const float *__restrict__ score,
+    float *W, float *Bm, float *__restrict__ trans, double *__restrict__ aux, float *__restrict__ sf, unsigned char *__restrict__ mask)
+{
+    const int bs = blockIdx.x, lane = threadIdx.x;
+    const float *a = pc1 + (size_t)bs * 3 * n, *f = flow + (size_t)bs * 3 * n, *sc = score + (size_t)bs * n;
+    float *w = W + (size_t)bs * n, *b = Bm + (size_t)bs * 3 * n;
+    double ssum = 0.0;
+    for (int i = lane; i < n; i += CMF_WAVE) ssum += (double)(sc[i] + eps);
+    const float tot = (float)wave_sum(ssum);
+    for (int i = lane; i < n; i += CMF_WAVE) {
+        w[i] = (sc[i] + eps) / tot;
+        for (int k = 0; k < 3; ++k) b[k * n + i] = a[k * n + i] + f[k * n + i];
+    }
+    __shared__ float Tsh[16];                       // lane 0 solves; the wave reads the transform back from LDS
+    kabsch_fwd_sample(n, a, b, w, Tsh, aux ? aux + (size_t)bs * KB_AUX : nullptr, lane);
+    __syncthreads();
+    if (lane < 16) trans[(size_t)bs * 16 + lane] = Tsh[lane];
+    float Tm[12];
+    for (int k = 0; k < 12; ++k) Tm[k] = Tsh[k];
+    for (int i = lane; i < n; i += CMF_WAVE) {
+        const float x = a[i], y = a[n + i], z = a[2 * n + i];
+        const bool m = sc[i] > thres;
+        mask[(size_t)bs * n + i] = m ? 1 : 0;
+        for (int r = 0; r < 3; ++r) {
+            const float rig = fmaf(Tm[r * 4 + 2], z, fmaf(Tm[r * 4 + 1], y, Tm[r * 4 + 0] * x)) + Tm[r * 4 + 3] - a[r * n + i];
+            sf[(size_t)bs * 3 * n + r * n + i] = m ? rig : f[r * n + i];
+        }
     }
 }
 
@@ -151,18 +191,14 @@ __global__ __launch_bounds__(CMF_WAVE) void kabsch_fwd_kernel(
 // (DESIGN.md "Kabsch backward").  Then
 //   H  = sum_n W_n (A_n - cA)(B_n - cB)^T,   cA = sum W_n A_n,   cB = sum W_n B_n,
 //   t  = -R cA + cB.
-__global__ __launch_bounds__(CMF_WAVE) void kabsch_bwd_kernel(
-    int n, const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ W,
-    const double *__restrict__ aux, const float *__restrict__ grad_trans,
-    float *__restrict__ gA, float *__restrict__ gB, float *__restrict__ gW)
+// one sample: gt = the gradient w.r.t. its (4,4) transform as 12 doubles (rows of [R | t]); a, b (3,n), w (n); outputs per sample
+__device__ __forceinline__ void kabsch_bwd_sample(int n, const float *a, const float *b, const float *w, const double *x, const double (&gt)[12],
+                                                  float *gA, float *gB, float *gW, int lane)
 {
-    const int bs = blockIdx.x, lane = threadIdx.x;
-    const double *x = aux + (size_t)bs * KB_AUX;
     double U[9], S[3], V[9], ca[3], cb[3];
     for (int k = 0; k < 9; ++k) { U[k] = x[k]; V[k] = x[12 + k]; }
     for (int k = 0; k < 3; ++k) { S[k] = x[9 + k]; ca[k] = x[21 + k]; cb[k] = x[24 + k]; }
     const double D = x[27], sw = x[28];
-    const float *gt = grad_trans + (size_t)bs * 16;
     double GR[9], g_t[3];
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) GR[r * 3 + c] = gt[r * 4 + c]; g_t[r] = gt[r * 4 + 3]; }
     // R as in forward
@@ -210,7 +246,6 @@ __global__ __launch_bounds__(CMF_WAVE) void kabsch_bwd_kernel(
         gcA[r] -= (GH[r * 3 + 0] * cb[0] + GH[r * 3 + 1] * cb[1] + GH[r * 3 + 2] * cb[2]) * k1;
         gcB[r] -= (GH[0 * 3 + r] * ca[0] + GH[1 * 3 + r] * ca[1] + GH[2 * 3 + r] * ca[2]) * k1;
     }
-    const float *a = A + (size_t)bs * 3 * n, *b = Bm + (size_t)bs * 3 * n, *w = W + (size_t)bs * n;
     for (int i = lane; i < n; i += CMF_WAVE) {
         const double wi = w[i];
         double da[3], db[3], av[3], bv[3];
@@ -220,14 +255,64 @@ __global__ __launch_bounds__(CMF_WAVE) void kabsch_bwd_kernel(
             hb[k] = GH[0 * 3 + k] * da[0] + GH[1 * 3 + k] * da[1] + GH[2 * 3 + k] * da[2];
             ha[k] = GH[k * 3 + 0] * db[0] + GH[k * 3 + 1] * db[1] + GH[k * 3 + 2] * db[2];
         }
-        if (gB) for (int k = 0; k < 3; ++k) gB[(size_t)bs * 3 * n + k * n + i] = (float)(wi * (hb[k] + gcB[k]));
-        if (gA) for (int k = 0; k < 3; ++k) gA[(size_t)bs * 3 * n + k * n + i] = (float)(wi * (ha[k] + gcA[k]));
+        if (gB) for (int k = 0; k < 3; ++k) gB[k * n + i] = (float)(wi * (hb[k] + gcB[k]));
+        if (gA) for (int k = 0; k < 3; ++k) gA[k * n + i] = (float)(wi * (ha[k] + gcA[k]));
         if (gW) {
             double g = da[0] * ha[0] + da[1] * ha[1] + da[2] * ha[2];
             for (int k = 0; k < 3; ++k) g += gcA[k] * av[k] + gcB[k] * bv[k];
-            gW[(size_t)bs * n + i] = (float)g;
+            gW[i] = (float)g;
         }
     }
+}
+
+__global__ __launch_bounds__(CMF_WAVE) void kabsch_bwd_kernel(
+    int n, const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ W,
+    const double *__restrict__ aux, const float *__restrict__ grad_trans,
+    float *__restrict__ gA, float *__restrict__ gB, float *__restrict__ gW)
+{
+    const int bs = blockIdx.x;
+    double gt[12];
+    for (int k = 0; k < 12; ++k) gt[k] = grad_trans[(size_t)bs * 16 + k];
+    kabsch_bwd_sample(n, A + (size_t)bs * 3 * n, Bm + (size_t)bs * 3 * n, W + (size_t)bs * n, aux + (size_t)bs * KB_AUX, gt,
+                      gA ? gA + (size_t)bs * 3 * n : nullptr, gB ? gB + (size_t)bs * 3 * n : nullptr, gW ? gW + (size_t)bs * n : nullptr, threadIdx.x);
+}
+
+// Backward of ego_refine_fwd_kernel: g_sf (b,3,n), g_trans (b,4,4) or null -> g_flow (b,3,n), g_score (b,n) or null.
+//   masked points: sf = R a + t - a  ->  G_R += g_sf a^T, g_t += g_sf;  the others hand g_sf to flow
+//   kabsch backward with the summed transform gradient -> g_B (= g_flow's second part: B = pc1 + flow), g_w
+//   w = s / sum(s)  ->  g_s = (g_w - sum(g_w w)) / sum(s)
+__global__ __launch_bounds__(CMF_WAVE) void ego_refine_bwd_kernel(
+    int n, float eps, const float *__restrict__ pc1, const float *__restrict__ score, const float *__restrict__ W, const float *__restrict__ Bm,
+    const unsigned char *__restrict__ mask, const double *__restrict__ aux, const float *__restrict__ g_sf, const float *__restrict__ g_trans,
+    float *__restrict__ g_flow, float *g_w, float *__restrict__ g_score)
+{
+    const int bs = blockIdx.x, lane = threadIdx.x;
+    const float *a = pc1 + (size_t)bs * 3 * n, *gs = g_sf + (size_t)bs * 3 * n, *w = W + (size_t)bs * n;
+    const unsigned char *mk = mask + (size_t)bs * n;
+    double gt[12];
+    for (int k = 0; k < 12; ++k) gt[k] = 0.0;
+    for (int i = lane; i < n; i += CMF_WAVE) {
+        if (!mk[i]) continue;
+        const double av[3] = {a[i], a[n + i], a[2 * n + i]};
+        for (int r = 0; r < 3; ++r) {
+            const double g = gs[r * n + i];
+            gt[r * 4 + 0] += g * av[0]; gt[r * 4 + 1] += g * av[1]; gt[r * 4 + 2] += g * av[2]; gt[r * 4 + 3] += g;
+        }
+    }
+    for (int k = 0; k < 12; ++k) gt[k] = wave_sum(gt[k]) + (g_trans ? (double)g_trans[(size_t)bs * 16 + k] : 0.0);
+    float *gf = g_flow + (size_t)bs * 3 * n, *gw = g_w + (size_t)bs * n;
+    kabsch_bwd_sample(n, a, Bm + (size_t)bs * 3 * n, w, aux + (size_t)bs * KB_AUX, gt, nullptr, gf, gw, lane);
+    // (a lane re-reads only the entries it wrote itself: no barrier)
+    double dot = 0.0, ssum = 0.0;
+    for (int i = lane; i < n; i += CMF_WAVE) {
+        if (!mk[i]) for (int k = 0; k < 3; ++k) gf[k * n + i] += gs[k * n + i];
+        dot += (double)gw[i] * (double)w[i];
+        ssum += (double)(score[(size_t)bs * n + i] + eps);
+    }
+    if (!g_score) return;
+    dot = wave_sum(dot);
+    const float tot = (float)wave_sum(ssum);
+    for (int i = lane; i < n; i += CMF_WAVE) g_score[(size_t)bs * n + i] = (float)(((double)gw[i] - dot) / (double)tot);
 }
 
 extern "C" int cmf_weighted_kabsch(int b, int n, const float *A, const float *Bm, const float *W,
@@ -249,6 +334,29 @@ extern "C" int cmf_weighted_kabsch_grad(int b, int n, const float *A, const floa
     CMF_CHECK_ARG(A && Bm && W && aux && grad_trans);
     hipLaunchKernelGGL(kabsch_bwd_kernel, dim3(b), dim3(CMF_WAVE), 0, (hipStream_t)stream,
                        n, A, Bm, W, aux, grad_trans, grad_A, grad_B, grad_W);
+    return cmf_launch_status();
+}
+
+extern "C" int cmf_ego_refine(int b, int n, float eps, float thres, const float *pc1, const float *flow, const float *score,
+                              float *W, float *Bm, float *trans, double *aux, float *sf, unsigned char *mask, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(pc1 && flow && score && W && Bm && trans && sf && mask);
+    hipLaunchKernelGGL(ego_refine_fwd_kernel, dim3(b), dim3(CMF_WAVE), 0, (hipStream_t)stream, n, eps, thres, pc1, flow, score, W, Bm, trans,
+                       aux, sf, mask);
+    return cmf_launch_status();
+}
+
+extern "C" int cmf_ego_refine_grad(int b, int n, float eps, const float *pc1, const float *score, const float *W, const float *Bm,
+                                   const unsigned char *mask, const double *aux, const float *g_sf, const float *g_trans,
+                                   float *g_flow, float *g_w, float *g_score, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(pc1 && score && W && Bm && mask && aux && g_sf && g_flow && g_w);
+    hipLaunchKernelGGL(ego_refine_bwd_kernel, dim3(b), dim3(CMF_WAVE), 0, (hipStream_t)stream, n, eps, pc1, score, W, Bm, mask, aux, g_sf,
+                       g_trans, g_flow, g_w, g_score);
     return cmf_launch_status();
 }
 

@@ -100,6 +100,50 @@ def weighted_kabsch(A, B, W):
     return _WeightedKabsch.apply(A, B, W)
 
 
+class _EgoRefine(Function):
+    """EgoMotionHead + refine_with_transform (models/cmflow.py:96-125) as one native call per direction (cmf_ego_refine):
+    flow (b,3,N), pc1 (b,3,N), score (b,N) -> pre_trans (b,4,4), sf_agg (b,3,N), mask (b,N) bool.  pc1 takes no gradient."""
+
+    @staticmethod
+    def forward(ctx, flow, pc1, score, eps, thres):
+        flow, pc1, score = flow.contiguous(), pc1.contiguous(), score.contiguous()
+        b, _, n = pc1.shape
+        dev = pc1.device
+        W = torch.empty(b, n, dtype=_f32, device=dev); Bm = torch.empty(b, 3, n, dtype=_f32, device=dev)
+        trans = torch.empty(b, 4, 4, dtype=_f32, device=dev); aux = torch.empty(b, 32, dtype=torch.float64, device=dev)
+        sf = torch.empty(b, 3, n, dtype=_f32, device=dev); mask = torch.empty(b, n, dtype=torch.uint8, device=dev)
+        err = _lib.lib().cmf_ego_refine(b, n, float(eps), float(thres), _lib.dev_ptr(pc1, _f32), _lib.dev_ptr(flow, _f32),
+                                        _lib.dev_ptr(score, _f32), _lib.dev_ptr(W, _f32), _lib.dev_ptr(Bm, _f32), _lib.dev_ptr(trans, _f32),
+                                        _lib.dev_ptr(aux, torch.float64), _lib.dev_ptr(sf, _f32), mask.data_ptr(), _lib.stream_ptr())
+        _lib.check(err, "cmf_ego_refine")
+        ctx.save_for_backward(pc1, score, W, Bm, mask, aux)
+        ctx.eps = float(eps)
+        mask_b = mask.view(torch.bool)
+        ctx.mark_non_differentiable(mask_b)
+        return trans, sf, mask_b
+
+    @staticmethod
+    def backward(ctx, g_trans, g_sf, _g_mask):
+        pc1, score, W, Bm, mask, aux = ctx.saved_tensors
+        b, _, n = pc1.shape
+        if g_sf is None:
+            g_sf = torch.zeros_like(Bm)
+        g_flow = torch.empty_like(Bm); g_w = torch.empty_like(W)
+        g_score = torch.empty_like(W) if ctx.needs_input_grad[2] else None
+        err = _lib.lib().cmf_ego_refine_grad(
+            b, n, ctx.eps, _lib.dev_ptr(pc1, _f32), _lib.dev_ptr(score, _f32), _lib.dev_ptr(W, _f32), _lib.dev_ptr(Bm, _f32), mask.data_ptr(),
+            _lib.dev_ptr(aux, torch.float64), _lib.dev_ptr(g_sf.contiguous(), _f32),
+            _lib.dev_ptr(g_trans.contiguous(), _f32) if g_trans is not None else None,
+            _lib.dev_ptr(g_flow, _f32), _lib.dev_ptr(g_w, _f32), _lib.dev_ptr(g_score, _f32), _lib.stream_ptr())
+        _lib.check(err, "cmf_ego_refine_grad")
+        return g_flow, None, g_score, None, None
+
+
+def ego_refine(flow, pc1, score, eps, thres):
+    """-> (pre_trans, sf_agg, mask): cmflow.py:96-125 with score (b,N) the (detached label or predicted) motion scores."""
+    return _EgoRefine.apply(flow, pc1, score, eps, thres)
+
+
 def _rows(t, pad4=False):
     """(B,C,N) channel-major -> (B,N,C) point-major rows (contiguous); pad4: zero columns up to a multiple of 4 floats
     (16-byte rows for the stacked first-conv GEMM)."""

@@ -92,6 +92,18 @@ int cmf_weighted_kabsch_grad(int b, int n, const float *A, const float *Bm, cons
                              const double *aux, const float *grad_trans,
                              float *grad_A, float *grad_B, float *grad_W, void *stream);
 
+/* The ego-motion head and the rigid refinement around that solve (models/cmflow.py:96-125) as one call per direction:
+ *   w = (score + eps) / sum(score + eps),  B = pc1 + flow,  trans = weighted_kabsch(pc1, B, w),  mask = score > thres,
+ *   sf = mask ? (R pc1 + t - pc1) : flow
+ * pc1, flow (b,3,n), score (b,n) -> W (b,n), Bm (b,3,n) [kept for the backward call], trans (b,4,4), aux (b,32) doubles,
+ * sf (b,3,n), mask (b,n) bytes.  One wavefront per sample. */
+int cmf_ego_refine(int b, int n, float eps, float thres, const float *pc1, const float *flow, const float *score,
+                   float *W, float *Bm, float *trans, double *aux, float *sf, unsigned char *mask, void *stream);
+/* Backward: g_sf (b,3,n), g_trans (b,4,4; may be NULL) -> g_flow (b,3,n), g_score (b,n; may be NULL); g_w (b,n) scratch. */
+int cmf_ego_refine_grad(int b, int n, float eps, const float *pc1, const float *score, const float *W, const float *Bm,
+                        const unsigned char *mask, const double *aux, const float *g_sf, const float *g_trans,
+                        float *g_flow, float *g_w, float *g_score, void *stream);
+
 /* ---- point-major grouping (the layout the fused path computes in) ------------------------------ */
 
 /* Row gather: feat (b,n,ldf) rows of c floats, idx (b,entries) -> out (b,entries,c) with

@@ -348,6 +348,43 @@ def test_kabsch_kat_and_grad(dev, golden_dir):
         np.testing.assert_allclose(got_g.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * scale, err_msg=name)
 
 
+@pytest.mark.parametrize("B,N,eps,thres,score_grad", [(8, 256, 1e-4, 0.3, True), (3, 200, 0.0, 0.5, True), (5, 256, 1e-4, 0.3, False)])
+def test_ego_refine_equals_the_torch_ops_around_the_solve(dev, B, N, eps, thres, score_grad):
+    """cmf_ego_refine (cmflow.py:96-125 as one call per direction: ego-motion weights, weighted Kabsch, rigid refinement, select)
+    against the same lines as torch ops around weighted_kabsch: outputs 2e-5 (t cancels 50 m centroids), mask equal, gradients
+    w.r.t. the flow and the scores 1e-4 of their largest entry."""
+    from cmflow_amd.radarflow_util import ego_refine, weighted_kabsch
+    from cmflow_amd.cmflow import CMFlow
+    g = torch.Generator().manual_seed(B + N)
+    pc1 = (torch.rand(B, 3, N, generator=g) * torch.tensor([100.0, 60.0, 6.0]).view(1, 3, 1) - torch.tensor([10.0, 30.0, 3.0]).view(1, 3, 1)).to(dev)
+    flow = (torch.randn(B, 3, N, generator=g) * 0.5 + torch.tensor([1.0, 0.2, 0.0]).view(1, 3, 1)).to(dev)
+    score = torch.rand(B, 1, N, generator=g).to(dev)
+    Gt, Gs = torch.randn(B, 4, 4, generator=g).to(dev), torch.randn(B, 3, N, generator=g).to(dev)
+    Gt[:, 3] = 0
+
+    def torch_tail(f, s):
+        mask = (s > thres).squeeze(1)
+        sc = s.squeeze(1) + eps if eps else s.squeeze(1)
+        w = sc / sc.sum(dim=1).unsqueeze(1)
+        T = weighted_kabsch(pc1, pc1 + f, w)
+        return T, torch.where(mask.unsqueeze(1), CMFlow.rigid_to_flow(pc1, T), f), mask
+
+    f0, s0 = flow.clone().requires_grad_(True), score.clone().requires_grad_(score_grad)
+    T0, sf0, m0 = torch_tail(f0, s0)
+    ((T0 * Gt).sum() + (sf0 * Gs).sum()).backward()
+    f1, s1 = flow.clone().requires_grad_(True), score.clone().requires_grad_(score_grad)
+    T1, sf1, m1 = ego_refine(f1, pc1, s1.squeeze(1), eps, thres)
+    ((T1 * Gt).sum() + (sf1 * Gs).sum()).backward()
+    assert torch.equal(m0, m1) and 0 < int(m0.sum()) < m0.numel()
+    np.testing.assert_allclose(T1.detach().cpu().numpy(), T0.detach().cpu().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(sf1.detach().cpu().numpy(), sf0.detach().cpu().numpy(), rtol=0, atol=5e-5)
+    for got, ref, name in ((f1.grad, f0.grad, "flow"),) + (((s1.grad, s0.grad, "score"),) if score_grad else ()):
+        ref = ref.cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-3, atol=1e-4 * np.abs(ref).max(), err_msg=name)
+    if not score_grad:
+        assert s1.grad is None
+
+
 @pytest.mark.parametrize("B,N,C,P,S,ld", [(4, 256, 512, 256, 32, 2048), (2, 256, 32, 256, 4, 32), (2, 100, 3, 100, 8, 3),
                                           (1, 300, 64, 50, 5, 64), (2, 256, 1027, 256, 8, 1027)])
 def test_group_rows_and_grad(dev, B, N, C, P, S, ld):
