@@ -24,6 +24,9 @@ SIGNATURES = {
     "cmf_group_points_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp],
     "cmf_query_and_group": [_ci, _ci, _ci, _cf, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_knn": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
+    "cmf_pad_rows": [_ll, _ci, _vp, _ll, _vp, _ci, _vp],
+    "cmf_inputs_point_major": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "cmf_rel_xyz": [_ci, _ci, _ci, _ci, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_weighted_kabsch_grad": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "cmf_ego_refine": [_ci, _ci, _cf, _cf, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],

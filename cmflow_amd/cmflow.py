@@ -75,10 +75,10 @@ class CMFlow(nn.Module):
 
     def _propagate_pm(self, pc1, pc2, feature1, feature2):
         """Same computation in point-major layout; returns prop_features as (B,256,N)."""
-        x1, x2 = pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous()       # (B,N,3)
-        # the input channels with one zero column behind them (rows of 4 floats for the stacked first-conv GEMM); a1 / a2 are views of it
-        a1p, a2p = torch.nn.functional.pad(feature1.transpose(1, 2), (0, 1)), torch.nn.functional.pad(feature2.transpose(1, 2), (0, 1))
-        a1, a2 = a1p[:, :, :-1], a2p[:, :, :-1]
+        # (B,N,3) coordinates and the input channels with zero columns behind them (rows of a multiple of 4 floats for the stacked
+        # first-conv GEMM; a1 / a2 are views of those): one launch for the four tensors
+        x1, x2, a1p, a2p = FB.inputs_point_major(pc1, pc2, feature1, feature2)
+        a1, a2 = a1p[:, :, :feature1.shape[1]], a2p[:, :, :feature2.shape[1]]
         if not self.mse_layer.training and x1.shape == x2.shape:
             # eval-mode BN has no batch statistics: the two clouds share one call of the (weight-shared) encoder
             B = x1.shape[0]

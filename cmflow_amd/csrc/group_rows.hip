@@ -53,6 +53,73 @@ extern "C" int cmf_group_rows(int b, int n, int c, int ldf, int entries,
     return cmf_launch_status();
 }
 
+// ---- small layout helpers of the host side: each replaces two or three torch kernels (fill + copy [+ sub]) by one launch ----
+// dst[r][c] = c < k ? src[r * ld_src + c] : 0   for c < ld_dst   (rows padded to 16-byte multiples for the GEMMs)
+__global__ __launch_bounds__(256) void pad_rows_kernel(long long rows, int k, const float *__restrict__ src, long long ld_src,
+                                                       float *__restrict__ dst, int ld_dst)
+{
+    const long long total = rows * ld_dst;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / ld_dst; const int c = (int)(i - r * ld_dst);
+        dst[i] = c < k ? src[r * ld_src + c] : 0.f;
+    }
+}
+extern "C" int cmf_pad_rows(long long rows, int k, const float *src, long long ld_src, float *dst, int ld_dst, void *stream)
+{
+    CMF_CHECK_ARG(rows >= 0 && k > 0 && ld_dst >= k && ld_src >= k);
+    if (rows == 0) return 0;
+    CMF_CHECK_ARG(src && dst);
+    const int grid = (int)std::min<long long>((rows * ld_dst + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rows, k, src, ld_src, dst, ld_dst);
+    return cmf_launch_status();
+}
+
+// The model's inputs in point-major rows, all four in one launch: pc1, pc2 (b,3,n) -> x1, x2 (b,n,3);  ft1, ft2 (b,c,n) -> a1, a2 (b,n,cp)
+// with zero columns c .. cp-1 (cmflow.py:59-64 keeps them channel-major; the fused path computes in rows)
+__global__ __launch_bounds__(256) void inputs_point_major_kernel(int n, int c, int cp, const float *__restrict__ pc1, const float *__restrict__ pc2,
+                                                                 const float *__restrict__ ft1, const float *__restrict__ ft2,
+                                                                 float *__restrict__ x1, float *__restrict__ x2, float *__restrict__ a1, float *__restrict__ a2)
+{
+    const int bs = blockIdx.y, per = 3 + cp;
+    const float *p = blockIdx.z ? pc2 : pc1, *f = blockIdx.z ? ft2 : ft1;
+    float *x = blockIdx.z ? x2 : x1, *a = blockIdx.z ? a2 : a1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n * per; i += gridDim.x * 256) {
+        const int pt = i / per, ch = i - pt * per;
+        if (ch < 3) x[((size_t)bs * n + pt) * 3 + ch] = p[((size_t)bs * 3 + ch) * n + pt];
+        else a[((size_t)bs * n + pt) * cp + (ch - 3)] = (ch - 3) < c ? f[((size_t)bs * c + (ch - 3)) * n + pt] : 0.f;
+    }
+}
+extern "C" int cmf_inputs_point_major(int b, int n, int c, int cp, const float *pc1, const float *pc2, const float *ft1, const float *ft2,
+                                      float *x1, float *x2, float *a1, float *a2, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && c > 0 && cp >= c);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(pc1 && pc2 && ft1 && ft2 && x1 && x2 && a1 && a2);
+    hipLaunchKernelGGL(inputs_point_major_kernel, dim3(cmf_divup(n * (3 + cp), 256), b, 2), dim3(256), 0, (hipStream_t)stream,
+                       n, c, cp, pc1, pc2, ft1, ft2, x1, x2, a1, a2);
+    return cmf_launch_status();
+}
+
+// Relative coordinates of the neighbours as 4-float rows: out[b][p][s] = (xyz[b][idx[b][p][s]] - centre[b][p], 0)   (radarflow_util.py:207-208)
+__global__ __launch_bounds__(256) void rel_xyz_kernel(int n, int m, int S, const float *__restrict__ xyz, const float *__restrict__ centre,
+                                                      const int *__restrict__ idx, float4 *__restrict__ out)
+{
+    const int bs = blockIdx.y;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < m * S; e += gridDim.x * 256) {
+        const int p = e / S;
+        const float *q = xyz + ((size_t)bs * n + idx[(size_t)bs * m * S + e]) * 3, *cc = centre + ((size_t)bs * m + p) * 3;
+        out[(size_t)bs * m * S + e] = make_float4(q[0] - cc[0], q[1] - cc[1], q[2] - cc[2], 0.f);
+    }
+}
+extern "C" int cmf_rel_xyz(int b, int n, int m, int S, const float *xyz, const float *centre, const int *idx, float *out, void *stream)
+{
+    CMF_CHECK_ARG(b >= 0 && n > 0 && m > 0 && S > 0);
+    if (b == 0) return 0;
+    CMF_CHECK_ARG(xyz && centre && idx && out && ((uintptr_t)out % 16 == 0));
+    hipLaunchKernelGGL(rel_xyz_kernel, dim3(cmf_divup(m * S, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, S, xyz, centre, idx, (float4 *)out);
+    return cmf_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Inverse index: per sample, offsets[n+1] and the entry list sorted by (target point, entry).
 // One workgroup per sample; thread j owns target point j and scans the sample's idx (staged in

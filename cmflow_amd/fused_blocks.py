@@ -505,12 +505,28 @@ class StackedFirstConvFn(Function):
         return (dfeats, None, None, *grads)
 
 
+def inputs_point_major(pc1, pc2, ft1, ft2):
+    """pc (B,3,N), ft (B,C,N) of both clouds -> x1, x2 (B,N,3), a1, a2 (B,N,C') with C' = C rounded up to a multiple of 4 floats, zero
+    columns behind the channels (cmf_inputs_point_major: one launch where torch takes two copies, two fills and two more copies)."""
+    B, C, N = ft1.shape
+    cp = (C + 4) // 4 * 4 if C % 4 else C
+    dev = pc1.device
+    same = pc2.shape == pc1.shape and ft2.shape == ft1.shape and pc1.is_cuda and all(t.dtype == _f32 for t in (pc1, pc2, ft1, ft2))
+    if not same:
+        f = lambda t: torch.nn.functional.pad(t.transpose(1, 2), (0, cp - t.shape[1]))
+        return pc1.transpose(1, 2).contiguous(), pc2.transpose(1, 2).contiguous(), f(ft1), f(ft2)
+    x1, x2 = torch.empty(B, N, 3, dtype=_f32, device=dev), torch.empty(B, N, 3, dtype=_f32, device=dev)
+    a1, a2 = torch.empty(B, N, cp, dtype=_f32, device=dev), torch.empty(B, N, cp, dtype=_f32, device=dev)
+    p = lambda t: _lib.dev_ptr(t.contiguous(), _f32)
+    _lib.check(_lib.lib().cmf_inputs_point_major(B, N, C, cp, p(pc1), p(pc2), p(ft1), p(ft2), x1.data_ptr(), x2.data_ptr(), a1.data_ptr(),
+                                                 a2.data_ptr(), _lib.stream_ptr()), "cmf_inputs_point_major")
+    return x1, x2, a1, a2
+
+
 def _pad_k(t):
     """Copy a 2-D tensor into a buffer whose row stride is a multiple of 4 floats (zero padded); returns the
     (rows, K) view of it."""
-    r, k = t.shape
-    ld = (k + 3) // 4 * 4
-    return torch.nn.functional.pad(t, (0, ld - k))[:, :k]            # one kernel (zeros + copy were two)
+    return _pad_cols(t)[:, :t.shape[1]]
 
 
 def _pad_cols(t):
@@ -519,7 +535,11 @@ def _pad_cols(t):
     ld = (k + 3) // 4 * 4
     if ld == k and t.is_contiguous():
         return t
-    return torch.nn.functional.pad(t, (0, ld - k))                   # one kernel (zeros + copy were two)
+    if not (t.is_cuda and t.dtype == _f32 and t.stride(1) == 1) or (torch.is_grad_enabled() and t.requires_grad):
+        return torch.nn.functional.pad(t, (0, ld - k))          # (differentiable where a caller outside a Function needs it)
+    buf = torch.empty(r, ld, dtype=_f32, device=t.device)            # one launch (torch: a fill and a copy)
+    _lib.check(_lib.lib().cmf_pad_rows(r, k, t.data_ptr(), t.stride(0), buf.data_ptr(), ld, _lib.stream_ptr()), "cmf_pad_rows")
+    return buf
 
 
 def linear(x, w, bias=None, act=0, preact_grad=False, in_bias=None):

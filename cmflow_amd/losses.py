@@ -89,8 +89,10 @@ class RadarFlowLossFn(Function):
     def backward(ctx, g_total, _g_items):
         g_f, g_t, g_m = ctx.grads
         need = ctx.needs_input_grad
-        return (g_f * g_total if need[0] else None, g_t * g_total if (need[1] and g_t is not None) else None,
-                g_m * g_total if (need[2] and g_m is not None) else None, None, None)
+        gs = [g for g, n in ((g_f, need[0]), (g_t, need[1]), (g_m, need[2])) if n and g is not None]
+        torch._foreach_mul_(gs, g_total)                        # one launch for the three (the buffers are this node's own)
+        return (g_f if need[0] else None, g_t if (need[1] and g_t is not None) else None,
+                g_m if (need[2] and g_m is not None) else None, None, None)
 
 
 SELF_ITEM_KEYS = ITEM_KEYS[:4]

@@ -48,10 +48,10 @@ def index_points_group(points, knn_idx):
     return group_rows(points, Neighbors(knn_idx.int().contiguous(), points.shape[1]))
 
 
-def knn_point(nsample, xyz, new_xyz, return_dist=False):
+def knn_point(nsample, xyz, new_xyz, return_dist=False, i32=False):
     """radarflow_util.py:88-99: xyz (B,N,3) database, new_xyz (B,S,3) queries -> (B,S,nsample)
-    int64 (torch.topk's dtype).  Order is canonical (ascending distance, lowest index first);
-    the reference's topk(sorted=False) order is unspecified."""
+    int64 (torch.topk's dtype; i32=True: the kernel's own int32 tensor, for the blocks).  Order is canonical (ascending distance,
+    lowest index first); the reference's topk(sorted=False) order is unspecified."""
     xyz = xyz.detach().contiguous()
     new_xyz = new_xyz.detach().contiguous()
     B, N, _ = xyz.shape
@@ -61,7 +61,21 @@ def knn_point(nsample, xyz, new_xyz, return_dist=False):
     err = _lib.lib().cmf_knn(B, N, S, nsample, _lib.dev_ptr(xyz, _f32), _lib.dev_ptr(new_xyz, _f32),
                              _lib.dev_ptr(idx, _i32), _lib.dev_ptr(dist, _f32), _lib.stream_ptr())
     _lib.check(err, "cmf_knn")
+    if i32:
+        return (idx, dist) if return_dist else idx
     return (idx.long(), dist) if return_dist else idx.long()
+
+
+def rel_xyz(xyz_t, centre_t, idx):
+    """(B,N,3) points, (B,P,3) centres, idx (B,P,S) int32 -> (B,P,S,4): neighbour minus centre with a zero fourth column
+    (radarflow_util.py:207-208 + the row padding of the narrow GEMMs), one launch.  No gradient (coordinates are inputs)."""
+    B, N, _ = xyz_t.shape
+    P, S = idx.shape[1], idx.shape[2]
+    out = torch.empty(B, P, S, 4, dtype=_f32, device=xyz_t.device)
+    err = _lib.lib().cmf_rel_xyz(B, N, P, S, _lib.dev_ptr(xyz_t.detach().contiguous(), _f32), _lib.dev_ptr(centre_t.detach().contiguous(), _f32),
+                                 _lib.dev_ptr(idx, _i32), _lib.dev_ptr(out, _f32), _lib.stream_ptr())
+    _lib.check(err, "cmf_rel_xyz")
+    return out
 
 
 class _WeightedKabsch(Function):
@@ -395,11 +409,11 @@ def _fc_blocks(self, xyz1_t, xyz2_t, f1, f2):
             st.wait_stream(main)
         FB.stress_point(list(side) + [main])
     with torch.cuda.stream(side[0]) if side else contextlib.nullcontext():
-        nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t).int(), xyz2_t.shape[1])     # needed after p1: off the main stream too
+        nbr = Neighbors(knn_point(K, xyz2_t, xyz1_t, i32=True), xyz2_t.shape[1])     # needed after p1: off the main stream too
         p2 = FB.stress_mark(FB.linear(f2, w0[:, D1:D1 + D2]))
     with torch.cuda.stream(side[1]) if side else contextlib.nullcontext():
-        nbr2 = Neighbors(knn_point(K, xyz1_t, xyz1_t).int(), xyz1_t.shape[1])
-        dxyz2 = F.pad(group_rows(xyz1_t, nbr2) - xyz1_t.unsqueeze(2), (0, 1))
+        nbr2 = Neighbors(knn_point(K, xyz1_t, xyz1_t, i32=True), xyz1_t.shape[1])
+        dxyz2 = rel_xyz(xyz1_t, xyz1_t, nbr2.idx)
         h2 = FB.stress_mark(self.weightnet2.hidden_pm(dxyz2))
     p1 = FB.linear(f1, w0[:, :D1], c0.bias)
     if side:

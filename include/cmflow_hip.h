@@ -106,6 +106,17 @@ int cmf_ego_refine_grad(int b, int n, float eps, const float *pc1, const float *
 
 /* ---- point-major grouping (the layout the fused path computes in) ------------------------------ */
 
+/* Layout helpers of the host side (each one launch where torch takes a fill, a copy and sometimes a subtraction):
+ * cmf_pad_rows: dst[r][c] = c < k ? src[r * ld_src + c] : 0 for c < ld_dst (rows padded to 16-byte multiples);
+ * cmf_inputs_point_major: the model's four inputs as point-major rows -- pc1, pc2 (b,3,n) -> x1, x2 (b,n,3); ft1, ft2 (b,c,n) ->
+ *   a1, a2 (b,n,cp) with zero columns c..cp-1 (models/cmflow.py:59-64 keeps them channel-major);
+ * cmf_rel_xyz: out (b,m,S,4) = (xyz[b][idx[b][p][s]] - centre[b][p], 0), the neighbours' relative coordinates
+ *   (utils/model_utils/radarflow_util.py:207-208). */
+int cmf_pad_rows(long long rows, int k, const float *src, long long ld_src, float *dst, int ld_dst, void *stream);
+int cmf_inputs_point_major(int b, int n, int c, int cp, const float *pc1, const float *pc2, const float *ft1, const float *ft2,
+                           float *x1, float *x2, float *a1, float *a2, void *stream);
+int cmf_rel_xyz(int b, int n, int m, int S, const float *xyz, const float *centre, const int *idx, float *out, void *stream);
+
 /* Row gather: feat (b,n,ldf) rows of c floats, idx (b,entries) -> out (b,entries,c) with
  * out[b,e,:] = feat[b,idx[b,e],:].  Same operation as cmf_group_points on the transposed layout
  * (reference: lib/src/group_points_gpu.cu:47-66 via utils/model_utils/radarflow_util.py:52-63),
