@@ -325,6 +325,19 @@ def gemm_dw(dZ, X, prob=None, w=None):
     if sink is not None:
         gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split, out=sink, accumulate=True)
         return None
+    tail = K % 128
+    if prob is None and 0 < tail <= 64 and K >= 512 and N >= 512 and N % 128 == 0 and X.data_ptr() % 16 == 0 and M >= 4096:
+        # a few columns past a multiple of 128 (the stacked first conv's 1040 = 1024 + 16): as one call the ninth column of tiles runs the
+        # ragged-edge loop on 128-wide tiles for 16 columns -- 800 us for 2048 x 1040 x 16384; as a 1024-wide call plus a 16-wide one with
+        # its own split count (one round of workgroups) 650 us (tools/dw1040_probe.py).  Same sums per element, another slab partition for the tail.
+        out = torch.empty(N, K, dtype=_f32, device=dZ.device)
+        K1 = K - tail
+        gemm(dZ, X[:, :K1], a_t=True, b_t=False, split_k=dw_split(M, N, K1), out=out[:, :K1])
+        ts = max(8, (768 // (N // 128)) // 8 * 8)
+        while ts > 8 and M // 16 // ts < 8:
+            ts -= 8
+        gemm(dZ, X[:, K1:], a_t=True, b_t=False, split_k=ts, out=out[:, K1:])
+        return out
     return gemm(dZ, X, a_t=True, b_t=False, prob=prob, split_k=split)
 
 
