@@ -81,6 +81,10 @@ struct CmfColsumArgs { int tiles, ncols; const float *partial; float *out; int C
 struct CmfActBwdArgs { long long rows; int C; const float *dY; long long ldy; const float *z; long long ldz;
                        const float *a, *c, *mean, *invstd; float *dU, *partial; };
 struct CmfAffineArgs { long long M; int C; const float *z; long long ldz; const float *a, *c; float *out; long long ldo; };
+// the narrow set-conv blocks' first layer (cmf_group_affine without centre rows: z, dxyz, statistics, z * d_k sums) and the max over the ball
+struct CmfGroupAffineArgs { int b, n_src, P, S, C; const float *ysrc; int ld_src; const float *xyz_src, *xyz_ctr, *Wx; int ldw; const int *idx;
+                            float *z, *dxyz, *partial, *partial_x; };
+struct CmfPoolArgs { long long P; int S, C; const float *z, *a, *c; float *out; long long ldo; unsigned char *argmax; int grid; };
 struct CmfSplitkArgs { int M, N, split_k; const float *workspace; float *C; long long ldc; int accumulate; };
 // one fused backward layer (cmf_thin_bwd_layer); nslab is filled in by the batch call
 struct CmfThinBwdCall { long long rows; int cout, cin; const float *dU; long long lddu; const float *z; long long ldz;
@@ -89,6 +93,8 @@ struct CmfThinBwdCall { long long rows; int cout, cin; const float *dU; long lon
                         float *dw; long long lddw; int accumulate; float *slabs; int nslab; };
 int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st);                 // pointwise.hip
 int cmf_colsum_batch(int n, const CmfColsumArgs *a, hipStream_t st);                     // pointwise.hip
+int cmf_group_affine_batch(int n, const CmfGroupAffineArgs *a, hipStream_t st);           // pointwise.hip: same C for all
+int cmf_bn_relu_maxpool_batch(int n, CmfPoolArgs *a, hipStream_t st);                    // pointwise.hip (fills in grid)
 int cmf_act_bwd_stats_batch(int n, const CmfActBwdArgs *a, hipStream_t st);              // pointwise.hip
 int cmf_affine_relu_batch(int n, const CmfAffineArgs *a, hipStream_t st);                // pointwise.hip
 int cmf_splitk_reduce_batch(int n, const CmfSplitkArgs *a, hipStream_t st);              // gemm.hip

@@ -581,26 +581,28 @@ __device__ __forceinline__ void ga_full_rows(const TileMap &tm, int C, const flo
                             o.z = o.z > 0.f ? o.z : 0.1f * o.z; o.w = o.w > 0.f ? o.w : 0.1f * o.w; }
             if (WR) *(float4 *)(zt + (size_t)r * C) = o;
             if (ST) {
+                // (explicit fused multiply-adds: every instantiation of this body -- stored / statistics-only / batched -- must sum alike)
                 a.s1.x += o.x; a.s1.y += o.y; a.s1.z += o.z; a.s1.w += o.w;
-                a.s2.x += o.x * o.x; a.s2.y += o.y * o.y; a.s2.z += o.z * o.z; a.s2.w += o.w * o.w;
+                a.s2.x = fmaf(o.x, o.x, a.s2.x); a.s2.y = fmaf(o.y, o.y, a.s2.y); a.s2.z = fmaf(o.z, o.z, a.s2.z); a.s2.w = fmaf(o.w, o.w, a.s2.w);
             }
             if (XS) {
-                a.tz0.x += o.x * dx; a.tz0.y += o.y * dx; a.tz0.z += o.z * dx; a.tz0.w += o.w * dx;
-                a.tz1.x += o.x * dy; a.tz1.y += o.y * dy; a.tz1.z += o.z * dy; a.tz1.w += o.w * dy;
-                a.tz2.x += o.x * dz; a.tz2.y += o.y * dz; a.tz2.z += o.z * dz; a.tz2.w += o.w * dz;
+                a.tz0.x = fmaf(o.x, dx, a.tz0.x); a.tz0.y = fmaf(o.y, dx, a.tz0.y); a.tz0.z = fmaf(o.z, dx, a.tz0.z); a.tz0.w = fmaf(o.w, dx, a.tz0.w);
+                a.tz1.x = fmaf(o.x, dy, a.tz1.x); a.tz1.y = fmaf(o.y, dy, a.tz1.y); a.tz1.z = fmaf(o.z, dy, a.tz1.z); a.tz1.w = fmaf(o.w, dy, a.tz1.w);
+                a.tz2.x = fmaf(o.x, dz, a.tz2.x); a.tz2.y = fmaf(o.y, dz, a.tz2.y); a.tz2.z = fmaf(o.z, dz, a.tz2.z); a.tz2.w = fmaf(o.w, dz, a.tz2.w);
                 a.ud0 += dx; a.ud1 += dy; a.ud2 += dz;
             }
         }
     }
 }
 
+// (body + single / batch entry: cmf_common.h "batched launches"; bx / nbx = this problem's block index and block count)
 template <bool CTR, bool ST, bool XS, bool WR = true>   // centre rows added / BN partial sums / z * d_k sums / z written (the call's NULL pointers)
-__global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
+__device__ __forceinline__ void group_affine_body(
     int n_src, int P, int S, int C, long long rows,
     const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr, int ld_ctr,
     const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
     const float *__restrict__ Wx, int ldw, const int *__restrict__ idx, int act,
-    float *__restrict__ z, float *__restrict__ dxyz, float *__restrict__ partial, float *__restrict__ partial_x)
+    float *__restrict__ z, float *__restrict__ dxyz, float *__restrict__ partial, float *__restrict__ partial_x, const int bx, const int nbx)
 {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const TileMap tm = tile_map(C);
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
         for (int k = 0; k < 3; ++k) wx[j][k] = Wx[(size_t)(tm.col + j) * ldw + k];
     // tiles of one sample on one XCD: the sample's n_src x C source rows (512 KB at C = 512) are fetched from HBM by that
     // L2 only (round 2 counted 1.41x the algorithmic bytes: all eight XCDs pulled all sources)
-    const long long tile = xcd_major_tile(blockIdx.x, gridDim.x);
+    const long long tile = xcd_major_tile(bx, nbx);
     const long long row0 = tile * PW_ROWS;
     // Per-row quantities (source row, centre row, relative xyz) are computed ONCE per tile into LDS: with C = 512 the 128 threads
     // that share a row used to issue the same idx load and six scalar xyz loads each -- nine memory instructions per
@@ -668,12 +670,12 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             if (WR) *(float4 *)(z + (size_t)(row0 + r) * C + tm.col) = o;
             if (ST) {
                 acc.s1.x += o.x; acc.s1.y += o.y; acc.s1.z += o.z; acc.s1.w += o.w;
-                acc.s2.x += o.x * o.x; acc.s2.y += o.y * o.y; acc.s2.z += o.z * o.z; acc.s2.w += o.w * o.w;
+                acc.s2.x = fmaf(o.x, o.x, acc.s2.x); acc.s2.y = fmaf(o.y, o.y, acc.s2.y); acc.s2.z = fmaf(o.z, o.z, acc.s2.z); acc.s2.w = fmaf(o.w, o.w, acc.s2.w);
             }
             if (XS) {
-                acc.tz0.x += o.x * dx; acc.tz0.y += o.y * dx; acc.tz0.z += o.z * dx; acc.tz0.w += o.w * dx;
-                acc.tz1.x += o.x * dy; acc.tz1.y += o.y * dy; acc.tz1.z += o.z * dy; acc.tz1.w += o.w * dy;
-                acc.tz2.x += o.x * dz; acc.tz2.y += o.y * dz; acc.tz2.z += o.z * dz; acc.tz2.w += o.w * dz;
+                acc.tz0.x = fmaf(o.x, dx, acc.tz0.x); acc.tz0.y = fmaf(o.y, dx, acc.tz0.y); acc.tz0.z = fmaf(o.z, dx, acc.tz0.z); acc.tz0.w = fmaf(o.w, dx, acc.tz0.w);
+                acc.tz1.x = fmaf(o.x, dy, acc.tz1.x); acc.tz1.y = fmaf(o.y, dy, acc.tz1.y); acc.tz1.z = fmaf(o.z, dy, acc.tz1.z); acc.tz1.w = fmaf(o.w, dy, acc.tz1.w);
+                acc.tz2.x = fmaf(o.x, dz, acc.tz2.x); acc.tz2.y = fmaf(o.y, dz, acc.tz2.y); acc.tz2.z = fmaf(o.z, dz, acc.tz2.z); acc.tz2.w = fmaf(o.w, dz, acc.tz2.w);
                 acc.ud0 += dx; acc.ud1 += dy; acc.ud2 += dz;
             }
         }
@@ -704,6 +706,45 @@ __global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
             px[2 * C + i] = sum;
         }
     }
+}
+
+template <bool CTR, bool ST, bool XS, bool WR = true>
+__global__ __launch_bounds__(PW_THREADS) void group_affine_kernel(
+    int n_src, int P, int S, int C, long long rows,
+    const float *__restrict__ ysrc, int ld_src, const float *__restrict__ yctr, int ld_ctr,
+    const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
+    const float *__restrict__ Wx, int ldw, const int *__restrict__ idx, int act,
+    float *__restrict__ z, float *__restrict__ dxyz, float *__restrict__ partial, float *__restrict__ partial_x)
+{
+    group_affine_body<CTR, ST, XS, WR>(n_src, P, S, C, rows, ysrc, ld_src, yctr, ld_ctr, xyz_src, xyz_ctr, Wx, ldw, idx, act, z, dxyz, partial,
+                                       partial_x, blockIdx.x, gridDim.x);
+}
+
+// the narrow blocks' first layer (no centre rows, statistics + z * d_k sums, z written) for up to CMF_MAX_BATCH blocks of one width
+__global__ __launch_bounds__(PW_THREADS) void group_affine_batch_kernel(const CmfBatch<CmfGroupAffineArgs> b)
+{
+    const CmfGroupAffineArgs &p = b.a[blockIdx.y];
+    const long long rows = (long long)p.b * p.P * p.S;
+    const int tiles = (int)((rows + PW_ROWS - 1) / PW_ROWS);
+    if ((int)blockIdx.x >= tiles) return;
+    group_affine_body<false, true, true, true>(p.n_src, p.P, p.S, p.C, rows, p.ysrc, p.ld_src, nullptr, 0, p.xyz_src, p.xyz_ctr, p.Wx, p.ldw, p.idx, 0,
+                                               p.z, p.dxyz, p.partial, p.partial_x, blockIdx.x, tiles);
+}
+
+int cmf_group_affine_batch(int n, const CmfGroupAffineArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfGroupAffineArgs> b;
+    int tmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const CmfGroupAffineArgs &q = a[i];
+        CMF_CHECK_ARG(q.b > 0 && q.n_src > 0 && q.P > 0 && q.S > 0 && tile_ok(q.C) && q.C == a[0].C && q.C >= 4 && q.ld_src % 4 == 0);
+        CMF_CHECK_ARG(q.ysrc && q.xyz_src && q.xyz_ctr && q.Wx && q.idx && q.z && q.dxyz && q.partial && q.partial_x);
+        b.a[i] = q;
+        tmax = std::max(tmax, cmf_divup((long long)q.b * q.P * q.S, PW_ROWS));
+    }
+    hipLaunchKernelGGL(group_affine_batch_kernel, dim3(tmax, n), dim3(PW_THREADS), tile_lds(a[0].C), st, b);
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_group_affine(int b, int n_src, int P, int S, int C,
@@ -798,12 +839,12 @@ extern "C" int cmf_group_perm(int b, int entries, const int *inv, const int *row
 // out[p, :] = max_s relu(a*z[p,s,:] + c)   (radarflow_util.py:151-155 fused: BN + ReLU + max over the ball)
 // argmax (uint8, first maximum) is kept for the backward pass.  out may be a column slice (ldo).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_kernel(
+__device__ __forceinline__ void bn_relu_maxpool_body(
     long long P, int S, int C, const float *__restrict__ z, const float *__restrict__ a, const float *__restrict__ c,
-    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax)
+    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax, const int bx, const int nbx)
 {
     const int cg = C / 4;
-    for (long long i = (long long)blockIdx.x * PW_THREADS + threadIdx.x; i < P * cg; i += (long long)gridDim.x * PW_THREADS) {
+    for (long long i = (long long)bx * PW_THREADS + threadIdx.x; i < P * cg; i += (long long)nbx * PW_THREADS) {
         const long long p = i / cg;
         const int col = (int)(i - p * cg) * 4;
         const float4 sa = *(const float4 *)(a + col), sc = *(const float4 *)(c + col);
@@ -824,13 +865,45 @@ __global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_kernel(
     }
 }
 
+__global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_kernel(
+    long long P, int S, int C, const float *__restrict__ z, const float *__restrict__ a, const float *__restrict__ c,
+    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax)
+{
+    bn_relu_maxpool_body(P, S, C, z, a, c, out, ldo, argmax, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_batch_kernel(const CmfBatch<CmfPoolArgs> b)
+{
+    const CmfPoolArgs &p = b.a[blockIdx.y];
+    if ((int)blockIdx.x >= p.grid) return;
+    bn_relu_maxpool_body(p.P, p.S, p.C, p.z, p.a, p.c, p.out, p.ldo, p.argmax, blockIdx.x, p.grid);
+}
+
+static int pool_grid(long long P, int C) { return (int)std::min<long long>((P * (C / 4) + PW_THREADS - 1) / PW_THREADS, 8192); }
+
+int cmf_bn_relu_maxpool_batch(int n, CmfPoolArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfPoolArgs> b;
+    int gmax = 0;
+    for (int i = 0; i < n; ++i) {
+        CmfPoolArgs &q = a[i];
+        CMF_CHECK_ARG(q.P > 0 && q.S > 0 && q.S <= 255 && q.C % 4 == 0 && q.ldo % 4 == 0 && q.z && q.a && q.c && q.out);
+        q.grid = pool_grid(q.P, q.C);
+        b.a[i] = q;
+        gmax = std::max(gmax, q.grid);
+    }
+    hipLaunchKernelGGL(bn_relu_maxpool_batch_kernel, dim3(gmax, n), dim3(PW_THREADS), 0, st, b);
+    return cmf_launch_status();
+}
+
 extern "C" int cmf_bn_relu_maxpool(long long P, int S, int C, const float *z, const float *a, const float *c,
                                    float *out, long long ldo, unsigned char *argmax, void *stream)
 {
     CMF_CHECK_ARG(P >= 0 && S > 0 && S <= 255 && C % 4 == 0 && ldo % 4 == 0);
     if (P == 0) return 0;
     CMF_CHECK_ARG(z && a && c && out);
-    const int grid = (int)std::min<long long>((P * (C / 4) + PW_THREADS - 1) / PW_THREADS, 8192);
+    const int grid = pool_grid(P, C);
     hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid), dim3(PW_THREADS), 0, (hipStream_t)stream, P, S, C, z, a, c, out, ldo, argmax);
     return cmf_launch_status();
 }

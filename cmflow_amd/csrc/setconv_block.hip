@@ -853,11 +853,83 @@ extern "C" int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, 
     return setconv_multi(n, descs, streams, true);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The slot-level bodies of up to CMF_MAX_BATCH NARROW blocks (the first encoder: 2 clouds x 4 scales, 32 / 32 / 64 channels) in lock
+// step: one batched launch per stage for all blocks instead of one kernel per block and stage on the stream pool.  At these widths
+// every kernel of a body is an HBM stream of 15-70 us -- eight chains of eight launches each kept four hardware queues busy with
+// launch gaps, and co-running bought nothing (the bodies' wall time equalled the sum of their kernels' isolated durations).  Same
+// kernels' device code, same arithmetic, same results as the per-block calls.  Train-mode BatchNorm only (eval-mode BN takes the
+// register chain); CMF_BODY_BATCH=0: the per-block chains (A/B).
+// ---------------------------------------------------------------------------------------------------------------
+static bool body_batchable(int n, const cmf_setconv_desc *descs)
+{
+    static const bool on = !(getenv("CMF_BODY_BATCH") && getenv("CMF_BODY_BATCH")[0] == '0');
+    if (!on || n < 2 || n > CMF_MAX_BATCH) return false;
+    for (int i = 0; i < n; ++i) {
+        const cmf_setconv_desc &d = descs[i];
+        const long long M = (long long)d.B * d.N * d.S;
+        if (!d.training || d.inference || !d.idx_ready || chain_train(&d) || train_gather(&d)) return false;
+        if (d.O1 != descs[0].O1 || d.C[0] != descs[0].C[0] || d.C[1] != descs[0].C[1]) return false;
+        if (d.O1 > 64 || d.O1 % 32 || d.C[0] > 64 || d.C[0] % 32 || d.C[1] > 64 || d.C[1] % 32) return false;
+        if (M % 128 || M >= (1ll << 31) || d.ldy % 4 || ((uintptr_t)d.y & 15)) return false;
+    }
+    return true;
+}
+
+static int setconv_forward_bodies_batch(int n, const cmf_setconv_desc *descs, hipStream_t st)
+{
+    Layout L[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        CMF_CHECK_ARG(descs[i].xyz && descs[i].y && descs[i].wx && descs[i].saved && descs[i].scratch && descs[i].out);
+        L[i] = make_layout(&descs[i], descs[i].saved, descs[i].scratch, false);
+    }
+    const int O1 = descs[0].O1, C2 = descs[0].C[0], C3 = descs[0].C[1];
+    {   // z1 = y[idx] + Wx . dxyz with its statistics; the z * d_k sums for dW_xyz
+        CmfGroupAffineArgs ga[CMF_MAX_BATCH];
+        CmfColsumArgs cs[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long M = (long long)d.B * d.N * d.S;
+            ga[i] = CmfGroupAffineArgs{d.B, d.N, d.N, d.S, O1, d.y, (int)d.ldy, d.xyz, d.xyz, d.wx, (int)d.ldwx, L[i].idx, L[i].z1, L[i].dxyz,
+                                       L[i].partial, L[i].partial_x};
+            cs[i] = CmfColsumArgs{tiles128(M), 3 * O1 + 4, L[i].partial_x, L[i].fwd_sums, 0, nullptr, nullptr, 0};
+        }
+        CMF_TRY(cmf_group_affine_batch(n, ga, st));
+        CMF_TRY(cmf_colsum_batch(n, cs, st));
+    }
+    for (int layer = 0; layer < 3; ++layer) {            // fold BN layer `layer`, then (layers 0, 1) the next 1x1 conv / (layer 2) the max over the ball
+        CmfBnFinArgs f[CMF_MAX_BATCH];
+        GemmArgs g[CMF_MAX_BATCH];
+        CmfPoolArgs pl[CMF_MAX_BATCH];
+        const int C = layer == 0 ? O1 : (layer == 1 ? C2 : C3), cout = layer == 0 ? C2 : C3;
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long P = (long long)d.B * d.N, M = P * d.S;
+            float *b = L[i].bn[layer];
+            f[i] = CmfBnFinArgs{tiles128(M), C, (double)M, L[i].partial, d.gamma[layer], d.beta[layer], d.eps[layer], d.momentum[layer],
+                                d.rmean[layer], d.rvar[layer], b, b + C, b + 2 * C, b + 3 * C, d.nbt[layer]};
+            if (layer < 2) {
+                GemmArgs &q = g[i];
+                q = GemmArgs{};
+                q.M = (int)M; q.N = cout; q.K = C; q.A = layer == 0 ? L[i].z1 : L[i].z2; q.lda = C; q.B = d.w[layer]; q.ldb = C;
+                q.C = layer == 0 ? L[i].z2 : L[i].z3; q.ldc = cout; q.pro_a = b + 2 * C; q.pro_c = b + 3 * C; q.stats = L[i].partial; q.split_k = 1;
+            } else
+                pl[i] = CmfPoolArgs{P, d.S, C3, L[i].z3, b + 2 * C3, b + 3 * C3, L[i].x, C3, L[i].argmax, 0};
+        }
+        CMF_TRY(cmf_bn_finalize_batch(n, f, st));
+        if (layer < 2) CMF_TRY(cmf_thin_fwd_batch(n, g, st));
+        else CMF_TRY(cmf_bn_relu_maxpool_batch(n, pl, st));
+    }
+    return 0;
+}
+
 // The same with the per-point tails taken out: forward stops behind the max over the ball, backward starts there.  The
 // caller runs cmf_setconv_tail_forward behind the forward heads (after joining the streams) and cmf_setconv_tail_backward in
 // front of the backward bodies (before forking): the tails of all blocks as batched launches on one stream.
 extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
+    CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
+    if (body_batchable(n, descs)) return setconv_forward_bodies_batch(n, descs, (hipStream_t)streams[0]);
     return setconv_multi(n, descs, streams, false, 1);
 }
 

@@ -379,6 +379,24 @@ def test_training_without_the_grouped_first_layer_tensor_is_bit_identical(dev, t
         assert not bad, (bn_mode, bad[:10])
 
 
+def test_batched_first_encoder_bodies_are_bit_identical_to_the_per_block_chains(dev, tmp_path):
+    """Default: the slot-level bodies of the first encoder's eight blocks (2 clouds x 4 scales) run in lock step as batched launches --
+    one per stage for all blocks -- instead of one chain of kernels per block on the stream pool (CMF_BODY_BATCH=0).  The same kernels'
+    device code on the same data: loss, every gradient and every BN buffer of a whole training step (B = 64) equal bit for bit."""
+    import subprocess, sys
+    outs = []
+    for i, env in enumerate((dict(CMF_BODY_BATCH="0"), dict(CMF_BODY_BATCH="1"))):
+        f = str(tmp_path / ("body%d.pt" % i))
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "64"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(f))
+    a, b = outs
+    assert a.keys() == b.keys() and len(a) > 300
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, bad[:10]
+
+
 def test_chain_training_matches_the_per_layer_kernels(dev, tmp_path):
     """CMF_CHAIN_TRAIN=1 (opt-in): the first encoder's blocks train through the register chain (csrc/setconv_chain.hip: slot-level
     activations never stored, every pass recomputes them; statistics rows per wave instead of per 128 rows).  Same terms as the

@@ -20,6 +20,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     for _ in range(STEPS):
         step(batch)
     torch.cuda.synchronize()
+kern = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+names = collections.Counter(e.name for e in kern)
+print("GPU kernels + copies + memsets per step (all streams): %.1f" % (len(kern) / STEPS))
+print("   of which memcpy/memset: %.1f" % (sum(v for k, v in names.items() if k.startswith("Mem")) / STEPS))
 rows = []
 for e in prof.key_averages(group_by_stack_n=25):
     if not e.key.startswith("aten::") or e.device_time_total <= 0 or e.self_device_time_total <= 0:
