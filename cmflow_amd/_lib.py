@@ -58,6 +58,8 @@ SIGNATURES = {
     "cmf_setconv_forward_multi": [_ci, _vp, _vp],
     "cmf_setconv_backward_multi": [_ci, _vp, _vp],
     "cmf_setconv_forward_heads_multi": [_ci, _vp, _vp],
+    "cmf_setconv_forward_bodies_batched": [_ci, _vp],
+    "cmf_setconv_backward_bodies_batched": [_ci, _vp],
     "cmf_setconv_tail_forward": [_ci, _vp, _vp],
     "cmf_setconv_tail_backward": [_ci, _vp, _vp],
     "cmf_setconv_backward_bodies_multi": [_ci, _vp, _vp],

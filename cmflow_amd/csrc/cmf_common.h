@@ -85,14 +85,27 @@ struct CmfAffineArgs { long long M; int C; const float *z; long long ldz; const 
 struct CmfGroupAffineArgs { int b, n_src, P, S, C; const float *ysrc; int ld_src; const float *xyz_src, *xyz_ctr, *Wx; int ldw; const int *idx;
                             float *z, *dxyz, *partial, *partial_x; };
 struct CmfPoolArgs { long long P; int S, C; const float *z, *a, *c; float *out; long long ldo; unsigned char *argmax; int grid; };
+// backward of the narrow blocks' bodies: max-pool backward per point, the inverse index, dW_xyz from column sums, the scatter with the
+// first layer's BN backward in closed form (cmf_maxpool_bwd_point, cmf_build_inverse_ps, cmf_setconv_dwx, cmf_group_rows_grad_bn_cf)
+struct CmfPoolBwdArgs { long long P; int S, C; const float *dout; long long ldd; const float *z, *a, *c, *mean, *invstd; const unsigned char *argmax;
+                        float *g, *partial; };
+struct CmfInverseArgs { int n, P, S; const int *idx; int *offsets, *inv; };
+struct CmfDwxArgs { int C; float inv_count; int train; const float *bwd5, *fwd, *a, *mean, *invstd; float *dwx; int ld, accumulate; };
+struct CmfScatterArgs { int n, entries, S; const float *dU, *y; long long ldy; const float *wx; long long ldw; const float *xyz_src, *xyz_ctr,
+                        *a, *mean, *invstd, *sums; float inv_count; const int *offsets, *inv; float *grad_feat; int ldg; };
 struct CmfSplitkArgs { int M, N, split_k; const float *workspace; float *C; long long ldc; int accumulate; };
 // one fused backward layer (cmf_thin_bwd_layer); nslab is filled in by the batch call
 struct CmfThinBwdCall { long long rows; int cout, cin; const float *dU; long long lddu; const float *z; long long ldz;
                         const float *a, *mean, *invstd, *sums; const float *w; long long ldw; const float *x; long long ldx; int in_mode;
                         const float *a_in, *c_in, *mean_in, *invstd_in; float *dx; long long lddx; float *stats;
-                        float *dw; long long lddw; int accumulate; float *slabs; int nslab; };
+                        float *dw; long long lddw; int accumulate; float *slabs; int nslab;
+                        const float *dxyz; const float *pool_g; const unsigned char *pool_am; int pool_S; };   // (in_mode 1: dxyz sums; pooled dU: rows = P * pool_S)
 int cmf_bn_finalize_batch(int n, const CmfBnFinArgs *a, hipStream_t st);                 // pointwise.hip
 int cmf_colsum_batch(int n, const CmfColsumArgs *a, hipStream_t st);                     // pointwise.hip
+int cmf_maxpool_bwd_point_batch(int n, const CmfPoolBwdArgs *a, hipStream_t st);          // pointwise.hip: same C for all
+int cmf_setconv_dwx_batch(int n, const CmfDwxArgs *a, hipStream_t st);                    // pointwise.hip
+int cmf_build_inverse_ps_batch(int n, int b, const CmfInverseArgs *a, hipStream_t st);    // group_rows.hip: b samples each, the matrix form
+int cmf_group_rows_grad_bn_cf_batch(int n, int b, int c, const CmfScatterArgs *a, hipStream_t st);   // group_rows.hip: narrow rows (c = 16 .. 128), same n for all
 int cmf_group_affine_batch(int n, const CmfGroupAffineArgs *a, hipStream_t st);           // pointwise.hip: same C for all
 int cmf_bn_relu_maxpool_batch(int n, CmfPoolArgs *a, hipStream_t st);                    // pointwise.hip (fills in grid)
 int cmf_act_bwd_stats_batch(int n, const CmfActBwdArgs *a, hipStream_t st);              // pointwise.hip

@@ -209,7 +209,7 @@ __device__ __forceinline__ int invm_block_scan(int v, int *wsum, int &block_tota
 // compiler could not overlap (the store may alias the next load), now 8 loads in flight per step; the column totals were
 // scanned by ONE thread over 256 LDS words, now a block scan: 33 -> ~10 us per call at P = n = 256, S = 32 (14 calls per
 // training step).
-__global__ __launch_bounds__(INVM_THREADS) void inverse_matrix_kernel(
+__device__ __forceinline__ void inverse_matrix_body(
     int n, int P, int S, const int *__restrict__ idx, int *__restrict__ offsets, int *__restrict__ inv)
 {
     extern __shared__ unsigned short cnt[];             // [P][ld], ld = n | 1 (odd stride spreads the banks) | rk[P * S] bytes
@@ -262,6 +262,41 @@ __global__ __launch_bounds__(INVM_THREADS) void inverse_matrix_kernel(
             const int j = ix[t * S + s];
             lst[off[j] + cnt[t * ld + j] + rk[t * S + s]] = t * S + s;
         }
+}
+
+__global__ __launch_bounds__(INVM_THREADS) void inverse_matrix_kernel(
+    int n, int P, int S, const int *__restrict__ idx, int *__restrict__ offsets, int *__restrict__ inv)
+{
+    inverse_matrix_body(n, P, S, idx, offsets, inv);
+}
+
+__global__ __launch_bounds__(INVM_THREADS) void inverse_matrix_batch_kernel(const CmfBatch<CmfInverseArgs> b)
+{
+    const CmfInverseArgs &p = b.a[blockIdx.y];
+    inverse_matrix_body(p.n, p.P, p.S, p.idx, p.offsets, p.inv);
+}
+
+// the inverse indices of up to CMF_MAX_BATCH groupings (b samples each) in one launch: the matrix form only (P <= 256 centres, S <= 64)
+int cmf_build_inverse_ps_batch(int n, int b, const CmfInverseArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a && b > 0);
+    CmfBatch<CmfInverseArgs> bt;
+    size_t mat = 0;
+    for (int i = 0; i < n; ++i) {
+        const CmfInverseArgs &q = a[i];
+        const size_t m = (((size_t)q.P * (q.n | 1) + 7) / 8) * 16 + (size_t)q.P * q.S;
+        CMF_CHECK_ARG(q.n > 0 && q.n < 40000 && q.P > 0 && q.P <= INVM_THREADS && q.S > 0 && q.S <= 64 && m <= 150 * 1024 && q.idx && q.offsets && q.inv);
+        bt.a[i] = q;
+        mat = std::max(mat, m);
+    }
+    static CmfPerDevice attr_set;
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
+        (void)hipFuncSetAttribute((const void *)inverse_matrix_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set.done(attr_dev);
+    }
+    hipLaunchKernelGGL(inverse_matrix_batch_kernel, dim3(b, n), dim3(INVM_THREADS), mat, st, bt);
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_build_inverse(int b, int n, int entries, const int *idx, int *offsets, int *inv, void *stream)
@@ -544,7 +579,7 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_kernel(
 // once -- the kernel above gives a wave one point and 256 columns, which left 56 of 64 lanes idle at c = 32 (0.5 TB/s).  Same order
 // of the row sums (ascending entries); D_j is reduced over the LPP lanes of the point.
 template <int LPP>
-__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_narrow_kernel(
+__device__ __forceinline__ void group_rows_grad_bn_cf_narrow_body(
     int n, int entries, int S, long long points, const float *__restrict__ dU, const float *__restrict__ y, long long ldy,
     const float *__restrict__ wx, long long ldw, const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
     const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -608,6 +643,47 @@ __global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_narrow_kerne
         }
     }
     *(float4 *)(grad_feat + ((size_t)bs * n + j) * ldg + col) = make_float4(sa.x * r[0], sa.y * r[1], sa.z * r[2], sa.w * r[3]);
+}
+
+template <int LPP>
+__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_narrow_kernel(
+    int n, int entries, int S, long long points, const float *__restrict__ dU, const float *__restrict__ y, long long ldy,
+    const float *__restrict__ wx, long long ldw, const float *__restrict__ xyz_src, const float *__restrict__ xyz_ctr,
+    const float *__restrict__ a, const float *__restrict__ mean, const float *__restrict__ invstd,
+    const float *__restrict__ sums, float inv_count,
+    const int *__restrict__ offsets, const int *__restrict__ inv, float *__restrict__ grad_feat, int ldg)
+{
+    group_rows_grad_bn_cf_narrow_body<LPP>(n, entries, S, points, dU, y, ldy, wx, ldw, xyz_src, xyz_ctr, a, mean, invstd, sums, inv_count, offsets,
+                                           inv, grad_feat, ldg);
+}
+
+template <int LPP>
+__global__ __launch_bounds__(GR_THREADS) void group_rows_grad_bn_cf_narrow_batch_kernel(const CmfBatch<CmfScatterArgs> b, long long points)
+{
+    const CmfScatterArgs &p = b.a[blockIdx.y];
+    group_rows_grad_bn_cf_narrow_body<LPP>(p.n, p.entries, p.S, points, p.dU, p.y, p.ldy, p.wx, p.ldw, p.xyz_src, p.xyz_ctr, p.a, p.mean, p.invstd,
+                                           p.sums, p.inv_count, p.offsets, p.inv, p.grad_feat, p.ldg);
+}
+
+// the scatters of up to CMF_MAX_BATCH narrow blocks over the same b x n source points (c = 16 .. 128 channels) in one launch
+int cmf_group_rows_grad_bn_cf_batch(int n, int b, int c, const CmfScatterArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a && b > 0 && (c == 16 || c == 32 || c == 64 || c == 128));
+    CmfBatch<CmfScatterArgs> bt;
+    for (int i = 0; i < n; ++i) {
+        const CmfScatterArgs &q = a[i];
+        CMF_CHECK_ARG(q.n > 0 && q.n == a[0].n && q.S > 0 && q.entries % q.S == 0 && q.ldg >= c && q.ldg % 4 == 0 && q.dU && q.a && q.offsets && q.inv && q.grad_feat);
+        CMF_CHECK_ARG(!q.sums || (q.y && q.wx && q.xyz_src && q.xyz_ctr && q.mean && q.invstd && q.ldy >= c && q.ldy % 4 == 0 && q.ldw >= 3));
+        CMF_CHECK_ARG((((uintptr_t)q.dU | (uintptr_t)q.y | (uintptr_t)q.grad_feat | (uintptr_t)q.a) & 15) == 0);
+        bt.a[i] = q;
+    }
+    const int lpp = c / 4;
+    const long long points = (long long)b * a[0].n, nw = (points * lpp + CMF_WAVE - 1) / CMF_WAVE;
+    const dim3 grid((unsigned)((nw * CMF_WAVE + GR_THREADS - 1) / GR_THREADS), n);
+#define CMF_GRNB(L) hipLaunchKernelGGL(group_rows_grad_bn_cf_narrow_batch_kernel<L>, grid, dim3(GR_THREADS), 0, st, bt, points)
+    if (lpp == 4) CMF_GRNB(4); else if (lpp == 8) CMF_GRNB(8); else if (lpp == 16) CMF_GRNB(16); else CMF_GRNB(32);
+#undef CMF_GRNB
+    return cmf_launch_status();
 }
 
 int cmf_group_rows_grad_bn_cf_impl(int b, int n, int c, int entries, int S, const float *dU, const float *y, long long ldy,

@@ -468,10 +468,10 @@ int cmf_colsum_store(int tiles, int ncols, const float *partial, float *out, int
 }
 
 // dW_xyz of the set-conv first layer from column sums (see cmflow_hip.h)
-__global__ void setconv_dwx_kernel(int C, float inv_count, int train, const float *__restrict__ bwd5,
-                                   const float *__restrict__ fwd, const float *__restrict__ a,
-                                   const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ dwx,
-                                   int ld, int accumulate)
+__device__ __forceinline__ void setconv_dwx_body(int C, float inv_count, int train, const float *__restrict__ bwd5,
+                                                 const float *__restrict__ fwd, const float *__restrict__ a,
+                                                 const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ dwx,
+                                                 int ld, int accumulate)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -486,6 +486,35 @@ __global__ void setconv_dwx_kernel(int C, float inv_count, int train, const floa
         float *dst = dwx + (size_t)c * ld + k;
         *dst = accumulate ? *dst + a[c] * g : a[c] * g;
     }
+}
+
+__global__ void setconv_dwx_kernel(int C, float inv_count, int train, const float *__restrict__ bwd5,
+                                   const float *__restrict__ fwd, const float *__restrict__ a,
+                                   const float *__restrict__ mean, const float *__restrict__ invstd, float *__restrict__ dwx,
+                                   int ld, int accumulate)
+{
+    setconv_dwx_body(C, inv_count, train, bwd5, fwd, a, mean, invstd, dwx, ld, accumulate);
+}
+
+__global__ void setconv_dwx_batch_kernel(const CmfBatch<CmfDwxArgs> b)
+{
+    const CmfDwxArgs &p = b.a[blockIdx.y];
+    setconv_dwx_body(p.C, p.inv_count, p.train, p.bwd5, p.fwd, p.a, p.mean, p.invstd, p.dwx, p.ld, p.accumulate);
+}
+
+int cmf_setconv_dwx_batch(int n, const CmfDwxArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfDwxArgs> b;
+    int cmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const CmfDwxArgs &q = a[i];
+        CMF_CHECK_ARG(q.C > 0 && q.bwd5 && q.a && q.dwx && q.ld >= 3 && (!q.train || (q.fwd && q.mean && q.invstd)));
+        b.a[i] = q;
+        cmax = std::max(cmax, q.C);
+    }
+    hipLaunchKernelGGL(setconv_dwx_batch_kernel, dim3(cmf_divup(cmax, 64), n), dim3(64), 0, st, b);
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_setconv_dwx(int C, float inv_count, int train, const float *bwd5, const float *fwd,
@@ -960,18 +989,18 @@ extern "C" int cmf_maxpool_bwd(long long P, int S, int C, const float *dout, lon
 // only slot of a point that receives a gradient is its argmax) with the BN-backward partial sums per 128 points --
 // identical sums to maxpool_bwd's (the other rows contribute exact zeros), P rows touched instead of P * S.  The consumer
 // (cmf_thin_bwd_layer_pooled) forms dU[p,s,:] = (s == argmax[p,:]) ? g[p,:] : 0 on the fly.
-__global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_kernel(
+__device__ __forceinline__ void maxpool_bwd_point_body(
     long long P, int S, int C, const float *__restrict__ dout, long long ldd, const float *__restrict__ z,
     const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
     const float *__restrict__ invstd, const unsigned char *__restrict__ argmax, float *__restrict__ g,
-    float *__restrict__ partial, int sel)
+    float *__restrict__ partial, int sel, const int bx)
 {
     extern __shared__ __attribute__((aligned(16))) float red[];
     const TileMap tm = tile_map(C);
     const float4 sa = *(const float4 *)(a + tm.col), sc = *(const float4 *)(c + tm.col);
     const float4 mu = *(const float4 *)(mean + tm.col), is = *(const float4 *)(invstd + tm.col);
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-    const long long p0 = (long long)blockIdx.x * PW_ROWS;
+    const long long p0 = (long long)bx * PW_ROWS;
     for (int r = tm.r0; r < PW_ROWS; r += tm.rl) {
         const long long p = p0 + r;
         if (p >= P) break;
@@ -995,7 +1024,39 @@ __global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_kernel(
         s2.x += d.x * ((vx - mu.x) * is.x); s2.y += d.y * ((vy - mu.y) * is.y);
         s2.z += d.z * ((vz - mu.z) * is.z); s2.w += d.w * ((vw - mu.w) * is.w);
     }
-    tile_reduce_store(s1, s2, tm, C, partial, red);
+    tile_reduce_store(s1, s2, tm, C, partial, red, bx);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_kernel(
+    long long P, int S, int C, const float *__restrict__ dout, long long ldd, const float *__restrict__ z,
+    const float *__restrict__ a, const float *__restrict__ c, const float *__restrict__ mean,
+    const float *__restrict__ invstd, const unsigned char *__restrict__ argmax, float *__restrict__ g,
+    float *__restrict__ partial, int sel)
+{
+    maxpool_bwd_point_body(P, S, C, dout, ldd, z, a, c, mean, invstd, argmax, g, partial, sel, blockIdx.x);
+}
+
+__global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_batch_kernel(const CmfBatch<CmfPoolBwdArgs> b)
+{
+    const CmfPoolBwdArgs &p = b.a[blockIdx.y];
+    if ((long long)blockIdx.x * PW_ROWS >= p.P) return;
+    maxpool_bwd_point_body(p.P, p.S, p.C, p.dout, p.ldd, p.z, p.a, p.c, p.mean, p.invstd, p.argmax, p.g, p.partial, 0, blockIdx.x);
+}
+
+int cmf_maxpool_bwd_point_batch(int n, const CmfPoolBwdArgs *a, hipStream_t st)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && a);
+    CmfBatch<CmfPoolBwdArgs> b;
+    long long pmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const CmfPoolBwdArgs &q = a[i];
+        CMF_CHECK_ARG(q.P > 0 && q.S > 0 && q.S <= 255 && tile_ok(q.C) && q.C == a[0].C && q.ldd % 4 == 0);
+        CMF_CHECK_ARG(q.dout && q.z && q.a && q.c && q.mean && q.invstd && q.argmax && q.g && q.partial);
+        b.a[i] = q;
+        pmax = std::max(pmax, q.P);
+    }
+    hipLaunchKernelGGL(maxpool_bwd_point_batch_kernel, dim3(cmf_divup(pmax, PW_ROWS), n), dim3(PW_THREADS), tile_lds(a[0].C), st, b);
+    return cmf_launch_status();
 }
 
 extern "C" int cmf_maxpool_bwd_point(long long P, int S, int C, const float *dout, long long ldd, const float *z,

@@ -923,9 +923,125 @@ static int setconv_forward_bodies_batch(int n, const cmf_setconv_desc *descs, hi
     return 0;
 }
 
+// backward of the same bodies (behind cmf_setconv_tail_backward, which has produced Layout::dx): the kernels of setconv_backward_part's
+// narrow path, one batched launch per stage
+static bool body_batchable_bwd(int n, const cmf_setconv_desc *descs)
+{
+    if (!body_batchable(n, descs)) return false;
+    static const bool fused = !(getenv("CMF_THIN_FUSED") && getenv("CMF_THIN_FUSED")[0] == '0');
+    for (int i = 0; i < n; ++i) {
+        const cmf_setconv_desc &d = descs[i];
+        if (!fused || !d.dw[0] || !d.dw[1] || !d.dout || !cmf_thin_bwd_supported(d.C[1], d.C[0]) || !cmf_thin_bwd_supported(d.C[0], d.O1)) return false;
+        if (d.C[1] != 64 || d.C[0] != 32 || d.O1 != 32) return false;                 // the batched instantiations of the fused layer
+        if ((d.dy != nullptr) != (descs[0].dy != nullptr) || (d.dwx != nullptr) != (descs[0].dwx != nullptr)) return false;
+        if (d.B != descs[0].B || d.N != descs[0].N || d.N > 256 || d.S > 64) return false;
+    }
+    return true;
+}
+
+static int splitk_batch_or_each(int n, const CmfSplitkArgs *sk, hipStream_t st)
+{
+    if (cmf_splitk_reduce_batch(n, sk, st) == 0) return 0;          // (refused without a launch when the problems want different kernels)
+    (void)hipGetLastError();
+    for (int i = 0; i < n; ++i) CMF_TRY(cmf_splitk_reduce(sk[i].M, sk[i].N, sk[i].split_k, sk[i].workspace, sk[i].C, sk[i].ldc, sk[i].accumulate, st));
+    return 0;
+}
+
+static int setconv_backward_bodies_batch(int n, const cmf_setconv_desc *descs, hipStream_t st)
+{
+    Layout L[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        CMF_CHECK_ARG(descs[i].xyz && descs[i].saved && descs[i].scratch && descs[i].dout);
+        L[i] = make_layout(&descs[i], descs[i].saved, descs[i].scratch, true);
+    }
+    const int O1 = descs[0].O1, C2 = descs[0].C[0], C3 = descs[0].C[1];
+    const bool want_dy = descs[0].dy != nullptr, want_dwx = descs[0].dwx != nullptr;
+    if (want_dy) {
+        CmfInverseArgs iv[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) iv[i] = CmfInverseArgs{descs[i].N, descs[i].N, descs[i].S, L[i].idx, L[i].offsets, L[i].inv};
+        CMF_TRY(cmf_build_inverse_ps_batch(n, descs[0].B, iv, st));
+    }
+    CmfColsumArgs cs[CMF_MAX_BATCH];
+    CmfThinBwdCall tb[CMF_MAX_BATCH];
+    CmfSplitkArgs sk[CMF_MAX_BATCH];
+    {   // max over the ball -> the pooled gradient per point with layer 3's BN-backward sums; layer 3 (64 <- 32) from the pooled gradient
+        CmfPoolBwdArgs pb[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long P = (long long)d.B * d.N;
+            const float *b2 = L[i].bn[2], *b1 = L[i].bn[1];
+            float *g = L[i].dU3;
+            pb[i] = CmfPoolBwdArgs{P, d.S, C3, L[i].dx, C3, L[i].z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L[i].argmax, g, L[i].partial};
+            cs[i] = CmfColsumArgs{tiles128(P), 2 * C3, L[i].partial, L[i].sums, C3, d.dbeta[2], d.dgamma[2], d.acc_bn[2] ? 0 : 1};
+            CmfThinBwdCall &q = tb[i];
+            q = CmfThinBwdCall{};
+            q.rows = P * d.S; q.cout = C3; q.cin = C2; q.dU = nullptr; q.lddu = C3; q.z = L[i].z3; q.ldz = C3;
+            q.a = b2 + 2 * C3; q.mean = b2; q.invstd = b2 + C3; q.sums = L[i].sums;
+            q.w = d.w[1]; q.ldw = C2; q.x = L[i].z2; q.ldx = C2; q.in_mode = 1;
+            q.a_in = b1 + 2 * C2; q.c_in = b1 + 3 * C2; q.mean_in = b1; q.invstd_in = b1 + C2;
+            q.dx = L[i].dU2; q.lddx = C2; q.stats = L[i].partial; q.dw = d.dw[1]; q.lddw = C2; q.accumulate = d.acc_w[1]; q.slabs = L[i].splitk;
+            q.pool_g = g; q.pool_am = L[i].argmax; q.pool_S = d.S;
+        }
+        CMF_TRY(cmf_maxpool_bwd_point_batch(n, pb, st));
+        CMF_TRY(cmf_colsum_batch(n, cs, st));
+        CMF_TRY(cmf_thin_bwd_layer_batch(n, tb, st));
+        for (int i = 0; i < n; ++i) sk[i] = CmfSplitkArgs{C3, C2, tb[i].nslab, tb[i].slabs, tb[i].dw, tb[i].lddw, tb[i].accumulate};
+        CMF_TRY(splitk_batch_or_each(n, sk, st));
+    }
+    {   // layer 2 (32 <- 32) with the dxyz sums of the first layer's coordinate weights
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long M = (long long)d.B * d.N * d.S;
+            const float *b1 = L[i].bn[1], *b0 = L[i].bn[0];
+            cs[i] = CmfColsumArgs{tiles128(M), 2 * C2, L[i].partial, L[i].sums, C2, d.dbeta[1], d.dgamma[1], d.acc_bn[1] ? 0 : 1};
+            CmfThinBwdCall &q = tb[i];
+            q = CmfThinBwdCall{};
+            q.rows = M; q.cout = C2; q.cin = O1; q.dU = L[i].dU2; q.lddu = C2; q.z = L[i].z2; q.ldz = C2;
+            q.a = b1 + 2 * C2; q.mean = b1; q.invstd = b1 + C2; q.sums = L[i].sums;
+            q.w = d.w[0]; q.ldw = O1; q.x = L[i].z1; q.ldx = O1; q.in_mode = 1;
+            q.a_in = b0 + 2 * O1; q.c_in = b0 + 3 * O1; q.mean_in = b0; q.invstd_in = b0 + O1; q.dxyz = L[i].dxyz;
+            q.dx = L[i].dU1; q.lddx = O1; q.stats = L[i].partial; q.dw = d.dw[0]; q.lddw = O1; q.accumulate = d.acc_w[0]; q.slabs = L[i].splitk;
+        }
+        CMF_TRY(cmf_colsum_batch(n, cs, st));
+        CMF_TRY(cmf_thin_bwd_layer_batch(n, tb, st));
+        for (int i = 0; i < n; ++i) sk[i] = CmfSplitkArgs{C2, O1, tb[i].nslab, tb[i].slabs, tb[i].dw, tb[i].lddw, tb[i].accumulate};
+        CMF_TRY(splitk_batch_or_each(n, sk, st));
+    }
+    {   // first layer: sums {s1, s2, q0, q1, q2}; dgamma / dbeta; dW_xyz; BN backward folded into the scatter
+        CmfDwxArgs dx[CMF_MAX_BATCH];
+        CmfScatterArgs sc[CMF_MAX_BATCH];
+        for (int i = 0; i < n; ++i) {
+            const cmf_setconv_desc &d = descs[i];
+            const long long M = (long long)d.B * d.N * d.S;
+            const float *b0 = L[i].bn[0];
+            cs[i] = CmfColsumArgs{tiles128(M), 5 * O1, L[i].partial, L[i].sums, O1, d.dbeta[0], d.dgamma[0], d.acc_bn[0] ? 0 : 1};
+            dx[i] = CmfDwxArgs{O1, (float)(1.0 / (double)M), d.training, L[i].sums, L[i].fwd_sums, b0 + 2 * O1, b0, b0 + O1, d.dwx, (int)d.lddwx, d.acc_wx};
+            sc[i] = CmfScatterArgs{d.N, d.N * d.S, d.S, L[i].dU1, d.y, d.ldy, d.wx, d.ldwx, d.xyz, d.xyz, b0 + 2 * O1, b0, b0 + O1, L[i].sums,
+                                   (float)(1.0 / (double)M), L[i].offsets, L[i].inv, d.dy, d.lddy ? (int)d.lddy : O1};
+        }
+        CMF_TRY(cmf_colsum_batch(n, cs, st));
+        if (want_dwx) CMF_TRY(cmf_setconv_dwx_batch(n, dx, st));
+        if (want_dy) CMF_TRY(cmf_group_rows_grad_bn_cf_batch(n, descs[0].B, O1, sc, st));
+    }
+    return 0;
+}
+
+// 1 when cmf_setconv_backward_bodies_multi will run these blocks' bodies as batched launches on streams[0] alone, else 0
+extern "C" int cmf_setconv_backward_bodies_batched(int n, const cmf_setconv_desc *descs)
+{
+    return (n >= 0 && n <= 16 && descs && body_batchable_bwd(n, descs)) ? 1 : 0;
+}
+
 // The same with the per-point tails taken out: forward stops behind the max over the ball, backward starts there.  The
 // caller runs cmf_setconv_tail_forward behind the forward heads (after joining the streams) and cmf_setconv_tail_backward in
 // front of the backward bodies (before forking): the tails of all blocks as batched launches on one stream.
+// 1 when cmf_setconv_forward_heads_multi will run these blocks' bodies as batched launches on streams[0] alone (the caller may then pass
+// its own stream for every entry and skip the fork / join around the call), else 0
+extern "C" int cmf_setconv_forward_bodies_batched(int n, const cmf_setconv_desc *descs)
+{
+    return (n >= 0 && n <= 16 && descs && body_batchable(n, descs)) ? 1 : 0;
+}
+
 extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
     CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
@@ -935,6 +1051,8 @@ extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *de
 
 extern "C" int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
+    CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
+    if (body_batchable_bwd(n, descs)) return setconv_backward_bodies_batch(n, descs, (hipStream_t)streams[0]);
     return setconv_multi(n, descs, streams, true, 2);
 }
 

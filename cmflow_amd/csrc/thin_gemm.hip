@@ -1176,26 +1176,37 @@ int cmf_thin_bwd_layer_batch(int n, CmfThinBwdCall *c, hipStream_t st)
         const CmfThinBwdCall &q = c[i];
         CMF_CHECK_ARG(q.rows > 0 && q.rows % 128 == 0 && q.cout == c[0].cout && q.cin == c[0].cin && q.cout % 32 == 0 && q.cin % 32 == 0 &&
                       q.cout <= 64 && q.cin <= 64 && (q.in_mode == 0 || q.in_mode == 1));
-        CMF_CHECK_ARG(q.dU && q.a && q.w && q.x && q.dx && q.dw && q.slabs && (!q.sums || (q.z && q.mean && q.invstd)));
-        CMF_CHECK_ARG(q.lddu % 4 == 0 && (uintptr_t)q.dU % 16 == 0 && (!q.sums || (q.ldz % 4 == 0 && (uintptr_t)q.z % 16 == 0)));
+        const bool pooled = q.pool_g != nullptr;
+        CMF_CHECK_ARG((pooled || q.dU) && q.a && q.w && q.x && q.dx && q.dw && q.slabs && (!q.sums || (q.z && q.mean && q.invstd)));
+        CMF_CHECK_ARG((pooled || (q.lddu % 4 == 0 && (uintptr_t)q.dU % 16 == 0)) && (!q.sums || (q.ldz % 4 == 0 && (uintptr_t)q.z % 16 == 0)));
+        if (pooled) CMF_CHECK_ARG(q.pool_am && q.pool_S > 0 && q.rows % q.pool_S == 0 && (uintptr_t)q.pool_g % 16 == 0 && (uintptr_t)q.pool_am % 4 == 0 &&
+                                  q.in_mode == 1 && !q.dxyz && (q.rows / q.pool_S) * q.cout * 4 < (1ll << 32));
         CMF_CHECK_ARG(((uintptr_t)q.a | (uintptr_t)q.mean | (uintptr_t)q.invstd | (uintptr_t)q.sums) % 16 == 0);
         CMF_CHECK_ARG(q.in_mode == 0 || (q.a_in && q.c_in && q.mean_in && q.invstd_in && q.stats));
         CMF_CHECK_ARG(128ll * std::max({q.lddu, q.ldz, q.ldx, q.lddx}) * 4 < (1ll << 31));
-        const int mode = (q.sums ? 1 : 0) | (q.in_mode ? 2 : 0);
+        const int mode = (q.sums ? 1 : 0) | (q.in_mode ? 2 : 0) | ((q.in_mode && q.dxyz) ? 4 : 0) | (pooled ? 8 : 0);
         if (i == 0) mode0 = mode;
         CMF_CHECK_ARG(mode == mode0);
         ThinBwdArgs &p = b.a[i];
         p.rows = q.rows; p.cout = q.cout; p.cin = q.cin; p.dU = q.dU; p.lddu = q.lddu; p.z = q.z; p.ldz = q.ldz;
         p.a = q.a; p.mean = q.mean; p.invstd = q.invstd; p.sums = q.sums; p.inv_count = (float)(1.0 / (double)q.rows);
         p.w = q.w; p.ldw = q.ldw; p.x = q.x; p.ldx = q.ldx; p.in_mode = q.in_mode;
-        p.a_in = q.a_in; p.c_in = q.c_in; p.mean_in = q.mean_in; p.invstd_in = q.invstd_in; p.dxyz = nullptr;
+        p.a_in = q.a_in; p.c_in = q.c_in; p.mean_in = q.mean_in; p.invstd_in = q.invstd_in; p.dxyz = q.in_mode == 1 ? q.dxyz : nullptr;
         p.dx = q.dx; p.lddx = q.lddx; p.stats = q.stats; p.slabs = q.slabs;
-        p.pool_g = nullptr; p.pool_am = nullptr; p.pool_S = 0;
+        p.pool_g = q.pool_g; p.pool_am = q.pool_am; p.pool_S = q.pool_S;
         c[i].nslab = thin_bwd_slabs_for(q.rows, q.cin > 32 ? 512 : 768, &p.tiles_per_wg);
         max_slab = std::max(max_slab, c[i].nslab);
         cmf_gemm_count_flops(4.0 * q.rows * q.cout * q.cin);
     }
     const dim3 grid(max_slab, n), block(TG_THREADS);
+    // the slot-level layers of the narrow blocks' bodies (train-mode BN): 64 <- 32 channels from the pooled gradient (mode 11) and
+    // 32 <- 32 with the dxyz sums (mode 7); other switch combinations of those forms have no batched instantiation
+    if (mode0 == 11 || mode0 == 7 || (mode0 & 12)) {
+        if (mode0 == 11 && c[0].cout == 64 && c[0].cin == 32) hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<2, 1, 11, true>), grid, block, 0, st, b);
+        else if (mode0 == 7 && c[0].cout == 32 && c[0].cin == 32) hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<1, 1, 7, true>), grid, block, 0, st, b);
+        else return (int)hipErrorInvalidValue;
+        return cmf_launch_status();
+    }
 #define CMF_TBB(NO, NI)                                                                                              \
     switch (mode0) {                                                                                                \
         case 0: hipLaunchKernelGGL((thin_bwd_layer_batch_kernel<NO, NI, 0, true>), grid, block, 0, st, b); break;   \

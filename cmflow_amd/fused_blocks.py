@@ -1046,6 +1046,22 @@ def _multi_call(backward, n, plan, sp, streams, main):
         _lib.check(L().cmf_setconv_queries(n, descs, main.cuda_stream), "cmf_setconv_queries")
         for i in range(n):
             plan.descs[i].idx_ready = 1
+    if not backward and L().cmf_setconv_forward_bodies_batched(n, descs):
+        # the bodies run in lock step as batched launches on ONE stream (narrow blocks: the first encoder): the caller's own -- no fork,
+        # no join, no cross-queue dependency in front of the tails
+        mp = (ctypes.c_void_p * n)(*([main.cuda_stream] * n))
+        stress_point([main])
+        _lib.check(L().cmf_setconv_forward_heads_multi(n, descs, ctypes.addressof(mp)), "cmf_setconv_forward_heads_multi")
+        stress_point([main])
+        _lib.check(L().cmf_setconv_tail_forward(n, descs, main.cuda_stream), "cmf_setconv_tail_forward")
+        return
+    if backward and L().cmf_setconv_backward_bodies_batched(n, descs):
+        # ... and their backward bodies likewise: batched launches on the caller's stream
+        mp = (ctypes.c_void_p * n)(*([main.cuda_stream] * n))
+        stress_point([main])
+        _lib.check(L().cmf_setconv_backward_bodies_multi(n, descs, ctypes.addressof(mp)), "cmf_setconv_backward_bodies_multi")
+        stress_point([main])
+        return
     for st in streams:
         st.wait_stream(main)
     stress_point(streams)

@@ -505,6 +505,11 @@ int cmf_setconv_backward_multi(int n, const cmf_setconv_desc *descs, void *const
  * Same kernels, same order per block: results are bit-identical to cmf_setconv_forward / _backward.  CMF_TAIL_BATCH=0 (or
  * blocks whose tails differ in width / mode) runs the tails block by block. */
 int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
+/* 1 when cmf_setconv_forward_heads_multi will run these blocks' slot-level bodies in lock step as batched launches on streams[0]
+ * alone (narrow blocks with train-mode BatchNorm and indices ready: the first encoder) -- the caller may then pass its own stream for
+ * every entry and needs no fork / join around the call; else 0. */
+int cmf_setconv_forward_bodies_batched(int n, const cmf_setconv_desc *descs);
+int cmf_setconv_backward_bodies_batched(int n, const cmf_setconv_desc *descs);      /* the same for cmf_setconv_backward_bodies_multi */
 int cmf_setconv_tail_forward(int n, const cmf_setconv_desc *descs, void *stream);
 int cmf_setconv_tail_backward(int n, const cmf_setconv_desc *descs, void *stream);
 int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams);
