@@ -598,16 +598,19 @@ __device__ __forceinline__ void group_rows_grad_bn_cf_narrow_body(
     const float *gu = dU + (size_t)bs * entries * c;
     const int col = sl * 4;
     float Dx = 0.f, Dy = 0.f, Dz = 0.f;
-    if (sums) {
-        const float *xs = xyz_src + ((size_t)bs * n + j) * 3;
-        const float sx = xs[0], sy = xs[1], sz = xs[2];
-        const float *xc = xyz_ctr + (size_t)bs * (entries / S) * 3;
+    // LPP == 8 (32 channels: the first encoder): the coordinate sums D ride in the row loop -- a group of 8 entries is one entry per lane
+    // of the point for D and 8 rows in flight per lane, all behind ONE index round trip (as a loop of its own in front, D cost as many
+    // dependent round trips again).  Same entries per lane in the same order: bit-identical sums.
+    constexpr bool MERGED = LPP == 8;
+    const float *xs = xyz_src + ((size_t)bs * n + j) * 3;
+    const float *xc = xyz_ctr + (size_t)bs * (entries / S) * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (sums) { sx = xs[0]; sy = xs[1]; sz = xs[2]; }
+    if (sums && !MERGED) {
         for (int t = beg + sl; t < end; t += LPP) {
             const int p = lst[t] / S;
             Dx += sx - xc[p * 3]; Dy += sy - xc[p * 3 + 1]; Dz += sz - xc[p * 3 + 2];
         }
-#pragma unroll
-        for (int m = LPP / 2; m > 0; m >>= 1) { Dx += __shfl_xor(Dx, m, CMF_WAVE); Dy += __shfl_xor(Dy, m, CMF_WAVE); Dz += __shfl_xor(Dz, m, CMF_WAVE); }
     }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     int t = beg;
@@ -616,14 +619,27 @@ __device__ __forceinline__ void group_rows_grad_bn_cf_narrow_body(
         float4 u[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) e[q] = lst[t + q];
+        const int me = (MERGED && sums) ? lst[t + sl] : 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) u[q] = *(const float4 *)(gu + (size_t)e[q] * c + col);
+        if (MERGED && sums) {
+            const int p = me / S;
+            Dx += sx - xc[p * 3]; Dy += sy - xc[p * 3 + 1]; Dz += sz - xc[p * 3 + 2];
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) { acc.x += u[q].x; acc.y += u[q].y; acc.z += u[q].z; acc.w += u[q].w; }
+    }
+    if (MERGED && sums && t + sl < end) {                   // (fewer than 8 entries left: one per lane)
+        const int p = lst[t + sl] / S;
+        Dx += sx - xc[p * 3]; Dy += sy - xc[p * 3 + 1]; Dz += sz - xc[p * 3 + 2];
     }
     for (; t < end; ++t) {
         const float4 u0 = *(const float4 *)(gu + (size_t)lst[t] * c + col);
         acc.x += u0.x; acc.y += u0.y; acc.z += u0.z; acc.w += u0.w;
+    }
+    if (sums) {
+#pragma unroll
+        for (int m = LPP / 2; m > 0; m >>= 1) { Dx += __shfl_xor(Dx, m, CMF_WAVE); Dy += __shfl_xor(Dy, m, CMF_WAVE); Dz += __shfl_xor(Dz, m, CMF_WAVE); }
     }
     if (!live) return;
     const float cnt = (float)(end - beg);
