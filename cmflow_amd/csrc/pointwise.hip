@@ -880,15 +880,23 @@ __device__ __forceinline__ void bn_relu_maxpool_body(
         float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);
         uchar4 bi = make_uchar4(0, 0, 0, 0);
         const float *src = z + (size_t)p * S * C + col;
-        for (int s = 0; s < S; ++s) {
-            const float4 v = *(const float4 *)(src + (size_t)s * C);
+        auto take = [&](const float4 v, int s) {
             const float x = fmaxf(fmaf(sa.x, v.x, sc.x), 0.f), y = fmaxf(fmaf(sa.y, v.y, sc.y), 0.f);
             const float zz = fmaxf(fmaf(sa.z, v.z, sc.z), 0.f), w = fmaxf(fmaf(sa.w, v.w, sc.w), 0.f);
             if (x > best.x) { best.x = x; bi.x = (unsigned char)s; }
             if (y > best.y) { best.y = y; bi.y = (unsigned char)s; }
             if (zz > best.z) { best.z = zz; bi.z = (unsigned char)s; }
             if (w > best.w) { best.w = w; bi.w = (unsigned char)s; }
+        };
+        int s = 0;
+        for (; s + 4 <= S; s += 4) {                         // four slots' rows in flight (a runtime-length loop of load -> compare is one round trip per slot)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const float4 *)(src + (size_t)(s + u) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) take(v[u], s + u);
         }
+        for (; s < S; ++s) take(*(const float4 *)(src + (size_t)s * C), s);
         *(float4 *)(out + (size_t)p * ldo + col) = best;
         if (argmax) *(uchar4 *)(argmax + (size_t)p * C + col) = bi;
     }
