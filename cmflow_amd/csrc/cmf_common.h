@@ -93,6 +93,10 @@ struct CmfInverseArgs { int n, P, S; const int *idx; int *offsets, *inv; };
 struct CmfDwxArgs { int C; float inv_count; int train; const float *bwd5, *fwd, *a, *mean, *invstd; float *dwx; int ld, accumulate; };
 struct CmfScatterArgs { int n, entries, S; const float *dU, *y; long long ldy; const float *wx; long long ldw; const float *xyz_src, *xyz_ctr,
                         *a, *mean, *invstd, *sums; float inv_count; const int *offsets, *inv; float *grad_feat; int ldg; };
+// one block's inference chain (setconv_chain.hip): the arguments of cmf_setconv_chain_infer
+struct CmfChainInferArgs { long long M; int N, S; const int *idx; const float *xyz, *y; long long ldy; const float *wx; long long ldwx;
+                           const float *bn0, *bn1, *bn2, *w2, *w3; float *out; long long ldo; };
+int cmf_setconv_chain_infer_batch(int n, const CmfChainInferArgs *q, void *stream);
 struct CmfSplitkArgs { int M, N, split_k; const float *workspace; float *C; long long ldc; int accumulate; };
 // one fused backward layer (cmf_thin_bwd_layer); nslab is filled in by the batch call
 struct CmfThinBwdCall { long long rows; int cout, cin; const float *dU; long long lddu; const float *z; long long ldz;

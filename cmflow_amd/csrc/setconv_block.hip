@@ -207,6 +207,20 @@ __global__ __launch_bounds__(256) void bn_fold_eval_kernel(const FoldAll f)
     }
 }
 
+__global__ __launch_bounds__(256) void bn_fold_eval_batch_kernel(const CmfBatch<FoldAll> b)
+{
+    const FoldAll &f = b.a[blockIdx.y];
+    const int l = blockIdx.x, C = f.C[l];
+    float *o = f.out[l];
+    for (int ch = threadIdx.x; ch < C; ch += 256) {
+        const double mean = f.rmean[l][ch], var = f.rvar[l][ch];
+        const double invstd = 1.0 / sqrt(var + (double)f.eps[l]);
+        const double a = (f.gamma[l] ? (double)f.gamma[l][ch] : 1.0) * invstd;
+        o[ch] = (float)mean; o[C + ch] = (float)invstd; o[2 * C + ch] = (float)a;
+        o[3 * C + ch] = (float)((f.beta[l] ? (double)f.beta[l][ch] : 0.0) - mean * a);
+    }
+}
+
 int fold_all_eval(const cmf_setconv_desc *d, const Layout &L, void *st)
 {
     FoldAll f;
@@ -876,6 +890,42 @@ static bool body_batchable(int n, const cmf_setconv_desc *descs)
     return true;
 }
 
+// inference of the narrow blocks (eval-mode BN, no backward call to follow): their register-chain kernels as ONE launch
+static bool infer_batchable(int n, const cmf_setconv_desc *descs)
+{
+    static const bool on = !(getenv("CMF_BODY_BATCH") && getenv("CMF_BODY_BATCH")[0] == '0');
+    if (!on || n < 2 || n > CMF_MAX_BATCH) return false;
+    for (int i = 0; i < n; ++i) {
+        const cmf_setconv_desc &d = descs[i];
+        const long long M = (long long)d.B * d.N * d.S;
+        if (d.training || !d.inference || !d.idx_ready || !cmf_setconv_chain_supported(d.N, d.S, d.O1, d.C[0], d.C[1], M) || d.ldy % 4 ||
+            ((uintptr_t)d.y & 15) || M >= (1ll << 31)) return false;
+        for (int l = 0; l < 6; ++l) if (!d.rmean[l] || !d.rvar[l]) return false;
+    }
+    return true;
+}
+
+static int setconv_infer_bodies_batch(int n, const cmf_setconv_desc *descs, hipStream_t st)
+{
+    CmfBatch<FoldAll> fb;
+    CmfChainInferArgs q[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) {
+        const cmf_setconv_desc &d = descs[i];
+        CMF_CHECK_ARG(d.xyz && d.y && d.wx && d.saved && d.scratch && d.out);
+        const Layout L = make_layout(&d, d.saved, d.scratch, false);
+        FoldAll &f = fb.a[i];
+        for (int l = 0; l < 6; ++l) {
+            f.C[l] = chan(&d, l); f.gamma[l] = d.gamma[l]; f.beta[l] = d.beta[l]; f.rmean[l] = d.rmean[l]; f.rvar[l] = d.rvar[l];
+            f.eps[l] = d.eps[l]; f.out[l] = L.bn[l];
+        }
+        q[i] = CmfChainInferArgs{(long long)d.B * d.N * d.S, d.N, d.S, L.idx, d.xyz, d.y, d.ldy, d.wx, d.ldwx, L.bn[0], L.bn[1], L.bn[2], d.w[0], d.w[1],
+                                 L.x, d.C[1]};
+    }
+    hipLaunchKernelGGL(bn_fold_eval_batch_kernel, dim3(6, n), dim3(256), 0, st, fb);
+    CMF_TRY(cmf_launch_status());
+    return cmf_setconv_chain_infer_batch(n, q, st);
+}
+
 static int setconv_forward_bodies_batch(int n, const cmf_setconv_desc *descs, hipStream_t st)
 {
     Layout L[CMF_MAX_BATCH];
@@ -1039,13 +1089,14 @@ extern "C" int cmf_setconv_backward_bodies_batched(int n, const cmf_setconv_desc
 // its own stream for every entry and skip the fork / join around the call), else 0
 extern "C" int cmf_setconv_forward_bodies_batched(int n, const cmf_setconv_desc *descs)
 {
-    return (n >= 0 && n <= 16 && descs && body_batchable(n, descs)) ? 1 : 0;
+    return (n >= 0 && n <= 16 && descs && (body_batchable(n, descs) || infer_batchable(n, descs))) ? 1 : 0;
 }
 
 extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
     CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
     if (body_batchable(n, descs)) return setconv_forward_bodies_batch(n, descs, (hipStream_t)streams[0]);
+    if (infer_batchable(n, descs)) return setconv_infer_bodies_batch(n, descs, (hipStream_t)streams[0]);
     return setconv_multi(n, descs, streams, false, 1);
 }
 

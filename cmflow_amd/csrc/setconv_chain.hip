@@ -84,7 +84,7 @@ constexpr int CH_TILE = 96 * CH_LDW;
 constexpr int CH_LDS_FWD = CH_TT, CH_LDS_BWD = CH_TT + 4 * CH_TILE;
 
 template <int MODE>
-__global__ __launch_bounds__(CH_THREADS, 2) void setconv_chain_kernel(const ChainArgs p)
+__device__ __forceinline__ void setconv_chain_body(const ChainArgs &p, const int bx)
 {
     constexpr bool BWD = MODE == CH_BWD3 || MODE == CH_BWD2;
     constexpr bool L3 = MODE == CH_INFER || MODE == CH_STATS3 || MODE == CH_POOL || MODE == CH_BWD3;      // third layer evaluated
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void setconv_chain_kernel(const Chai
     }
     float *tt = cst + CH_TT + wv * CH_TILE;                           // this wave's transposition tile: [96 channels][33]
 
-    const int wave = blockIdx.x * (CH_THREADS / 64) + wv;               // (rows < 2^31: 32-bit index arithmetic, wave-uniform where it can be)
+    const int wave = bx * (CH_THREADS / 64) + wv;               // (rows < 2^31: 32-bit index arithmetic, wave-uniform where it can be)
     const int nblocks = (int)(p.M / 32);
     const int blk0 = wave * p.blocks_per_wave;
     const int nb = max(0, min(p.blocks_per_wave, nblocks - blk0));
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(CH_THREADS, 2) void setconv_chain_kernel(const Chai
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[wv * NOB * 1024 + (32 * ob + ch_of(r, h)) * 32 + j] = dwa[ob][r];
         __syncthreads();
-        float *slab = p.slabs + (long long)blockIdx.x * NOB * 1024;
+        float *slab = p.slabs + (long long)bx * NOB * 1024;
         for (int i = tid; i < NOB * 1024; i += CH_THREADS) slab[i] = ((red[i] + red[NOB * 1024 + i]) + red[2 * NOB * 1024 + i]) + red[3 * NOB * 1024 + i];
     }
 }
@@ -426,6 +426,20 @@ int chain_blocks_per_wave(long long blocks, bool bwd)
 {
     const long long target = bwd ? 2048 : 3072;
     return (int)std::max<long long>(4, std::min<long long>(bwd ? 32 : 16, (blocks + target - 1) / target));
+}
+
+template <int MODE>
+__global__ __launch_bounds__(CH_THREADS, 2) void setconv_chain_kernel(const ChainArgs p)
+{
+    setconv_chain_body<MODE>(p, blockIdx.x);
+}
+
+// inference of up to CMF_MAX_BATCH blocks in one launch (cmf_common.h "batched launches"): blockIdx.y = block
+struct ChainBatch { ChainArgs a[CMF_MAX_BATCH]; int grid[CMF_MAX_BATCH]; };
+__global__ __launch_bounds__(CH_THREADS, 2) void setconv_chain_infer_batch_kernel(const ChainBatch b)
+{
+    if ((int)blockIdx.x >= b.grid[blockIdx.y]) return;
+    setconv_chain_body<CH_INFER>(b.a[blockIdx.y], blockIdx.x);
 }
 
 template <int MODE>
@@ -452,6 +466,31 @@ int chain_launch(ChainArgs &a, void *stream)
 }
 
 }  // namespace
+
+// internal (setconv_block.hip): the inference chains of n blocks (cmf_setconv_chain_infer's arguments per block) in ONE launch
+int cmf_setconv_chain_infer_batch(int n, const CmfChainInferArgs *q, void *stream)
+{
+    CMF_CHECK_ARG(n >= 1 && n <= CMF_MAX_BATCH && q);
+    ChainBatch b;
+    int gmax = 0;
+    for (int i = 0; i < n; ++i) {
+        const CmfChainInferArgs &c = q[i];
+        CMF_CHECK_ARG(c.M > 0 && c.M < (1ll << 31) && c.idx && c.xyz && c.y && c.wx && c.bn0 && c.bn1 && c.bn2 && c.w2 && c.w3 && c.ldy % 4 == 0 &&
+                      ((uintptr_t)c.y & 15) == 0 && c.out && c.ldo % 4 == 0 && ((uintptr_t)c.out & 15) == 0);
+        ChainArgs &a = b.a[i];
+        a = ChainArgs{};
+        a.M = c.M; a.N = c.N; a.S = c.S; a.lgS = c.S == 4 ? 2 : c.S == 8 ? 3 : c.S == 16 ? 4 : 5; a.idx = c.idx; a.xyz = c.xyz; a.y = c.y; a.ldy = c.ldy;
+        a.wx = c.wx; a.ldwx = c.ldwx; a.bn0 = c.bn0; a.bn1 = c.bn1; a.bn2 = c.bn2; a.w2 = c.w2; a.w3 = c.w3; a.out = c.out; a.ldo = c.ldo;
+        a.inv_count = (float)(1.0 / (double)c.M);
+        const long long blocks = a.M / 32;
+        a.blocks_per_wave = chain_blocks_per_wave(blocks, false);
+        const long long waves = (blocks + a.blocks_per_wave - 1) / a.blocks_per_wave;
+        b.grid[i] = (int)((waves + CH_THREADS / 64 - 1) / (CH_THREADS / 64));
+        gmax = std::max(gmax, b.grid[i]);
+    }
+    hipLaunchKernelGGL(setconv_chain_infer_batch_kernel, dim3(gmax, n), dim3(CH_THREADS), (size_t)CH_LDS_FWD * sizeof(float), (hipStream_t)stream, b);
+    return cmf_launch_status();
+}
 
 // internal (setconv_block.hip): the block's neighbour-slot layers as chain passes, when the shape is the chain's
 bool cmf_setconv_chain_supported(int N, int S, int O1, int C2, int C3, long long M)
