@@ -84,11 +84,11 @@ struct CmfAffineArgs { long long M; int C; const float *z; long long ldz; const 
 // the narrow set-conv blocks' first layer (cmf_group_affine without centre rows: z, dxyz, statistics, z * d_k sums) and the max over the ball
 struct CmfGroupAffineArgs { int b, n_src, P, S, C; const float *ysrc; int ld_src; const float *xyz_src, *xyz_ctr, *Wx; int ldw; const int *idx;
                             float *z, *dxyz, *partial, *partial_x; };
-struct CmfPoolArgs { long long P; int S, C; const float *z, *a, *c; float *out; long long ldo; unsigned char *argmax; int grid; };
+struct CmfPoolArgs { long long P; int S, C; const float *z, *a, *c; float *out; long long ldo; unsigned char *argmax; int grid; float *zsel; };
 // backward of the narrow blocks' bodies: max-pool backward per point, the inverse index, dW_xyz from column sums, the scatter with the
 // first layer's BN backward in closed form (cmf_maxpool_bwd_point, cmf_build_inverse_ps, cmf_setconv_dwx, cmf_group_rows_grad_bn_cf)
 struct CmfPoolBwdArgs { long long P; int S, C; const float *dout; long long ldd; const float *z, *a, *c, *mean, *invstd; const unsigned char *argmax;
-                        float *g, *partial; };
+                        float *g, *partial; int sel; };     // sel: z = the (P, C) pre-activations at the arg-max slots (bn_relu_maxpool's zsel)
 struct CmfInverseArgs { int n, P, S; const int *idx; int *offsets, *inv; };
 struct CmfDwxArgs { int C; float inv_count; int train; const float *bwd5, *fwd, *a, *mean, *invstd; float *dwx; int ld, accumulate; };
 struct CmfScatterArgs { int n, entries, S; const float *dU, *y; long long ldy; const float *wx; long long ldw; const float *xyz_src, *xyz_ctr,

@@ -870,23 +870,23 @@ extern "C" int cmf_group_perm(int b, int entries, const int *inv, const int *row
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bn_relu_maxpool_body(
     long long P, int S, int C, const float *__restrict__ z, const float *__restrict__ a, const float *__restrict__ c,
-    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax, const int bx, const int nbx)
+    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax, float *__restrict__ zsel, const int bx, const int nbx)
 {
     const int cg = C / 4;
     for (long long i = (long long)bx * PW_THREADS + threadIdx.x; i < P * cg; i += (long long)nbx * PW_THREADS) {
         const long long p = i / cg;
         const int col = (int)(i - p * cg) * 4;
         const float4 sa = *(const float4 *)(a + col), sc = *(const float4 *)(c + col);
-        float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);
+        float4 best = make_float4(-1.f, -1.f, -1.f, -1.f), zb = make_float4(0.f, 0.f, 0.f, 0.f);
         uchar4 bi = make_uchar4(0, 0, 0, 0);
         const float *src = z + (size_t)p * S * C + col;
         auto take = [&](const float4 v, int s) {
             const float x = fmaxf(fmaf(sa.x, v.x, sc.x), 0.f), y = fmaxf(fmaf(sa.y, v.y, sc.y), 0.f);
             const float zz = fmaxf(fmaf(sa.z, v.z, sc.z), 0.f), w = fmaxf(fmaf(sa.w, v.w, sc.w), 0.f);
-            if (x > best.x) { best.x = x; bi.x = (unsigned char)s; }
-            if (y > best.y) { best.y = y; bi.y = (unsigned char)s; }
-            if (zz > best.z) { best.z = zz; bi.z = (unsigned char)s; }
-            if (w > best.w) { best.w = w; bi.w = (unsigned char)s; }
+            if (x > best.x) { best.x = x; bi.x = (unsigned char)s; zb.x = v.x; }
+            if (y > best.y) { best.y = y; bi.y = (unsigned char)s; zb.y = v.y; }
+            if (zz > best.z) { best.z = zz; bi.z = (unsigned char)s; zb.z = v.z; }
+            if (w > best.w) { best.w = w; bi.w = (unsigned char)s; zb.w = v.w; }
         };
         int s = 0;
         for (; s + 4 <= S; s += 4) {                         // four slots' rows in flight (a runtime-length loop of load -> compare is one round trip per slot)
@@ -899,21 +899,24 @@ __device__ __forceinline__ void bn_relu_maxpool_body(
         for (; s < S; ++s) take(*(const float4 *)(src + (size_t)s * C), s);
         *(float4 *)(out + (size_t)p * ldo + col) = best;
         if (argmax) *(uchar4 *)(argmax + (size_t)p * C + col) = bi;
+        // the pre-activations at the arg-max slots, (P, C) contiguous: what the backward pass needs of z per point (it would otherwise
+        // gather them as 4-byte reads from P * C different 32-byte sectors)
+        if (zsel) *(float4 *)(zsel + (size_t)p * C + col) = zb;
     }
 }
 
 __global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_kernel(
     long long P, int S, int C, const float *__restrict__ z, const float *__restrict__ a, const float *__restrict__ c,
-    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax)
+    float *__restrict__ out, long long ldo, unsigned char *__restrict__ argmax, float *__restrict__ zsel)
 {
-    bn_relu_maxpool_body(P, S, C, z, a, c, out, ldo, argmax, blockIdx.x, gridDim.x);
+    bn_relu_maxpool_body(P, S, C, z, a, c, out, ldo, argmax, zsel, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(PW_THREADS) void bn_relu_maxpool_batch_kernel(const CmfBatch<CmfPoolArgs> b)
 {
     const CmfPoolArgs &p = b.a[blockIdx.y];
     if ((int)blockIdx.x >= p.grid) return;
-    bn_relu_maxpool_body(p.P, p.S, p.C, p.z, p.a, p.c, p.out, p.ldo, p.argmax, blockIdx.x, p.grid);
+    bn_relu_maxpool_body(p.P, p.S, p.C, p.z, p.a, p.c, p.out, p.ldo, p.argmax, p.zsel, blockIdx.x, p.grid);
 }
 
 static int pool_grid(long long P, int C) { return (int)std::min<long long>((P * (C / 4) + PW_THREADS - 1) / PW_THREADS, 8192); }
@@ -934,14 +937,23 @@ int cmf_bn_relu_maxpool_batch(int n, CmfPoolArgs *a, hipStream_t st)
     return cmf_launch_status();
 }
 
+int cmf_bn_relu_maxpool_sel(long long P, int S, int C, const float *z, const float *a, const float *c,
+                            float *out, long long ldo, unsigned char *argmax, float *zsel, void *stream);
 extern "C" int cmf_bn_relu_maxpool(long long P, int S, int C, const float *z, const float *a, const float *c,
                                    float *out, long long ldo, unsigned char *argmax, void *stream)
+{
+    return cmf_bn_relu_maxpool_sel(P, S, C, z, a, c, out, ldo, argmax, nullptr, stream);
+}
+
+// ... also keeping the pre-activations at the arg-max slots: zsel (P, C) or NULL (internal: the set-conv block calls)
+int cmf_bn_relu_maxpool_sel(long long P, int S, int C, const float *z, const float *a, const float *c,
+                            float *out, long long ldo, unsigned char *argmax, float *zsel, void *stream)
 {
     CMF_CHECK_ARG(P >= 0 && S > 0 && S <= 255 && C % 4 == 0 && ldo % 4 == 0);
     if (P == 0) return 0;
     CMF_CHECK_ARG(z && a && c && out);
     const int grid = pool_grid(P, C);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid), dim3(PW_THREADS), 0, (hipStream_t)stream, P, S, C, z, a, c, out, ldo, argmax);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid), dim3(PW_THREADS), 0, (hipStream_t)stream, P, S, C, z, a, c, out, ldo, argmax, zsel);
     return cmf_launch_status();
 }
 
@@ -1048,7 +1060,7 @@ __global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_point_batch_kernel(con
 {
     const CmfPoolBwdArgs &p = b.a[blockIdx.y];
     if ((long long)blockIdx.x * PW_ROWS >= p.P) return;
-    maxpool_bwd_point_body(p.P, p.S, p.C, p.dout, p.ldd, p.z, p.a, p.c, p.mean, p.invstd, p.argmax, p.g, p.partial, 0, blockIdx.x);
+    maxpool_bwd_point_body(p.P, p.S, p.C, p.dout, p.ldd, p.z, p.a, p.c, p.mean, p.invstd, p.argmax, p.g, p.partial, p.sel, blockIdx.x);
 }
 
 int cmf_maxpool_bwd_point_batch(int n, const CmfPoolBwdArgs *a, hipStream_t st)
@@ -1059,7 +1071,7 @@ int cmf_maxpool_bwd_point_batch(int n, const CmfPoolBwdArgs *a, hipStream_t st)
     for (int i = 0; i < n; ++i) {
         const CmfPoolBwdArgs &q = a[i];
         CMF_CHECK_ARG(q.P > 0 && q.S > 0 && q.S <= 255 && tile_ok(q.C) && q.C == a[0].C && q.ldd % 4 == 0);
-        CMF_CHECK_ARG(q.dout && q.z && q.a && q.c && q.mean && q.invstd && q.argmax && q.g && q.partial);
+        CMF_CHECK_ARG(q.dout && q.z && q.a && q.c && q.mean && q.invstd && (q.sel || q.argmax) && q.g && q.partial);
         b.a[i] = q;
         pmax = std::max(pmax, q.P);
     }

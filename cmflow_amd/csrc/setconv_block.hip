@@ -86,6 +86,7 @@ struct Layout {
     int *idx, *offsets, *inv;
     float *dxyz, *z1, *z2, *z3, *x, *z4, *z5, *z6, *fwd_sums;
     unsigned char *argmax;
+    float *zsel;                  // (P, C3) pre-activations of layer 3 at the arg-max slots (per-layer path; the chain keeps them in z3's slot)
     float *bn[6];                 // per layer: mean | invstd | a | c   (4 * C_l)
     // scratch
     float *partial, *partial_x, *sums, *t6, *t5, *t4, *dx, *dU3, *dU2, *dU1, *splitk;
@@ -131,6 +132,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
     L.z6 = s.take(P * C6);
     L.fwd_sums = s.take(3 * O1 + 4);
     for (int l = 0; l < 6; ++l) L.bn[l] = s.take(4 * (size_t)chan(d, l));
+    L.zsel = s.take(P * C3);       // (behind everything else: the offsets of the older slots are part of the Python side's contract)
     L.saved_floats = s.off;
 
     Bump t(scratch);
@@ -181,6 +183,8 @@ int cmf_setconv_chain_pass(int mode, long long M, int N, int S, const int *idx, 
                            long long ldo, float *zsel, unsigned char *argmax, float *partial, const float *g, const float *sums,
                            const float *dU_in, float *dU_out, float *slabs, void *stream);
 // csrc/pointwise.hip (internal)
+int cmf_bn_relu_maxpool_sel(long long P, int S, int C, const float *z, const float *a, const float *c, float *out, long long ldo,
+                            unsigned char *argmax, float *zsel, void *stream);
 int cmf_maxpool_bwd_point_sel(long long P, int C, const float *dout, long long ldd, const float *zsel, const float *a, const float *c,
                               const float *mean, const float *invstd, float *g, float *partial, void *stream);
 int cmf_setconv_chain_infer(long long M, int N, int S, const int *idx, const float *xyz, const float *y, long long ldy, const float *wx,
@@ -465,7 +469,7 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
     CMF_TRY(fold(d, L, 1, M, st));
     CMF_TRY(fwd_gemm(d, L, M, C2, C3, L.z2, 1, d->w[1], L.z3, st));
     CMF_TRY(fold(d, L, 2, M, st));
-    CMF_TRY(cmf_bn_relu_maxpool(P, d->S, C3, L.z3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, L.x, C3, L.argmax, st));
+    CMF_TRY(cmf_bn_relu_maxpool_sel(P, d->S, C3, L.z3, L.bn[2] + 2 * C3, L.bn[2] + 3 * C3, L.x, C3, L.argmax, L.zsel, st));
     if (part == 1) return 0;
     // timing diagnostic (results are garbage): the per-point tail left out -- an upper bound for what fusing it can save
     CMF_TRY(fwd_gemm(d, L, P, C3, C4, L.x, -1, d->w[2], L.z4, st));
@@ -710,7 +714,7 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
         // narrow layers: the gradient of the pooled tensor is kept per POINT (g, in L.dx's neighbour L.dU3) and expanded
         // by the fused layer kernel on the fly -- the [M, C3] matrix is neither written nor read
         float *g = L.dU3;
-        CMF_TRY(cmf_maxpool_bwd_point(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, g, L.partial, st));
+        CMF_TRY(cmf_maxpool_bwd_point_sel(P, C3, L.dx, C3, L.zsel, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, g, L.partial, st));
         if (d->acc_bn[2]) CMF_TRY(cmf_colsum_finalize(tiles128(P), C3, L.partial, L.sums, d->dbeta[2], d->dgamma[2], st));
         else CMF_TRY(cmf_colsum_store(tiles128(P), 2 * C3, L.partial, L.sums, C3, d->dbeta[2], d->dgamma[2], st));
         const float *b1 = L.bn[1];
@@ -720,7 +724,7 @@ static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
     } else if (fused && wide && cmf_thin_bwd_wide_supported(C3, C2) && M % 128 == 0 && d->dw[1]) {
         // 64 <- 256 channels (second encoder): the same single pass, a workgroup per (row range, 128 input channels)
         float *g = L.dU3;
-        CMF_TRY(cmf_maxpool_bwd_point(P, d->S, C3, L.dx, C3, L.z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L.argmax, g, L.partial, st));
+        CMF_TRY(cmf_maxpool_bwd_point_sel(P, C3, L.dx, C3, L.zsel, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, g, L.partial, st));
         if (d->acc_bn[2]) CMF_TRY(cmf_colsum_finalize(tiles128(P), C3, L.partial, L.sums, d->dbeta[2], d->dgamma[2], st));
         else CMF_TRY(cmf_colsum_store(tiles128(P), 2 * C3, L.partial, L.sums, C3, d->dbeta[2], d->dgamma[2], st));
         const float *b1 = L.bn[1];
@@ -964,7 +968,7 @@ static int setconv_forward_bodies_batch(int n, const cmf_setconv_desc *descs, hi
                 q.M = (int)M; q.N = cout; q.K = C; q.A = layer == 0 ? L[i].z1 : L[i].z2; q.lda = C; q.B = d.w[layer]; q.ldb = C;
                 q.C = layer == 0 ? L[i].z2 : L[i].z3; q.ldc = cout; q.pro_a = b + 2 * C; q.pro_c = b + 3 * C; q.stats = L[i].partial; q.split_k = 1;
             } else
-                pl[i] = CmfPoolArgs{P, d.S, C3, L[i].z3, b + 2 * C3, b + 3 * C3, L[i].x, C3, L[i].argmax, 0};
+                pl[i] = CmfPoolArgs{P, d.S, C3, L[i].z3, b + 2 * C3, b + 3 * C3, L[i].x, C3, L[i].argmax, 0, L[i].zsel};
         }
         CMF_TRY(cmf_bn_finalize_batch(n, f, st));
         if (layer < 2) CMF_TRY(cmf_thin_fwd_batch(n, g, st));
@@ -1021,7 +1025,7 @@ static int setconv_backward_bodies_batch(int n, const cmf_setconv_desc *descs, h
             const long long P = (long long)d.B * d.N;
             const float *b2 = L[i].bn[2], *b1 = L[i].bn[1];
             float *g = L[i].dU3;
-            pb[i] = CmfPoolBwdArgs{P, d.S, C3, L[i].dx, C3, L[i].z3, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L[i].argmax, g, L[i].partial};
+            pb[i] = CmfPoolBwdArgs{P, d.S, C3, L[i].dx, C3, L[i].zsel, b2 + 2 * C3, b2 + 3 * C3, b2, b2 + C3, L[i].argmax, g, L[i].partial, 1};
             cs[i] = CmfColsumArgs{tiles128(P), 2 * C3, L[i].partial, L[i].sums, C3, d.dbeta[2], d.dgamma[2], d.acc_bn[2] ? 0 : 1};
             CmfThinBwdCall &q = tb[i];
             q = CmfThinBwdCall{};
