@@ -1092,7 +1092,10 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
         for (int hv = 0; hv < WM / 64; ++hv) {
         const int rbase = m0 + wms * WM + hv * 64;
         if (hv > 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous half's reads of wdq are complete
-        *(f32x4 *)(wdq + lane * 4) = *(const f32x4 *)(p.dxyz + (long long)(rbase + lane) * 4);
+        // the relative coordinates of row `lane` stay in the lane and are read per row with v_readlane (scalar operands of the row's
+        // arithmetic: no LDS read, no vector registers)
+        const f32x4 dq4 = *(const f32x4 *)(p.dxyz + (long long)(rbase + lane) * 4);
+        const int dqx = __float_as_int(dq4[0]), dqy = __float_as_int(dq4[1]), dqz = __float_as_int(dq4[2]);
         // the source point of row `lane` stays in the lane (read per row with v_readlane); the rows where it changes as a wave mask
         const int ptv = p.ga_rows[rbase + lane];
         const int ptb = __shfl_up(ptv, 1, 64);
@@ -1100,14 +1103,18 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
         const long long range = rbase / 64;
         float seg = 0.f;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (wave-private LDS: the wave's own writes above, in order)
+        if (p.trace && hv == 0) t_e[0] = wall_clock64();
         int pt_cur = 0;
-        // the per-point rows of 8 output rows at a time, requested one group ahead (rows of one run re-read the same 256 bytes)
-        float ya[8], yb[8];
-        auto load_y = [&](int row0, float (&y)[8]) {
+        // the per-point rows of a whole 32-row block row requested at once (32 loads in flight; rows of one run re-read the same 256
+        // bytes), the second block row's while the first is walked.  [Eight at a time, one group ahead, each group of 8 rows exposed a
+        // full load round trip under the other workgroups' operand streams: 12-14 us per block row, 30 us per tile's epilogue against a
+        // 27 us main loop -- tools/dxsum_probe.py, DXSUM_TIMELINE=1]
+        float ya[32], yb[32];
+        auto load_y = [&](int row0, float (&y)[32]) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) y[u] = ycol[(long long)__builtin_amdgcn_readlane(ptv, row0 + u) * p.ldz];
+            for (int u = 0; u < 32; ++u) y[u] = ycol[(long long)__builtin_amdgcn_readlane(ptv, row0 + u) * p.ldz];
         };
-        auto rows8 = [&](int i, int row0, const float (&y)[8]) {       // rows row0 .. row0 + 7 of the half (block row i of it)
+        auto rows8 = [&](int i, int row0, const float *y) {           // rows row0 .. row0 + 7 of the half (block row i of it); y: their 8 values
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = row0 + u;
@@ -1115,12 +1122,14 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
                     if (row > 0) { pcol[((long long)pt_cur + range) * p.N] = seg; t1 += seg; }
                     seg = 0.f; pt_cur = __builtin_amdgcn_readlane(ptv, row);
                 }
-                const f32x4 d4 = *(const f32x4 *)(wdq + row * 4);
+                const float ddx = __int_as_float(__builtin_amdgcn_readlane(dqx, row));
+                const float ddy = __int_as_float(__builtin_amdgcn_readlane(dqy, row));
+                const float ddz = __int_as_float(__builtin_amdgcn_readlane(dqz, row));
                 float x = wt[(row - i * 32) * 64 + lane];
-                const float z = y[u] + fmaf(g2, d4.z, fmaf(g1, d4.y, g0 * d4.x));
+                const float z = y[u] + fmaf(g2, ddz, fmaf(g1, ddy, g0 * ddx));
                 x = (fmaf(k0, z, k1) > 0.f) ? x : 0.f;
                 t2 += x * ((z - k2) * k3);
-                q0 += x * d4.x; q1 += x * d4.y; q2 += x * d4.z;
+                q0 += x * ddx; q1 += x * ddy; q2 += x * ddz;
                 seg += x;
             }
         };
@@ -1132,25 +1141,22 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     wt[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + j * 32 + (lane & 31)] = acc[(2 * hv + i) % TM][j][r];
+            if (i == 0) load_y(32, yb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // (a real loop with compiler fences: unrolled, the scheduler hoists every LDS read and per-point load of the block row above
-            //  the arithmetic -- 235 spilled registers)
-#pragma unroll 1
-            for (int g = 0; g < 2; ++g) {
-                const int r0 = i * 32 + g * 16;
-                load_y(r0 + 8, yb);
+            // (compiler fences between the groups of 8 rows: without them the scheduler hoists every LDS read of the block row above
+            //  the arithmetic and spills)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
                 asm volatile("" ::: "memory");
-                rows8(i, r0, ya);
-                asm volatile("" ::: "memory");
-                if (r0 + 16 < 64) load_y(r0 + 16, ya);
-                asm volatile("" ::: "memory");
-                rows8(i, r0 + 8, yb);
-                asm volatile("" ::: "memory");
+                rows8(i, i * 32 + g * 8, (i == 0 ? ya : yb) + g * 8);
             }
+            asm volatile("" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the tile is read before the next block row overwrites it
+            if (p.trace && hv == 0 && i == 0) t_e[1] = wall_clock64();
         }
         pcol[((long long)pt_cur + range) * p.N] = seg; t1 += seg;    // (s1 = the sum of the runs' sums)
         }
+        if (p.trace) t_e[2] = wall_clock64();
         // statistics: one partial row per 128 rows like the other epilogues -- the wave rows of a 128-row slice through LDS
         lds_barrier();
         float *red = smem;                                            // [WARPS_M][5][BN]
@@ -1568,6 +1574,13 @@ static int launch(const GemmArgs &a, hipStream_t st)
     return cmf_launch_status();
 }
 
+// timing-only ablation bits of the diagnostics builds (-DCMF_GEMM_DIAG; results invalid): read once
+static int gemm_diag_rt()
+{
+    static const int v = getenv("CMF_GEMM_DIAG_RT") ? atoi(getenv("CMF_GEMM_DIAG_RT")) : 0;
+    return v;
+}
+
 // 256 x 128 tiles for tall interior shapes (env CMF_GEMM_TALL=0: the 128 x 128 tiles everywhere, A/B)
 static int gemm_tall_mode()
 {
@@ -1678,6 +1691,7 @@ extern "C" int cmf_gemm_gather_affine(int M, int N, int K, const float *Y, long 
     g.M = M; g.N = N; g.K = K; g.A = Y; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc;
     g.pro_a = pro_a; g.pro_c = pro_c; g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
     g.stats = stats;                                    // train mode: [M / 128][2][N] partial sums of the output
+    g.diag = gemm_diag_rt();
     // (256 x 128 tiles measured here, round 5: 111 against 118 TF -- the per-row state of the gathering loads and the fragment prologue
     //  do not fit 256 registers beside a 128 x 64 wave tile; CMF_GEMM_TALL=2 keeps that form reachable)
     if (gemm_tall_mode() == 2 && M % 256 == 0 && (long long)(M / 256) * (N / 128) >= 384)
@@ -1708,6 +1722,7 @@ extern "C" int cmf_gemm_dx_gather(int M, int cin, int cout, const float *dZ, lon
     g.M = M; g.N = cin; g.K = cout; g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = dU; g.ldc = ldu;
     g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz;
     g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.split_k = 1;
+    g.diag = gemm_diag_rt();
     return launch<128, 128, false, false, 4, 3>(g, st);
 }
 
@@ -1731,6 +1746,7 @@ extern "C" int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ,
     g.M = M; g.N = cin; g.K = cout; g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = pieces; g.ldc = cin;
     g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz2;
     g.ga_rows = pts; g.ga_dxyz = dxyz2; g.ga_wx = wx3; g.ga_arows = arows; g.ga_pieces = pieces; g.split_k = 1;
+    g.diag = gemm_diag_rt();
     // (256-row tiles -- wave tile 128 x 64 = two 64-row ranges of `pieces` -- measured here, round 5: 99.7 against 105 TF at 524288 rows:
     //  the serial row walk of the epilogue doubles per wave while only two workgroups per CU are left to cover it; CMF_GEMM_TALL=2: A/B)
     if (gemm_tall_mode() == 2 && M % 256 == 0 && (long long)(M / 256) * (cin / 128) >= 384) return launch<256, 128, false, false, 4, 4>(g, st);
