@@ -1110,9 +1110,19 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
         // full load round trip under the other workgroups' operand streams: 12-14 us per block row, 30 us per tile's epilogue against a
         // 27 us main loop -- tools/dxsum_probe.py, DXSUM_TIMELINE=1]
         float ya[32], yb[32];
+        // (a 64-bit scalar multiply-add per row was 9 of a load's 10 instructions; with the matrix below 4 GB the row offset is one
+        //  32-bit scalar product and the lane's column sits in the buffer instruction's offset register)
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)p.Z, 0, -1, 0x00020000);
+        const unsigned ycol_off = (unsigned)c * 4u, ldz4 = (unsigned)p.ldz * 4u;
         auto load_y = [&](int row0, float (&y)[32]) {
+            if (p.ga_y32) {
 #pragma unroll
-            for (int u = 0; u < 32; ++u) y[u] = ycol[(long long)__builtin_amdgcn_readlane(ptv, row0 + u) * p.ldz];
+                for (int u = 0; u < 32; ++u)
+                    y[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, ycol_off, (unsigned)__builtin_amdgcn_readlane(ptv, row0 + u) * ldz4, 0));
+            } else {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) y[u] = ycol[(long long)__builtin_amdgcn_readlane(ptv, row0 + u) * p.ldz];
+            }
         };
         auto rows8 = [&](int i, int row0, const float *y) {           // rows row0 .. row0 + 7 of the half (block row i of it); y: their 8 values
 #pragma unroll
@@ -1732,6 +1742,10 @@ extern "C" int cmf_gemm_dx_gather(int M, int cin, int cout, const float *dZ, lon
 // every run of equal source points inside a 64-row range, the run's column sums to pieces[(point + m / 64)][cin]
 // (P + M / 64 rows suffice).  The sum of a point's pieces, in range order, equals the sum of cmf_gemm_dx_gather's rows over its slots
 // up to fp32 association; the five statistics are the same sums in another order.
+// internal (setconv_block.hip): the number of source points behind the next cmf_gemm_dx_gather_sum call of this host thread (0 = unknown)
+static thread_local long long g_dxsum_points_hint = 0;
+void cmf_gemm_dx_gather_sum_hint(long long points) { g_dxsum_points_hint = points; }
+
 extern "C" int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ, long long ldz, const float *W, long long ldw,
                                       const float *Y, long long ldy, const int *arows, const int *pts, const float *dxyz2,
                                       const float *wx3, const float *ea, const float *ec, const float *emean, const float *einvstd,
@@ -1746,6 +1760,10 @@ extern "C" int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ,
     g.M = M; g.N = cin; g.K = cout; g.A = dZ; g.lda = ldz; g.B = W; g.ldb = ldw; g.C = pieces; g.ldc = cin;
     g.stats = stats; g.bwd_mode = 1; g.Z = Y; g.ldz = ldy; g.ea = ea; g.ec = ec; g.emean = emean; g.einvstd = einvstd; g.dxyz = dxyz2;
     g.ga_rows = pts; g.ga_dxyz = dxyz2; g.ga_wx = wx3; g.ga_arows = arows; g.ga_pieces = pieces; g.split_k = 1;
+    // every source point has at least one slot, so a point index is below M; the set-conv blocks pass theirs (B * N points: cmf_gemm_dx_gather_sum_hint)
+    const long long npts = g_dxsum_points_hint > 0 ? g_dxsum_points_hint : (long long)M;
+    g.ga_y32 = (npts * ldy + cin) * 4 < (1ll << 32) ? 1 : 0;
+    g_dxsum_points_hint = 0;                            // (a hint serves one call)
     g.diag = gemm_diag_rt();
     // (256-row tiles -- wave tile 128 x 64 = two 64-row ranges of `pieces` -- measured here, round 5: 99.7 against 105 TF at 524288 rows:
     //  the serial row walk of the epilogue doubles per wave while only two workgroups per CU are left to cover it; CMF_GEMM_TALL=2: A/B)

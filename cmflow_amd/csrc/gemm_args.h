@@ -41,6 +41,7 @@ struct GemmArgs {
     // point): ga_arows[m] = the row of A for output row m, ga_rows[m] = its source point; nothing of C is stored -- the sums over runs of
     // equal source points inside a 64-row range go to ga_pieces[(point + range)][N]
     const int *ga_arows; float *ga_pieces;
+    int ga_y32;                 // GMODE 4: every byte offset into the per-point matrix fits 32 bits (rows through a buffer descriptor + scalar offsets)
     int split_k;                // >1: C is [split][M][N] partial slabs (ldc = N), reduced by a second kernel
     int accumulate;             // C += result (beta = 1)
     int thin_general;           // diagnostics (env CMF_THIN_GENERAL=1): the narrow forward layers take their general body on full tiles too (A/B)

@@ -185,6 +185,7 @@ int cmf_setconv_chain_pass(int mode, long long M, int N, int S, const int *idx, 
 // csrc/pointwise.hip (internal)
 int cmf_bn_relu_maxpool_sel(long long P, int S, int C, const float *z, const float *a, const float *c, float *out, long long ldo,
                             unsigned char *argmax, float *zsel, void *stream);
+void cmf_gemm_dx_gather_sum_hint(long long points);
 int cmf_maxpool_bwd_point_sel(long long P, int C, const float *dout, long long ldd, const float *zsel, const float *a, const float *c,
                               const float *mean, const float *invstd, float *g, float *partial, void *stream);
 int cmf_setconv_chain_infer(long long M, int N, int S, const int *idx, const float *xyz, const float *y, long long ldy, const float *wx,
@@ -366,6 +367,7 @@ int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, i
     if (train_gather_sum(d)) {
         const SumSlots q = sum_slots(d, L);
         CMF_TRY(cmf_group_perm(d->B, d->N * d->S, L.inv, gather_rows(L), L.dxyz, q.perm, q.pts, q.dq2, st));
+        cmf_gemm_dx_gather_sum_hint((long long)d->B * d->N);
         return cmf_gemm_dx_gather_sum((int)M, O1, C2, L.dU2, C2, d->w[0], O1, d->y, d->ldy, q.perm, q.pts, q.dq2, gather_wx3(L, M),
                                       b0 + 2 * O1, b0 + 3 * O1, b0, b0 + O1, q.pieces, L.partial, st);
     }
