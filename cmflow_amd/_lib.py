@@ -45,6 +45,8 @@ SIGNATURES = {
     "cmf_gemm_trace_arm": [],
     "cmf_gemm_trace_read": [_vp, _ll],
     "cmf_gemm_profile_begin": [ctypes.c_double],
+    "cmf_gemm_profile_sampling": [_ci],
+    "cmf_gemm_profile_eligible": [_vp, _vp],
     "cmf_gemm_profile_end": [_vp, _vp, _vp, _vp, _vp],
     "cmf_gemm_profile_records": [_vp, _ll],
     "cmf_setconv_sizes": [_vp, _vp, _vp, _vp],
@@ -252,8 +254,12 @@ TRACK_MIN_UNITS = {"cmf_gemm": 1.0e9}
 _prof_open = False
 
 
+SAMPLE_EVERY = 1                                  # bench.py sets 4: an event pair around EVERY large launch costs ~0.15 ms per training step
+
+
 def profile_begin():
     global _prof_open
+    check(lib().cmf_gemm_profile_sampling(int(SAMPLE_EVERY)), "cmf_gemm_profile_sampling")
     check(lib().cmf_gemm_profile_begin(TRACK_MIN_UNITS["cmf_gemm"]), "cmf_gemm_profile_begin")
     _prof_open = True
 
@@ -275,5 +281,8 @@ def profile_end():
         e = shapes.setdefault(key, [0, 0.0])
         e[0] += 1
         e[1] += r.ms
+    n_el, fl_el = ctypes.c_longlong(), ctypes.c_double()
+    check(lib().cmf_gemm_profile_eligible(ctypes.addressof(n_el), ctypes.addressof(fl_el)), "cmf_gemm_profile_eligible")
     return {"kernel": "cmf_gemm", "bound": "mfma", "launches": n.value, "ms": ms.value, "units": fl.value,
-            "launches_all": n_all.value, "units_all": fl_all.value, "shapes": shapes}
+            "launches_all": n_all.value, "units_all": fl_all.value, "shapes": shapes,
+            "launches_eligible": n_el.value, "units_eligible": fl_el.value, "sample_every": int(SAMPLE_EVERY)}

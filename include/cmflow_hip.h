@@ -207,6 +207,10 @@ typedef struct cmf_gemm_launch_record {
     float ms;             /* duration between the two events */
 } cmf_gemm_launch_record;
 int cmf_gemm_profile_begin(double min_flops);
+/* Bracket only every n-th launch that reaches min_flops (default 1 = all; the event pairs themselves cost 0.13-0.18 ms per training step
+ * when every large launch carries one); every eligible launch is still counted: cmf_gemm_profile_eligible (after cmf_gemm_profile_end). */
+int cmf_gemm_profile_sampling(int every);
+int cmf_gemm_profile_eligible(long long *launches, double *flops);
 int cmf_gemm_profile_end(long long *launches_timed, double *ms_timed, double *flops_timed, long long *launches_all,
                          double *flops_all);
 /* per-launch records of the last closed window (shape, layout, kind, duration); returns the number available */
