@@ -932,8 +932,20 @@ static int setconv_infer_bodies_batch(int n, const cmf_setconv_desc *descs, hipS
     return cmf_setconv_chain_infer_batch(n, q, st);
 }
 
-static int setconv_forward_bodies_batch(int n, const cmf_setconv_desc *descs, hipStream_t st)
+// largest block first: blockIdx.y = block and the dispatcher walks y slowest, so the blocks with the most rows start first and the small
+// ones fill the tail of the launch
+static void largest_first(int n, const cmf_setconv_desc *in, cmf_setconv_desc *out)
 {
+    int ord[CMF_MAX_BATCH];
+    for (int i = 0; i < n; ++i) ord[i] = i;
+    std::stable_sort(ord, ord + n, [&](int a, int b) { return (long long)in[a].B * in[a].N * in[a].S > (long long)in[b].B * in[b].N * in[b].S; });
+    for (int i = 0; i < n; ++i) out[i] = in[ord[i]];
+}
+
+static int setconv_forward_bodies_batch(int n, const cmf_setconv_desc *descs_in, hipStream_t st)
+{
+    cmf_setconv_desc descs[CMF_MAX_BATCH];
+    largest_first(n, descs_in, descs);
     Layout L[CMF_MAX_BATCH];
     for (int i = 0; i < n; ++i) {
         CMF_CHECK_ARG(descs[i].xyz && descs[i].y && descs[i].wx && descs[i].saved && descs[i].scratch && descs[i].out);
@@ -1003,8 +1015,10 @@ static int splitk_batch_or_each(int n, const CmfSplitkArgs *sk, hipStream_t st)
     return 0;
 }
 
-static int setconv_backward_bodies_batch(int n, const cmf_setconv_desc *descs, hipStream_t st)
+static int setconv_backward_bodies_batch(int n, const cmf_setconv_desc *descs_in, hipStream_t st)
 {
+    cmf_setconv_desc descs[CMF_MAX_BATCH];
+    largest_first(n, descs_in, descs);
     Layout L[CMF_MAX_BATCH];
     for (int i = 0; i < n; ++i) {
         CMF_CHECK_ARG(descs[i].xyz && descs[i].saved && descs[i].scratch && descs[i].dout);
