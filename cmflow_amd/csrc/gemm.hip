@@ -1125,6 +1125,12 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
             }
         };
         auto rows8 = [&](int i, int row0, const float *y) {           // rows row0 .. row0 + 7 of the half (block row i of it); y: their 8 values
+            // the group's 8 accumulator values out of the LDS tile up front: behind the run-boundary branches below each read would be
+            // issued and awaited row by row
+            float xr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xr[u] = wt[(row0 + u - i * 32) * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int row = row0 + u;
@@ -1135,7 +1141,7 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
                 const float ddx = __int_as_float(__builtin_amdgcn_readlane(dqx, row));
                 const float ddy = __int_as_float(__builtin_amdgcn_readlane(dqy, row));
                 const float ddz = __int_as_float(__builtin_amdgcn_readlane(dqz, row));
-                float x = wt[(row - i * 32) * 64 + lane];
+                float x = xr[u];
                 const float z = y[u] + fmaf(g2, ddz, fmaf(g1, ddy, g0 * ddx));
                 x = (fmaf(k0, z, k1) > 0.f) ? x : 0.f;
                 t2 += x * ((z - k2) * k3);
