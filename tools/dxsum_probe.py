@@ -48,6 +48,11 @@ for S, r in ((32, 16.0), (16, 8.0), (8, 4.0), (4, 2.0)):
     r_gat = rate(lambda: _lib.check(L.cmf_gemm_dx_gather(M, K, NO, dZ.data_ptr(), NO, W.data_ptr(), K, dU.data_ptr(), K, y.data_ptr(), y.stride(1),
                                                          rows.data_ptr(), dq.data_ptr(), wx3.data_ptr(), ea.data_ptr(), ec.data_ptr(), em.data_ptr(),
                                                          ei.data_ptr(), stats.data_ptr(), st), "dxg"), f)
+    ident = torch.arange(M, dtype=torch.int32, device=dev)          # timing only: A rows in storage order (what a pre-permuted dZ would give)
+    r_seq = rate(lambda: _lib.check(L.cmf_gemm_dx_gather_sum(M, K, NO, dZ.data_ptr(), NO, W.data_ptr(), K, y.data_ptr(), y.stride(1), ident.data_ptr(),
+                                                             pts.data_ptr(), dq2.data_ptr(), wx3.data_ptr(), ea.data_ptr(), ec.data_ptr(), em.data_ptr(),
+                                                             ei.data_ptr(), pieces.data_ptr(), stats.data_ptr(), st), "dxs"), f)
+    print("   (summed with its A rows in storage order: %.1f TF)" % r_seq)
     L.cmf_gemm_persist_config(0, 0)
     r_pln = rate(lambda: gemm(dZ, W, b_t=False, out=dU, bwd=(1, dU, ea, ec, em, ei, dq)), f)
     L.cmf_gemm_persist_config(1, 0)
