@@ -348,6 +348,34 @@ def test_kabsch_kat_and_grad(dev, golden_dir):
         np.testing.assert_allclose(got_g.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * scale, err_msg=name)
 
 
+def test_layout_helpers_equal_their_torch_forms(dev):
+    """cmf_pad_rows, cmf_inputs_point_major, cmf_rel_xyz: one launch each where the host side used a fill, a copy and sometimes a
+    subtraction -- pure data movement (and one fp32 subtraction per coordinate), so equality is exact."""
+    from cmflow_amd import fused_blocks as FB
+    from cmflow_amd.radarflow_util import rel_xyz, knn_point
+    g = torch.Generator().manual_seed(5)
+    for rows, k in ((7, 3), (64, 5), (1000, 13), (16, 8)):
+        t = torch.randn(rows, k + 6, generator=g).to(dev)[:, 2:2 + k]                # a strided view
+        got = FB._pad_cols(t)
+        ld = (k + 3) // 4 * 4
+        assert got.shape == (rows, ld) and torch.equal(got[:, :k], t) and (ld == k or bool((got[:, k:] == 0).all()))
+    for B, N, C in ((3, 200, 3), (2, 256, 5), (1, 64, 4)):
+        pc1, pc2 = torch.randn(B, 3, N, generator=g).to(dev), torch.randn(B, 3, N, generator=g).to(dev)
+        f1, f2 = torch.randn(B, C, N, generator=g).to(dev), torch.randn(B, C, N, generator=g).to(dev)
+        x1, x2, a1, a2 = FB.inputs_point_major(pc1, pc2, f1, f2)
+        cp = a1.shape[2]
+        assert cp % 4 == 0 and cp >= C and cp - C < 4
+        assert torch.equal(x1, pc1.transpose(1, 2)) and torch.equal(x2, pc2.transpose(1, 2))
+        for a, f in ((a1, f1), (a2, f2)):
+            assert torch.equal(a[:, :, :C], f.transpose(1, 2)) and bool((a[:, :, C:] == 0).all())
+    xyz = (torch.rand(2, 300, 3, generator=g) * 40).to(dev)
+    ctr = xyz[:, :100].contiguous()
+    idx = knn_point(8, xyz, ctr, i32=True)
+    d = rel_xyz(xyz, ctr, idx)
+    want = torch.gather(xyz.unsqueeze(1).expand(-1, 100, -1, -1), 2, idx.long().unsqueeze(-1).expand(-1, -1, -1, 3)) - ctr.unsqueeze(2)
+    assert d.shape == (2, 100, 8, 4) and torch.equal(d[..., :3], want) and bool((d[..., 3] == 0).all())
+
+
 @pytest.mark.parametrize("B,N,eps,thres,score_grad", [(8, 256, 1e-4, 0.3, True), (3, 200, 0.0, 0.5, True), (5, 256, 1e-4, 0.3, False)])
 def test_ego_refine_equals_the_torch_ops_around_the_solve(dev, B, N, eps, thres, score_grad):
     """cmf_ego_refine (cmflow.py:96-125 as one call per direction: ego-motion weights, weighted Kabsch, rigid refinement, select)
