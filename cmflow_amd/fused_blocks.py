@@ -184,6 +184,9 @@ def enable_grad_sinks(params, on=True):
         p._cmf_sink = bool(on)
 
 
+_COL_SINKS = os.environ.get("CMF_COL_SINKS", "1") != "0"       # 0: column blocks of a weight hand their gradients to autograd (A/B)
+
+
 def grad_sink(t):
     """The gradient buffer a parameter-gradient can be accumulated into directly, or None (= hand the gradient to autograd).
     Only parameters opted in with enable_grad_sinks (the flat bucket's) have one.
@@ -200,6 +203,14 @@ def grad_sink(t):
         return base.grad
     if t.dim() == 2 and base.dim() == 4 and t.is_contiguous() and t.numel() == base.numel():
         return base.grad.view(t.shape)
+    # a block of columns of the (out, in) matrix (the cost volume's first conv is used as three column blocks): the same columns of
+    # the gradient buffer -- as separate gradients autograd builds each block's full-size zero-padded copy and adds the three
+    if _COL_SINKS and t.dim() == 2 and base.dim() in (2, 4) and base.is_contiguous():
+        rows = base.shape[0]
+        K = base.numel() // rows
+        col = t.storage_offset() - base.storage_offset()
+        if t.shape[0] == rows and t.stride() == (K, 1) and 0 <= col and col + t.shape[1] <= K:
+            return base.grad.view(rows, K)[:, col:col + t.shape[1]]
     return None
 
 
@@ -1324,6 +1335,7 @@ class CostVolumeMLPFn(Function):
         # preact_grad: the consumer of x3 (WeightedKSumFn with leaky=True) already applies leaky'(x3), i.e. the
         # incoming gradient is w.r.t. the pre-activation z3
         ctx.preact_grad = preact_grad
+        ctx.wd_in = wd
         B, N1, C = p1.shape
         K = nbr.S
         p1c, p2c = p1.contiguous(), p2.contiguous()
@@ -1358,6 +1370,10 @@ class CostVolumeMLPFn(Function):
         # (as a 512 x 4 GEMM over the 131072 rows it re-read dz1: 154 us)
         dz1, part1 = gemm(dz2, w2, b_t=False, bwd=(2, x1, None, None, None, None, dxyz.view(-1, 4)), stats=True)
         dwd = colsum_n(part1)[2:5].t()
+        sink_d = grad_sink(ctx.wd_in)
+        if sink_d is not None and sink_d.shape == dwd.shape:
+            sink_d.add_(dwd)                # (a column block of the first conv's gradient buffer: one small add instead of zeros + copy + add)
+            dwd = None
         dp1 = dz1.view(B, N1, K, C).sum(dim=2)
         dp2 = torch.empty(B, N2, C, dtype=_f32, device=dz1.device)
         err = L().cmf_group_rows_grad(B, N2, C, C, N1 * K, 0, _p(dz1), _p(off), _p(inv), _p(dp2), _lib.stream_ptr())
