@@ -117,12 +117,15 @@ SIGNATURES = {
     "cmf_unstack_first_conv_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
     "cmf_global_max_cat_grad": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _ll, _vp],
     "cmf_radar_loss_workspace": [_ci, _ci],
+    "cmf_radar_loss_workspace_nb": [_ci, _ci, _ci],
+    "cmf_radar_loss_workspace_tiled": [_ci, _ci, _ci],
     "cmf_radar_loss": [_vp, _vp],
+    "cmf_radar_loss_tiled": [_vp, _vp],
     "cmf_pseudo_labels": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp, _vp],
     "cmf_debug_spin": [_cf, _vp],
     "cmf_eval_metrics": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _cf, _cf, _vp, _vp, _vp],
 }
-RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_gemm_trace_read": _ll, "cmf_gemm_profile_records": _ll}
+RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_radar_loss_workspace_nb": _ll, "cmf_radar_loss_workspace_tiled": _ll, "cmf_gemm_trace_read": _ll, "cmf_gemm_profile_records": _ll}
 
 
 class GemmLaunchRecord(ctypes.Structure):

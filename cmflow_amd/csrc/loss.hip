@@ -449,15 +449,362 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const LossArgs a, flo
     }
 }
 
-extern "C" long long cmf_radar_loss_workspace(int b, int n)
+// ---------------------------------------------------------------------------------------------------------------
+// Tiled form for clouds that do not fit one workgroup's LDS (N > 704) or another neighbour count (num_nb in {4, 8, 16};
+// losses/radar_loss.py has no size limit).  The same terms in the same arithmetic, a sample's working set in a global
+// workspace instead of LDS:
+//   loss_nn_kernel<NB>          : the N x N work of pass 1, 256 points per workgroup, the cloud streamed through LDS in
+//                                 tiles of 256 points (neighbour lists, exp(-d/alpha), nearest-neighbour arguments ->
+//                                 workspace; chamfer partial sum and max exp per workgroup)
+//   loss_big_sample_kernel<NB>  : one 1024-thread workgroup per sample: soft-max normaliser, pass 2 (per-point terms, own
+//                                 gradients, pair gradients), the inverse lists and pass 3 (pushed gradients in id order:
+//                                 no atomics in any floating-point sum), the per-sample partial sums
+// followed by loss_finalize_kernel as above.  Per-point gradients accumulate their terms in the order of
+// loss_sample_kernel; the partial sums are folded in another (fixed) association.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int LG_THREADS = 1024;
+constexpr int LG_TILE = 256;
+
+struct LossBigWs { int *nbr; float *ev, *gv; int *am1, *arg2; float *g; int *inv_lst, *inv_end; float *wgp; };
+
+__host__ __device__ inline size_t lg_sample_floats(int N, int NB)
 {
-    (void)n;
-    return 4 + (long long)b * LS_PARTIALS;
+    const size_t nwg = (size_t)(N + LG_TILE - 1) / LG_TILE;
+    const size_t n = (size_t)N * (6 * NB + 7) + 4 + 2 * nwg;
+    return (n + 3) / 4 * 4;
 }
 
-extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
+__host__ __device__ inline LossBigWs lg_carve(float *base, int N, int NB)
 {
-    CMF_CHECK_ARG(d && d->B >= 0 && d->N > LS_NB && d->N <= LS_MAX_N && d->num_nb == LS_NB);
+    LossBigWs w;
+    float *p = base;
+    w.nbr = reinterpret_cast<int *>(p); p += (size_t)N * NB;
+    w.ev = p; p += (size_t)N * NB;
+    w.gv = p; p += (size_t)N * NB * 3;
+    w.am1 = reinterpret_cast<int *>(p); p += N;
+    w.arg2 = reinterpret_cast<int *>(p); p += N;
+    w.g = p; p += 3 * (size_t)N;
+    w.inv_lst = reinterpret_cast<int *>(p); p += (size_t)N * (NB + 1);
+    w.inv_end = reinterpret_cast<int *>(p); p += N + 4;
+    w.wgp = p;
+    return w;
+}
+
+template <int T>
+__device__ __forceinline__ float lg_block_sum(float v, float *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) s += red[w];
+    return s;
+}
+
+template <int NB>
+__global__ __launch_bounds__(LG_TILE) void loss_nn_kernel(const LossArgs a, float *__restrict__ ws_base, size_t ws_stride)
+{
+    __shared__ float t[12][LG_TILE];                    // pc1 xyz |.|^2, pc2 xyz |.|^2, pc1 + flow xyz |.|^2 of the tile
+    __shared__ float red[LG_TILE / 64];
+    const int N = a.N, tid = threadIdx.x, bs = blockIdx.y;
+    const int i = blockIdx.x * LG_TILE + tid;
+    const bool live = i < N;
+    const int ic = live ? i : N - 1;
+    const size_t o3 = (size_t)bs * 3 * N;
+    const LossBigWs w = lg_carve(ws_base + (size_t)bs * ws_stride, N, NB);
+    const float ax = a.pc1[o3 + ic], ay = a.pc1[o3 + N + ic], az = a.pc1[o3 + 2 * N + ic];
+    const float wx = ax + a.pred_f[o3 + ic], wy = ay + a.pred_f[o3 + N + ic], wz = az + a.pred_f[o3 + 2 * N + ic];
+    const float bx = a.pc2[o3 + ic], by = a.pc2[o3 + N + ic], bz = a.pc2[o3 + 2 * N + ic];
+    const float aa = ls_sqnorm3(ax, ay, az), ww = ls_sqnorm3(wx, wy, wz), bb = ls_sqnorm3(bx, by, bz);
+    float bd[NB + 1];
+    int bi[NB + 1];
+#pragma unroll
+    for (int q = 0; q <= NB; ++q) { bd[q] = __builtin_inff(); bi[q] = 0; }
+    float dens1 = 0.f, dens2 = 0.f, min1 = __builtin_inff(), min2 = __builtin_inff();
+    int am1 = 0, am2 = 0;
+    for (int j0 = 0; j0 < N; j0 += LG_TILE) {
+        __syncthreads();
+        const int jl = j0 + tid;
+        if (jl < N) {
+            const float x1 = a.pc1[o3 + jl], y1 = a.pc1[o3 + N + jl], z1 = a.pc1[o3 + 2 * N + jl];
+            const float x2 = a.pc2[o3 + jl], y2 = a.pc2[o3 + N + jl], z2 = a.pc2[o3 + 2 * N + jl];
+            const float xw = x1 + a.pred_f[o3 + jl], yw = y1 + a.pred_f[o3 + N + jl], zw = z1 + a.pred_f[o3 + 2 * N + jl];
+            t[0][tid] = x1; t[1][tid] = y1; t[2][tid] = z1; t[3][tid] = ls_sqnorm3(x1, y1, z1);
+            t[4][tid] = x2; t[5][tid] = y2; t[6][tid] = z2; t[7][tid] = ls_sqnorm3(x2, y2, z2);
+            t[8][tid] = xw; t[9][tid] = yw; t[10][tid] = zw; t[11][tid] = ls_sqnorm3(xw, yw, zw);
+        }
+        __syncthreads();
+        const int nj = min(LG_TILE, N - j0);
+        if (live)
+            for (int jj = 0; jj < nj; ++jj) {
+                const int j = j0 + jj;
+                const float qx = t[0][jj], qy = t[1][jj], qz = t[2][jj], qq = t[3][jj];
+                const float rx = t[4][jj], ry = t[5][jj], rz = t[6][jj], rr = t[7][jj];
+                const float d11 = ls_sqdist(ax, ay, az, aa, qx, qy, qz, qq);
+                if (d11 < bd[NB]) {
+                    bd[NB] = d11; bi[NB] = j;
+#pragma unroll
+                    for (int q = NB; q > 0; --q)
+                        if (bd[q] < bd[q - 1]) {
+                            const float td = bd[q]; bd[q] = bd[q - 1]; bd[q - 1] = td;
+                            const int ti = bi[q]; bi[q] = bi[q - 1]; bi[q - 1] = ti;
+                        }
+                }
+                const float d12 = ls_sqdist(ax, ay, az, aa, rx, ry, rz, rr);
+                dens1 += expf(-d12 / 2.0f) / 2.5f;
+                const float dw = ls_sqdist(wx, wy, wz, ww, rx, ry, rz, rr);
+                if (dw < min1) { min1 = dw; am1 = j; }
+                const float d21 = ls_sqdist(bx, by, bz, bb, qx, qy, qz, qq);
+                dens2 += expf(-d21 / 2.0f) / 2.5f;
+                const float dwt = ls_sqdist(t[8][jj], t[9][jj], t[10][jj], t[11][jj], bx, by, bz, bb);
+                if (dwt < min2) { min2 = dwt; am2 = j; }
+            }
+    }
+    float part0 = 0.f, emax_local = 0.f;
+    if (live) {
+        const bool mask1 = dens1 / (float)N > a.zeta, mask2 = dens2 / (float)N > a.zeta;
+        const float r1 = min1 - 0.01f, r2 = min2 - 0.01f;
+        if (mask1 && r1 > 0.f) part0 += r1;
+        if (mask2 && r2 > 0.f) part0 += r2;
+        w.arg2[i] = (mask2 && r2 > 0.f) ? am2 : -1;
+        w.am1[i] = (mask1 && r1 > 0.f) ? am1 : -1;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            w.nbr[(size_t)i * NB + q] = bi[q + 1];
+            const float e = expf(-bd[q + 1] / a.alpha);
+            w.ev[(size_t)i * NB + q] = e;
+            emax_local = fmaxf(emax_local, e);
+        }
+    }
+    const float ps = ls_block_sum(part0, red);
+    const float em = ls_block_max(emax_local, red);
+    if (tid == 0) { w.wgp[2 * blockIdx.x] = ps; w.wgp[2 * blockIdx.x + 1] = em; }
+}
+
+template <int NB>
+__global__ __launch_bounds__(LG_THREADS) void loss_big_sample_kernel(const LossArgs a, float *__restrict__ ws_base, size_t ws_stride)
+{
+    __shared__ float red[LG_THREADS / 64];
+    __shared__ int wsum[LG_THREADS / 64];
+    __shared__ float sT[32];
+    __shared__ float sC[9 + 16];
+    const int N = a.N, tid = threadIdx.x, bs = blockIdx.x;
+    const int nwg = (N + LG_TILE - 1) / LG_TILE;
+    const LossBigWs w = lg_carve(ws_base + (size_t)bs * ws_stride, N, NB);
+    const size_t o3 = (size_t)bs * 3 * N, o1 = (size_t)bs * N;
+    const float *p1 = a.pc1 + o3, *p2 = a.pc2 + o3, *fl = a.pred_f + o3;
+    if (!a.self_only) {
+        if (tid < 16) { sT[tid] = a.pre_trans[(size_t)bs * 16 + tid]; sT[16 + tid] = a.gt_trans[(size_t)bs * 16 + tid]; }
+        if (tid < 9) sC[tid] = a.cam_inv[tid];
+        if (tid >= 32 && tid < 48) sC[9 + tid - 32] = a.t_cr[tid - 32];
+    }
+    __syncthreads();
+    const float inv_bn = 1.0f / ((float)a.B * (float)N);
+    const float cnt0 = a.self_only ? 1.f : a.counts[0], cnt1 = a.self_only ? 1.f : a.counts[1];
+    const float den_of = a.self_only ? 1.f : fmaxf(a.counts[2], 1.0f), den_dyn = a.self_only ? 1.f : fmaxf(a.counts[3], 1.0f);
+    float part[LS_PARTIALS];
+#pragma unroll
+    for (int q = 0; q < LS_PARTIALS; ++q) part[q] = 0.f;
+    float et[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) et[q] = 0.f;
+    // soft-max normaliser of the sample's N * NB values exp(-d / alpha)
+    float emax = 0.f;
+    for (int g = 0; g < nwg; ++g) emax = fmaxf(emax, w.wgp[2 * g + 1]);
+    float zl = 0.f;
+    for (int e = tid; e < N * NB; e += LG_THREADS) zl += expf(w.ev[e] - emax);
+    const float zsum = lg_block_sum<LG_THREADS>(zl, red);
+    const float k_self = a.w_self * inv_bn;
+    // ---------------- pass 2 ----------------
+    for (int i = tid; i < N; i += LG_THREADS) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        const float ax = p1[i], ay = p1[N + i], az = p1[2 * N + i];
+        const float fx = fl[i], fy = fl[N + i], fz = fl[2 * N + i];
+        const float wx = ax + fx, wy = ay + fy, wz = az + fz;
+        const int am1 = w.am1[i];
+        if (am1 >= 0) {
+            gx += k_self * 2.0f * (wx - p2[am1]);
+            gy += k_self * 2.0f * (wy - p2[N + am1]);
+            gz += k_self * 2.0f * (wz - p2[2 * N + am1]);
+        }
+        float ss_i = 0.f;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const size_t e = (size_t)i * NB + q;
+            const int j = w.nbr[e];
+            const float sw = expf(w.ev[e] - emax) / zsum;
+            const float dx = fl[j] - fx, dy = fl[N + j] - fy, dz = fl[2 * N + j] - fz;
+            const float nrm = sqrtf(ls_sqnorm3(dx, dy, dz));
+            const float nw_ = (float)N * sw;
+            ss_i += nw_ * nrm;
+            const float s = nrm > 0.f ? k_self * nw_ / nrm : 0.f;
+            const float vx = s * dx, vy = s * dy, vz = s * dz;
+            gx -= vx; gy -= vy; gz -= vz;
+            w.gv[e * 3] = vx; w.gv[e * 3 + 1] = vy; w.gv[e * 3 + 2] = vz;
+        }
+        part[1] += ss_i;
+        const float pn = sqrtf(ls_sqnorm3(ax, ay, az));
+        const float fr = ((fx * ax + fy * ay) + fz * az) / pn;
+        const float rdv = a.vel1[o1 + i] * 0.1f - fr;
+        part[2] += fabsf(rdv);
+        const float sg = rdv > 0.f ? -1.f : (rdv < 0.f ? 1.f : 0.f);
+        gx += k_self * sg * ax / pn; gy += k_self * sg * ay / pn; gz += k_self * sg * az / pn;
+        if (a.self_only) {
+            if (a.d_mseg_pre) a.d_mseg_pre[o1 + i] = 0.f;
+        } else {
+            float e3[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const float pre = ((sT[4 * r] * ax + sT[4 * r + 1] * ay) + sT[4 * r + 2] * az) + sT[4 * r + 3];
+                const float gt = ((sT[16 + 4 * r] * ax + sT[16 + 4 * r + 1] * ay) + sT[16 + 4 * r + 2] * az) + sT[16 + 4 * r + 3];
+                e3[r] = pre - gt;
+            }
+            const float en = sqrtf(ls_sqnorm3(e3[0], e3[1], e3[2]));
+            part[3] += en;
+            if (en > 0.f) {
+                const float ke = a.w_em * inv_bn / en;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    et[4 * r] += ke * e3[r] * ax; et[4 * r + 1] += ke * e3[r] * ay;
+                    et[4 * r + 2] += ke * e3[r] * az; et[4 * r + 3] += ke * e3[r];
+                }
+            }
+            const float p = a.mseg_pre[o1 + i], y = a.mseg_gt[o1 + i];
+            const float bce = -(y * fmaxf(logf(p), -100.f) + (1.f - y) * fmaxf(logf(1.f - p), -100.f));
+            float dms = 0.f;
+            if (y == 0.f) { part[4] += bce; dms = 0.5f / cnt0; }
+            else if (y == 1.f) { part[5] += bce; dms = 0.5f / cnt1; }
+            if (a.d_mseg_pre) a.d_mseg_pre[o1 + i] = a.w_ms * dms * (p - y) / fmaxf((1.f - p) * p, 1e-12f);
+            const float u = a.radar_u[o1 + i] + a.opt[(o1 + i) * 2], v = a.radar_v[o1 + i] + a.opt[(o1 + i) * 2 + 1];
+            float ray[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ray[r] = (sC[3 * r] * u + sC[3 * r + 1] * v) + sC[3 * r + 2];
+            const float rn = sqrtf(ls_sqnorm3(ray[0], ray[1], ray[2]));
+            const float ux = ray[0] / rn, uy = ray[1] / rn, uz = ray[2] / rn;
+            const float *T = sC + 9;
+            float wc[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) wc[r] = ((T[4 * r] * wx + T[4 * r + 1] * wy) + T[4 * r + 2] * wz) + T[4 * r + 3];
+            const float cx = uy * wc[2] - uz * wc[1], cy = uz * wc[0] - ux * wc[2], cz = ux * wc[1] - uy * wc[0];
+            const float cn = sqrtf(ls_sqnorm3(cx, cy, cz));
+            const float om = 1.f - y;
+            const float div = cn - a.lower_bound;
+            if (div > 0.f) {
+                part[6] += om * div;
+                if (cn > 0.f) {
+                    const float ko = a.w_opt * om / den_of / cn;
+                    const float hx = cy * uz - cz * uy, hy = cz * ux - cx * uz, hz = cx * uy - cy * ux;
+                    gx += ko * ((T[0] * hx + T[4] * hy) + T[8] * hz);
+                    gy += ko * ((T[1] * hx + T[5] * hy) + T[9] * hz);
+                    gz += ko * ((T[2] * hx + T[6] * hy) + T[10] * hz);
+                }
+            }
+            const float od = 1.f - a.dyn_mask[o1 + i];
+            const float ex = a.gt_f[o3 + i] - fx, ey = a.gt_f[o3 + N + i] - fy, ez = a.gt_f[o3 + 2 * N + i] - fz;
+            const float dn = sqrtf(ls_sqnorm3(ex, ey, ez));
+            part[7] += od * dn;
+            if (dn > 0.f) {
+                const float kd = a.w_dyn * od / den_dyn / dn;
+                gx -= kd * ex; gy -= kd * ey; gz -= kd * ez;
+            }
+        }
+        w.g[i] = gx; w.g[N + i] = gy; w.g[2 * N + i] = gz;
+    }
+    __syncthreads();
+    // ---------------- pass 3: pushes binned by target, each bin sorted by id (the order a scan would visit them) ----------------
+    if (a.d_pred_f) {
+        for (int i = tid; i <= N; i += LG_THREADS) w.inv_end[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < N; j += LG_THREADS) if (w.arg2[j] >= 0) atomicAdd(&w.inv_end[w.arg2[j] + 1], 1);
+        for (int e = tid; e < N * NB; e += LG_THREADS) atomicAdd(&w.inv_end[w.nbr[e] + 1], 1);
+        __syncthreads();
+        {   // inclusive scan of inv_end[1 .. N]: a run of consecutive entries per thread, wave scan of the run sums, wave totals
+            const int run = (N + LG_THREADS - 1) / LG_THREADS;
+            const int i0 = 1 + tid * run, i1 = min(N, i0 + run - 1);
+            int s = 0;
+            for (int k = i0; k <= i1; ++k) s += w.inv_end[k];
+            int incl = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int u = __shfl_up(incl, off, 64); if ((tid & 63) >= off) incl += u; }
+            if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+            __syncthreads();
+            int before = incl - s;
+            for (int q = 0; q < (tid >> 6); ++q) before += wsum[q];
+            for (int k = i0; k <= i1; ++k) { before += w.inv_end[k]; w.inv_end[k] = before; }
+        }
+        __syncthreads();
+        for (int j = tid; j < N; j += LG_THREADS)
+            if (w.arg2[j] >= 0) w.inv_lst[atomicAdd(&w.inv_end[w.arg2[j]], 1)] = j;
+        for (int e = tid; e < N * NB; e += LG_THREADS) w.inv_lst[atomicAdd(&w.inv_end[w.nbr[e]], 1)] = N + e;
+        __syncthreads();
+        for (int i = tid; i < N; i += LG_THREADS) {
+            float gx = w.g[i], gy = w.g[N + i], gz = w.g[2 * N + i];
+            const float wx = p1[i] + fl[i], wy = p1[N + i] + fl[N + i], wz = p1[2 * N + i] + fl[2 * N + i];
+            const int s0 = i > 0 ? w.inv_end[i - 1] : 0, s1 = w.inv_end[i];
+            for (int u = s0 + 1; u < s1; ++u) {
+                const int v = w.inv_lst[u];
+                int q = u - 1;
+                while (q >= s0 && w.inv_lst[q] > v) { w.inv_lst[q + 1] = w.inv_lst[q]; --q; }
+                w.inv_lst[q + 1] = v;
+            }
+            for (int u = s0; u < s1; ++u) {
+                const int id = w.inv_lst[u];
+                if (id < N) {
+                    gx += k_self * 2.0f * (wx - p2[id]);
+                    gy += k_self * 2.0f * (wy - p2[N + id]);
+                    gz += k_self * 2.0f * (wz - p2[2 * N + id]);
+                } else {
+                    const size_t e = (size_t)(id - N);
+                    gx += w.gv[e * 3]; gy += w.gv[e * 3 + 1]; gz += w.gv[e * 3 + 2];
+                }
+            }
+            a.d_pred_f[o3 + i] = gx; a.d_pred_f[o3 + N + i] = gy; a.d_pred_f[o3 + 2 * N + i] = gz;
+        }
+    }
+    // ---------------- per-sample partial sums ----------------
+    if (tid == 0) {
+        float s = 0.f;
+        for (int g = 0; g < nwg; ++g) s += w.wgp[2 * g];
+        a.partials[(size_t)bs * LS_PARTIALS] = s;
+    }
+#pragma unroll
+    for (int q = 1; q < LS_PARTIALS; ++q) {
+        const float s = lg_block_sum<LG_THREADS>(part[q], red);
+        if (tid == 0) a.partials[(size_t)bs * LS_PARTIALS + q] = s;
+    }
+    if (a.d_pre_trans) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float s = lg_block_sum<LG_THREADS>(et[q], red);
+            if (tid == 0) a.d_pre_trans[(size_t)bs * 16 + q] = s;
+        }
+        if (tid < 4) a.d_pre_trans[(size_t)bs * 16 + 12 + tid] = 0.f;
+    }
+}
+
+static bool lg_nb_ok(int nb) { return nb == 4 || nb == 8 || nb == 16; }
+
+extern "C" long long cmf_radar_loss_workspace_nb(int b, int n, int num_nb)
+{
+    const long long head = 4 + (long long)b * LS_PARTIALS;
+    if (n <= LS_MAX_N && num_nb == LS_NB) return head;
+    return (head + 3) / 4 * 4 + (long long)b * (long long)lg_sample_floats(n, lg_nb_ok(num_nb) ? num_nb : 16);
+}
+
+extern "C" long long cmf_radar_loss_workspace(int b, int n) { return cmf_radar_loss_workspace_nb(b, n, LS_NB); }
+
+extern "C" long long cmf_radar_loss_workspace_tiled(int b, int n, int num_nb)
+{
+    const long long head = 4 + (long long)b * LS_PARTIALS;
+    return (head + 3) / 4 * 4 + (long long)b * (long long)lg_sample_floats(n, lg_nb_ok(num_nb) ? num_nb : 16);
+}
+
+static int radar_loss_impl(const cmf_radar_loss_desc *d, void *stream, bool force_tiled)
+{
+    CMF_CHECK_ARG(d && d->B >= 0 && lg_nb_ok(d->num_nb) && d->N > d->num_nb && d->N <= CMF_RADAR_LOSS_MAX_N);
     if (d->B == 0) return 0;
     CMF_CHECK_ARG(d->pc1 && d->pc2 && d->pred_f && d->vel1 && d->items && d->workspace && d->alpha > 0.f);
     CMF_CHECK_ARG(d->self_only || (d->gt_f && d->mseg_pre && d->mseg_gt && d->dyn_mask && d->radar_u && d->radar_v &&
@@ -476,15 +823,42 @@ extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream)
         hipLaunchKernelGGL(loss_count_kernel, dim3(1), dim3(1024), 0, st, (long long)d->B * d->N, d->mseg_gt, d->dyn_mask,
                            d->workspace);
     a.use_inv = d->N <= LS_INV_MAX_N ? 1 : 0;
-    const size_t lds = ((size_t)(LS_WORDS_PER_POINT + (a.use_inv ? LS_NB + 2 : 0)) * d->N + 4) * sizeof(float);
-    static CmfPerDevice attr_set;                       // the dynamic-LDS limit is per (function, device)
-    int attr_dev;
-    if (attr_set.need(attr_dev)) {
-        (void)hipFuncSetAttribute((const void *)loss_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  LS_WORDS_PER_POINT * LS_MAX_N * (int)sizeof(float));
-        attr_set.done(attr_dev);
+    if (!force_tiled && d->N <= LS_MAX_N && d->num_nb == LS_NB) {
+        // a sample in one workgroup's LDS (the reference's training size, N = 256)
+        const size_t lds = ((size_t)(LS_WORDS_PER_POINT + (a.use_inv ? LS_NB + 2 : 0)) * d->N + 4) * sizeof(float);
+        static CmfPerDevice attr_set;                   // the dynamic-LDS limit is per (function, device)
+        int attr_dev;
+        if (attr_set.need(attr_dev)) {
+            (void)hipFuncSetAttribute((const void *)loss_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      LS_WORDS_PER_POINT * LS_MAX_N * (int)sizeof(float));
+            attr_set.done(attr_dev);
+        }
+        hipLaunchKernelGGL(loss_sample_kernel, dim3(d->B), dim3(LS_THREADS), lds, st, a);
+    } else {
+        // tiled form: the caller sized the workspace with cmf_radar_loss_workspace_nb(B, N, num_nb)
+        const long long head = (4 + (long long)d->B * LS_PARTIALS + 3) / 4 * 4;
+        float *ws = d->workspace + head;
+        const size_t stride = lg_sample_floats(d->N, d->num_nb);
+        const dim3 grid_nn((d->N + LG_TILE - 1) / LG_TILE, d->B);
+        switch (d->num_nb) {
+        case 4:
+            hipLaunchKernelGGL(loss_nn_kernel<4>, grid_nn, dim3(LG_TILE), 0, st, a, ws, stride);
+            hipLaunchKernelGGL(loss_big_sample_kernel<4>, dim3(d->B), dim3(LG_THREADS), 0, st, a, ws, stride);
+            break;
+        case 8:
+            hipLaunchKernelGGL(loss_nn_kernel<8>, grid_nn, dim3(LG_TILE), 0, st, a, ws, stride);
+            hipLaunchKernelGGL(loss_big_sample_kernel<8>, dim3(d->B), dim3(LG_THREADS), 0, st, a, ws, stride);
+            break;
+        default:
+            hipLaunchKernelGGL(loss_nn_kernel<16>, grid_nn, dim3(LG_TILE), 0, st, a, ws, stride);
+            hipLaunchKernelGGL(loss_big_sample_kernel<16>, dim3(d->B), dim3(LG_THREADS), 0, st, a, ws, stride);
+            break;
+        }
     }
-    hipLaunchKernelGGL(loss_sample_kernel, dim3(d->B), dim3(LS_THREADS), lds, st, a);
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, a, d->items);
     return cmf_launch_status();
 }
+
+extern "C" int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream) { return radar_loss_impl(d, stream, false); }
+
+extern "C" int cmf_radar_loss_tiled(const cmf_radar_loss_desc *d, void *stream) { return radar_loss_impl(d, stream, true); }

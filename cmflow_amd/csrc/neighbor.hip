@@ -400,6 +400,7 @@ __global__ __launch_bounds__(256) void bq_grid_query_kernel(int n, int m, float 
 constexpr int BQB_WAVES = 4;                 // waves per workgroup (independent of each other)
 constexpr int BQB_CHUNK = 256;               // points per register chunk (4 per lane)
 constexpr int BQB_MAX_N = 1024;
+constexpr size_t BQB_LDS_LIMIT = 64 * 1024;     // dynamic LDS of one launch (no hipFuncSetAttribute)
 
 template <int NCH>
 struct BqbCloud { float x[NCH][4], y[NCH][4], z[NCH][4]; };
@@ -692,6 +693,18 @@ extern "C" int cmf_ball_query(int b, int n, int m, float radius, int nsample,
     return cmf_launch_status();
 }
 
+// whether cmf_ball_query_multi takes this set of scales (cloud size, list lengths, LDS of one wave's lists at G = 1)
+bool cmf_ball_query_multi_takes(int n, int nq, const int *nsamples)
+{
+    if (n <= 0 || n > BQB_MAX_N || nq < 1 || nq > 4) return false;
+    size_t tot = 0;
+    for (int q = 0; q < nq; ++q) {
+        if (nsamples[q] <= 0 || nsamples[q] > 256) return false;
+        tot += (size_t)nsamples[q];
+    }
+    return (size_t)BQB_WAVES * tot * sizeof(int) <= BQB_LDS_LIMIT;
+}
+
 // nq <= 4 ball queries (radii[q], nsamples[q]) -> idx[c][q] (B, M, nsamples[q]) over the same centres and cloud, for nclouds <= 2
 // (centres, cloud) pairs of equal geometry, in ONE launch; every list equals cmf_ball_query's for that scale.  zero_empty != 0: the
 // rows of empty balls are written as zeros (a caller that does not pre-zero idx).  Clouds of up to 1024 points (the ballot kernel).
@@ -716,6 +729,10 @@ extern "C" int cmf_ball_query_multi(int b, int n, int m, int nq, const float *ra
         for (int q = 0; q < nq; ++q) { CMF_CHECK_ARG(idx[c * nq + q]); a.idx[c][q] = idx[c * nq + q]; }
     }
     a.G = bqb_group(b * nclouds, m, nsmax);
+    // a wave's lists of all nq scales for its G centres live in LDS: G shrinks until the workgroup fits the 64 KB a launch may ask for
+    // without an attribute (4 scales of 256 entries fit at G = 4); callers with longer lists use the single-scale queries
+    while (a.G > 1 && (size_t)BQB_WAVES * a.G * tot * sizeof(int) > BQB_LDS_LIMIT) --a.G;
+    CMF_CHECK_ARG((size_t)BQB_WAVES * a.G * tot * sizeof(int) <= BQB_LDS_LIMIT);
     const dim3 grid(cmf_divup(m, a.G * BQB_WAVES), b, nclouds), block(BQB_WAVES * CMF_WAVE);
     const size_t lds = (size_t)BQB_WAVES * a.G * tot * sizeof(int);
     hipStream_t st = (hipStream_t)stream;

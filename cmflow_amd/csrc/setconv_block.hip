@@ -15,6 +15,7 @@
 
 bool cmf_setconv_chain_supported(int N, int S, int O1, int C2, int C3, long long M);
 long long cmf_setconv_chain_waves(long long M, int backward);
+bool cmf_ball_query_multi_takes(int n, int nq, const int *nsamples);      // csrc/neighbor.hip
 
 namespace {
 
@@ -504,7 +505,9 @@ extern "C" int cmf_setconv_queries(int n, const cmf_setconv_desc *descs, void *s
             }
             if (same) nclouds = 2;
         }
-        if (d0.N > 1024) {                                    // large clouds: the single-scale queries (cell grid)
+        int ns_chk[4];
+        for (int q = 0; q < nq; ++q) ns_chk[q] = descs[i + q].S;
+        if (!cmf_ball_query_multi_takes(d0.N, nq, ns_chk)) {  // large clouds (cell grid) / lists too long for one launch: the single-scale queries
             for (int q = 0; q < nq * nclouds; ++q) {
                 const cmf_setconv_desc &d = descs[i + q];
                 const Layout L = make_layout(&d, d.saved, nullptr, false);
@@ -1112,18 +1115,57 @@ extern "C" int cmf_setconv_forward_bodies_batched(int n, const cmf_setconv_desc 
     return (n >= 0 && n <= 16 && descs && (body_batchable(n, descs) || infer_batchable(n, descs))) ? 1 : 0;
 }
 
+// The batched forms run every block on streams[0].  A caller that prepared block i's inputs on streams[i] (the contract of the
+// per-chain form: INTEGRATION.md "fork / join") is still ordered: streams[0] waits for what is queued on every other distinct stream
+// before the batched launches, and those streams wait for streams[0] behind them.  With all entries equal (the Python host, which asks
+// cmf_setconv_*_bodies_batched first) nothing is recorded.
+static int batched_order(int n, void *const *streams, bool before)
+{
+    hipStream_t s0 = (hipStream_t)streams[0];
+    hipEvent_t back = nullptr;
+    for (int i = 1; i < n; ++i) {
+        hipStream_t si = (hipStream_t)streams[i];
+        if (si == s0) continue;
+        bool seen = false;
+        for (int j = 1; j < i; ++j) seen = seen || streams[j] == streams[i];
+        if (seen) continue;
+        if (before) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+            if (hipEventRecord(ev, si) != hipSuccess || hipStreamWaitEvent(s0, ev, 0) != hipSuccess) { (void)hipEventDestroy(ev); return (int)hipGetLastError(); }
+            (void)hipEventDestroy(ev);                  // (released by the runtime once the recorded work has completed)
+        } else {
+            if (!back) {
+                if (hipEventCreateWithFlags(&back, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+                if (hipEventRecord(back, s0) != hipSuccess) { (void)hipEventDestroy(back); return (int)hipGetLastError(); }
+            }
+            if (hipStreamWaitEvent(si, back, 0) != hipSuccess) { (void)hipEventDestroy(back); return (int)hipGetLastError(); }
+        }
+    }
+    if (back) (void)hipEventDestroy(back);
+    return 0;
+}
+
 extern "C" int cmf_setconv_forward_heads_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
     CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
-    if (body_batchable(n, descs)) return setconv_forward_bodies_batch(n, descs, (hipStream_t)streams[0]);
-    if (infer_batchable(n, descs)) return setconv_infer_bodies_batch(n, descs, (hipStream_t)streams[0]);
+    const bool body = body_batchable(n, descs);
+    if (body || infer_batchable(n, descs)) {
+        CMF_TRY(batched_order(n, streams, true));
+        CMF_TRY(body ? setconv_forward_bodies_batch(n, descs, (hipStream_t)streams[0]) : setconv_infer_bodies_batch(n, descs, (hipStream_t)streams[0]));
+        return batched_order(n, streams, false);
+    }
     return setconv_multi(n, descs, streams, false, 1);
 }
 
 extern "C" int cmf_setconv_backward_bodies_multi(int n, const cmf_setconv_desc *descs, void *const *streams)
 {
     CMF_CHECK_ARG(n >= 0 && n <= 16 && (n == 0 || (descs && streams)));
-    if (body_batchable_bwd(n, descs)) return setconv_backward_bodies_batch(n, descs, (hipStream_t)streams[0]);
+    if (body_batchable_bwd(n, descs)) {
+        CMF_TRY(batched_order(n, streams, true));
+        CMF_TRY(setconv_backward_bodies_batch(n, descs, (hipStream_t)streams[0]));
+        return batched_order(n, streams, false);
+    }
     return setconv_multi(n, descs, streams, true, 2);
 }
 

@@ -16,7 +16,12 @@ import torch.distributed as dist
 
 class FlatGradBucket:
     def __init__(self, module: torch.nn.Module):
-        self.params = [p for p in module.parameters() if p.requires_grad and not getattr(p, '_cmf_unused', False)]
+        allp = list(module.parameters())
+        keep = [i for i, p in enumerate(allp) if p.requires_grad and not getattr(p, '_cmf_unused', False)]
+        self.params = [allp[i] for i in keep]
+        # position of every bucket parameter in module.parameters() order, and that list's length: an optimizer checkpoint saved over
+        # ALL parameters of the module (the reference's torch.optim.Adam(net.parameters()), main.py:107) is indexed that way
+        self.module_index, self.module_params = keep, len(allp)
         n = sum(p.numel() for p in self.params)
         p0 = self.params[0]
         self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
@@ -131,27 +136,43 @@ class FlatAdam(torch.optim.Optimizer):
         return d
 
     def load_state_dict(self, d):
-        """Accepts this class's own format (`flat`) and a torch.optim.Adam checkpoint over the same parameters in the same order (per-
-        parameter `state` with exp_avg / exp_avg_sq / step -- what the previous TrainStep or a CPU run saved): the moments are scattered
-        into the flat arrays.  Anything else raises: restarting the moments silently would change the training run."""
+        """Accepts this class's own format (`flat`) and a torch.optim.Adam checkpoint -- per-parameter `state` with exp_avg /
+        exp_avg_sq / step -- saved over the bucket's parameters in bucket order (what the previous TrainStep saved) OR over all of
+        the module's parameters (the reference's `torch.optim.Adam(net.parameters())`, main.py:107, or an oracle / CPU run): its
+        indices are then positions in module.parameters(); the parameters outside the bucket (never used, frozen) have no state in
+        such a checkpoint either and are skipped.  The moments are scattered into the flat arrays.  Anything else raises:
+        restarting the moments silently would change the training run."""
         d = dict(d)
         flat = d.pop("flat", None)
         per_param = d.get("state") or {}
-        super().load_state_dict(dict(d, state={}))
-        if len(self.param_groups) != 1:
-            raise ValueError("FlatAdam: the checkpoint has %d parameter groups, one is supported" % len(self.param_groups))
+        ps = self.bucket.params
+        groups = d.get("param_groups")
+        if groups is None or len(groups) != 1:
+            raise ValueError("FlatAdam: the checkpoint has %s parameter groups, one is supported" % (len(groups) if groups is not None else "no"))
+        saved = list(groups[0]["params"])
+        if len(saved) == len(ps):
+            key_of = list(saved)                              # bucket order
+        elif len(saved) == self.bucket.module_params:
+            key_of = [saved[i] for i in self.bucket.module_index]
+            extra = set(per_param.keys()) - set(key_of)
+            if extra:
+                raise ValueError("FlatAdam: the checkpoint holds optimizer state for %d parameters outside the gradient bucket" % len(extra))
+        else:
+            raise ValueError("FlatAdam: the checkpoint covers %d parameters; the bucket holds %d of the module's %d"
+                             % (len(saved), len(ps), self.bucket.module_params))
+        group = dict(groups[0], params=list(range(len(ps))))
+        super().load_state_dict(dict(d, state={}, param_groups=[group]))
         if flat is not None:
             self.exp_avg.copy_(flat["exp_avg"]); self.exp_avg_sq.copy_(flat["exp_avg_sq"]); self.steps = int(flat["steps"])
             return
         if not per_param:
             return                                           # a fresh optimizer's checkpoint: nothing to restore
-        ps = self.bucket.params
-        if sorted(per_param.keys()) != list(range(len(ps))):
+        if not all(k in per_param for k in key_of):
             raise ValueError("FlatAdam: the checkpoint's per-parameter state does not cover the bucket's %d parameters" % len(ps))
         steps = set()
         off = 0
         for i, p in enumerate(ps):
-            st = per_param[i]
+            st = per_param[key_of[i]]
             n = p.numel()
             if st["exp_avg"].numel() != n:
                 raise ValueError("FlatAdam: state %d has %d elements, the parameter %d" % (i, st["exp_avg"].numel(), n))

@@ -3,12 +3,14 @@
 Mirrors ``losses/radar_loss.py`` (RadarFlowLoss :260-292 and its components :17-258) and the label prep of
 ``main_util.py`` (:209-225 extract_dynamic_from_fg, :253-265 mseg_label_RRV).
 
-ONE execution path: ``RadarFlowLoss`` runs the fused HIP kernel ``cmf_radar_loss`` (csrc/loss.hip: all seven terms and their
-gradients w.r.t. the network outputs in one call, 3 launches), ``make_labels`` runs ``cmf_pseudo_labels`` (csrc/eval.hip).  The
-kernel keeps a sample's working set in LDS, which bounds the cloud size (9 <= N <= 704; the reference trains at N = 256): outside
-that range, for another neighbour count than the reference's 8, or on CPU tensors the call RAISES -- there is no torch-op
-fallback in the product (the torch-op restatement of the terms is a test fixture, tests/loss_torch.py).  Unlike the reference
-the loss items stay on the device (no 8 ``.item()`` host syncs per step, radar_loss.py:156-159,285-288) until the caller asks.
+ONE execution path: ``RadarFlowLoss`` runs the fused HIP kernels behind ``cmf_radar_loss`` (csrc/loss.hip: all seven terms and
+their gradients w.r.t. the network outputs in one call), ``make_labels`` runs ``cmf_pseudo_labels`` (csrc/eval.hip).  Like the
+reference's loss (radar_loss.py:17-97) the call takes any cloud size: up to 704 points with the reference's 8 smoothness
+neighbours (it trains at N = 256) a sample lives in one workgroup's LDS (3 launches); larger clouds and num_nb in {4, 16} take
+the tiled kernels of the same file (the cloud streamed through LDS, a sample's lists in a workspace; 4 launches) -- same terms,
+same per-point arithmetic.  On CPU tensors the call RAISES: there is no torch-op fallback in the product (the torch-op
+restatement of the terms is a test fixture, tests/loss_torch.py).  Unlike the reference the loss items stay on the device (no 8
+``.item()`` host syncs per step, radar_loss.py:156-159,285-288) until the caller asks.
 """
 import ctypes
 
@@ -38,7 +40,8 @@ def make_labels(batch, vr_thres):
 
 
 
-NATIVE_MIN_N, NATIVE_MAX_N = 9, 704          # csrc/loss.hip: a sample's working set lives in LDS
+MAX_N = 65536                                # include/cmflow_hip.h CMF_RADAR_LOSS_MAX_N
+NUM_NB = (4, 8, 16)                          # csrc/loss.hip: the neighbour counts the kernels are instantiated for
 ITEM_KEYS = ('Loss', 'smoothnessLoss', 'chamferLoss', 'veloLoss', 'egoLoss', 'maskLoss', 'opticalLoss', 'superviseLoss')
 
 
@@ -71,7 +74,9 @@ class RadarFlowLossFn(Function):
         d.w_self, d.w_em, d.w_ms, d.w_opt, d.w_dyn = hyper["w"]
         d.zeta, d.alpha, d.num_nb, d.lower_bound = hyper["zeta"], hyper["alpha"], hyper["num_nb"], hyper["lower_bound"]
         items = torch.empty(9, dtype=f32, device=dev)
-        ws = torch.empty(_lib.lib().cmf_radar_loss_workspace(B, N), dtype=f32, device=dev)
+        tiled = bool(hyper.get("tiled", False))              # tests: the tiled kernels at a size the LDS kernel would take
+        size = _lib.lib().cmf_radar_loss_workspace_tiled if tiled else _lib.lib().cmf_radar_loss_workspace_nb
+        ws = torch.empty(size(B, N, int(hyper["num_nb"])), dtype=f32, device=dev)
         d.items, d.workspace = items.data_ptr(), ws.data_ptr()
         if need:
             g_f = torch.empty(B, 3, N, dtype=f32, device=dev)
@@ -81,7 +86,8 @@ class RadarFlowLossFn(Function):
             d.d_pre_trans = g_t.data_ptr() if g_t is not None else None
             d.d_mseg_pre = g_m.data_ptr() if g_m is not None else None
             ctx.grads = (g_f, g_t, g_m)
-        _lib.check(_lib.lib().cmf_radar_loss(ctypes.addressof(d), _lib.stream_ptr()), "cmf_radar_loss")
+        call = _lib.lib().cmf_radar_loss_tiled if tiled else _lib.lib().cmf_radar_loss
+        _lib.check(call(ctypes.addressof(d), _lib.stream_ptr()), "cmf_radar_loss")
         ctx.mark_non_differentiable(items)
         return items[0], items
 
@@ -89,10 +95,14 @@ class RadarFlowLossFn(Function):
     def backward(ctx, g_total, _g_items):
         g_f, g_t, g_m = ctx.grads
         need = ctx.needs_input_grad
-        gs = [g for g, n in ((g_f, need[0]), (g_t, need[1]), (g_m, need[2])) if n and g is not None]
-        torch._foreach_mul_(gs, g_total)                        # one launch for the three (the buffers are this node's own)
-        return (g_f if need[0] else None, g_t if (need[1] and g_t is not None) else None,
-                g_m if (need[2] and g_m is not None) else None, None, None)
+        live = [i for i, (g, n) in enumerate(((g_f, need[0]), (g_t, need[1]), (g_m, need[2]))) if n and g is not None]
+        # out of place (one launch for the three): the saved buffers stay what the kernel wrote, so a second backward through
+        # the node (retain_graph=True) scales them by ITS incoming gradient, not by the product of both
+        scaled = torch._foreach_mul([(g_f, g_t, g_m)[i] for i in live], g_total)
+        out = [None, None, None]
+        for i, g in zip(live, scaled):
+            out[i] = g
+        return out[0], out[1], out[2], None, None
 
 
 SELF_ITEM_KEYS = ITEM_KEYS[:4]
@@ -102,6 +112,8 @@ class RadarFlowLoss(Module):
     """radar_loss.py:260-292 for model in {'cmflow','cmflow_t'}; weights (1,1,1,0.1,1) (:262); hyper-parameters of the terms as the
     reference constructs them (zeta = 0.005 :20, alpha = 0.5 / num_nb = 8 :63, lower_bound = 0.25 :210).
     Returns (total_loss, items) with items as 0-d device tensors (call .item() when needed)."""
+
+    tiled = False                # tests: force the tiled kernels (cmf_radar_loss_tiled) at any size
 
     def __init__(self, camera_projection, t_camera_radar, w_self=1, w_em=1, w_ms=1, w_opt=0.1, w_dyn=1,
                  zeta=0.005, alpha=0.5, num_nb=8, lower_bound=0.25):
@@ -116,9 +128,9 @@ class RadarFlowLoss(Module):
         N = pc1.shape[2]
         if not pc1.is_cuda:
             raise RuntimeError("cmflow_amd.losses.RadarFlowLoss runs on the GPU only (got %s tensors)" % pc1.device)
-        if not (NATIVE_MIN_N <= N <= NATIVE_MAX_N) or self.num_nb != 8:
-            raise RuntimeError("cmf_radar_loss keeps a sample in LDS: %d <= N <= %d points and num_nb = 8 (got N = %d, num_nb = %d)"
-                               % (NATIVE_MIN_N, NATIVE_MAX_N, N, self.num_nb))
+        if self.num_nb not in NUM_NB or not (self.num_nb < N <= MAX_N):
+            raise RuntimeError("cmf_radar_loss: num_nb in %s and num_nb < N <= %d points (got N = %d, num_nb = %d)"
+                               % (NUM_NB, MAX_N, N, self.num_nb))
 
     def forward(self, pc1, pc2, pred_f, vel1, gt_f=None, pre_trans=None, mseg_pre=None, gt_trans=None, mseg_gt=None,
                 dyn_mask=None, radar_u=None, radar_v=None, opt=None):
@@ -127,13 +139,13 @@ class RadarFlowLoss(Module):
         self._check(pc1)
         if gt_f is None:
             hyper = dict(w=(self.w_self, 0.0, 0.0, 0.0, 0.0), zeta=self.zeta, alpha=self.alpha, num_nb=self.num_nb,
-                         lower_bound=0.0, self_only=True)
+                         lower_bound=0.0, self_only=True, tiled=self.tiled)
             total, items = RadarFlowLossFn.apply(pred_f, None, None, dict(pc1=pc1, pc2=pc2, vel1=vel1), hyper)
             return total, {k: items[i + 1] for i, k in enumerate(SELF_ITEM_KEYS)}
         data = dict(pc1=pc1, pc2=pc2, gt_f=gt_f, vel1=vel1, gt_trans=gt_trans, mseg_gt=mseg_gt.to(pc1.dtype),
                     dyn_mask=dyn_mask.to(pc1.dtype), radar_u=radar_u, radar_v=radar_v, opt=opt,
                     camera_inverse=self.camera_inverse, t_camera_radar=self.t_camera_radar)
         hyper = dict(w=(self.w_self, self.w_em, self.w_ms, self.w_opt, self.w_dyn), zeta=self.zeta, alpha=self.alpha,
-                     num_nb=self.num_nb, lower_bound=self.lower_bound)
+                     num_nb=self.num_nb, lower_bound=self.lower_bound, tiled=self.tiled)
         total, items = RadarFlowLossFn.apply(pred_f, pre_trans, mseg_pre, data, hyper)
         return total, {k: items[i + 1] for i, k in enumerate(ITEM_KEYS)}

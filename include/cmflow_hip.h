@@ -574,7 +574,13 @@ int cmf_unstack_first_conv_grad(int n_w, int O1, int cin, int n_tail, int Kp, co
  * reference reads 8 loss items back with .item(), :156-159,285-288).  Layouts are the reference's:
  * clouds/flows (B,3,N), per-point scalars (B,N), opt (B,N,2), transforms (B,4,4) row-major.
  * items[9] = total, Loss (self-supervised sum), smoothnessLoss, chamferLoss, veloLoss, egoLoss, maskLoss,
- * opticalLoss, superviseLoss.  Gradient outputs may be NULL (evaluation).  9 <= N <= 704, num_nb == 8. */
+ * opticalLoss, superviseLoss.  Gradient outputs may be NULL (evaluation).
+ * Cloud size: num_nb < N <= CMF_RADAR_LOSS_MAX_N, num_nb in {4, 8, 16} (the reference has no limit, radar_loss.py:60-97).
+ * N <= 704 with num_nb == 8 (the reference's training size is 256) keeps a sample in one workgroup's LDS; everything else
+ * takes the tiled form (the cloud streamed through LDS in tiles of 256 points, a sample's lists in `workspace`): same terms,
+ * same per-point arithmetic, the per-sample sums folded in another fixed order.  cmf_radar_loss_tiled forces the tiled
+ * form at any size (tests compare the two forms on the same input). */
+#define CMF_RADAR_LOSS_MAX_N 65536
 typedef struct cmf_radar_loss_desc {
     int B, N;
     const float *pc1, *pc2, *pred_f, *gt_f;                                    /* (B,3,N) */
@@ -589,10 +595,13 @@ typedef struct cmf_radar_loss_desc {
                                   the inputs of the other four may be NULL, their items are reported as 0 */
     float *items;                                                              /* [9] */
     float *d_pred_f, *d_pre_trans, *d_mseg_pre;                                /* (B,3,N), (B,4,4), (B,N) or NULL */
-    float *workspace;                                                          /* cmf_radar_loss_workspace floats */
+    float *workspace;                                                          /* cmf_radar_loss_workspace_nb floats */
 } cmf_radar_loss_desc;
-long long cmf_radar_loss_workspace(int b, int n);
+long long cmf_radar_loss_workspace(int b, int n);                  /* = cmf_radar_loss_workspace_nb(b, n, 8) */
+long long cmf_radar_loss_workspace_nb(int b, int n, int num_nb);   /* floats; num_nb as in the descriptor */
 int cmf_radar_loss(const cmf_radar_loss_desc *d, void *stream);
+int cmf_radar_loss_tiled(const cmf_radar_loss_desc *d, void *stream);   /* workspace: cmf_radar_loss_workspace_tiled */
+long long cmf_radar_loss_workspace_tiled(int b, int n, int num_nb);
 
 /* ---- evaluation metrics of one batch ------------------------------------------------------
  * utils/eval_util.py: eval_scene_flow :42-86, eval_motion_seg :104-118, eval_trans_RPE :89-102 (with

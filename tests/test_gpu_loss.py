@@ -53,9 +53,15 @@ def _stable_topk(x, k, dim=-1, largest=False, sorted=True):
     return v.narrow(dim, 0, k), i.narrow(dim, 0, k)
 
 
-def _oracle(batch, pred_f, pre_trans, mseg_pre, dtype, monkeypatch=None):
+_SMOOTHNESS = TO.smoothness
+
+
+def _oracle(batch, pred_f, pre_trans, mseg_pre, dtype, monkeypatch=None, num_nb=8):
     if monkeypatch is not None:
         monkeypatch.setattr(torch, "topk", _stable_topk)
+    if num_nb != 8:                                            # radar_loss.py:63: a constructor argument of the smoothness term
+        import functools
+        monkeypatch.setattr(TO, "smoothness", functools.partial(_SMOOTHNESS, num_nb=num_nb))
     if dtype == torch.float64:
         monkeypatch.setattr(TO, "index_points_group", _gather_group)
     b = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
@@ -69,12 +75,25 @@ def _oracle(batch, pred_f, pre_trans, mseg_pre, dtype, monkeypatch=None):
 
 @pytest.mark.parametrize("B,N,seed,real_like", [(4, 256, 1, False), (2, 256, 2, True), (3, 100, 3, False),
                                                 (1, 300, 4, False), (2, 640, 5, False), (64, 256, 6, False),
-                                                (1, 512, 7, True), (1, 520, 8, False)])     # 512 / 520: last size with / first without the inverse list of pass 3
+                                                (1, 512, 7, True), (1, 520, 8, False),      # 512 / 520: last size with / first without the inverse list of pass 3
+                                                (2, 704, 9, False), (2, 705, 10, False),   # last size in LDS / first of the tiled kernels
+                                                (1, 1024, 11, True), (2, 4096, 12, False)])
 def test_fused_loss_matches_oracle(dev, monkeypatch, B, N, seed, real_like):
+    _check_against_oracle(dev, monkeypatch, B, N, seed, real_like)
+
+
+@pytest.mark.parametrize("num_nb,N,tiled", [(4, 256, False), (16, 256, False), (16, 1000, False), (8, 256, True), (8, 100, True)])
+def test_fused_loss_other_neighbour_counts_and_forced_tiling(dev, monkeypatch, num_nb, N, tiled):
+    """radar_loss.py:63: num_nb is a constructor argument; the tiled kernels also at sizes the LDS kernel takes."""
+    _check_against_oracle(dev, monkeypatch, 2, N, 31 + num_nb, False, num_nb=num_nb, tiled=tiled)
+
+
+def _check_against_oracle(dev, monkeypatch, B, N, seed, real_like, num_nb=8, tiled=False):
     batch, pred_f, pre_trans, mseg_pre = _case(B, N, seed, real_like)
-    ref_total, ref_items, ref_g32 = _oracle(batch, pred_f, pre_trans, mseg_pre, torch.float32, monkeypatch)
-    _, _, ref_g = _oracle(batch, pred_f, pre_trans, mseg_pre, torch.float64, monkeypatch)
-    crit = RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR).to(dev)
+    ref_total, ref_items, ref_g32 = _oracle(batch, pred_f, pre_trans, mseg_pre, torch.float32, monkeypatch, num_nb)
+    _, _, ref_g = _oracle(batch, pred_f, pre_trans, mseg_pre, torch.float64, monkeypatch, num_nb)
+    crit = RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR, num_nb=num_nb).to(dev)
+    crit.tiled = tiled
     bd = {k: v.to(dev) for k, v in batch.items()}
     dyn, mseg = make_labels(bd, 0.3)
     pf, pt, pm = (x.to(dev).requires_grad_(True) for x in (pred_f, pre_trans, mseg_pre))
@@ -126,6 +145,44 @@ def test_fused_loss_matches_torch_terms_and_is_reproducible(dev):
         np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=5e-3, atol=1e-4 * float(y.abs().max()))
 
 
+@pytest.mark.parametrize("B,N,seed", [(4, 256, 41), (2, 640, 42), (3, 77, 43)])
+def test_tiled_loss_equals_the_lds_kernel(dev, B, N, seed):
+    """The two forms of cmf_radar_loss on the same input: same decisions, same per-point arithmetic; only the soft-max normaliser and
+    the per-sample sums are folded in another order (a few ulp)."""
+    batch, pred_f, pre_trans, mseg_pre = _case(B, N, seed)
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    dyn, mseg = make_labels(bd, 0.3)
+    out = []
+    for tiled in (False, True, True):
+        crit = RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR).to(dev)
+        crit.tiled = tiled
+        pf, pt, pm = (x.to(dev).requires_grad_(True) for x in (pred_f, pre_trans, mseg_pre))
+        total, items = crit(bd["pc1"], bd["pc2"], pf, bd["ft1"][:, 0], bd["flow_label"].transpose(2, 1), pt, pm,
+                            bd["gt_trans"], mseg, dyn, bd["radar_u"], bd["radar_v"], bd["opt_flow"])
+        total.backward()
+        out.append((total.detach(), torch.stack([items[k].detach() for k in ITEM_KEYS]), pf.grad, pt.grad, pm.grad))
+    a, b, b2 = out
+    assert all(torch.equal(x, y) for x, y in zip(b, b2))        # the tiled form is reproducible (integer atomics only)
+    assert torch.equal(a[4], b[4])                              # d mseg_pre: per-point, no sums involved
+    for x, y in zip(a[:4], b[:4]):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=2e-5, atol=2e-6 * float(x.abs().max()))
+
+
+def test_loss_backward_twice_scales_by_each_incoming_gradient(dev):
+    """backward used to scale the saved buffers in place -- a second backward returned g * g1 * g2."""
+    batch, pred_f, pre_trans, mseg_pre = _case(2, 128, 51)
+    bd = {k: v.to(dev) for k, v in batch.items()}
+    dyn, mseg = make_labels(bd, 0.3)
+    crit = RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR).to(dev)
+    pf, pt, pm = (x.to(dev).requires_grad_(True) for x in (pred_f, pre_trans, mseg_pre))
+    total, _ = crit(bd["pc1"], bd["pc2"], pf, bd["ft1"][:, 0], bd["flow_label"].transpose(2, 1), pt, pm,
+                    bd["gt_trans"], mseg, dyn, bd["radar_u"], bd["radar_v"], bd["opt_flow"])
+    g1 = torch.autograd.grad(2.0 * total, (pf, pt, pm), retain_graph=True)
+    g2 = torch.autograd.grad(3.0 * total, (pf, pt, pm))
+    for x, y in zip(g1, g2):
+        assert torch.equal(x * 1.5, y)                          # exact: both are (kernel output) * a small power-of-two-ish scalar
+
+
 def test_fused_loss_forward_only_and_bounds(dev):
     batch, pred_f, pre_trans, mseg_pre = _case(2, 256, 21)
     bd = {k: v.to(dev) for k, v in batch.items()}
@@ -137,20 +194,28 @@ def test_fused_loss_forward_only_and_bounds(dev):
                             bd["opt_flow"])
     ref_total, _, _ = _oracle(batch, pred_f, pre_trans, mseg_pre, torch.float32)
     assert abs(total.item() - ref_total) < 1e-4 * max(1.0, abs(ref_total))
-    # the C-ABI refuses cloud sizes whose working set does not fit LDS instead of computing something else
+    # the C-ABI refuses what it has no kernel for instead of computing something else: a cloud no larger than the neighbour count
+    # (the reference's topk(num_nb + 1) fails there too), a neighbour count outside {4, 8, 16}, more than CMF_RADAR_LOSS_MAX_N points
     import ctypes
     from cmflow_amd import _lib
     d = _lib.RadarLossDesc()
-    d.B, d.N, d.num_nb = 1, 705, 8
+    d.B, d.N, d.num_nb = 1, 8, 8
     assert _lib.lib().cmf_radar_loss(ctypes.addressof(d), None) != 0
-    d.N = 8
+    d.N, d.num_nb = 256, 5
     assert _lib.lib().cmf_radar_loss(ctypes.addressof(d), None) != 0
-    # ... and so does the module: one loss path, no torch-op fallback (larger clouds, another neighbour count, CPU tensors)
-    big = synth.make_batch(1, 720, seed=5, train_extras=True)
-    with pytest.raises(RuntimeError, match="keeps a sample in LDS"):
-        crit(big["pc1"].to(dev), big["pc2"].to(dev), torch.zeros(1, 3, 720, device=dev), big["ft1"][:, 0].to(dev))
+    d.N, d.num_nb = 65537, 8
+    assert _lib.lib().cmf_radar_loss(ctypes.addressof(d), None) != 0
+    # ... and so does the module: one loss path, no torch-op fallback (CPU tensors, unsupported neighbour counts)
     with pytest.raises(RuntimeError, match="GPU only"):
         crit(batch["pc1"], batch["pc2"], pred_f, batch["ft1"][:, 0])
-    with pytest.raises(RuntimeError, match="num_nb = 8"):
-        RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR, num_nb=4).to(dev)(
+    with pytest.raises(RuntimeError, match="num_nb in"):
+        RadarFlowLoss(synth.CAMERA_PROJECTION, synth.T_CAMERA_RADAR, num_nb=5).to(dev)(
             bd["pc1"], bd["pc2"], pred_f.to(dev), bd["ft1"][:, 0])
+    # the self-supervised form (model 'raflow') on a cloud the LDS kernel cannot hold
+    big = synth.make_batch(1, 720, seed=5, train_extras=True)
+    pf = (0.1 * torch.randn(1, 3, 720)).to(dev).requires_grad_(True)
+    total, items = crit(big["pc1"].to(dev), big["pc2"].to(dev), pf, big["ft1"][:, 0].to(dev))
+    total.backward()
+    ref_total, ref_items = TO.self_supervised_loss(big, pf.detach().cpu())
+    assert abs(total.item() - float(ref_total)) < 1e-4 * max(1.0, abs(float(ref_total)))
+    assert torch.isfinite(pf.grad).all() and float(pf.grad.abs().max()) > 0

@@ -1072,6 +1072,47 @@ def test_flat_adam_matches_torch_adam(dev):
     with pytest.raises(ValueError):
         bad = ob.state_dict(); bad["state"] = {k: v for k, v in bad["state"].items() if k != 0}
         FlatAdam(bucket).load_state_dict(bad)
+    # a checkpoint of torch.optim.Adam(net.parameters()) -- the reference's optimizer, main.py:107 -- over a module that
+    # also holds parameters OUTSIDE the bucket (never-used ones with grad None, frozen ones): indices are positions in
+    # module.parameters(); the outsiders carry no state and are skipped
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(7, 5)
+            self.unused = torch.nn.BatchNorm1d(5)
+            self.b = torch.nn.Linear(5, 3)
+            self.frozen = torch.nn.Linear(3, 3)
+            for q in self.unused.parameters():
+                q._cmf_unused = True
+            for q in self.frozen.parameters():
+                q.requires_grad_(False)
+
+        def forward(self, x):
+            return self.frozen(self.b(torch.relu(self.a(x))))
+    torch.manual_seed(5)
+    m1, m2 = Net().to(dev), Net().to(dev)
+    m2.load_state_dict(m1.state_dict())
+    for q in m2.unused.parameters():
+        q._cmf_unused = True
+    ref_opt = torch.optim.Adam(m1.parameters(), lr=1e-3, weight_decay=1e-4)
+    for _ in range(3):
+        ref_opt.zero_grad()
+        m1(torch.randn(16, 7, device=dev)).square().mean().backward()
+        ref_opt.step()
+    bk = FlatGradBucket(m2)
+    assert bk.module_params == 8 and bk.module_index == [0, 1, 4, 5]
+    fa = FlatAdam(bk, lr=1e-3, weight_decay=1e-4)
+    fa.load_state_dict(ref_opt.state_dict())
+    assert fa.steps == 3
+    off = 0
+    for q in (m1.a.weight, m1.a.bias, m1.b.weight, m1.b.bias):
+        st = ref_opt.state[q]
+        assert torch.equal(fa.exp_avg[off:off + q.numel()], st["exp_avg"].reshape(-1))
+        assert torch.equal(fa.exp_avg_sq[off:off + q.numel()], st["exp_avg_sq"].reshape(-1))
+        off += q.numel()
+    with pytest.raises(ValueError):                           # a checkpoint over some other parameter list
+        other = torch.optim.Adam(list(m1.parameters())[:3]).state_dict()
+        FlatAdam(bk).load_state_dict(other)
     # the raw-pointer update bumps the parameters' version counters like an in-place torch op
     p0 = next(a.parameters())
     v0 = p0._version
