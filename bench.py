@@ -177,6 +177,13 @@ def hbm_op_rooflines(dev, iters=20):
         rel = xyz[0][:, want.long()] - xyz[0][:, :, None]
         assert torch.equal(fused[0], torch.cat((rel, g), dim=0)), "query_and_group: timed output differs from its definition"
 
+    # the launch floor of this box: an (almost) empty one-wave kernel back to back on the same stream, timed the same way -- what a
+    # launch costs before it moves a byte; the latency-bound rows below are printed as multiples of it (`x_floor`)
+    floor1 = timed(lambda: _lib.check(L.cmf_debug_spin(0.0, st), "spin"))
+
+    def two():
+        _lib.check(L.cmf_debug_spin(0.0, st), "spin"); _lib.check(L.cmf_debug_spin(0.0, st), "spin")
+    floor2 = timed(two)
     rows = []
     for (B, N, K, r, lidar), Cs in (((64, 256, 32, 2.0, False), (3, 64, 1027)), ((32, 4096, 64, 2.0, True), (64, 128))):
         xyz = synth.make_batch(B, N=N, seed=1234, lidar=lidar)["pc1"].to(dev)          # (B,3,N) channel-major
@@ -212,6 +219,8 @@ def hbm_op_rooflines(dev, iters=20):
                                              "frac": round(nb / t_qg / 1e9 / HBM_PEAK_GBS, 4)},
                          "group_grad": {"bytes": ng, "us": round(t_gg * 1e6, 1), "achieved": round(ng / t_gg / 1e9, 1),
                                         "frac": round(ng / t_gg / 1e9 / HBM_PEAK_GBS, 4)}})
+            for k in ("ball_query+group", "query_and_group", "group_grad"):
+                rows[-1][k]["x_floor"] = round(rows[-1][k]["us"] * 1e-6 / floor1, 1)
             del feats, out, gp
     # counted HBM bytes per call from the committed PMC passes over the same calls (tools/session.sh op_pmc): constants of a
     # profiled build, NOT measured by this run
@@ -226,6 +235,9 @@ def hbm_op_rooflines(dev, iters=20):
             row["query_and_group"]["traffic_committed"] = table.get(("query_and_group", key))
             row["group_grad"]["traffic_committed"] = table.get(("group_points_grad", key))
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "launch_floor_us": round(floor1 * 1e6, 2), "launch_floor_pair_us": round(floor2 * 1e6, 2),
+            "launch_floor_note": "one / two back-to-back launches of a one-wave kernel that returns at once (cmf_debug_spin(0)), timed like the "
+                                 "rows; x_floor = row us / launch_floor_us",
             "traffic_source": ("per-row traffic_committed: constants from the committed rocprofv3 PMC passes (profiles/%s), not measured by "
                                "this run; null when the profile was taken on other kernel sources" % OP_TRAFFIC_PROFILE),
             "traffic_profile": "profiles/" + OP_TRAFFIC_PROFILE, "traffic_profile_matches_sources": src_ok, "source_id": _lib.source_id(),
@@ -318,7 +330,7 @@ def main():
         from cmflow_amd.dp import pin_rank_to_cores
         # opt-in (CMF_PIN_CORES=1), before the library creates its chain-worker threads (they inherit the mask); ranks on THIS host
         pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
-    if world == 1 and a.force_allreduce:
+    if world == 1 and (a.force_allreduce or os.environ.get("CMF_BENCH_PG_ONLY") == "1"):    # (PG_ONLY: diagnostic -- the process group exists, no collective runs)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
@@ -505,6 +517,34 @@ def main():
         if iso:
             iso["note"] = "3 extra steps with every chain on one stream (outside the timed region): the kernel's own rate"
 
+    # peak device memory of the timed regions: torch's allocator (every tensor and arena of the step) + what the library holds itself
+    peak_mem = {"torch_max_allocated": int(torch.cuda.max_memory_allocated(dev)), "torch_max_reserved": int(torch.cuda.max_memory_reserved(dev)),
+                "library_scratch": int(_lib.lib().cmf_mem_stats())}
+    peak_mem["total"] = peak_mem["torch_max_allocated"] + peak_mem["library_scratch"]
+
+    # BASELINE config 2 (fwd only, eval-mode BN, same batch) timed in the same run: 20 steps behind 3 warm-up steps, the chains back
+    # on the stream pool.  Not part of `value`.  (Every rank runs it: no collective inside.)
+    config2 = None
+    if a.mode == "train" and a.model == "cmflow":
+        from cmflow_amd import fused_blocks as _FB
+        _FB.set_serial(net, bool(a.serial))
+        net.eval()
+
+        def fwd():
+            with torch.no_grad():
+                net(batch["pc1"], batch["pc2"], batch["ft1"], batch["ft2"], None, "test")
+        for _ in range(3):
+            fwd()
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(20):
+            fwd()
+        fence()
+        d2 = (time.perf_counter() - t2) / 20
+        config2 = {"ms_per_step": round(d2 * 1e3, 3), "frame_pairs_per_s": round(a.batch * world / d2, 1), "steps": 20,
+                   "workload": "cmflow fwd-only inference (eval-mode BN), N=256, B=%d per GPU: BASELINE config 2" % a.batch}
+        net.train()
+
     # the gradient all-reduce alone (world > 1, or forced at world 1): 20 back-to-back all-reduces of the flat bucket between one
     # event pair on the current stream -- every rank enters them
     allreduce_ms = None
@@ -575,7 +615,9 @@ def main():
                       # per-launch durations bracketed inside the timed region: launches on four streams overlap, so their sum exceeds
                       # the wall time -- a concurrency artefact, not a roofline figure
                       "contended_per_launch": ({k: contended[k] for k in ("achieved", "frac", "avg_us", "launches")} if contended else None),
-                      "host_cores": host_cores},
+                      "host_cores": host_cores,
+                      "peak_mem_bytes": peak_mem, "config2_fwd": config2,
+                      "config2_fwd_ms_per_step": config2["ms_per_step"] if config2 else None},
             "ranks_seen": ranks_seen, "devices": devices, "backend": backend, "allreduce_ms": allreduce_ms,
             "source_id": _lib.source_id(),
         }

@@ -116,6 +116,7 @@ SIGNATURES = {
     "cmf_stack_first_conv": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
     "cmf_unstack_first_conv_grad": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _vp],
     "cmf_global_max_cat_grad": [_ci, _ci, _ci, _vp, _ll, _vp, _vp, _ll, _vp],
+    "cmf_mem_stats": [],
     "cmf_radar_loss_workspace": [_ci, _ci],
     "cmf_radar_loss_workspace_nb": [_ci, _ci, _ci],
     "cmf_radar_loss_workspace_tiled": [_ci, _ci, _ci],
@@ -125,7 +126,7 @@ SIGNATURES = {
     "cmf_debug_spin": [_cf, _vp],
     "cmf_eval_metrics": [_ci, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _cf, _cf, _vp, _vp, _vp],
 }
-RESTYPES = {"cmf_radar_loss_workspace": _ll, "cmf_radar_loss_workspace_nb": _ll, "cmf_radar_loss_workspace_tiled": _ll, "cmf_gemm_trace_read": _ll, "cmf_gemm_profile_records": _ll}
+RESTYPES = {"cmf_mem_stats": _ll, "cmf_radar_loss_workspace": _ll, "cmf_radar_loss_workspace_nb": _ll, "cmf_radar_loss_workspace_tiled": _ll, "cmf_gemm_trace_read": _ll, "cmf_gemm_profile_records": _ll}
 
 
 class GemmLaunchRecord(ctypes.Structure):

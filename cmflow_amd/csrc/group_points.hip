@@ -1289,13 +1289,34 @@ static void launch_bal(dim3 grid, size_t lds, hipStream_t st, int c, int n, int 
 #include <mutex>
 #include <tuple>
 #include <vector>
+namespace {
+struct ScratchRetired { void *p; hipEvent_t done; size_t cap; };
+struct ScratchEntry { void *p = nullptr; size_t cap = 0; std::mutex in_use; std::vector<ScratchRetired> retired; };
+std::mutex g_scratch_mu;
+std::map<std::tuple<int, hipStream_t, int>, ScratchEntry> *g_scratch_table =
+    new std::map<std::tuple<int, hipStream_t, int>, ScratchEntry>();   // leaked on purpose (runtime teardown order)
+}  // namespace
+
+extern "C" long long cmf_mem_stats(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    long long total = 0;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    for (auto &kv : *g_scratch_table) {
+        if (std::get<0>(kv.first) != dev) continue;
+        std::lock_guard<std::mutex> use(kv.second.in_use);
+        total += (long long)kv.second.cap;
+        for (const auto &r : kv.second.retired) total += (long long)r.cap;
+    }
+    return total;
+}
+
 CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
 {
-    struct Retired { void *p; hipEvent_t done; };
-    struct Entry { void *p = nullptr; size_t cap = 0; std::mutex in_use; std::vector<Retired> retired; };
-    static std::mutex mu;
-    static std::map<std::tuple<int, hipStream_t, int>, Entry> *table =
-        new std::map<std::tuple<int, hipStream_t, int>, Entry>();      // leaked on purpose (runtime teardown order)
+    typedef ScratchEntry Entry;
+    std::mutex &mu = g_scratch_mu;
+    auto *table = g_scratch_table;
     CmfScratchLease lease;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return lease;
@@ -1322,7 +1343,7 @@ CmfScratchLease cmf_stream_scratch(hipStream_t stream, int slot, size_t bytes)
         if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); lease.hold.unlock(); return lease; }
         if (e->p) {
             hipEvent_t ev = nullptr;
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, stream) == hipSuccess) e->retired.push_back({e->p, ev});
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, stream) == hipSuccess) e->retired.push_back({e->p, ev, e->cap});
             else { (void)hipGetLastError(); if (ev) (void)hipEventDestroy(ev); }       // could not fence it: keep it allocated (the old behaviour)
         }
         e->p = p; e->cap = want;

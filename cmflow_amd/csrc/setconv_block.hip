@@ -113,6 +113,28 @@ inline bool bnb_fusable(long long rows, int cout, int cin)
     return on && cout % 128 == 0 && cin % 128 == 0 && rows % 16 == 0 && rows >= 32768 && rows < (1ll << 31);
 }
 
+// The arenas are sized by PATH (VERDICT r5 item 7 / ADVICE r4).  A block that never materialises its grouped first-layer tensor
+// (gather_layout: the second encoder's shapes) keeps in that tensor's slot of `saved` only what the gathering GEMMs read -- M row
+// indices and the three coordinate planes of Wx -- instead of M x O1 floats (1 GB at the largest scale, B = 64); and the slot of
+// the data gradient into that layer in the backward scratch holds, when the gradient is summed inside the GEMM
+// (gather_sum_layout: an input gradient is wanted, d->dy set), the pieces matrix, the permutation, the permuted source points
+// and relative coordinates.  Both predicates are pure functions of the descriptor's SHAPE fields (and of d->dy being set or
+// not for the second): cmf_setconv_sizes, the forward and the backward call must agree on them, so the pointer-alignment
+// conditions of the gathering kernels are NOT part of them -- a block with the compact layout and a misaligned y is refused
+// (CMF_CHECK_ARG in the calls) instead of overrunning a slot that was never sized for the materialised tensor.
+// CMF_TRAIN_GATHER=0 / CMF_TRAIN_GATHER_SUM=0 (A/B) bring the materialised sizes back.
+inline bool gather_layout(const cmf_setconv_desc *d)
+{
+    static const bool on = !(getenv("CMF_TRAIN_GATHER") && getenv("CMF_TRAIN_GATHER")[0] == '0');
+    const long long M = (long long)d->B * d->N * d->S;
+    return on && M % 128 == 0 && M < (1ll << 31) && d->C[0] % 128 == 0 && d->O1 % 128 == 0 && d->ldy % 4 == 0;
+}
+inline bool gather_sum_layout(const cmf_setconv_desc *d)
+{
+    static const bool on = !(getenv("CMF_TRAIN_GATHER_SUM") && getenv("CMF_TRAIN_GATHER_SUM")[0] == '0');
+    return on && gather_layout(d) && d->dy != nullptr && d->S >= 2;
+}
+
 Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool backward)
 {
     Layout L;
@@ -123,7 +145,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
     L.offsets = (int *)s.take((size_t)d->B * (d->N + 1));
     L.inv = (int *)s.take(M);
     L.dxyz = s.take(M * 4);
-    L.z1 = s.take(M * O1);
+    L.z1 = s.take(gather_layout(d) ? (size_t)((M + 3) / 4 * 4) + 3 * (size_t)O1 : (size_t)M * O1);
     L.z2 = s.take(M * C2);
     L.z3 = s.take(M * C3);
     L.argmax = (unsigned char *)s.take((P * C3 + 3) / 4);
@@ -148,7 +170,8 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         L.dx = t.take(P * C3);
         L.dU3 = t.take(M * C3);
         L.dU2 = t.take(M * C2);
-        L.dU1 = t.take(M * O1);
+        // (summed inside the GEMM: pieces (P + M/64) x O1 | perm M | source points M | relative coordinates 4 M -- sum_slots below)
+        L.dU1 = t.take(gather_sum_layout(d) ? (size_t)(P + M / 64) * O1 + 6 * (size_t)M : (size_t)M * O1);
         L.dZ2 = (d->training && bnb_fusable(M, C2, O1)) ? t.take(M * C2) : nullptr;
         size_t sk = 0;
         sk = std::max(sk, (size_t)dw_split(P, C6, C5) * C6 * C5);
@@ -321,13 +344,13 @@ int bwd_layer(const cmf_setconv_desc *d, const Layout &L, int l_out, long long r
 // tensor's slot in `saved` holds the row indices and the coordinate planes of Wx.
 bool train_gather(const cmf_setconv_desc *d)
 {
-    static const bool on = !(getenv("CMF_TRAIN_GATHER") && getenv("CMF_TRAIN_GATHER")[0] == '0');
-    const long long M = (long long)d->B * d->N * d->S;
     // (train-mode or eval-mode BatchNorm alike: with eval-mode statistics -- the regime of every epoch after the first in the reference's
     //  training loop -- the forward pass is the inference form and the backward pass the same two gathering GEMMs)
-    return on && M % 128 == 0 && M < (1ll << 31) && d->C[0] % 128 == 0 && d->O1 % 128 == 0 && d->ldy % 4 == 0 &&
-           (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0;
+    // = the layout predicate: the slot of the tensor is sized for the gathering form, there is no other form to fall back to
+    return gather_layout(d);
 }
+// the gathering kernels' 16-byte loads: with the compact layout a misaligned operand is an argument error, not a fallback
+bool gather_operands_aligned(const cmf_setconv_desc *d) { return (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0; }
 int *gather_rows(const Layout &L) { return reinterpret_cast<int *>(L.z1); }
 float *gather_wx3(const Layout &L, long long M) { return L.z1 + (M + 3) / 4 * 4; }
 
@@ -337,11 +360,7 @@ float *gather_wx3(const Layout &L, long long M) { return L.z1 + (M + 3) / 4 * 4;
 // slots in inverse-index order and reduces runs of equal source points in its epilogue (cmf_gemm_dx_gather_sum); the scatter at the end
 // of the block adds a point's pieces.  CMF_TRAIN_GATHER_SUM=0 keeps the stored gradient (A/B).  The slot of dU1 holds the pieces, the
 // permutation, the permuted source points and relative coordinates.
-bool train_gather_sum(const cmf_setconv_desc *d)
-{
-    static const bool on = !(getenv("CMF_TRAIN_GATHER_SUM") && getenv("CMF_TRAIN_GATHER_SUM")[0] == '0');
-    return on && train_gather(d) && d->dy != nullptr && d->S >= 2;
-}
+bool train_gather_sum(const cmf_setconv_desc *d) { return gather_sum_layout(d); }
 struct SumSlots { float *pieces; int *perm, *pts; float *dq2; };
 SumSlots sum_slots(const cmf_setconv_desc *d, const Layout &L)
 {
@@ -393,6 +412,7 @@ extern "C" int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_flo
 static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
 {
     CMF_CHECK_ARG(d && d->xyz && d->y && d->wx && d->saved && d->scratch && d->out);
+    CMF_CHECK_ARG(!gather_layout(d) || gather_operands_aligned(d));
     const Layout L = make_layout(d, d->saved, d->scratch, false);
     const long long P = (long long)d->B * d->N, M = P * d->S;
     const int O1 = d->O1, C2 = d->C[0], C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];
@@ -445,7 +465,7 @@ static int setconv_forward_part(const cmf_setconv_desc *d, void *st, int part)
         return cmf_affine_relu(P, C6, L.z6, C6, L.bn[5] + 2 * C6, L.bn[5] + 3 * C6, d->out, d->ldo, st);
     }
     const bool gather = !d->training && ((d->inference && M % 128 == 0 && C2 % 128 == 0 && O1 % 16 == 0 && d->ldy % 4 == 0 &&
-                                          (((uintptr_t)d->y | (uintptr_t)d->w[0]) & 15) == 0 && M < (1ll << 31)) || train_gather(d));
+                                          gather_operands_aligned(d) && M < (1ll << 31)) || train_gather(d));
     if (d->training && train_gather(d)) {
         CMF_TRY(cmf_group_affine(d->B, d->N, d->N, d->S, O1, d->y, (int)d->ldy, nullptr, 0, d->xyz, d->xyz, d->wx, (int)d->ldwx, L.idx, 0,
                                  nullptr, L.dxyz, L.partial, L.partial_x, st));
@@ -677,6 +697,7 @@ extern "C" int cmf_setconv_tail_backward(int n, const cmf_setconv_desc *descs, v
 static int setconv_backward_part(const cmf_setconv_desc *d, void *st, int part)
 {
     CMF_CHECK_ARG(d && d->xyz && d->saved && d->scratch && d->dout);
+    CMF_CHECK_ARG(!gather_layout(d) || (d->y && gather_operands_aligned(d)));
     const Layout L = make_layout(d, d->saved, d->scratch, true);
     const long long P = (long long)d->B * d->N, M = P * d->S;
     const int O1 = d->O1, C2 = d->C[0], C3 = d->C[1], C4 = d->C[2], C5 = d->C[3], C6 = d->C[4];

@@ -91,14 +91,55 @@ def set_serial(net, on):
             m.__dict__.pop(attr, None)
 
 
+# WHICH streams make up the pool matters: the runtime deals streams to its hardware queues as they are created, balancing by how many
+# streams each queue already carries -- so a library that created streams earlier shifts the deal.  Measured (tools/stream_queue_probe.py,
+# profiles/r06_stream_queue_probe.txt): with a `nccl` process group initialised first (RCCL + c10d create their streams at init -- the
+# normal order of a multi-GPU run), the FIRST torch.cuda.Stream() created afterwards shares the hardware queue of the default stream, i.e.
+# side stream 0 serialised against the caller's stream: + 0.45 ms per training step with no collective running at all.  The pool is
+# therefore picked by measurement: candidates are created one by one and a candidate is taken only if a 300 us one-wave spin kernel on
+# it runs SIDE BY SIDE with the same kernel on the caller's stream and on every stream already taken (two streams of one hardware queue
+# run them one after the other).  ~10 ms once per device; CMF_STREAM_PROBE=0 takes the first N_SIDE streams as they come (A/B).
+_PROBE = os.environ.get("CMF_STREAM_PROBE", "1") != "0"
+
+
+def _share_a_queue(a, b, us=300.0):
+    import time
+    best = 1e9
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        L().cmf_debug_spin(us, a.cuda_stream)
+        L().cmf_debug_spin(us, b.cuda_stream)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best > 1.6e-6 * us
+
+
+def _build_pool(key):
+    main = torch.cuda.current_stream(key)
+    if not _PROBE or torch.cuda.is_current_stream_capturing():
+        return [torch.cuda.Stream(device=key) for _ in range(N_SIDE)]
+    taken, spare = [], []
+    with torch.cuda.device(key):
+        for _ in range(N_SIDE + 6):                       # (4 hardware queues: a conflict-free set exists among the first few)
+            if len(taken) == N_SIDE:
+                break
+            c = torch.cuda.Stream(device=key)
+            if any(_share_a_queue(c, o) for o in [main] + taken):
+                spare.append(c)
+            else:
+                taken.append(c)
+    return taken + spare[:N_SIDE - len(taken)]            # (fewer free queues than N_SIDE: the rest share, as before)
+
+
 def side_stream(slot, device=None):
     if SERIAL:
         return torch.cuda.current_stream(device)
     dev = torch.device(device if device is not None else torch.cuda.current_device())
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
-    pool = _side_pool.setdefault(key, [])
-    while len(pool) < N_SIDE:
-        pool.append(torch.cuda.Stream(device=key))
+    pool = _side_pool.get(key)
+    if pool is None:
+        pool = _side_pool[key] = _build_pool(key)
     return pool[slot % N_SIDE]
 
 
@@ -916,7 +957,7 @@ class EncoderPlan:
         self.key = (B, N, O1, bool(training), str(device), clouds)
         self.descs = (_lib.SetConvDesc * n)()
         self.keep, self.params, self.bns = [], [], []
-        self.n_saved, self.n_fwd, self.n_bwd = [], [], []
+        self.n_saved, self.n_fwd, self.n_bwd, self.n_bwd_dy = [], [], [], []
         defer = clouds > 1 and training
         for i in range(n):
             m = modules[i % ns]
@@ -937,10 +978,15 @@ class EncoderPlan:
                 d.nbt[l] = bn.num_batches_tracked.data_ptr() if (training and bn.track_running_stats and not defer) else None
             d.wx, d.ldwx = wx.data_ptr(), wx.stride(0)
             d.ldy = ns * O1                                         # y is a column slice of the stacked (B,N,ns*O1) GEMM output
-            c_s, c_f, c_b = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
+            c_s, c_f, c_b, c_bd = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong()
             _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), ctypes.addressof(c_s), ctypes.addressof(c_f),
                                              ctypes.addressof(c_b)), "cmf_setconv_sizes")
-            self.n_saved.append(c_s.value); self.n_fwd.append(c_f.value); self.n_bwd.append(c_b.value)
+            # the backward scratch is sized by path (cmflow_hip.h cmf_setconv_sizes): with an input gradient to produce (d.dy set) the
+            # second encoder's blocks sum the first layer's data gradient inside the GEMM and need no M x O1 slot for it
+            d.dy = 8                                                # (any non-null value: never dereferenced by the sizes call)
+            _lib.check(L().cmf_setconv_sizes(ctypes.addressof(d), None, None, ctypes.addressof(c_bd)), "cmf_setconv_sizes")
+            d.dy = None
+            self.n_saved.append(c_s.value); self.n_fwd.append(c_f.value); self.n_bwd.append(c_b.value); self.n_bwd_dy.append(c_bd.value)
             self.params.append(params); self.bns.append(bns)
         self.co = self.params[0][15].shape[0]
         self.modules = list(modules)
@@ -971,11 +1017,13 @@ class EncoderPlan:
         self.off_saved = [0]
         for v in self.n_saved:
             self.off_saved.append(self.off_saved[-1] + al(v))
-        self.off_fwd, self.off_bwd = [0], [0]
+        self.off_fwd, self.off_bwd, self.off_bwd_dy = [0], [0], [0]
         for v in self.n_fwd:
             self.off_fwd.append(self.off_fwd[-1] + al(v))
         for v in self.n_bwd:
             self.off_bwd.append(self.off_bwd[-1] + al(v))
+        for v in self.n_bwd_dy:
+            self.off_bwd_dy.append(self.off_bwd_dy[-1] + al(v))
         self.saved_per_cloud = self.off_saved[ns]                   # floats: the second call's arena starts here
 
     def _live_ptrs(self):
@@ -1148,7 +1196,8 @@ class MultiScaleBlockFn(Function):
             dout = dout.contiguous()
         main = torch.cuda.current_stream()
         need_dy = ctx.needs_input_grad[1]
-        scratch = torch.empty(plan.off_bwd[-1], dtype=_f32, device=dev)
+        off_bwd = plan.off_bwd_dy if need_dy else plan.off_bwd
+        scratch = torch.empty(off_bwd[-1], dtype=_f32, device=dev)
         dy_all = torch.empty(B, N, n * o1, dtype=_f32, device=dev) if need_dy else None
         grads = []
         if ctx.sink_mode and not plan.sinks_ready():
@@ -1156,7 +1205,7 @@ class MultiScaleBlockFn(Function):
         for i in range(n):
             d, params = plan.descs[i], plan.params[i]
             d.xyz, d.y = xyz_t.data_ptr(), y_all.data_ptr() + 4 * i * o1
-            d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * plan.off_bwd[i]
+            d.saved, d.scratch = saved.data_ptr() + 4 * plan.off_saved[i], scratch.data_ptr() + 4 * off_bwd[i]
             d.dout, d.lddout = dout.data_ptr() + 4 * i * co, dout.stride(0)
             d.dy, d.lddy = (dy_all.data_ptr() + 4 * i * o1, n * o1) if need_dy else (None, 0)
             if ctx.sink_mode:                                       # sink pointers already sit in the descriptors
@@ -1244,7 +1293,7 @@ class DualCloudBlockFn(Function):
         if not plan.sinks_ready():
             raise RuntimeError("parameter .grad buffers disappeared between forward and backward")
         main = torch.cuda.current_stream()
-        scratch = torch.empty(plan.off_bwd[-1], dtype=_f32, device=dev)
+        scratch = torch.empty(plan.off_bwd[-1], dtype=_f32, device=dev)      # (sized without d.dy: never smaller than with it)
         need = (ctx.needs_input_grad[1], ctx.needs_input_grad[3])
         dys = [torch.empty(B, N, ns * o1, dtype=_f32, device=dev) if need[c] else None for c in range(2)]
         for i in range(n):

@@ -439,7 +439,16 @@ typedef struct cmf_setconv_desc {
     int idx_ready;               /* 1: this block's ball query has been issued already (cmf_setconv_queries wrote the indices into
                                     `saved`); the forward call does not launch its own */
 } cmf_setconv_desc;
+/* Arena sizes in floats (each pointer may be NULL).  The arenas are sized by PATH: a block whose shapes take the gathering GEMMs
+ * (M = B*N*S and O1, C[0] multiples of 128, ldy a multiple of 4: the second encoder) keeps M row indices + 3*O1 floats where the
+ * materialised first-layer tensor would take M x O1, and -- in scratch_bwd, when d->dy is set at the time of the sizes call, i.e. the
+ * backward call will produce an input gradient -- (B*N + M/64) x O1 + 6 M floats where the data gradient into that layer would
+ * take M x O1.  scratch_bwd asked with d->dy == NULL is never smaller than with it set, so it is valid for either backward call.
+ * With the compact sizes d->y and d->w[0] must be 16-byte aligned (the forward / backward calls refuse them otherwise). */
 int cmf_setconv_sizes(const cmf_setconv_desc *d, long long *saved_floats, long long *scratch_fwd, long long *scratch_bwd);
+/* Device memory the library holds on the current device outside caller-provided arenas: the per-(stream, slot) scratch buffers of the
+ * drop-in entry points (cmf_ball_query spill lists, cmf_group_points_grad plans / inverse indices), live + retired, in bytes. */
+long long cmf_mem_stats(void);
 /* The ball queries of n blocks, issued ahead of their forward calls on ONE stream: blocks that share centres and cloud (the scales of
  * a MultiScaleEncoder call, radarflow_util.py:111-118) are served by one cmf_ball_query_multi launch, two clouds of equal geometry
  * (the weight-shared first encoder, models/cmflow.py:72-73) by the same launch -- 12 launches per CMFlow forward become 2.  The

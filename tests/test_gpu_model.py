@@ -458,6 +458,56 @@ def test_summed_data_gradient_changes_nothing_but_the_association(dev, tmp_path)
     print("summed data gradient: worst relative gradient difference %.3g" % worst)
 
 
+# Every run-time A/B switch the product keeps (README "switches") is forced here once -- or the path behind it goes.
+# A training step (B = 4, bench.py's weights) under the switch against the default build of the step: `None` = every gradient, the loss
+# and every BN buffer bit-identical (the same kernels' arithmetic, issued or scheduled differently); a number = the documented bound for
+# "same terms, another association" (relative to each tensor's norm), the forward pass (loss, BN buffers) still bit-identical unless noted.
+_AB_SWITCHES = [
+    (dict(CMF_TAIL_BATCH="0"), None),                   # per-block tails instead of batched launches
+    (dict(CMF_NESTED_QUERIES="0"), None),               # every block issues its own ball query
+    (dict(CMF_BALL_QUERY_BALLOT="0"), None),            # scan kernels instead of the ballot kernel: same indices
+    (dict(CMF_SIDE_STREAMS="2"), None),                 # another deal of the chains onto the stream pool
+    (dict(CMF_GEMM_NO_DIRECT="1"), None),               # register-staged main loop everywhere: same MFMA sequence per element
+    (dict(CMF_GEMM_WIDE="0"), None),                    # 128 x 128 tiles for the gathering forward GEMM
+    (dict(CMF_THIN_GENERAL="1"), None),                 # the narrow forward layers' general body on full tiles
+    (dict(CMF_FIN_WIDE="0"), None),                     # 4-column fold kernels for every partial matrix
+    (dict(CMF_FIN_WIDE="1"), None),                     # 16-column fold kernels for every partial matrix
+    (dict(CMF_THIN_FUSED="0"), 2e-5),                   # narrow backward layers as three kernels: other split-K slabs
+    (dict(CMF_THIN_WIDE="0"), 2e-5),                    # 64 <- 256 backward layer as max-pool backward + BN backward + two tiled GEMMs
+    (dict(CMF_BNB_FUSED="1"), 2e-5),                    # BN backward inside the weight-gradient GEMM's staging
+]
+
+
+@pytest.fixture(scope="module")
+def default_step_b4(tmp_path_factory):
+    import subprocess, sys
+    f = str(tmp_path_factory.mktemp("ab") / "default.pt")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "4"],
+                       env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return torch.load(f)
+
+
+@pytest.mark.parametrize("env,bound", _AB_SWITCHES, ids=[",".join("%s=%s" % kv for kv in e.items()) for e, _ in _AB_SWITCHES])
+def test_ab_switch_leaves_the_training_step_unchanged(dev, tmp_path, default_step_b4, env, bound):
+    import subprocess, sys
+    f = str(tmp_path / "switched.pt")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "4"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    a, b = default_step_b4, torch.load(f)
+    assert a.keys() == b.keys() and len(a) > 300
+    differ = [k for k in a if not torch.equal(a[k], b[k])]
+    worst = max([float((a[k].double() - b[k].double()).norm() / (a[k].double().norm() + 1e-30)) for k in differ if a[k].is_floating_point()] or [0.0])
+    print("%s: %d of %d tensors differ, worst relative difference %.3g" % (env, len(differ), len(a), worst))
+    if bound is None:
+        assert not differ, (env, differ[:10])
+    else:
+        fwd = [k for k in differ if k.startswith("b.") or k == "loss"]
+        assert not fwd, (env, fwd[:10])                               # the forward pass does not go through the switched kernels
+        assert worst <= bound, (env, worst)
+
+
 def test_full_size_train_step_matches_oracle(dev):
     """BASELINE config 3 (the headline) at its own size: one training step of bench.py's batch and weights, train-mode
     BN, 7 losses -- loss within 2e-4, every loss item within 2e-4, labels bit-equal, outputs as in the forward test,
@@ -878,6 +928,48 @@ def test_dense_cloud_forward_matches_oracle(dev, manifest, golden_dir, args):
     assert float(epe[~flips].max()) < 1e-4
     assert float((got[1].cpu() - want[1]).abs().max()) < 1e-4
     assert float((got[2].cpu() - want[2]).abs().max()) < 1e-4
+
+
+def test_dense_cloud_train_step_matches_oracle(dev, manifest, golden_dir, args):
+    """A whole training step at BASELINE config 5's cloud size (N = 4096 LiDAR-like points, B = 2, train-mode BN, the seven
+    losses): the fused loss takes the cloud through its tiled kernels (losses/radar_loss.py has no size limit), the backward
+    pass runs the large-N forms of the inverse index, the scatter and the gathering GEMMs.  Against the CPU oracle: labels
+    bit-equal, loss and items within 2e-4, every gradient tensor by norm / direction / largest element."""
+    from cmflow_amd.cmflow import CMFlow
+    from cmflow_amd.fused_blocks import join_side_streams
+    from cmflow_amd.train import TrainStep
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    sd = _weights(manifest, golden_dir)
+    ref = O.CMFlow(args)
+    ref.load_state_dict(sd)
+    ref.train()
+    net = CMFlow(args)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    b = synth.make_batch(2, N=4096, seed=2026, lidar=True, train_extras=True)
+    bd = {k: v.to(dev) for k, v in b.items()}
+    P, Tcr = torch.tensor(synth.CAMERA_PROJECTION), torch.tensor(synth.T_CAMERA_RADAR)
+
+    class NoStep:
+        def zero_grad(self): ref.zero_grad()
+        def step(self): pass
+    loss_ref, items_ref, out_ref, (dyn_ref, mseg_ref) = TO.train_step(ref, NoStep(), b, P, Tcr)
+    step = TrainStep(net, vr_thres=0.3)
+    loss, items, outs, (dyn, mseg) = step.forward_loss(bd)
+    step.bucket.zero()
+    loss.backward()
+    join_side_streams()
+    assert torch.equal(dyn.cpu(), dyn_ref) and torch.equal(mseg.cpu(), mseg_ref)
+    assert abs(loss.item() - loss_ref.item()) <= 2e-4 * max(1.0, abs(loss_ref.item())), (loss.item(), loss_ref.item())
+    for k, v in items.items():
+        assert abs(v.item() - items_ref[k]) <= 2e-4 * max(1.0, abs(items_ref[k])), (k, v.item(), items_ref[k])
+    assert float((outs[1].detach().cpu() - out_ref[1].detach()).abs().max()) <= 1e-4
+    gref = {k: p.grad for k, p in ref.named_parameters()}
+    # (two samples instead of 64: fewer terms per sum, but the near-tie decisions of 8192 points' neighbour searches weigh more)
+    n, worst, wcos, welem = _check_gradients(net, gref, "N=4096 CMFlow", bounds=(2e-2, 5e-4, 0.1))
+    assert n >= 180
+    print("dense train: loss %.6f vs %.6f, worst grad-norm rel err %.3g (%s), worst 1-cos %.3g (%s), worst element %.3g (%s)"
+          % (loss.item(), loss_ref.item(), worst[1], worst[0], wcos[1], wcos[0], welem[1], welem[0]))
 
 
 def test_bench_two_ranks_control_flow(dev):

@@ -111,3 +111,26 @@ def test_shared_mlp_native_path_matches_torch_modules(dev, spec, shape, bn):
             assert torch.allclose(u, v, rtol=5e-4, atol=5e-5 * float(v.abs().max()) + 1e-6), (mode, float((u - v).abs().max()), float(v.abs().max()))
     for k, v in res[False]["state"].items():
         assert torch.allclose(res[True]["state"][k].float(), v.float(), rtol=1e-4, atol=1e-6), k
+
+
+from test_host_logic import PYTORCH_UTILS_CASES, _pytorch_utils_case
+
+
+@pytest.mark.parametrize("name", PYTORCH_UTILS_CASES)
+def test_pytorch_utils_classes_match_reference_goldens_on_the_gpu(dev, golden_dir, name, monkeypatch):
+    """The same goldens through the device path: every 1x1 conv / linear layer on cmf_gemm (cmf_mlp_forward / _backward for the
+    conv + BN + ReLU stacks), outputs 1e-4, gradients 1e-3 of their largest entry, BN buffers 1e-4 -- and the library's GEMM really ran
+    (no silent torch path)."""
+    from cmflow_amd import fused_blocks as FB
+    calls = []
+    for fn in ("linear", "mlp_chain_w"):
+        real = getattr(FB, fn)
+        monkeypatch.setattr(FB, fn, (lambda real: lambda *a, **k: (calls.append(1), real(*a, **k))[1])(real))
+    g, res, m = _pytorch_utils_case(golden_dir, name, dev)
+    n_layers = sum(1 for x in m.modules() if isinstance(x, (torch.nn.Conv1d, torch.nn.Conv2d, torch.nn.Linear)))
+    assert len(calls) >= 2 and len(calls) <= 2 * n_layers, (name, len(calls))          # eval + train call: every conv through the library
+    for k, v in res.items():
+        want = g[name + "/" + k]
+        scale = max(1.0, float(np.abs(want).max()))
+        tol = 1e-4 if (k in ("eval", "train") or k.startswith("buf/")) else 1e-3
+        np.testing.assert_allclose(v.detach().cpu().numpy(), want, rtol=tol, atol=tol * scale, err_msg=name + "/" + k)

@@ -747,3 +747,27 @@ def test_group_affine_statistics_only_form(dev, B, N, S, C, r):
     assert z0 is None and torch.equal(d, d0) and torch.equal(p, p0) and torch.equal(px, px0)
     z1, d1, p1 = FB.group_affine(y, None, xyz, xyz, wx, idx, write_z=False)
     assert z1 is None and torch.equal(d, d1) and torch.equal(p, p1)
+
+
+@pytest.mark.parametrize("env", [dict(CMF_BALL_QUERY_GRID="0"), dict(CMF_BALL_QUERY_BALLOT="0"), dict(CMF_GROUP_GRAD_PLAN="0"),
+                                 dict(CMF_GROUP_GRAD_CSR="0")],
+                         ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
+def test_drop_in_ab_switches_change_nothing(tmp_path, env):
+    """The A/B switches of the drop-in neighbour search / grouping calls (cell grid vs scan at N = 4096, ballot vs scan kernels at N = 256,
+    plan / CSR forms of the grouping gradient vs their predecessors), each forced in a child process (the library reads its environment
+    once): indices and grouped tensors bit-identical; the gradient bit-identical where both forms are deterministic sums in the same
+    order, else within 1e-6 of its largest entry (the LDS-atomic predecessor adds in arrival order)."""
+    import os, subprocess, sys
+    outs = []
+    for i, e in enumerate(({}, env)):
+        f = str(tmp_path / ("ops%d.pt" % i))
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "op_dump.py"), f],
+                           env=dict(os.environ, **e), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(torch.load(f))
+    a, b = outs
+    for k in a:
+        if k.endswith(".grad"):
+            assert float((a[k] - b[k]).abs().max()) <= 1e-6 * float(a[k].abs().max()), (env, k)
+        else:
+            assert torch.equal(a[k], b[k]), (env, k)

@@ -3,6 +3,8 @@ modules, the gradient bucket, deterministic synthetic data."""
 import json
 import os
 
+import numpy as np
+import pytest
 import torch
 
 from cmflow_amd import synth
@@ -200,3 +202,49 @@ def test_raflow_checkpoint_layout(golden_dir):
     sd = RaFlow(A).state_dict()
     assert [k for k, _, _ in man] == list(sd.keys())
     assert all(list(sd[k].shape) == list(s) for k, s, _ in man)
+
+
+def _pytorch_utils_case(golden_dir, name, device):
+    """Build CASES[name] from cmflow_amd.pytorch_utils, load the reference-built module's state (strict: same keys), run it like
+    make_golden_pytorch_utils.run; -> (golden npz, results dict, module)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_pytorch_utils", os.path.join(golden_dir, "make_golden_pytorch_utils.py"))
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    from cmflow_amd import pytorch_utils as U
+    g = np.load(os.path.join(golden_dir, "pytorch_utils_kat.npz"))
+    cls, a, kw, shape = G.CASES[name]
+    m = getattr(U, cls)(*a, **kw)
+    sd = {k[len(name) + 7:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(name + "/state/")}
+    m.load_state_dict(sd, strict=True)
+    m = m.to(device)
+    x, w = torch.from_numpy(g[name + "/x"]).to(device), torch.from_numpy(g[name + "/w"]).to(device)
+    res = {}
+    m.eval()
+    with torch.no_grad():
+        res["eval"] = m(x.clone())
+    m.train()
+    xi = x.clone().requires_grad_(True)
+    y = m(xi)
+    (y * w).sum().backward()
+    res["train"], res["dx"] = y.detach(), xi.grad
+    for k, p in m.named_parameters():
+        res["grad/" + k] = p.grad
+    for k, b in m.named_buffers():
+        res["buf/" + k] = b
+    return g, res, m
+
+
+PYTORCH_UTILS_CASES = ["mlp_default", "mlp_preact_first", "mlp_preact", "mlp_nobn", "mlp_odd", "conv1d_bn", "conv1d_preact", "conv1d_plain",
+                       "conv2d_bias", "fc_bn", "fc_bias", "fc_preact", "fc_noact"]
+
+
+@pytest.mark.parametrize("name", PYTORCH_UTILS_CASES)
+def test_pytorch_utils_classes_match_reference_goldens_on_cpu(golden_dir, name):
+    """lib/pytorch_utils.py:5-236 (SharedMLP incl. preact / first, Conv1d, Conv2d, FC, BatchNorm1d): same state_dict keys (strict load
+    of the reference-built module's state), and on CPU tensors -- the plain torch modules of the Sequential -- the outputs, gradients
+    and BN buffers of the reference's own classes (tests/golden/pytorch_utils_kat.npz, made by make_golden_pytorch_utils.py)."""
+    g, res, _ = _pytorch_utils_case(golden_dir, name, "cpu")
+    for k, v in res.items():
+        want = g[name + "/" + k]
+        np.testing.assert_allclose(v.detach().numpy(), want, rtol=1e-5, atol=1e-6 * max(1.0, float(np.abs(want).max())), err_msg=name + "/" + k)

@@ -264,18 +264,28 @@ def test_raflow_oracle_train_step_matches_reference(golden_dir):
 def test_oracle_is_not_a_strawman(manifest, golden_dir, args):
     """the CPU baseline bench.py reports (`cpu_baseline.kind == "port"`) must be in the same league as the
     reference's own Python on the same cores.  tests/golden/ref_cpu_timing.json holds the reference's forward time
-    (B=1, 8 threads, this container, measured by make_golden.py); the oracle gets a generous 3x."""
+    (B=1, 8 threads, this container, measured by make_golden.py); the oracle gets a generous 3x.
+    A wall-clock bound must not go red because the box is busy: the bound is scaled by a calibration measured in THIS process
+    right around the timed calls (a fixed 2048^3 fp32 matmul against its time on the idle container,
+    tests/golden/make_cpu_calib.py), and the oracle's time is the minimum of 5 calls behind a warm-up."""
     import json
     import time
+    import importlib.util
     ref = json.load(open(os.path.join(golden_dir, "ref_cpu_timing.json")))
+    spec = importlib.util.spec_from_file_location("make_cpu_calib", os.path.join(golden_dir, "make_cpu_calib.py"))
+    cal = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cal)
     torch.set_num_threads(ref["threads"])
     net = _net(manifest, golden_dir, args).eval()
     b = synth.make_batch(1, seed=3)
+    load0 = cal.calib(ref["threads"]) / ref["calib_mm2048_s"]
     with torch.no_grad():
         net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
         ts = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             net(b["pc1"], b["pc2"], b["ft1"], b["ft2"], None, "test")
             ts.append(time.perf_counter() - t0)
-    assert sorted(ts)[1] <= 3.0 * ref["ref_cpu_fwd_b1_s"], (ts, ref)
+    load1 = cal.calib(ref["threads"]) / ref["calib_mm2048_s"]
+    slowdown = max(1.0, load0, load1)                   # how much slower this host runs the calibration than the idle container did
+    assert min(ts) <= 3.0 * ref["ref_cpu_fwd_b1_s"] * slowdown, (ts, ref, load0, load1)

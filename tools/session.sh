@@ -105,6 +105,28 @@ bnb_ab() {             # BN backward of the 512 -> 256 layer inside the weight-g
     python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "fused_bn_backward or block or setconv or set_conv" 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
     for v in 0 1 0 1; do CMF_BNB_FUSED=$v python bench.py --steps 40 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused $v', d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'])"; done | tee $R/bnb_ab.txt
 }
+ar_trace() {            # kernel + HIP API trace of the step's tail with and without the forced world-1 all-reduce (tools/step_tail_probe.py)
+    for v in base forced; do
+        rm -rf /tmp/ar_$v
+        F=""; [ $v = forced ] && F="--force-allreduce"
+        (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/ar_$v -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-op-rooflines $F > $R/ar_bench_$v.json 2>/dev/null)
+        python tools/step_tail_probe.py $(find /tmp/ar_$v -name "*kernel_trace.csv" | head -1) 10 > $R/ar_tail_$v.txt 2>&1
+    done
+    for v in base forced base forced; do F=""; [ $v = forced ] && F="--force-allreduce"
+        python bench.py --no-cpu-baseline --no-op-rooflines $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d['extra']['ms_per_step_regions'])"; done | tee $R/ar_ab.txt
+}
+ar_diag() {             # where the forced world-1 all-reduce's step time goes: process group only / per-kernel totals base vs forced
+    for v in base pgonly forced base pgonly forced; do F=""; E=0; [ $v = forced ] && F="--force-allreduce"; [ $v = pgonly ] && E=1
+        CMF_BENCH_PG_ONLY=$E python bench.py --no-cpu-baseline --no-op-rooflines $F 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d['extra']['ms_per_step_regions'])"; done | tee $R/ar_diag.txt
+    for v in base forced; do
+        rm -rf /tmp/ard_$v
+        F=""; [ $v = forced ] && F="--force-allreduce"
+        (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ard_$v -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-op-rooflines $F > /dev/null 2>&1)
+        cp $(find /tmp/ard_$v -name "*kernel_stats.csv" | head -1) $R/ard_stats_$v.csv
+    done
+}
+dense_train() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -s -k "dense_cloud" 2>&1 | tail -25 > $R/dense_train.txt; cat $R/dense_train.txt; }
+adam_test() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "flat_adam" 2>&1 | tail -8 > $R/adam_test.txt; cat $R/adam_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
 bench() { python bench.py > $R/bench.json 2> $R/bench.err; tail -3 $R/bench.err; cat $R/bench.json; }
 
