@@ -179,10 +179,10 @@ def hbm_op_rooflines(dev, iters=20):
 
     # the launch floor of this box: an (almost) empty one-wave kernel back to back on the same stream, timed the same way -- what a
     # launch costs before it moves a byte; the latency-bound rows below are printed as multiples of it (`x_floor`)
-    floor1 = timed(lambda: _lib.check(L.cmf_debug_spin(0.0, st), "spin"))
+    floor1 = timed(lambda: _lib.check(L.cmf_debug_spin(0.005, st), "spin"))
 
     def two():
-        _lib.check(L.cmf_debug_spin(0.0, st), "spin"); _lib.check(L.cmf_debug_spin(0.0, st), "spin")
+        _lib.check(L.cmf_debug_spin(0.005, st), "spin"); _lib.check(L.cmf_debug_spin(0.005, st), "spin")
     floor2 = timed(two)
     rows = []
     for (B, N, K, r, lidar), Cs in (((64, 256, 32, 2.0, False), (3, 64, 1027)), ((32, 4096, 64, 2.0, True), (64, 128))):
@@ -236,7 +236,7 @@ def hbm_op_rooflines(dev, iters=20):
             row["group_grad"]["traffic_committed"] = table.get(("group_points_grad", key))
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "launch_floor_us": round(floor1 * 1e6, 2), "launch_floor_pair_us": round(floor2 * 1e6, 2),
-            "launch_floor_note": "one / two back-to-back launches of a one-wave kernel that returns at once (cmf_debug_spin(0)), timed like the "
+            "launch_floor_note": "one / two back-to-back launches of a one-wave kernel that returns at once (cmf_debug_spin with zero ticks), timed like the "
                                  "rows; x_floor = row us / launch_floor_us",
             "traffic_source": ("per-row traffic_committed: constants from the committed rocprofv3 PMC passes (profiles/%s), not measured by "
                                "this run; null when the profile was taken on other kernel sources" % OP_TRAFFIC_PROFILE),

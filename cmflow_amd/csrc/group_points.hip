@@ -437,20 +437,13 @@ __device__ __forceinline__ int gp_block_scan(int v, int *wsum, int &block_total)
     return v + add;
 }
 
+// phases A-C (see above): the row's entries sorted by target into `sorted` (position | last-of-target << 15), offs[n + 1]
 template <int E>
-__global__ __launch_bounds__(GPL_THREADS) void gpg_plan_kernel(int n, int total, const int *__restrict__ idx, unsigned *__restrict__ plan_all)
+__device__ __forceinline__ void gpg_sort_row(int n, int total, const int *__restrict__ ix, unsigned short *run, unsigned short *sorted, int *offs, int *scan)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-    __shared__ int scan[GPL_WAVES];
     constexpr int CH = E / 4;                                         // 64-entry chunks per wave
     constexpr unsigned PAD = (unsigned)(GG_THREADS * E);              // padding reads the zero slot behind the row
-    unsigned short *run = reinterpret_cast<unsigned short *>(psm);    // [GPL_WAVES][n] per-wave counts, then exclusive prefixes over the waves
-    size_t o = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16;
-    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += (size_t)GG_THREADS * E * 2;   // positions by target | last-of-target << 15
-    int *offs = reinterpret_cast<int *>(psm + o);                     // [n + 1]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, bs = blockIdx.x;
-    const int *ix = idx + (size_t)bs * total;
-    unsigned *plan = plan_all + (size_t)bs * gpg_plan_words(E, n);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int key[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
@@ -511,6 +504,57 @@ __global__ __launch_bounds__(GPL_THREADS) void gpg_plan_kernel(int n, int total,
     }
     for (int i = total + t; i < GG_THREADS * E; i += GPL_THREADS) sorted[i] = (unsigned short)PAD;
     __syncthreads();
+}
+
+// Narrow features (C <= 4: the gradient of grouped coordinates, 8.6 MB at (64,256,32)): sort and sum in ONE launch -- the plan never
+// leaves LDS.  A thread per (channel, target) adds the target's entries in list order (ascending position: the order of the oracle's
+// loop), eight loads in flight.  Two launches (plan + scatter) took 10.6 + 8.2 us for what is 2-3 launch floors of work.
+template <int E>
+__global__ __launch_bounds__(GPL_THREADS) void gpg_narrow_kernel(int c, int n, int total, const int *__restrict__ idx, const float *__restrict__ grad_out,
+                                                                 float *__restrict__ grad_points)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    __shared__ int scan[GPL_WAVES];
+    unsigned short *run = reinterpret_cast<unsigned short *>(psm);
+    size_t o = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16;
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += (size_t)GG_THREADS * E * 2;
+    int *offs = reinterpret_cast<int *>(psm + o);
+    const int t = threadIdx.x, bs = blockIdx.x;
+    gpg_sort_row<E>(n, total, idx + (size_t)bs * total, run, sorted, offs, scan);
+    const float *g = grad_out + (size_t)bs * c * total;
+    float *gp = grad_points + (size_t)bs * c * n;
+    for (int q = t; q < c * n; q += GPL_THREADS) {
+        const int ch = q / n, j = q - ch * n;
+        const float *row = g + (size_t)ch * total;
+        const int e0 = offs[j], e1 = offs[j + 1];
+        if (e0 == e1) continue;
+        float sum = 0.f;
+        int e = e0;
+        for (; e + 8 <= e1; e += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[sorted[e + u] & 0x7FFF];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; e < e1; ++e) sum += row[sorted[e] & 0x7FFF];
+        gp[q] += sum;
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(GPL_THREADS) void gpg_plan_kernel(int n, int total, const int *__restrict__ idx, unsigned *__restrict__ plan_all)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+    __shared__ int scan[GPL_WAVES];
+    unsigned short *run = reinterpret_cast<unsigned short *>(psm);    // [GPL_WAVES][n] per-wave counts, then exclusive prefixes over the waves
+    size_t o = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16;
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += (size_t)GG_THREADS * E * 2;   // positions by target | last-of-target << 15
+    int *offs = reinterpret_cast<int *>(psm + o);                     // [n + 1]
+    const int t = threadIdx.x, bs = blockIdx.x;
+    unsigned *plan = plan_all + (size_t)bs * gpg_plan_words(E, n);
+    gpg_sort_row<E>(n, total, idx + (size_t)bs * total, run, sorted, offs, scan);
+    int base = 0;
     // D: the scatter workgroup's register image
     const unsigned *sw = reinterpret_cast<const unsigned *>(sorted);
     for (int i = t; i < GG_THREADS * (E / 2); i += GPL_THREADS) plan[i] = sw[i] & 0x7FFF7FFFu;
@@ -632,6 +676,19 @@ static int launch_plan(int b, int c, int n, int total, int ch_per_wg, const floa
     const size_t lds = (size_t)((GG_THREADS * E + 4) + 2 * n + GG_THREADS) * 4;
     hipLaunchKernelGGL(group_points_grad_plan_kernel<E>, dim3(b, cmf_divup(c, ch_per_wg)), dim3(GG_THREADS), lds, st, c, n, total, ch_per_wg,
                        grad_out, plan, grad_points);
+    return cmf_launch_status();
+}
+
+template <int E>
+static int launch_narrow(int b, int c, int n, int total, const float *grad_out, const int *idx, float *grad_points, hipStream_t st)
+{
+    static CmfPerDevice attr_set;
+    int attr_dev;
+    if (attr_set.need(attr_dev)) {
+        (void)hipFuncSetAttribute((const void *)gpg_narrow_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpg_plan_lds(E, GPL_MAX_N));
+        attr_set.done(attr_dev);
+    }
+    hipLaunchKernelGGL(gpg_narrow_kernel<E>, dim3(b), dim3(GPL_THREADS), gpg_plan_lds(E, n), st, c, n, total, idx, grad_out, grad_points);
     return cmf_launch_status();
 }
 
@@ -1414,6 +1471,14 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     // rows of the model's sizes: one plan kernel + the plan form of the balanced kernel (CMF_GROUP_GRAD_PLAN=0: the inverse
     // index + balanced kernel below, diagnostics)
     static const bool use_plan = !(getenv("CMF_GROUP_GRAD_PLAN") && getenv("CMF_GROUP_GRAD_PLAN")[0] == '0');
+    if (use_plan && balanced && n <= GPL_MAX_N && c <= 4) {          // narrow features: sort + sum in one launch
+        const int e_need = (int)cmf_divup(total, GG_THREADS);
+        const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
+        return E == 4 ? launch_narrow<4>(b, c, n, (int)total, grad_out, idx, grad_points, st)
+             : E == 8 ? launch_narrow<8>(b, c, n, (int)total, grad_out, idx, grad_points, st)
+             : E == 16 ? launch_narrow<16>(b, c, n, (int)total, grad_out, idx, grad_points, st)
+                       : launch_narrow<32>(b, c, n, (int)total, grad_out, idx, grad_points, st);
+    }
     if (use_plan && balanced && n <= GPL_MAX_N) {
         int ch_per_wg = GG_CH;
         while (ch_per_wg > 2 && (long long)b * cmf_divup(c, ch_per_wg) < 1024) ch_per_wg /= 2;

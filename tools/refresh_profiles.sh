@@ -5,9 +5,9 @@ R=$GRAFT_REPO_ROOT/gpurun_out/r; mkdir -p $R
 export TMPDIR=/tmp
 # PMC constants first (bench.py reports them only beside matching kernel sources): the in-step GEMM traffic and the drop-in op table
 bash tools/session.sh r pmc_gemm > /dev/null 2>&1
-cp $R/gemm_traffic.json profiles/r05_gemm_traffic_instep.json
+cp $R/gemm_traffic.json profiles/r06_gemm_traffic_instep.json
 bash tools/session.sh r op_pmc > /dev/null 2>&1
-cp $R/op_hbm_pmc.json profiles/r05_op_hbm_pmc.json
+cp $R/op_hbm_pmc.json profiles/r06_op_hbm_pmc.json
 python bench.py --gemm-table $R/gemm_shapes_train.md > $R/bench_train.json 2> $R/bench_train.err
 python bench.py --mode fwd --gemm-table $R/gemm_shapes_fwd.md > $R/bench_fwd.json 2> $R/bench_fwd.err
 python bench.py --model cmflow_t --no-cpu-baseline --no-op-rooflines > $R/bench_cmflow_t.json 2>/dev/null

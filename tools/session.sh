@@ -125,6 +125,15 @@ ar_diag() {             # where the forced world-1 all-reduce's step time goes: 
         cp $(find /tmp/ard_$v -name "*kernel_stats.csv" | head -1) $R/ard_stats_$v.csv
     done
 }
+knobs() {               # hardware-queue count and side-stream count re-measured on the current step (round 1-2 settled them at a 27 ms step)
+    one() { python bench.py --steps 60 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['extra']['ms_per_step_regions'])"; }
+    for r in 1 2; do
+        one "default"
+        for q in 2 3 6 8; do GPU_MAX_HW_QUEUES=$q one "GPU_MAX_HW_QUEUES=$q"; done
+        for s in 1 2 4; do CMF_SIDE_STREAMS=$s one "CMF_SIDE_STREAMS=$s"; done
+        CMF_STREAM_PROBE=0 one "CMF_STREAM_PROBE=0"
+    done | tee $R/knobs.txt
+}
 dense_train() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -s -k "dense_cloud" 2>&1 | tail -25 > $R/dense_train.txt; cat $R/dense_train.txt; }
 adam_test() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "flat_adam" 2>&1 | tail -8 > $R/adam_test.txt; cat $R/adam_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
