@@ -84,6 +84,8 @@ SIGNATURES = {
     "cmf_group_rows_grad_bn_cf_pieces": [_ci, _ci, _ci, _ci, _ci, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _cf, _vp, _vp, _vp,
                                          _ci, _vp],
     "cmf_gemm_dw_gather_split": [_ci, _ci, _ll],
+    "cmf_gemm_dw_gather_bn_bwd": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll,
+                                  _ci, _vp, _ci, _vp],
     "cmf_gemm_dw_gather": [_ci, _ci, _ll, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ci, _vp, _ci, _vp],
     "cmf_colsum": [_ci, _ci, _vp, _vp, _ci, _vp, _vp, _vp],
     "cmf_setconv_dwx": [_ci, _cf, _ci, _vp, _vp, _vp, _vp, _vp, _vp, _ci, _ci, _vp],

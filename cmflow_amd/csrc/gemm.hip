@@ -1841,6 +1841,37 @@ extern "C" int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const floa
     return 0;
 }
 
+// cmf_gemm_dw_gather with the train-mode BatchNorm backward of the output gradient formed while the A operand is staged (the bnb_*
+// path of cmf_gemm_dw_bn_bwd) -- BOTH operands of the second encoder's largest weight gradient are then formed in the staging loop:
+//   dZ = al * dU + be * (Z - mean) + ga   (written to dZ_out for the data-gradient GEMM),   B = relu(prob (Y[rows] + wx3 . dxyz))
+// and the stand-alone cmf_bn_bwd_apply pass over (rows, cout) -- read dU, read Z, write dZ -- disappears.  Same operations in the same
+// order as cmf_bn_bwd_apply followed by cmf_gemm_dw_gather: bit-identical results.
+extern "C" int cmf_gemm_dw_gather_bn_bwd(int cout, int cin, long long nrows, const float *dU, long long ldu, const float *Z, long long ldz,
+                                         const float *a, const float *mean, const float *invstd, const float *sums, float *dZ_out, long long ldo,
+                                         const float *Y, long long ldy, const int *rows, const float *dxyz, const float *wx3,
+                                         const float *prob_a, const float *prob_c, float *dW, long long lddw, int split_k, float *workspace,
+                                         int accumulate, void *stream)
+{
+    CMF_CHECK_ARG(cout > 0 && cin > 0 && nrows > 0 && nrows < (1ll << 31) && split_k >= 1);
+    CMF_CHECK_ARG(cout % 128 == 0 && cin % 128 == 0 && nrows % G_BK == 0);
+    CMF_CHECK_ARG(dU && Z && a && mean && invstd && sums && dZ_out && dZ_out != dU && Y && rows && dxyz && wx3 && prob_a && prob_c && dW && (split_k == 1 || workspace));
+    CMF_CHECK_ARG(ldu % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0 && ldy % 4 == 0 && lddw % 4 == 0);
+    CMF_CHECK_ARG((((uintptr_t)dU | (uintptr_t)Z | (uintptr_t)dZ_out | (uintptr_t)Y | (uintptr_t)dxyz | (uintptr_t)wx3 | (uintptr_t)dW) & 15) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{};
+    g.M = cout; g.N = cin; g.K = (int)nrows; g.A = dU; g.lda = ldu; g.B = Y; g.ldb = ldy;
+    g.C = split_k > 1 ? workspace : dW; g.ldc = split_k > 1 ? cin : lddw;
+    g.prob_a = prob_a; g.prob_c = prob_c; g.split_k = split_k; g.accumulate = split_k > 1 ? 0 : accumulate;
+    g.ga_rows = rows; g.ga_dxyz = dxyz; g.ga_wx = wx3; g.no_direct = 1;
+    g.bnb_z = Z; g.ldbz = ldz; g.bnb_a = a; g.bnb_mean = mean; g.bnb_invstd = invstd; g.bnb_sums = sums;
+    g.bnb_ic = (float)(1.0 / (double)nrows); g.bnb_out = dZ_out; g.ldbo = ldo;
+    const bool tall = split_k > 1 && split_k == cmf_gemm_dw_gather_split(cout, cin, nrows);
+    const int err = tall ? launch<256, 128, true, false, 0, 2>(g, st) : launch<128, 128, true, false, 0, 2>(g, st);
+    if (err) return err;
+    if (split_k > 1) return cmf_splitk_reduce(cout, cin, split_k, workspace, dW, lddw, accumulate, st);
+    return 0;
+}
+
 // Weight gradient of a layer whose output gradient still has to go through the train-mode BatchNorm backward:
 //   dZ = al * dU + be * (Z - mean) + ga  (cmf_common.h cmf_bnb_coef of a / mean / invstd / sums, 1 / rows),   dW (+)= dZ^T @ act(X)
 // formed while the A operand is staged -- the stand-alone cmf_bn_bwd_apply pass (read dU, read Z, write dZ) disappears and dZ

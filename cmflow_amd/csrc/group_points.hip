@@ -507,37 +507,66 @@ __device__ __forceinline__ void gpg_sort_row(int n, int total, const int *__rest
 }
 
 // Narrow features (C <= 4: the gradient of grouped coordinates, 8.6 MB at (64,256,32)): sort and sum in ONE launch -- the plan never
-// leaves LDS.  A thread per (channel, target) adds the target's entries in list order (ascending position: the order of the oracle's
-// loop), eight loads in flight.  Two launches (plan + scatter) took 10.6 + 8.2 us for what is 2-3 launch floors of work.
+// leaves LDS.  The c gradient rows are requested before the sort (registers), parked in LDS behind it, and a thread per (channel,
+// target) adds the target's entries in list order (ascending position: the order of the oracle's loop) from LDS.  Two launches
+// (plan + scatter) took 10.6 + 8.2 us for what is 2-3 launch floors of work.
+constexpr int GPN_MAX_N = 512;              // targets of the one-launch form (its LDS: sort arrays + c rows)
+template <int E>
+inline size_t gpg_narrow_lds(int c, int n)        // sorted | offs | max(per-wave counts of the sort, the c rows parked behind it)
+{
+    const size_t run = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16, rows = (size_t)c * GG_THREADS * E * sizeof(float);
+    return (size_t)GG_THREADS * E * 2 + ((size_t)(n + 1) * 4 + 15) / 16 * 16 + (run > rows ? run : rows);
+}
+
 template <int E>
 __global__ __launch_bounds__(GPL_THREADS) void gpg_narrow_kernel(int c, int n, int total, const int *__restrict__ idx, const float *__restrict__ grad_out,
                                                                  float *__restrict__ grad_points)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
     __shared__ int scan[GPL_WAVES];
-    unsigned short *run = reinterpret_cast<unsigned short *>(psm);
-    size_t o = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16;
-    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm + o); o += (size_t)GG_THREADS * E * 2;
-    int *offs = reinterpret_cast<int *>(psm + o);
+    constexpr int ROW = GG_THREADS * E;                               // entries of a row, padded
+    constexpr int V = ROW / 4 / GPL_THREADS > 0 ? ROW / 4 / GPL_THREADS : 1;     // float4 per thread and row
+    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm);
+    size_t o = (size_t)GG_THREADS * E * 2;
+    int *offs = reinterpret_cast<int *>(psm + o); o += ((size_t)(n + 1) * 4 + 15) / 16 * 16;
+    unsigned short *run = reinterpret_cast<unsigned short *>(psm + o);  // the sort's per-wave counts ...
+    float *rows = reinterpret_cast<float *>(psm + o);                   // ... dead when the [c][ROW] rows are parked in their place
     const int t = threadIdx.x, bs = blockIdx.x;
-    gpg_sort_row<E>(n, total, idx + (size_t)bs * total, run, sorted, offs, scan);
     const float *g = grad_out + (size_t)bs * c * total;
+    const bool vec = (total & 3) == 0 && ((uintptr_t)grad_out & 15) == 0;
+    float4 r[4][V];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int i = (v * GPL_THREADS + t) * 4;
+            r[ch][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ch < c && i < ROW) {
+                const float *src = g + (size_t)ch * total + i;
+                if (vec) { if (i < total) r[ch][v] = *(const float4 *)src; }
+                else {
+                    r[ch][v].x = i < total ? src[0] : 0.f;     r[ch][v].y = i + 1 < total ? src[1] : 0.f;
+                    r[ch][v].z = i + 2 < total ? src[2] : 0.f; r[ch][v].w = i + 3 < total ? src[3] : 0.f;
+                }
+            }
+        }
+    gpg_sort_row<E>(n, total, idx + (size_t)bs * total, run, sorted, offs, scan);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const int i = (v * GPL_THREADS + t) * 4;
+            if (ch < c && i < ROW) *(float4 *)(rows + (size_t)ch * ROW + i) = r[ch][v];
+        }
+    __syncthreads();
     float *gp = grad_points + (size_t)bs * c * n;
     for (int q = t; q < c * n; q += GPL_THREADS) {
         const int ch = q / n, j = q - ch * n;
-        const float *row = g + (size_t)ch * total;
+        const float *row = rows + (size_t)ch * ROW;
         const int e0 = offs[j], e1 = offs[j + 1];
         if (e0 == e1) continue;
         float sum = 0.f;
-        int e = e0;
-        for (; e + 8 <= e1; e += 8) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = row[sorted[e + u] & 0x7FFF];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) sum += v[u];
-        }
-        for (; e < e1; ++e) sum += row[sorted[e] & 0x7FFF];
+        for (int e = e0; e < e1; ++e) sum += row[sorted[e] & 0x7FFF];
         gp[q] += sum;
     }
 }
@@ -685,10 +714,10 @@ static int launch_narrow(int b, int c, int n, int total, const float *grad_out, 
     static CmfPerDevice attr_set;
     int attr_dev;
     if (attr_set.need(attr_dev)) {
-        (void)hipFuncSetAttribute((const void *)gpg_narrow_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpg_plan_lds(E, GPL_MAX_N));
+        (void)hipFuncSetAttribute((const void *)gpg_narrow_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpg_narrow_lds<E>(4, GPN_MAX_N));
         attr_set.done(attr_dev);
     }
-    hipLaunchKernelGGL(gpg_narrow_kernel<E>, dim3(b), dim3(GPL_THREADS), gpg_plan_lds(E, n), st, c, n, total, idx, grad_out, grad_points);
+    hipLaunchKernelGGL(gpg_narrow_kernel<E>, dim3(b), dim3(GPL_THREADS), gpg_narrow_lds<E>(c, n), st, c, n, total, idx, grad_out, grad_points);
     return cmf_launch_status();
 }
 
@@ -1471,7 +1500,7 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     // rows of the model's sizes: one plan kernel + the plan form of the balanced kernel (CMF_GROUP_GRAD_PLAN=0: the inverse
     // index + balanced kernel below, diagnostics)
     static const bool use_plan = !(getenv("CMF_GROUP_GRAD_PLAN") && getenv("CMF_GROUP_GRAD_PLAN")[0] == '0');
-    if (use_plan && balanced && n <= GPL_MAX_N && c <= 4) {          // narrow features: sort + sum in one launch
+    if (use_plan && balanced && n <= GPN_MAX_N && c <= 4) {          // narrow features: sort + sum in one launch
         const int e_need = (int)cmf_divup(total, GG_THREADS);
         const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
         return E == 4 ? launch_narrow<4>(b, c, n, (int)total, grad_out, idx, grad_points, st)

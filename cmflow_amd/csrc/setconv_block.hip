@@ -135,6 +135,14 @@ inline bool gather_sum_layout(const cmf_setconv_desc *d)
     return on && gather_layout(d) && d->dy != nullptr && d->S >= 2;
 }
 
+// BN backward of the layer behind the gathered first layer inside its weight-gradient GEMM (cmf_gemm_dw_gather_bn_bwd): the stand-alone
+// pass over (M, C2) goes, dZ lands in a buffer of its own for the data-gradient GEMM.  CMF_BNB_GATHER=1 (A/B).
+inline bool bnb_gather(const cmf_setconv_desc *d)
+{
+    static const bool on = getenv("CMF_BNB_GATHER") && getenv("CMF_BNB_GATHER")[0] == '1';
+    return on && d->training && gather_layout(d) && ((long long)d->B * d->N * d->S) >= 32768;
+}
+
 Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool backward)
 {
     Layout L;
@@ -172,7 +180,7 @@ Layout make_layout(const cmf_setconv_desc *d, float *saved, float *scratch, bool
         L.dU2 = t.take(M * C2);
         // (summed inside the GEMM: pieces (P + M/64) x O1 | perm M | source points M | relative coordinates 4 M -- sum_slots below)
         L.dU1 = t.take(gather_sum_layout(d) ? (size_t)(P + M / 64) * O1 + 6 * (size_t)M : (size_t)M * O1);
-        L.dZ2 = (d->training && bnb_fusable(M, C2, O1)) ? t.take(M * C2) : nullptr;
+        L.dZ2 = (d->training && (bnb_fusable(M, C2, O1) || bnb_gather(d))) ? t.take(M * C2) : nullptr;
         size_t sk = 0;
         sk = std::max(sk, (size_t)dw_split(P, C6, C5) * C6 * C5);
         sk = std::max(sk, (size_t)dw_split(P, C5, C4) * C5 * C4);
@@ -378,20 +386,29 @@ int bwd_layer1_gather(const cmf_setconv_desc *d, const Layout &L, long long M, i
     const float *b = L.bn[1], *b0 = L.bn[0];
     if (d->acc_bn[1]) CMF_TRY(cmf_colsum_finalize(tiles128(M), C2, L.partial, L.sums, d->dbeta[1], d->dgamma[1], st));
     else CMF_TRY(cmf_colsum_store(tiles128(M), 2 * C2, L.partial, L.sums, C2, d->dbeta[1], d->dgamma[1], st));
+    const float *dZ2 = L.dU2;
+    if (bnb_gather(d) && L.dZ2 && d->dw[0]) {
+        const int split = dwg_split(M, C2, O1);
+        CMF_TRY(cmf_gemm_dw_gather_bn_bwd(C2, O1, M, L.dU2, C2, L.z2, C2, b + 2 * C2, b, b + C2, L.sums, L.dZ2, C2, d->y, d->ldy, gather_rows(L),
+                                          L.dxyz, gather_wx3(L, M), b0 + 2 * O1, b0 + 3 * O1, d->dw[0], O1, split, split > 1 ? L.splitk : nullptr,
+                                          d->acc_w[0], st));
+        dZ2 = L.dZ2;
+    } else {
     CMF_TRY(cmf_bn_bwd_apply(M, C2, L.dU2, L.z2, C2, b + 2 * C2, b, b + C2, d->training ? L.sums : nullptr, st));
     if (d->dw[0]) {
         const int split = dwg_split(M, C2, O1);
         CMF_TRY(cmf_gemm_dw_gather(C2, O1, M, L.dU2, C2, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M), b0 + 2 * O1, b0 + 3 * O1,
                                    d->dw[0], O1, split, split > 1 ? L.splitk : nullptr, d->acc_w[0], st));
     }
+    }
     if (train_gather_sum(d)) {
         const SumSlots q = sum_slots(d, L);
         CMF_TRY(cmf_group_perm(d->B, d->N * d->S, L.inv, gather_rows(L), L.dxyz, q.perm, q.pts, q.dq2, st));
         cmf_gemm_dx_gather_sum_hint((long long)d->B * d->N);
-        return cmf_gemm_dx_gather_sum((int)M, O1, C2, L.dU2, C2, d->w[0], O1, d->y, d->ldy, q.perm, q.pts, q.dq2, gather_wx3(L, M),
+        return cmf_gemm_dx_gather_sum((int)M, O1, C2, dZ2, C2, d->w[0], O1, d->y, d->ldy, q.perm, q.pts, q.dq2, gather_wx3(L, M),
                                       b0 + 2 * O1, b0 + 3 * O1, b0, b0 + O1, q.pieces, L.partial, st);
     }
-    return cmf_gemm_dx_gather((int)M, O1, C2, L.dU2, C2, d->w[0], O1, L.dU1, O1, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M),
+    return cmf_gemm_dx_gather((int)M, O1, C2, dZ2, C2, d->w[0], O1, L.dU1, O1, d->y, d->ldy, gather_rows(L), L.dxyz, gather_wx3(L, M),
                               b0 + 2 * O1, b0 + 3 * O1, b0, b0 + O1, L.partial, st);
 }
 

@@ -284,6 +284,14 @@ int cmf_gemm_dx_gather_sum(int M, int cin, int cout, const float *dZ, long long 
 int cmf_gemm_dw_gather(int cout, int cin, long long nrows, const float *dZ, long long ldz, const float *Y, long long ldy,
                        const int *rows, const float *dxyz, const float *wx3, const float *prob_a, const float *prob_c,
                        float *dW, long long lddw, int split_k, float *workspace, int accumulate, void *stream);
+/* cmf_gemm_dw_gather with the train-mode BatchNorm backward of its output gradient formed in the A-operand staging as in
+ * cmf_gemm_dw_bn_bwd (dU, Z (nrows, cout); sums[2][cout]; dZ_out (nrows, cout) receives dZ and must not alias dU): bit-identical to
+ * cmf_bn_bwd_apply followed by cmf_gemm_dw_gather. */
+int cmf_gemm_dw_gather_bn_bwd(int cout, int cin, long long nrows, const float *dU, long long ldu, const float *Z, long long ldz,
+                              const float *a, const float *mean, const float *invstd, const float *sums, float *dZ_out, long long ldo,
+                              const float *Y, long long ldy, const int *rows, const float *dxyz, const float *wx3,
+                              const float *prob_a, const float *prob_c, float *dW, long long lddw, int split_k, float *workspace,
+                              int accumulate, void *stream);
 /* The split count with which cmf_gemm_dw_gather takes its 256-row tiles (workspace: split * cout * cin floats); 0 = no preference. */
 int cmf_gemm_dw_gather_split(int cout, int cin, long long nrows);
 

@@ -823,6 +823,43 @@ def test_gather_weight_gradient_is_bit_identical_to_the_materialised_path(dev, B
             assert torch.equal(got, want) or float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) * 50
 
 
+@pytest.mark.parametrize("B,N,S,K,NO,r", [(8, 256, 16, 512, 256, 8.0), (16, 256, 32, 512, 256, 16.0), (4, 256, 32, 128, 128, 16.0)])
+def test_gather_weight_gradient_with_fused_bn_backward(dev, B, N, S, K, NO, r):
+    """cmf_gemm_dw_gather_bn_bwd (BOTH operands formed while staging: the BN backward of the output gradient on A, the gathered first layer
+    on B) against cmf_bn_bwd_apply in place followed by cmf_gemm_dw_gather: dZ and dW bit for bit, at the split count the block calls use."""
+    from cmflow_amd import _lib, synth, pointnet2_utils as pu
+    L = _lib.lib()
+    torch.manual_seed(B * 10 + S)
+    xyz = synth.make_batch(B, N=N, seed=11)["pc1"].to(dev).transpose(1, 2).contiguous()
+    idx = pu.ball_query(r, S, xyz, xyz)
+    M = B * N * S
+    y = torch.randn(B, N, 2 * K, device=dev)[:, :, :K]
+    wx = torch.randn(K, 3, device=dev)
+    pa, pc = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+    dU, Z = torch.randn(M, NO, device=dev), torch.randn(M, NO, device=dev) * 2 + 0.5
+    a, mean, invstd = torch.rand(NO, device=dev) + 0.5, torch.randn(NO, device=dev) * 0.3 + 0.5, torch.rand(NO, device=dev) + 0.4
+    sums = torch.stack((dU.sum(0), (dU * ((Z - mean) * invstd)).sum(0))).contiguous()
+    st = _lib.stream_ptr()
+    rows = torch.empty(M, dtype=torch.int32, device=dev); dq = torch.empty(M, 4, device=dev); wx3 = torch.empty(3, K, device=dev)
+    _lib.check(L.cmf_group_prep(B, N, N, S, K, xyz.data_ptr(), xyz.data_ptr(), wx.data_ptr(), 3, idx.data_ptr(), rows.data_ptr(),
+                                dq.data_ptr(), wx3.data_ptr(), st), "prep")
+    split = L.cmf_gemm_dw_gather_split(NO, K, M) or 8
+    ws = torch.empty(split * NO * K, device=dev)
+    dZ_ref = dU.clone()
+    _lib.check(L.cmf_bn_bwd_apply(M, NO, dZ_ref.data_ptr(), Z.data_ptr(), NO, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(), sums.data_ptr(), st), "bnb")
+    for acc in (0, 1):
+        want, got = torch.full((NO, K), 0.5, device=dev), torch.full((NO, K), 0.5, device=dev)
+        dZ = torch.full((M, NO), float("nan"), device=dev)
+        _lib.check(L.cmf_gemm_dw_gather(NO, K, M, dZ_ref.data_ptr(), NO, y.data_ptr(), y.stride(1), rows.data_ptr(), dq.data_ptr(), wx3.data_ptr(),
+                                        pa.data_ptr(), pc.data_ptr(), want.data_ptr(), K, split, ws.data_ptr(), acc, st), "dwg")
+        _lib.check(L.cmf_gemm_dw_gather_bn_bwd(NO, K, M, dU.data_ptr(), NO, Z.data_ptr(), NO, a.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                               sums.data_ptr(), dZ.data_ptr(), NO, y.data_ptr(), y.stride(1), rows.data_ptr(), dq.data_ptr(),
+                                               wx3.data_ptr(), pa.data_ptr(), pc.data_ptr(), got.data_ptr(), K, split, ws.data_ptr(), acc, st), "dwgb")
+        torch.cuda.synchronize()
+        assert torch.equal(dZ, dZ_ref), float((dZ - dZ_ref).abs().max())
+        assert torch.equal(got, want), float((got - want).abs().max())
+
+
 @pytest.mark.parametrize("B,N,S,K,NO,r", [(4, 256, 8, 512, 256, 4.0), (2, 256, 32, 128, 64, 16.0), (1, 128, 4, 256, 16, 2.0)])
 def test_gather_data_gradient_is_bit_identical_to_the_materialised_path(dev, B, N, S, K, NO, r):
     """cmf_gemm_dx_gather (the first layer's pre-activations formed from the per-point rows in the backward epilogue) against

@@ -134,6 +134,11 @@ knobs() {               # hardware-queue count and side-stream count re-measured
         CMF_STREAM_PROBE=0 one "CMF_STREAM_PROBE=0"
     done | tee $R/knobs.txt
 }
+peak_mem() {            # peak device memory of the step: this tree, CMF_TRAIN_GATHER=0 (materialised sizes), and the pre-change worktree if present
+    python tools/peak_mem_probe.py 2>&1 | filter | tee $R/peak_mem.txt
+    CMF_TRAIN_GATHER=0 python tools/peak_mem_probe.py 2>&1 | filter | sed 's/^/CMF_TRAIN_GATHER=0 /' | tee -a $R/peak_mem.txt
+    [ -d tools/diag/old ] && python tools/peak_mem_probe.py tools/diag/old 2>&1 | filter | tee -a $R/peak_mem.txt
+}
 dense_train() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -s -k "dense_cloud" 2>&1 | tail -25 > $R/dense_train.txt; cat $R/dense_train.txt; }
 adam_test() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "flat_adam" 2>&1 | tail -8 > $R/adam_test.txt; cat $R/adam_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
