@@ -506,71 +506,12 @@ __device__ __forceinline__ void gpg_sort_row(int n, int total, const int *__rest
     __syncthreads();
 }
 
-// Narrow features (C <= 4: the gradient of grouped coordinates, 8.6 MB at (64,256,32)): sort and sum in ONE launch -- the plan never
-// leaves LDS.  The c gradient rows are requested before the sort (registers), parked in LDS behind it, and a thread per (channel,
-// target) adds the target's entries in list order (ascending position: the order of the oracle's loop) from LDS.  Two launches
-// (plan + scatter) took 10.6 + 8.2 us for what is 2-3 launch floors of work.
-constexpr int GPN_MAX_N = 512;              // targets of the one-launch form (its LDS: sort arrays + c rows)
-template <int E>
-inline size_t gpg_narrow_lds(int c, int n)        // sorted | offs | max(per-wave counts of the sort, the c rows parked behind it)
-{
-    const size_t run = ((size_t)GPL_WAVES * n * 2 + 15) / 16 * 16, rows = (size_t)c * GG_THREADS * E * sizeof(float);
-    return (size_t)GG_THREADS * E * 2 + ((size_t)(n + 1) * 4 + 15) / 16 * 16 + (run > rows ? run : rows);
-}
-
-template <int E>
-__global__ __launch_bounds__(GPL_THREADS) void gpg_narrow_kernel(int c, int n, int total, const int *__restrict__ idx, const float *__restrict__ grad_out,
-                                                                 float *__restrict__ grad_points)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-    __shared__ int scan[GPL_WAVES];
-    constexpr int ROW = GG_THREADS * E;                               // entries of a row, padded
-    constexpr int V = ROW / 4 / GPL_THREADS > 0 ? ROW / 4 / GPL_THREADS : 1;     // float4 per thread and row
-    unsigned short *sorted = reinterpret_cast<unsigned short *>(psm);
-    size_t o = (size_t)GG_THREADS * E * 2;
-    int *offs = reinterpret_cast<int *>(psm + o); o += ((size_t)(n + 1) * 4 + 15) / 16 * 16;
-    unsigned short *run = reinterpret_cast<unsigned short *>(psm + o);  // the sort's per-wave counts ...
-    float *rows = reinterpret_cast<float *>(psm + o);                   // ... dead when the [c][ROW] rows are parked in their place
-    const int t = threadIdx.x, bs = blockIdx.x;
-    const float *g = grad_out + (size_t)bs * c * total;
-    const bool vec = (total & 3) == 0 && ((uintptr_t)grad_out & 15) == 0;
-    float4 r[4][V];
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const int i = (v * GPL_THREADS + t) * 4;
-            r[ch][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ch < c && i < ROW) {
-                const float *src = g + (size_t)ch * total + i;
-                if (vec) { if (i < total) r[ch][v] = *(const float4 *)src; }
-                else {
-                    r[ch][v].x = i < total ? src[0] : 0.f;     r[ch][v].y = i + 1 < total ? src[1] : 0.f;
-                    r[ch][v].z = i + 2 < total ? src[2] : 0.f; r[ch][v].w = i + 3 < total ? src[3] : 0.f;
-                }
-            }
-        }
-    gpg_sort_row<E>(n, total, idx + (size_t)bs * total, run, sorted, offs, scan);
-#pragma unroll
-    for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-            const int i = (v * GPL_THREADS + t) * 4;
-            if (ch < c && i < ROW) *(float4 *)(rows + (size_t)ch * ROW + i) = r[ch][v];
-        }
-    __syncthreads();
-    float *gp = grad_points + (size_t)bs * c * n;
-    for (int q = t; q < c * n; q += GPL_THREADS) {
-        const int ch = q / n, j = q - ch * n;
-        const float *row = rows + (size_t)ch * ROW;
-        const int e0 = offs[j], e1 = offs[j + 1];
-        if (e0 == e1) continue;
-        float sum = 0.f;
-        for (int e = e0; e < e1; ++e) sum += row[sorted[e] & 0x7FFF];
-        gp[q] += sum;
-    }
-}
-
+// [Round 6, measured and not kept: a one-launch form for C <= 4 -- this sort followed by a thread per (channel, target) summing the
+//  target's entries, from global memory (24.7 us) or from rows parked in LDS (40 us walked one by one, 22.7 us with eight entries in
+//  flight) -- against 18.2 us for the plan + scatter pair at (64,256,32,3): one 1024-thread workgroup per sample leaves 192 of 256 CUs
+//  idle for the whole call and the per-target walk is a chain of dependent LDS reads as long as the sample's longest list, where the
+//  scatter kernel's 4 x 64 workgroups spread both.  The launch floor of the box is 3.6 us (bench.py roofline_hbm.launch_floor_us): the pair
+//  runs at 5 floors for 8.6 MB.]
 template <int E>
 __global__ __launch_bounds__(GPL_THREADS) void gpg_plan_kernel(int n, int total, const int *__restrict__ idx, unsigned *__restrict__ plan_all)
 {
@@ -705,19 +646,6 @@ static int launch_plan(int b, int c, int n, int total, int ch_per_wg, const floa
     const size_t lds = (size_t)((GG_THREADS * E + 4) + 2 * n + GG_THREADS) * 4;
     hipLaunchKernelGGL(group_points_grad_plan_kernel<E>, dim3(b, cmf_divup(c, ch_per_wg)), dim3(GG_THREADS), lds, st, c, n, total, ch_per_wg,
                        grad_out, plan, grad_points);
-    return cmf_launch_status();
-}
-
-template <int E>
-static int launch_narrow(int b, int c, int n, int total, const float *grad_out, const int *idx, float *grad_points, hipStream_t st)
-{
-    static CmfPerDevice attr_set;
-    int attr_dev;
-    if (attr_set.need(attr_dev)) {
-        (void)hipFuncSetAttribute((const void *)gpg_narrow_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gpg_narrow_lds<E>(4, GPN_MAX_N));
-        attr_set.done(attr_dev);
-    }
-    hipLaunchKernelGGL(gpg_narrow_kernel<E>, dim3(b), dim3(GPL_THREADS), gpg_narrow_lds<E>(c, n), st, c, n, total, idx, grad_out, grad_points);
     return cmf_launch_status();
 }
 
@@ -1500,14 +1428,6 @@ extern "C" int cmf_group_points_grad(int b, int c, int n, int npoints, int nsamp
     // rows of the model's sizes: one plan kernel + the plan form of the balanced kernel (CMF_GROUP_GRAD_PLAN=0: the inverse
     // index + balanced kernel below, diagnostics)
     static const bool use_plan = !(getenv("CMF_GROUP_GRAD_PLAN") && getenv("CMF_GROUP_GRAD_PLAN")[0] == '0');
-    if (use_plan && balanced && n <= GPN_MAX_N && c <= 4) {          // narrow features: sort + sum in one launch
-        const int e_need = (int)cmf_divup(total, GG_THREADS);
-        const int E = e_need <= 4 ? 4 : e_need <= 8 ? 8 : e_need <= 16 ? 16 : 32;
-        return E == 4 ? launch_narrow<4>(b, c, n, (int)total, grad_out, idx, grad_points, st)
-             : E == 8 ? launch_narrow<8>(b, c, n, (int)total, grad_out, idx, grad_points, st)
-             : E == 16 ? launch_narrow<16>(b, c, n, (int)total, grad_out, idx, grad_points, st)
-                       : launch_narrow<32>(b, c, n, (int)total, grad_out, idx, grad_points, st);
-    }
     if (use_plan && balanced && n <= GPL_MAX_N) {
         int ch_per_wg = GG_CH;
         while (ch_per_wg > 2 && (long long)b * cmf_divup(c, ch_per_wg) < 1024) ch_per_wg /= 2;

@@ -136,10 +136,14 @@ inline bool gather_sum_layout(const cmf_setconv_desc *d)
 }
 
 // BN backward of the layer behind the gathered first layer inside its weight-gradient GEMM (cmf_gemm_dw_gather_bn_bwd): the stand-alone
-// pass over (M, C2) goes, dZ lands in a buffer of its own for the data-gradient GEMM.  CMF_BNB_GATHER=1 (A/B).
+// pass over (M, C2) -- read dU, read Z, write dZ: 3 GB per step at B = 64 -- goes, dZ lands in a buffer of its own for the data-gradient
+// GEMM (other column tiles of the slab still read dU).  Bit-identical to the two-kernel form.  [measured, round 6, A/B/A/B on one box:
+// 18.999 / 19.035 -> 18.809 / 18.844 ms per step; the four GEMMs that absorb the pass run 2 points further from their MFMA roof --
+// isolated cmf_gemm 0.739 -> 0.719 -- which is what the round-3 form of this fusion (CMF_BNB_FUSED, non-gathering) was left opt-in for:
+// the step is the figure of merit.]  CMF_BNB_GATHER=0: the stand-alone pass (A/B).
 inline bool bnb_gather(const cmf_setconv_desc *d)
 {
-    static const bool on = getenv("CMF_BNB_GATHER") && getenv("CMF_BNB_GATHER")[0] == '1';
+    static const bool on = !(getenv("CMF_BNB_GATHER") && getenv("CMF_BNB_GATHER")[0] == '0');
     return on && d->training && gather_layout(d) && ((long long)d->B * d->N * d->S) >= 32768;
 }
 

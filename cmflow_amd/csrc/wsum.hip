@@ -229,19 +229,31 @@ __global__ __launch_bounds__(WS_THREADS, 3) void wn_ksum_bwd_kernel(
     float dbh = 0.f;                                    // threads tid < R*8: column sum of the masked dh they write
     const int MK = M * K;
     int it = 0;
+    // the row's two streams (x, dcost) are requested one iteration ahead: an iteration is a dependent chain load -> ~110 FMAs -> wave
+    // reduction -> barrier, and with three workgroups per CU nothing else covered the loads' latency (2 us per iteration for 0.65 us of
+    // arithmetic: tools/fc_profile.py)
+    auto request = [&](int row0, float4 &g4, float4 &x4) {
+        const int mk = __builtin_amdgcn_readfirstlane(row0 + r);
+        if (mk < MK) {
+            const int m = mk / K;
+            const long long row = idx ? (long long)(m / n1) * n_src + idx[mk] : mk;
+            g4 = *(const float4 *)(dcost + (long long)m * ldd + c);
+            x4 = *(const float4 *)(x + row * C + c);
+        }
+    };
+    float4 g4n = make_float4(0.f, 0.f, 0.f, 0.f), x4n = g4n;
+    request((int)blockIdx.x * R, g4n, x4n);
     for (int row0 = (int)blockIdx.x * R; row0 < MK; row0 += (int)gridDim.x * R, ++it) {
         const int mk = __builtin_amdgcn_readfirstlane(row0 + r);
         float p[WN_J];
 #pragma unroll
         for (int j = 0; j < WN_J; ++j) p[j] = 0.f;
+        const float4 g4 = g4n, x4 = x4n;
+        if (row0 + (int)gridDim.x * R < MK) request(row0 + (int)gridDim.x * R, g4n, x4n);
         if (mk < MK) {
-            const int m = mk / K;
             float hv[WN_J];
 #pragma unroll
             for (int j = 0; j < WN_J; ++j) hv[j] = h[(long long)mk * WN_J + j];
-            const long long row = idx ? (long long)(m / n1) * n_src + idx[mk] : mk;
-            const float4 g4 = *(const float4 *)(dcost + (long long)m * ldd + c);
-            const float4 x4 = *(const float4 *)(x + row * C + c);
             const float g[4] = {g4.x, g4.y, g4.z, g4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
             float pre[4], d[4];
             wn_pre(W, b, hv, pre);

@@ -475,7 +475,7 @@ _AB_SWITCHES = [
     (dict(CMF_THIN_FUSED="0"), 2e-5),                   # narrow backward layers as three kernels: other split-K slabs
     (dict(CMF_THIN_WIDE="0"), 2e-5),                    # 64 <- 256 backward layer as max-pool backward + BN backward + two tiled GEMMs
     (dict(CMF_BNB_FUSED="1"), 2e-5),                    # BN backward inside the weight-gradient GEMM's staging
-    (dict(CMF_BNB_GATHER="1"), None),                   # ... and inside the GATHERING weight-gradient GEMM of the second encoder
+    (dict(CMF_BNB_GATHER="0"), None),                   # stand-alone BN-backward pass in front of the gathering weight-gradient GEMM
     (dict(CMF_STREAM_PROBE="0"), None),                 # side-stream pool as the streams come, not picked by the queue probe
 ]
 

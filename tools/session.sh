@@ -139,6 +139,11 @@ peak_mem() {            # peak device memory of the step: this tree, CMF_TRAIN_G
     CMF_TRAIN_GATHER=0 python tools/peak_mem_probe.py 2>&1 | filter | sed 's/^/CMF_TRAIN_GATHER=0 /' | tee -a $R/peak_mem.txt
     [ -d tools/diag/old ] && python tools/peak_mem_probe.py tools/diag/old 2>&1 | filter | tee -a $R/peak_mem.txt
 }
+bnbg_ab() {             # BN backward inside the gathering weight-gradient GEMM (CMF_BNB_GATHER=1) against the stand-alone pass
+    python -m pytest tests/test_gpu_gemm.py -x -q -m gpu -k "fused_bn_backward" 2>&1 | grep -E "passed|failed|Error|assert" | tail -5 | tee $R/bnbg_tests.txt
+    for v in 1 0 1 0; do CMF_BNB_GATHER=$v python bench.py --steps 60 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('CMF_BNB_GATHER=$v', d['ms_per_step'], d['extra']['ms_per_step_regions'], d['roofline_isolated']['frac'])"; done | tee $R/bnbg_ab.txt
+}
+fc() { for s in 1 0; do echo "== FC_SERIAL=$s"; FC_SERIAL=$s python tools/fc_profile.py 2>&1 | filter | head -40; done > $R/fc_profile.txt; head -12 $R/fc_profile.txt; }
 dense_train() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -s -k "dense_cloud" 2>&1 | tail -25 > $R/dense_train.txt; cat $R/dense_train.txt; }
 adam_test() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "flat_adam" 2>&1 | tail -8 > $R/adam_test.txt; cat $R/adam_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
