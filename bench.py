@@ -32,9 +32,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_PROFILE = "r05_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
+TRAFFIC_PROFILE = "r06_gemm_traffic_instep.json"   # committed FETCH_SIZE / WRITE_SIZE passes the `roofline.traffic` constant comes from
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA dense peak
-OP_TRAFFIC_PROFILE = "r05_op_hbm_pmc.json"        # committed PMC passes over the drop-in calls (tools/session.sh op_pmc)
+OP_TRAFFIC_PROFILE = "r06_op_hbm_pmc.json"        # committed PMC passes over the drop-in calls (tools/session.sh op_pmc)
 
 
 class Args:

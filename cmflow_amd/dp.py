@@ -46,8 +46,12 @@ class FlatGradBucket:
 
     def all_reduce_mean(self, group=None, force=False):
         if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.mul_(1.0 / dist.get_world_size(group))
+            if dist.get_backend(group) == "nccl":
+                # RCCL averages inside the collective (ncclAvg, as SegmentedReducer does): no scaling kernel behind it
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=group)
+            else:                                             # gloo (CPU tests, the one-GPU two-rank tests) has no AVG
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.mul_(1.0 / dist.get_world_size(group))
 
     # ---- segments: all-reduce overlapped with the backward pass ---------------------------------------------------
     def segment_of(self, modules):

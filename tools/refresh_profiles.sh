@@ -26,6 +26,9 @@ python tools/gemm_vendor_compare.py 2>&1 | grep -v amdgpu.ids > $R/gemm_vendor_c
 python tools/host_time_probe.py 20 2>&1 | grep -v amdgpu.ids > $R/host_time_probe.txt
 python tools/phase_probe.py 2>&1 | grep -v amdgpu.ids > $R/phase_probe.txt
 python tools/gather_probe.py 2>&1 | grep rows > $R/gather_probe.txt
+python tools/aten_census.py 2>&1 | grep -v "amdgpu.ids\|_warn_once" > $R/aten_census.txt
+for s in 1 0; do echo "== FC_SERIAL=$s"; FC_SERIAL=$s python tools/fc_profile.py 2>&1 | grep -v "Warning\|_warn_once\|amdgpu.ids" | head -40; done > $R/fc_profile.txt
+python tools/peak_mem_probe.py 2>&1 | grep -v "amdgpu.ids" > $R/peak_mem_now.txt
 timeout 300 tools/lab/gemm_lab 131072x512x256 131072x512x512 131072x512x1024 524288x256x512 16384x2048x1024 65536x256x512 > $R/gemm_lab.txt 2>&1
 LAB_FLAGS=1 timeout 300 tools/lab/gemm_lab 131072x512x256 131072x512x512 131072x512x1024 > $R/gemm_lab_nostore.txt 2>&1
 timeout 200 tools/lab/mfma_peak > $R/mfma_peak.txt 2>&1
