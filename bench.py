@@ -285,6 +285,8 @@ def main():
     ap.add_argument("--force-allreduce", action="store_true",
                     help="diagnostic at N=1: run the RCCL all-reduce of the gradient bucket (world size 1) inside every step")
     ap.add_argument("--no-op-rooflines", action="store_true", help="skip the roofline_hbm op benchmarks after the timed region")
+    ap.add_argument("--no-config2", action="store_true", help="skip the fwd-only (BASELINE config 2) timing behind the timed regions (profiling runs: "
+                                                              "keeps the kernel statistics of a training run free of inference steps)")
     ap.add_argument("--clip", type=int, default=5, help="cmflow_t: frames per mini-clip (clip_util.py:34-62)")
     ap.add_argument("--gemm-table", default=None, help="write a markdown table of the bracketed cmf_gemm launches by shape to this file")
     ap.add_argument("--host-cores", type=int, default=0,
@@ -525,7 +527,7 @@ def main():
     # BASELINE config 2 (fwd only, eval-mode BN, same batch) timed in the same run: 20 steps behind 3 warm-up steps, the chains back
     # on the stream pool.  Not part of `value`.  (Every rank runs it: no collective inside.)
     config2 = None
-    if a.mode == "train" and a.model == "cmflow":
+    if a.mode == "train" and a.model == "cmflow" and not a.no_config2:
         from cmflow_amd import fused_blocks as _FB
         _FB.set_serial(net, bool(a.serial))
         net.eval()

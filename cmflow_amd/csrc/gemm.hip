@@ -1115,6 +1115,11 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void *)p.Z, 0, -1, 0x00020000);
         const unsigned ycol_off = (unsigned)c * 4u, ldz4 = (unsigned)p.ldz * 4u;
         auto load_y = [&](int row0, float (&y)[32]) {
+            if (GDIAG(p) & 32) {                                     // timing diagnostic: no per-point loads
+#pragma unroll
+                for (int u = 0; u < 32; ++u) y[u] = 1.f;
+                return;
+            }
             if (p.ga_y32) {
 #pragma unroll
                 for (int u = 0; u < 32; ++u)
@@ -1164,6 +1169,7 @@ __global__ __launch_bounds__(G_THREADS, (BM > 128 || BN > 128) ? 2 : 3) void gem
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 asm volatile("" ::: "memory");
+                if (GDIAG(p) & 64) { seg += ya[g] + yb[g]; continue; }       // timing diagnostic: no row walk
                 rows8(i, i * 32 + g * 8, (i == 0 ? ya : yb) + g * 8);
             }
             asm volatile("" ::: "memory");

@@ -474,30 +474,28 @@ _AB_SWITCHES = [
     (dict(CMF_FIN_WIDE="1"), None),                     # 16-column fold kernels for every partial matrix
     (dict(CMF_THIN_FUSED="0"), 2e-5),                   # narrow backward layers as three kernels: other split-K slabs
     (dict(CMF_THIN_WIDE="0"), 2e-5),                    # 64 <- 256 backward layer as max-pool backward + BN backward + two tiled GEMMs
-    (dict(CMF_BNB_FUSED="1"), 2e-5),                    # BN backward inside the weight-gradient GEMM's staging
+    # BN backward inside the NON-gathering weight-gradient GEMM's staging (round 3): only reachable with the materialised first layer
+    (dict(CMF_TRAIN_GATHER="0", CMF_BNB_FUSED="1"), 5e-5),
     (dict(CMF_BNB_GATHER="0"), None),                   # stand-alone BN-backward pass in front of the gathering weight-gradient GEMM
     (dict(CMF_STREAM_PROBE="0"), None),                 # side-stream pool as the streams come, not picked by the queue probe
 ]
 
 
+def _dump_step(path, env, mode="train"):
+    import subprocess, sys
+    args = [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), path, "4"] + (["eval"] if mode == "eval" else [])
+    r = subprocess.run(args, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return torch.load(path)
+
+
 @pytest.fixture(scope="module")
 def default_step_b4(tmp_path_factory):
-    import subprocess, sys
-    f = str(tmp_path_factory.mktemp("ab") / "default.pt")
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "4"],
-                       env=dict(os.environ), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    return torch.load(f)
+    d = tmp_path_factory.mktemp("ab")
+    return {"train": _dump_step(str(d / "default.pt"), {}), "eval": _dump_step(str(d / "default_eval.pt"), {}, "eval")}
 
 
-@pytest.mark.parametrize("env,bound", _AB_SWITCHES, ids=[",".join("%s=%s" % kv for kv in e.items()) for e, _ in _AB_SWITCHES])
-def test_ab_switch_leaves_the_training_step_unchanged(dev, tmp_path, default_step_b4, env, bound):
-    import subprocess, sys
-    f = str(tmp_path / "switched.pt")
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "train_step_dump.py"), f, "4"],
-                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    a, b = default_step_b4, torch.load(f)
+def _compare_steps(a, b, env, bound, fwd_exact=True):
     assert a.keys() == b.keys() and len(a) > 300
     differ = [k for k in a if not torch.equal(a[k], b[k])]
     worst = max([float((a[k].double() - b[k].double()).norm() / (a[k].double().norm() + 1e-30)) for k in differ if a[k].is_floating_point()] or [0.0])
@@ -505,9 +503,24 @@ def test_ab_switch_leaves_the_training_step_unchanged(dev, tmp_path, default_ste
     if bound is None:
         assert not differ, (env, differ[:10])
     else:
-        fwd = [k for k in differ if k.startswith("b.") or k == "loss"]
-        assert not fwd, (env, fwd[:10])                               # the forward pass does not go through the switched kernels
+        if fwd_exact:                                                 # the forward pass does not go through the switched kernels
+            fwd = [k for k in differ if k.startswith("b.") or k == "loss"]
+            assert not fwd, (env, fwd[:10])
         assert worst <= bound, (env, worst)
+
+
+@pytest.mark.parametrize("env,bound", _AB_SWITCHES, ids=[",".join("%s=%s" % kv for kv in e.items()) for e, _ in _AB_SWITCHES])
+def test_ab_switch_leaves_the_training_step_unchanged(dev, tmp_path, default_step_b4, env, bound):
+    _compare_steps(default_step_b4["train"], _dump_step(str(tmp_path / "switched.pt"), env), env, bound)
+
+
+def test_ab_switch_chain_off_in_eval_mode_bn_training(dev, tmp_path, default_step_b4):
+    """CMF_CHAIN=0: the first encoder's blocks through the per-layer kernels where the default takes the register chain -- training with
+    eval-mode BatchNorm (the reference's regime after its first epoch; the default there).  Every layer of the chain is bit-identical to
+    the per-layer kernels in the forward pass; the backward passes sum their weight-gradient slabs and statistics rows per wave instead
+    of per 128 rows: same terms, another association."""
+    env = dict(CMF_CHAIN="0")
+    _compare_steps(default_step_b4["eval"], _dump_step(str(tmp_path / "switched.pt"), env, "eval"), env, 5e-5, fwd_exact=False)
 
 
 def test_full_size_train_step_matches_oracle(dev):

@@ -14,12 +14,12 @@ python bench.py --model cmflow_t --no-cpu-baseline --no-op-rooflines > $R/bench_
 python bench.py --model raflow --no-cpu-baseline --no-op-rooflines > $R/bench_raflow.json 2>/dev/null
 python bench.py --force-allreduce --no-cpu-baseline --no-op-rooflines > $R/bench_forced_allreduce.json 2>/dev/null
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines > /dev/null 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --no-config2 > /dev/null 2>&1)
 cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $R/train_kernel_stats.csv
 python tools/trace_overlap.py $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) loss_sample_kernel 5 11 > $R/train_overlap.txt 2>&1
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --mode fwd > /dev/null 2>&1)
 cp $(find /tmp/p2 -name "*kernel_stats.csv" | head -1) $R/fwd_kernel_stats.csv
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --serial > /dev/null 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --no-config2 --serial > /dev/null 2>&1)
 cp $(find /tmp/p3 -name "*kernel_stats.csv" | head -1) $R/train_serial_kernel_stats.csv
 for c in 0 1; do echo "== CMF_CHAIN_TRAIN=$c (ENC1_SERIAL=1: isolated kernel durations)"; ENC1_SERIAL=1 CMF_CHAIN_TRAIN=$c python tools/enc1_profile.py 2>&1 | grep -v "Warning\|_warn_once\|amdgpu.ids" | head -22; done > $R/enc1_profile.txt
 python tools/gemm_vendor_compare.py 2>&1 | grep -v amdgpu.ids > $R/gemm_vendor_compare.txt

@@ -54,7 +54,7 @@ model_full() { python -m pytest tests/test_gpu_model.py -q -m gpu -s -k "full_si
 opbench() { python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>$R/opbench.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); [print(r) for r in d['roofline_hbm']['rows']]" > $R/opbench.txt; tail -3 $R/opbench.err; }
 trace() {              # kernel trace of 10 timed steps (csv copied back for tools/trace_overlap.py / offline analysis) + aten attribution
     rm -rf /tmp/p1
-    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines > /dev/null 2>&1)
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --no-config2 > /dev/null 2>&1)
     cp $(find /tmp/p1 -name "*kernel_stats.csv" | head -1) $R/train_kernel_stats.csv
     cp $(find /tmp/p1 -name "*kernel_trace.csv" | head -1) $R/train_kernel_trace.csv
     python tools/trace_overlap.py $R/train_kernel_trace.csv loss_sample_kernel 5 11 > $R/train_overlap.txt 2>&1
@@ -79,7 +79,7 @@ serial_ab() { for i in 1 2; do python bench.py --no-cpu-baseline --no-op-rooflin
 pmc_gemm() {           # HBM traffic of cmf_gemm inside the training step: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slot limit)
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/pm_$c
-        (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-op-rooflines > /dev/null 2>&1)
+        (cd /tmp && rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pm_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-op-rooflines --no-config2 > /dev/null 2>&1)
         cp $(find /tmp/pm_$c -name "*counter_collection.csv" | head -1) $R/pmc_$c.csv
     done
     python tools/gemm_traffic.py $R/pmc_FETCH_SIZE.csv $R/pmc_WRITE_SIZE.csv > $R/gemm_traffic.json; cat $R/gemm_traffic.json
@@ -89,7 +89,7 @@ serial_profile() {     # the product's launches with every chain on one stream: 
     python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-op-rooflines --gemm-table $R/gemm_shapes_train.md > $R/bench_short.json 2>/dev/null
     python -c "import json; d=json.load(open('$R/bench_short.json')); print(d['ms_per_step'], d['roofline']['frac'], d['roofline_isolated']['frac'], d['roofline_isolated']['launches'])"
     rm -rf /tmp/p3
-    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --serial > $R/bench_serial.json 2>/dev/null)
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p3 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-op-rooflines --no-config2 --serial > $R/bench_serial.json 2>/dev/null)
     cp $(find /tmp/p3 -name "*kernel_stats.csv" | head -1) $R/train_serial_kernel_stats.csv
     python -c "import json; d=json.load(open('$R/bench_serial.json')); print('serial', d['ms_per_step'], d['roofline']['frac'])"
 }
@@ -144,6 +144,10 @@ bnbg_ab() {             # BN backward inside the gathering weight-gradient GEMM 
     for v in 1 0 1 0; do CMF_BNB_GATHER=$v python bench.py --steps 60 --no-cpu-baseline --no-op-rooflines 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('CMF_BNB_GATHER=$v', d['ms_per_step'], d['extra']['ms_per_step_regions'], d['roofline_isolated']['frac'])"; done | tee $R/bnbg_ab.txt
 }
 fc() { for s in 1 0; do echo "== FC_SERIAL=$s"; FC_SERIAL=$s python tools/fc_profile.py 2>&1 | filter | head -40; done > $R/fc_profile.txt; head -12 $R/fc_profile.txt; }
+dxsum_diag() {          # summed data gradient: product build, then the diagnostics build with 32 no per-point loads / 64 no row walk / 96 both / 8 no epilogue
+    echo "== product"; python tools/dxsum_probe.py 2>&1 | filter | grep -v "storage order" | tee $R/dxsum_product.txt
+    for d in 0 32 64 96 8; do echo "== diag build, CMF_GEMM_DIAG_RT=$d"; CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_x.so CMF_GEMM_DIAG_RT=$d python tools/dxsum_probe.py 2>&1 | filter | grep -v "storage order"; done | tee $R/dxsum_diag.txt
+}
 dense_train() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -s -k "dense_cloud" 2>&1 | tail -25 > $R/dense_train.txt; cat $R/dense_train.txt; }
 adam_test() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "flat_adam" 2>&1 | tail -8 > $R/adam_test.txt; cat $R/adam_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
