@@ -807,6 +807,11 @@ struct ThinBwdWideLds {
 // One workgroup = (a range of 128-row tiles) x (ONE chunk of 64 input channels): 64 weight-gradient accumulators per lane
 // leave room to request the next tile's layer input while the current tile computes.  The cin / 64 workgroups of a row range
 // get consecutive slots on the SAME XCD (id % 8), so the dZ inputs they all read come from that XCD's L2 after the first.
+// timing ablations (tools/diag builds with -DCMF_TBW_DIAG=bits, results invalid): 1 no dZ inputs (constants), 2 no dx stores, 4 no per-tile
+// statistics barriers / stores, 8 no weight-gradient MFMAs, 16 no data-gradient MFMAs
+#ifndef CMF_TBW_DIAG
+#define CMF_TBW_DIAG 0
+#endif
 template <int MODE>                          // bit 0: train-mode BN, bit 3: pooled dU (in_mode 1, both products, whole tiles)
 __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const ThinBwdArgs p, const int nchunk, const int nslab)
 {
@@ -893,6 +898,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
             float4 dv[8], zv[8];
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
+                if (CMF_TBW_DIAG & 1) { dv[k8] = make_float4(1.f, 2.f, 3.f, 4.f); zv[k8] = make_float4(0.5f, 0.25f, 0.125f, 1.f); continue; }
                 if (pooled) {
                     const float4 g4 = tb_ld4(src, ou + 32u * k8);
                     const uchar4 am = *(const uchar4 *)(p.pool_am + (ou >> 2) + 8u * k8);
@@ -933,6 +939,7 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float4 b = *(const float4 *)&S.wt[oW + j * 32 * LDO + 8 * k8];
+                if (CMF_TBW_DIAG & 16) { acc[j][k8] += d.x * b.x; continue; }
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.x, b.x, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.y, b.y, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(d.z, b.z, acc[j], 0, 0, 0);
@@ -950,7 +957,8 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
                 const float v = (fmaf(ia, zz, ic) > 0.f) ? acc[j][r] : 0.f;
                 s1 += v; s2 += v * ((zz - im) * ii);
                 float *dr = dxt + (long long)((int)(w0 + (unsigned)((r & 3) + 8 * (r >> 2))) * lddx_s) + j * 32;
-                *(float *)((char *)dr + ldx_) = v;
+                if (!(CMF_TBW_DIAG & 2)) *(float *)((char *)dr + ldx_) = v;
+                else asm volatile("" :: "v"(v), "v"(dr));
                 xc[j][r] = fmaxf(fmaf(ia, zz, ic), 0.f);           // activated: B operand of the weight gradient
             }
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
@@ -964,16 +972,20 @@ __global__ __launch_bounds__(TG_THREADS, 2) void thin_bwd_wide_kernel(const Thin
             for (int i = 0; i < 2; ++i) {
                 const float dz = src[i * 32];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) {
+                    if (CMF_TBW_DIAG & 8) { accw[i][j][r] += dz * xc[j][r]; continue; }
                     accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz, xc[j][r], accw[i][j], 0, 0, 0);
+                }
             }
         }
+        if (!(CMF_TBW_DIAG & 4)) {
         __syncthreads();
         if (threadIdx.x < 128) {
             const int which = threadIdx.x >> 6, n = threadIdx.x & 63;
             p.stats[(tile * 2 + which) * p.cin + col0 + n] = S.sred[0][which][n] + S.sred[1][which][n] + S.sred[2][which][n] + S.sred[3][which][n];
         }
         __syncthreads();                    // the sums are rewritten by the next tile
+        }
         if (more) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
