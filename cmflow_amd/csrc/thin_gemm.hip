@@ -808,7 +808,8 @@ struct ThinBwdWideLds {
 // leave room to request the next tile's layer input while the current tile computes.  The cin / 64 workgroups of a row range
 // get consecutive slots on the SAME XCD (id % 8), so the dZ inputs they all read come from that XCD's L2 after the first.
 // timing ablations (tools/diag builds with -DCMF_TBW_DIAG=bits, results invalid): 1 no dZ inputs (constants), 2 no dx stores, 4 no per-tile
-// statistics barriers / stores, 8 no weight-gradient MFMAs, 16 no data-gradient MFMAs
+// statistics barriers / stores, 8 no weight-gradient MFMAs, 16 no data-gradient MFMAs.  [Also tried, round 6: the two co-resident workgroups at different wave priorities so
+// that their phases fall out of step -- 512-522 against 522-525 us at 524288 rows, noise elsewhere.]
 #ifndef CMF_TBW_DIAG
 #define CMF_TBW_DIAG 0
 #endif
