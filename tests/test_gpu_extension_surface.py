@@ -127,3 +127,19 @@ def test_integration_md_stub_runs_as_written(dev):
         gx = orc.group_points(xyz.transpose(1, 2).contiguous(), ref_idx) - new.transpose(1, 2).unsqueeze(-1)
         parts = ([gx] if (use_xyz or not with_feats) else []) + ([orc.group_points(f, ref_idx)] if with_feats else [])
         assert torch.equal(got.cpu(), torch.cat(parts, dim=1))
+
+
+def test_library_memory_statistics_count_the_drop_in_scratch():
+    """cmf_mem_stats (bench.py's extra.peak_mem_bytes.library_scratch): the per-(stream, slot) working buffers the drop-in calls keep --
+    the inverse index / plan of cmf_group_points_grad has no argument in the reference's signature, so the library owns it."""
+    from cmflow_amd import _lib, pointnet2_utils as pu, synth
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    before = L.cmf_mem_stats()
+    xyz = synth.make_batch(2, N=256, seed=5)["pc1"].to(dev).transpose(1, 2).contiguous()
+    idx = pu.ball_query(2.0, 16, xyz, xyz)
+    feats = torch.randn(2, 8, 256, device=dev, requires_grad=True)
+    pu.grouping_operation(feats, idx).sum().backward()
+    torch.cuda.synchronize()
+    after = L.cmf_mem_stats()
+    assert after >= before and after > 0 and after % (1 << 20) == 0          # grown in whole MiB, kept for the process

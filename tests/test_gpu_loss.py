@@ -82,7 +82,8 @@ def test_fused_loss_matches_oracle(dev, monkeypatch, B, N, seed, real_like):
     _check_against_oracle(dev, monkeypatch, B, N, seed, real_like)
 
 
-@pytest.mark.parametrize("num_nb,N,tiled", [(4, 256, False), (16, 256, False), (16, 1000, False), (8, 256, True), (8, 100, True)])
+@pytest.mark.parametrize("num_nb,N,tiled", [(4, 256, False), (16, 256, False), (16, 1000, False), (8, 256, True), (8, 100, True),
+                                            (16, 17, False), (4, 5, False), (8, 9, True), (8, 257, True)])     # clouds barely larger than the neighbour count; a ragged last tile
 def test_fused_loss_other_neighbour_counts_and_forced_tiling(dev, monkeypatch, num_nb, N, tiled):
     """radar_loss.py:63: num_nb is a constructor argument; the tiled kernels also at sizes the LDS kernel takes."""
     _check_against_oracle(dev, monkeypatch, 2, N, 31 + num_nb, False, num_nb=num_nb, tiled=tiled)
