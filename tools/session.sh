@@ -148,6 +148,13 @@ dxsum_diag() {          # summed data gradient: product build, then the diagnost
     echo "== product"; python tools/dxsum_probe.py 2>&1 | filter | grep -v "storage order" | tee $R/dxsum_product.txt
     for d in 0 32 64 96 8; do echo "== diag build, CMF_GEMM_DIAG_RT=$d"; CMF_LIB=$GRAFT_REPO_ROOT/tools/diag/libcmflow_x.so CMF_GEMM_DIAG_RT=$d python tools/dxsum_probe.py 2>&1 | filter | grep -v "storage order"; done | tee $R/dxsum_diag.txt
 }
+allreduce_abab() {      # world-1 RCCL all-reduce inside every step, two rounds: none / one bucket after backward / three segments overlapped with backward
+    for r in 1 2; do
+        python bench.py --steps 60 --no-cpu-baseline --no-op-rooflines --no-config2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('none   ', d['ms_per_step'], d['extra']['ms_per_step_regions'])"
+        python bench.py --steps 60 --no-cpu-baseline --no-op-rooflines --no-config2 --force-allreduce 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('single ', d['ms_per_step'], d['extra']['ms_per_step_regions'], d['allreduce_ms'])"
+        CMF_OVERLAP_ALLREDUCE=1 python bench.py --steps 60 --no-cpu-baseline --no-op-rooflines --no-config2 --force-allreduce 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('overlap', d['ms_per_step'], d['extra']['ms_per_step_regions'])"
+    done | tee $R/allreduce_abab.txt
+}
 dense_train() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -s -k "dense_cloud" 2>&1 | tail -25 > $R/dense_train.txt; cat $R/dense_train.txt; }
 adam_test() { python -m pytest tests/test_gpu_model.py -x -q -m gpu -k "flat_adam" 2>&1 | tail -8 > $R/adam_test.txt; cat $R/adam_test.txt; }
 suite() { python -m pytest tests -x -q -m gpu 2>&1 | tail -15 > $R/suite.txt; }
